@@ -1,0 +1,190 @@
+/*
+ * mscnn_hip.h -- C ABI of libmscnn_hip.so: the MI355X (gfx950) device ops of the MS-CNN
+ * inference hot path.  This is the drop-in boundary: every entry point is
+ * what a caffe::Layer<float>::Forward_gpu of the reference would bind for that layer.
+ * Plain pointers and sizes only; all tensors are fp32, NCHW, contiguous (blob.hpp:153-164);
+ * every pointer is a DEVICE pointer unless the parameter name ends in _host.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream, which is what every
+ * reference layer uses, device_alternate.hpp:84-90).
+ *
+ * Return value: 0 = ok, non-zero = error (see mscnn_status).  Nothing here aborts; the C++
+ * layer shim (mscnn_amd/host) turns a non-zero status into a CHECK-style fatal to mimic the
+ * reference's glog convention (device_alternate.hpp:48-67).
+ *
+ * There is NO CPU fallback behind any of these functions.
+ */
+#ifndef MSCNN_HIP_H_
+#define MSCNN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define MSCNN_API __attribute__((visibility("default")))
+#else
+#define MSCNN_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MSCNN_OK = 0,
+  MSCNN_ERR_BAD_ARG = 1,      /* shape / parameter the kernel cannot honour */
+  MSCNN_ERR_HIP = 2,          /* a HIP runtime call or launch failed; see mscnn_last_error() */
+  MSCNN_ERR_WORKSPACE = 3,    /* workspace too small; query the *_workspace_bytes function */
+  MSCNN_ERR_UNSUPPORTED = 4
+} mscnn_status;
+
+/* Text of the last error on this host thread (static storage, never NULL). */
+MSCNN_API const char* mscnn_last_error(void);
+/* Library / device identification: "mscnn_hip <ver> gfx950". */
+MSCNN_API const char* mscnn_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution  -- replaces ConvolutionLayer<Dtype>::Forward_gpu (src/caffe/layers/conv_layer.cu:8-23
+ * -> base_conv_layer.cpp:325-349: im2col_gpu + cublasSgemm + bias GEMM) and
+ * CuDNNConvolutionLayer::Forward_gpu (cudnn_conv_layer.cu:11-46), fused with the in-place
+ * ReLULayer::Forward_gpu that follows it in every deploy net (relu_layer.cu:17-26) when relu != 0.
+ * Cross-correlation, weights w[Cout][Cin/group][Kh][Kw] (base_conv_layer.cpp:135-140), bias may be NULL.
+ *
+ * The hot shapes (stride 1, group 1) run on an im2col-free implicit-GEMM MFMA kernel that reads a
+ * pre-packed copy of the weights: create a plan once per layer (weights are constants at inference),
+ * call mscnn_conv2d_pack_weights whenever the Caffe weight blob changes, then mscnn_conv2d_fwd_f32.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mscnn_conv_plan mscnn_conv_plan;   /* opaque */
+
+typedef struct {
+  int N, Cin, H, W;          /* bottom shape */
+  int Cout, Kh, Kw;
+  int pad_h, pad_w, stride_h, stride_w, group;
+  int relu;                  /* 1: apply max(x,0) in the epilogue (negative_slope 0) */
+} mscnn_conv_desc;
+
+MSCNN_API int mscnn_conv2d_plan_create(const mscnn_conv_desc* desc, mscnn_conv_plan** plan_out);
+MSCNN_API void mscnn_conv2d_plan_destroy(mscnn_conv_plan* plan);
+/* Bytes of device memory the plan needs for packed weights and for split-K partial tiles. */
+MSCNN_API size_t mscnn_conv2d_packed_weight_bytes(const mscnn_conv_plan* plan);
+MSCNN_API size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* plan);
+/* "igemm_mfma_f32" | "direct_f32": which kernel family the plan selected. */
+MSCNN_API const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* plan);
+/* Algorithmic FLOPs (2*MACs) of one forward call, for roofline accounting. */
+MSCNN_API double mscnn_conv2d_plan_flops(const mscnn_conv_plan* plan);
+/* Re-shape a plan for a new batch size N (ROI count changes per image, layer.hpp:451-456). */
+MSCNN_API int mscnn_conv2d_plan_set_batch(mscnn_conv_plan* plan, int N);
+MSCNN_API int mscnn_conv2d_pack_weights(const mscnn_conv_plan* plan, const float* w, float* packed, void* stream);
+MSCNN_API int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* plan, const float* x, const float* w, const float* packed,
+                         const float* bias, float* y, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ReLU -- ReLULayer::Forward_gpu (relu_layer.cu:9-26); in place allowed (y == x). */
+MSCNN_API int mscnn_relu_fwd_f32(const float* x, float* y, size_t count, float negative_slope, void* stream);
+
+/* Pooling -- PoolingLayer::Forward_gpu (pooling_layer.cu:11-47 MAX, :50-81 AVE; output size
+ * pooling_layer.cpp:90-107, ceil mode).  method: 0 MAX, 1 AVE.  The argmax mask the reference
+ * also writes is not produced (unused at TEST). */
+MSCNN_API int mscnn_pool_out_dim(int in, int kernel, int pad, int stride);
+MSCNN_API int mscnn_pool2d_fwd_f32(const float* x, float* y, int N, int C, int H, int W, int kernel_h, int kernel_w,
+                         int pad_h, int pad_w, int stride_h, int stride_w, int method, void* stream);
+
+/* InnerProduct -- InnerProductLayer::Forward_gpu (inner_product_layer.cu:10-31):
+ * y[M,N] = x[M,K] * w[N,K]^T + bias[N]  (transpose_ = false), optional fused ReLU. */
+MSCNN_API int mscnn_inner_product_fwd_f32(const float* x, const float* w, const float* bias, float* y,
+                                int M, int N, int K, int relu, void* stream);
+
+/* Concat along channels -- ConcatLayer::Forward_gpu (concat_layer.cu:9-46).
+ * Copies x[N, C, inner] into y[N, C_total, inner] at channel offset c_offset. */
+MSCNN_API int mscnn_concat_channels_f32(const float* x, float* y, int N, int C, int inner, int C_total, int c_offset, void* stream);
+
+/* Deconvolution -- DeconvolutionLayer::Forward_gpu (deconv_layer.cu:8-23), depthwise case used by the
+ * "-2x" deploy nets (group == Cin == Cout, w[C][1][Kh][Kw], no bias or bias[C]). */
+MSCNN_API int mscnn_deconv_depthwise_fwd_f32(const float* x, const float* w, const float* bias, float* y,
+                                   int N, int C, int H, int W, int Kh, int Kw, int pad_h, int pad_w,
+                                   int stride_h, int stride_w, void* stream);
+
+/* Softmax over axis 1 of x[outer][C][inner] -- SoftmaxLayer::Forward_gpu (softmax_layer.cu:83-120). */
+MSCNN_API int mscnn_softmax_fwd_f32(const float* x, float* y, int outer, int C, int inner, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ROIPooling -- ROIPoolingLayer<Dtype>::Forward_gpu (roi_pooling_layer.cu:19-104; CPU twin
+ * roi_pooling_layer.cpp:48-139) with the MS-CNN pad_ratio context padding.  rois[R][5] =
+ * [batch x1 y1 x2 y2].  Writes out[R][C_total][PH][PW] at channel offset c_offset so that two
+ * calls fill the buffer the following Concat layer would produce (C_total == C, c_offset == 0
+ * for the stand-alone layer).  A roi's batch index outside [0, N) is NOT checked on the device
+ * (the reference CHECKs it on the CPU path only, roi_pooling_layer.cpp:64-65).
+ * ------------------------------------------------------------------------------------------ */
+MSCNN_API int mscnn_roipool_fwd_f32(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W,
+                          int pooled_h, int pooled_w, float spatial_scale, float pad_ratio,
+                          int C_total, int c_offset, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BoxOutput -- BoxOutputLayer<Dtype>::Forward_cpu (box_output_layer.cpp:66-234; the reference has
+ * no GPU version, box_output_layer.hpp:39-40): per-anchor decode + filter, descending sort on
+ * (score, candidate index), top max_nms_num, greedy NMS (nmsMax :38-63, BoxIOU
+ * math_functions.cpp:12-35), emit rois [b x1 y1 x2 y2] and proposals+score [b x1 y1 x2 y2 s].
+ * ------------------------------------------------------------------------------------------ */
+#define MSCNN_BOXOUT_MAX_HEADS 16
+typedef struct {
+  int num_heads;                              /* number of bottoms */
+  int num;                                    /* batch size (images) */
+  int channels;                               /* cls_num + 4 */
+  int head_h[MSCNN_BOXOUT_MAX_HEADS], head_w[MSCNN_BOXOUT_MAX_HEADS];
+  float field_w[MSCNN_BOXOUT_MAX_HEADS], field_h[MSCNN_BOXOUT_MAX_HEADS], downsample_rate[MSCNN_BOXOUT_MAX_HEADS];
+  float fg_thr, iou_thr;
+  int nms_mode;                               /* 0 "IOU", 1 "IOMU", 2 "IOFU" */
+  float field_whr, field_xyr;
+  int max_nms_num, max_post_nms_num;
+  float min_size;
+  int do_bbox_norm;                           /* bbox_reg_param present with 4 means and 4 stds */
+  float bbox_mean[4], bbox_std[4];
+} mscnn_boxoutput_desc;
+
+MSCNN_API size_t mscnn_boxoutput_workspace_bytes(const mscnn_boxoutput_desc* desc);
+/* Row capacity needed for rois_out / props_out / anchor_ids_out. */
+MSCNN_API int mscnn_boxoutput_max_rows(const mscnn_boxoutput_desc* desc);
+/*
+ * heads_host: host array of num_heads DEVICE pointers.  rois_out[cap][5], props_out[cap][6]
+ * (NULL allowed), anchor_ids_out[cap] (NULL allowed; global anchor id = head offset + h*w index of
+ * each emitted row, -1 for the dummy row), count_out_dev: device int[2] = {R, num_real}
+ * (R includes the dummy row [0 1 1 10 10] emitted when nothing survives, :195-199).
+ * Asynchronous on `stream`; the caller copies count_out_dev back when it needs R on the host.
+ */
+MSCNN_API int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* desc, const float* const* heads_host,
+                            float* rois_out, float* props_out, int* anchor_ids_out, int cap,
+                            int* count_out_dev, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Greedy NMS on already score-sorted boxes [n][4] = x y w h (nmsMax, greedy = true):
+ * keep_out[n] bytes 0/1.  Exposed for the index-exactness parity tests. */
+MSCNN_API size_t mscnn_nms_workspace_bytes(int n);
+MSCNN_API int mscnn_nms_greedy_f32(const float* boxes_xywh, int n, float iou_thr, int nms_mode, unsigned char* keep_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* DecodeBBox (TEST phase) -- DecodeBBoxLayer<Dtype>::Forward_cpu (decode_bbox_layer.cpp:54-123,
+ * DecodeBBoxesWithPrior math_functions.cpp:46-75); bbox[R][8] (columns 4..7 used), prior[R][5],
+ * mean/std host arrays of 4. */
+MSCNN_API int mscnn_decodebbox_fwd_f32(const float* bbox, const float* prior, float* out, int R, int bbox_dim,
+                             const float* mean_host, const float* std_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Final detection stage -- the MATLAB post-processing the reference runs on the net outputs
+ * (examples/kitti_car/run_mscnn_detection.m:75-120, utils/bbNms.m:112-126): proposal filter,
+ * bbox de-normalisation + transform, softmax prob of class cls_id (1-based), rescale to the
+ * original image, clip, greedy NMS (stable sort, union, double precision).
+ * dets_out[cap][5] doubles [x y w h prob], ids_out[cap] input row of each detection,
+ * count_out_dev: device int[1] = D.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int ncls, cls_id;
+  float bbox_mean[4], bbox_std[4];
+  float proposal_thr;
+  double ratio_h, ratio_w, org_h, org_w, nms_overlap;
+} mscnn_detections_desc;
+MSCNN_API size_t mscnn_detections_workspace_bytes(int R);
+MSCNN_API int mscnn_detections_fwd(const mscnn_detections_desc* desc, const float* bbox_pred, const float* cls_pred,
+                         const float* props, int R, double* dets_out, int* ids_out, int* count_out_dev,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* MSCNN_HIP_H_ */

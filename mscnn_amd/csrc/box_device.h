@@ -1,0 +1,127 @@
+// Device helpers shared by boxoutput.hip and detections.hip (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mscnn_dev {
+
+typedef unsigned long long u64;
+constexpr int kMaxK = 4032;               // 63 bitmap words: LDS bitonic (32 KB) + scan double buffer (63 KB) fit
+constexpr int kSortThreads = 1024;
+constexpr int kSortCap = 4096;            // bitonic network size (power of two >= kMaxK)
+
+// ---- expf with glibc's algorithm (sysdeps/ieee754/flt-32/e_expf.c, Szabolcs Nagy's exp2f table
+// method: N = 32 table, degree-3 polynomial in double).  The reference's `exp(Dtype)` resolves to
+// libm expf on the host; device ocml expf is not bit-identical to it, this restatement is (checked
+// exhaustively on the host against libm for |x| <= 80: 2 differing inputs out of 2.2e9, none in the
+// clamp range [-ln 2, ln 2] used here).  Valid for |x| < 88 (the callers clamp).
+__device__ __constant__ u64 kExp2fTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+__device__ __forceinline__ float expf_libm(float x) {
+  if (!(fabsf(x) < 87.f)) return expf(x);   // outside the table method's plain range: ocml (overflow/underflow/NaN)
+  const double N = 32.0;
+  const double InvLn2N = 0x1.71547652b82fep+0 * N, SHIFT = 0x1.8p+52;
+  const double C0 = 0x1.c6af84b912394p-5 / N / N / N, C1 = 0x1.ebfce50fac4f3p-3 / N / N, C2 = 0x1.62e42ff0c52d6p-1 / N;
+  const double xd = (double)x;
+  double z = InvLn2N * xd;
+  double kd = z + SHIFT;
+  const u64 ki = (u64)__double_as_longlong(kd);
+  kd -= SHIFT;
+  const double r = z - kd;
+  u64 t = kExp2fTab[ki % 32];
+  t += ki << 47;
+  const double s = __longlong_as_double((long long)t);
+  z = C0 * r + C1;
+  const double r2 = r * r;
+  double y = C2 * r + 1.0;
+  y = z * r2 + y;
+  y = y * s;
+  return (float)y;
+}
+
+__device__ __forceinline__ unsigned orderable(float s) {
+  if (s == 0.f) s = 0.f;                                // -0 and +0 compare equal in the reference's sort
+  const unsigned b = __float_as_uint(s);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ u64 readlane64(u64 v, int lane) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, lane);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
+  return ((u64)hi << 32) | lo;
+}
+
+// Greedy scan over the upper-triangular bit matrix (nmsMax, box_output_layer.cpp:38-63) by one 256-thread
+// workgroup.  Wave 0 owns the removed-bitmap (lane w = boxes [64w, 64w+64)) and walks the boxes in chunks of
+// 64: a 64-step register-only pass over the diagonal word of each row (v_readlane broadcasts), then an OR of
+// the kept rows.  Waves 1-3 stream the NEXT chunk's 64 mask rows from L2 into the other half of a double
+// buffer in LDS meanwhile (one barrier per chunk).  W = words per row actually used (<= 64).
+// `buf` = dynamic LDS of 2 * 64 * W u64.  Result: lane c of wave 0 returns the keep-word of chunk c.
+__device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, int wpr, int W, u64* buf) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunks = (n + 63) >> 6;
+  auto fill = [&](int c, int b, int t0, int stride) {
+    u64* dst = buf + (size_t)b * 64 * W;
+    for (int idx = t0; idx < 64 * W; idx += stride) {
+      const int i = idx / W, w = idx - i * W;
+      const int row = c * 64 + i;
+      dst[idx] = (row < n && w >= c && w < wpr) ? mask[(size_t)row * wpr + w] : 0ull;
+    }
+  };
+  fill(0, 0, tid, 256);
+  __syncthreads();
+  u64 removed = 0, mykeep = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const u64* cur_rows = buf + (size_t)(c & 1) * 64 * W;
+    if (wave != 0) {
+      if (c + 1 < nchunks) fill(c + 1, (c + 1) & 1, tid - 64, 192);
+    } else {
+      const int valid = min(64, n - c * 64);
+      const u64 dg = cur_rows[lane * W + c];            // diagonal word of row (c*64 + lane)
+      u64 cur = readlane64(removed, c);
+      u64 keep = 0;
+#pragma unroll 8
+      for (int i = 0; i < 64; ++i) {
+        const u64 di = readlane64(dg, i);                // uniform
+        const bool alive = (i < valid) && !((cur >> i) & 1ull);
+        if (alive) { keep |= 1ull << i; cur |= di; }
+      }
+      if (lane == c) mykeep = keep;
+      if (lane < W) {
+        u64 kk = keep;
+        while (kk) {                                     // uniform loop over kept rows
+          const int i = __ffsll((long long)kk) - 1;
+          kk &= kk - 1;
+          removed |= cur_rows[i * W + lane];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  return mykeep;
+}
+
+// Bitonic sort (descending) of P (power of two, <= kMaxK) 64-bit keys in LDS by one workgroup.
+__device__ __forceinline__ void bitonic_desc(u64* sk, int P, int tid, int nthreads) {
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += nthreads) {
+        const int lo = (t / stride) * (stride << 1) + (t % stride);
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const u64 a = sk[lo], b = sk[hi];
+        const bool swap = desc ? (a < b) : (a > b);
+        if (swap) { sk[lo] = b; sk[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace mscnn_dev

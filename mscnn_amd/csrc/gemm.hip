@@ -1,0 +1,233 @@
+// InnerProduct forward for gfx950: y[M,N] = x[M,K] * w[N,K]^T + bias (+ReLU).
+// Replaces InnerProductLayer<Dtype>::Forward_gpu (src/caffe/layers/inner_product_layer.cu:10-31:
+// cublasSgemm / cublasSgemv + cublasSaxpy for the bias).
+//
+// fc6 (M = #ROIs, K = 12800, N = 4096): fp32 MFMA GEMM.  Both operands are K-contiguous in HBM, so tiles
+// are staged [row][k] into LDS with float4 loads/stores (row stride BK+4 floats keeps 16-B alignment and
+// limits the ds_read_b32 bank conflict to 4-way, invisible behind the 64-cycle v_mfma_f32_32x32x2_f32).
+// The ROI rows are the MFMA "M" side and the output units the "N" side so that each accumulator register
+// is a 128-B run of y[m][n..n+31] (coalesced stores).  Work split is stream-K over (tile, k-chunk), as in
+// conv.hip: M is data dependent (1..2000 ROIs) so tile counts never match the 256 CUs; partial tiles go
+// through fp32 slabs + a fix-up kernel that also applies bias/ReLU.  Tiles are ordered with the ROI-tile
+// index fastest so that the workgroups sharing a 128-row slice of W run together and share it in L2
+// (W for fc6 is 210 MB: it must stream from HBM once, not once per ROI tile).
+// cls_pred / bbox_pred (N = 5 / 20): one workgroup per row, lanes split K, wave reductions.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 4;
+
+struct GemmArgs {
+  const float* x; const float* w; const float* bias; float* y; float* ws;
+  int M, N, K, MT, NT, KI, G, relu;
+  long total_iters;
+};
+
+__device__ __forceinline__ void wg_range(long total, int G, int g, long& b, long& e) {
+  b = total * g / G;
+  e = total * (g + 1) / G;
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float ldsX[BM * LDK];
+  __shared__ __attribute__((aligned(16))) float ldsW[BN * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;      // 2 x 2 waves, 64 x 64 each
+
+  long it, it_end;
+  wg_range(a.total_iters, a.G, blockIdx.x, it, it_end);
+
+  // staging map: 128 rows x 8 float4 per operand = 1024 float4 -> 4 per thread
+  int s_row[4], s_k4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int v = tid + i * 256;
+    s_row[i] = v >> 3;
+    s_k4[i] = (v & 7) * 4;
+  }
+
+  while (it < it_end) {
+    const int t = (int)(it / a.KI);
+    const int k0 = (int)(it % a.KI);
+    const int k1 = (int)min((long)a.KI, k0 + (it_end - it));
+    const int nt = t / a.MT, mt = t % a.MT;      // ROI tile fastest
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 rx[4], rw[4];
+    auto load_chunk = [&](int kc) {
+      const int kb = kc * BK;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = kb + s_k4[i];
+        const int m = m0 + s_row[i], n = n0 + s_row[i];
+        rx[i] = (m < a.M && k < a.K) ? *reinterpret_cast<const float4*>(a.x + (long)m * a.K + k) : make_float4(0, 0, 0, 0);
+        rw[i] = (n < a.N && k < a.K) ? *reinterpret_cast<const float4*>(a.w + (long)n * a.K + k) : make_float4(0, 0, 0, 0);
+      }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<float4*>(&ldsX[s_row[i] * LDK + s_k4[i]]) = rx[i];
+        *reinterpret_cast<float4*>(&ldsW[s_row[i] * LDK + s_k4[i]]) = rw[i];
+      }
+    };
+
+    load_chunk(k0);
+    for (int kc = k0; kc < k1; ++kc) {
+      __syncthreads();
+      store_chunk();
+      __syncthreads();
+      if (kc + 1 < k1) load_chunk(kc + 1);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float av[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = ldsX[(wm * 64 + i * 32 + l31) * LDK + kk + khalf];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = ldsW[(wn * 64 + j * 32 + l31) * LDK + kk + khalf];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+
+    const bool full = (k0 == 0 && k1 == a.KI);
+    float* slab = a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nl = wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          if (full) {
+            const int m = m0 + ml, n = n0 + nl;
+            if (m < a.M && n < a.N) {
+              float v = acc[i][j][r];
+              if (a.bias) v += a.bias[n];
+              if (a.relu) v = v > 0.f ? v : 0.f;
+              a.y[(long)m * a.N + n] = v;
+            }
+          } else {
+            slab[ml * BN + nl] = acc[i][j][r];
+          }
+        }
+      }
+    it += (k1 - k0);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmArgs a) {
+  const int t = blockIdx.x;
+  const long its = (long)t * a.KI, ite = its + a.KI;
+  int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
+  long b, e;
+  wg_range(a.total_iters, a.G, gf, b, e);
+  while (e <= its) { ++gf; wg_range(a.total_iters, a.G, gf, b, e); }
+  while (b > its) { --gf; wg_range(a.total_iters, a.G, gf, b, e); }
+  wg_range(a.total_iters, a.G, gl, b, e);
+  while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
+  while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
+  if (gf == gl) return;
+  const int nt = t / a.MT, mt = t % a.MT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  for (int i = threadIdx.x; i < BM * BN; i += 256) {
+    const int ml = i / BN, nl = i % BN;
+    float v = 0.f;
+    for (int g = gf; g <= gl; ++g) {
+      wg_range(a.total_iters, a.G, g, b, e);
+      v += a.ws[((long)g * 2 + (b > its ? 0 : 1)) * (BM * BN) + i];
+    }
+    const int m = m0 + ml, n = n0 + nl;
+    if (m < a.M && n < a.N) {
+      if (a.bias) v += a.bias[n];
+      if (a.relu) v = v > 0.f ? v : 0.f;
+      a.y[(long)m * a.N + n] = v;
+    }
+  }
+}
+
+// Small-N path: one workgroup per row m.
+__global__ __launch_bounds__(256) void ip_rowwise_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int M, int N,
+                                                         int K, int relu) {
+  __shared__ float red[4];
+  const int m = blockIdx.x;
+  const float* xr = x + (long)m * K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int n = 0; n < N; ++n) {
+    const float* wr = w + (long)n * K;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) acc += xr[k] * wr[k];
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float v = (red[0] + red[1]) + (red[2] + red[3]);
+      if (bias) v += bias[n];
+      if (relu) v = v > 0.f ? v : 0.f;
+      y[(long)m * N + n] = v;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+using namespace mscnn;
+
+// Workspace for the stream-K slabs is owned by the library (grown on demand, per device) because the Caffe
+// layer interface has no workspace argument for InnerProduct.
+static float* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+
+extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
+                                           int relu, void* stream) {
+  MSCNN_REQUIRE(M >= 0 && N > 0 && K > 0, "inner_product: bad shape M=%d N=%d K=%d", M, N, K);
+  if (M == 0) return MSCNN_OK;
+  MSCNN_REQUIRE(x && w && y, "inner_product: null pointer");
+  hipStream_t st = as_stream(stream);
+  const bool aligned = (K % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(w) % 16 == 0);
+  if (N < 64 || !aligned) {
+    ip_rowwise_kernel<<<M, 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+    MSCNN_POST_LAUNCH();
+    return MSCNN_OK;
+  }
+  GemmArgs a;
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.M = M; a.N = N; a.K = K; a.relu = relu;
+  a.MT = cdiv(M, BM); a.NT = cdiv(N, BN); a.KI = cdiv(K, BK);
+  a.total_iters = (long)a.MT * a.NT * a.KI;
+  long G = 512;
+  if (a.total_iters / 8 < G) G = a.total_iters / 8;
+  if (G < 1) G = 1;
+  a.G = (int)G;
+  const size_t need = (size_t)a.G * 2 * BM * BN * sizeof(float);
+  if (need > g_ws_bytes) {
+    if (g_ws) MSCNN_HIP_TRY(hipFree(g_ws));
+    g_ws = nullptr; g_ws_bytes = 0;
+    MSCNN_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_ws), need));
+    g_ws_bytes = need;
+  }
+  a.ws = g_ws;
+  gemm_tn_kernel<<<a.G, 256, 0, st>>>(a);
+  MSCNN_POST_LAUNCH();
+  gemm_fixup_kernel<<<a.MT * a.NT, 256, 0, st>>>(a);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}

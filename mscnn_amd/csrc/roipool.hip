@@ -1,0 +1,91 @@
+// ROIPooling with MS-CNN context padding for gfx950.
+// Reference: ROIPoolingLayer<Dtype>::Forward_gpu, src/caffe/layers/roi_pooling_layer.cu:19-104
+// (CPU twin roi_pooling_layer.cpp:48-139).  Pure compare/select arithmetic => bit-exact.
+//
+// Mapping: one workgroup per (roi, channel block).  The ROI geometry (4 roundf + bin sizes) is
+// computed once per workgroup into SGPR-uniform values instead of once per output as the
+// reference kernel does.  A wavefront owns channels; its 64 lanes cover the PH*PW bins of one or
+// more channels, so the stores of a wave are one contiguous run of out[r][c..][:][:] (coalesced),
+// and the feature-map reads of a wave stay inside a handful of rows of one channel plane
+// (conv4_3 is 35 MB: L2 / Infinity-Cache resident across ROIs).
+#include "common.h"
+#include <cfloat>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void roipool_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
+                                                           float* __restrict__ out, int C, int H, int W, int PH, int PW,
+                                                           float spatial_scale, float pad_ratio, int C_total, int c_offset,
+                                                           int chan_per_block) {
+  const int r = blockIdx.x;
+  const int c_begin = blockIdx.y * chan_per_block;
+  const int c_end = min(C, c_begin + chan_per_block);
+
+  const float* roi = rois + 5 * (size_t)r;
+  const int b = (int)roi[0];
+  const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+  // roi_pooling_layer.cu:33-41 -- context padding, no clipping of the roi itself
+  const float pad_w = (x2 - x1 + 1) * pad_ratio;
+  const float pad_h = (y2 - y1 + 1) * pad_ratio;
+  const int roi_start_w = (int)roundf((x1 - pad_w) * spatial_scale);
+  const int roi_start_h = (int)roundf((y1 - pad_h) * spatial_scale);
+  const int roi_end_w = (int)roundf((x2 + pad_w) * spatial_scale);
+  const int roi_end_h = (int)roundf((y2 + pad_h) * spatial_scale);
+  const int roi_width = max(roi_end_w - roi_start_w + 1, 1);
+  const int roi_height = max(roi_end_h - roi_start_h + 1, 1);
+  const float bin_size_h = (float)roi_height / (float)PH;
+  const float bin_size_w = (float)roi_width / (float)PW;
+
+  const int bins = PH * PW;
+  const int work = (c_end - c_begin) * bins;
+  const float* fbase = feat + (size_t)b * C * H * W;
+  float* obase = out + ((size_t)r * C_total + c_offset) * bins;
+
+  for (int i = threadIdx.x; i < work; i += kThreads) {
+    const int c = c_begin + i / bins;
+    const int bin = i % bins;
+    const int ph = bin / PW, pw = bin % PW;
+    int hstart = (int)floorf((float)ph * bin_size_h);
+    int wstart = (int)floorf((float)pw * bin_size_w);
+    int hend = (int)ceilf((float)(ph + 1) * bin_size_h);
+    int wend = (int)ceilf((float)(pw + 1) * bin_size_w);
+    hstart = min(max(hstart + roi_start_h, 0), H);
+    hend = min(max(hend + roi_start_h, 0), H);
+    wstart = min(max(wstart + roi_start_w, 0), W);
+    wend = min(max(wend + roi_start_w, 0), W);
+    const bool is_empty = (hend <= hstart) || (wend <= wstart);
+    float maxval = is_empty ? 0.f : -FLT_MAX;
+    const float* plane = fbase + (size_t)c * H * W;
+    for (int h = hstart; h < hend; ++h)
+      for (int w = wstart; w < wend; ++w) {
+        const float v = plane[h * W + w];
+        if (v > maxval) maxval = v;   // first max wins; value only (argmax is not needed at TEST)
+      }
+    obase[(size_t)c * bins + bin] = maxval;
+  }
+}
+
+}  // namespace
+
+using namespace mscnn;
+
+extern "C" int mscnn_roipool_fwd_f32(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W,
+                                     int pooled_h, int pooled_w, float spatial_scale, float pad_ratio, int C_total,
+                                     int c_offset, void* stream) {
+  MSCNN_REQUIRE(feat && rois && out, "roipool: null pointer");
+  MSCNN_REQUIRE(R >= 0 && N > 0 && C > 0 && H > 0 && W > 0, "roipool: bad shape");
+  MSCNN_REQUIRE(pooled_h > 0 && pooled_w > 0, "roipool: pooled_h/pooled_w must be > 0");   // roi_pooling_layer.cpp:26-29
+  MSCNN_REQUIRE(c_offset >= 0 && c_offset + C <= C_total, "roipool: channel window outside the output buffer");
+  if (R == 0) return MSCNN_OK;
+  // ~4 waves of work per block: 256 threads x a few bins each
+  const int bins = pooled_h * pooled_w;
+  int chan_per_block = max(1, (kThreads * 4) / bins);
+  if (chan_per_block > C) chan_per_block = C;
+  dim3 grid(R, cdiv(C, chan_per_block));
+  roipool_kernel<<<grid, kThreads, 0, as_stream(stream)>>>(feat, rois, out, C, H, W, pooled_h, pooled_w, spatial_scale,
+                                                           pad_ratio, C_total, c_offset, chan_per_block);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}

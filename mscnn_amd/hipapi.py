@@ -1,0 +1,340 @@
+"""ctypes binding of libmscnn_hip.so (include/mscnn_hip.h) for Python callers.
+
+Tensors are torch CUDA (ROCm) tensors; torch is used only as the device allocator and stream
+owner -- every computation is done by the hand-written HIP kernels behind the C ABI.
+There is no CPU fallback: a missing library or a host tensor raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmscnn_hip.so")
+_lib = None
+
+
+class MscnnError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "Cin", "H", "W", "Cout", "Kh", "Kw", "pad_h", "pad_w",
+                                       "stride_h", "stride_w", "group", "relu")]
+
+
+MAX_HEADS = 16
+
+
+class BoxOutputDesc(C.Structure):
+    _fields_ = [("num_heads", C.c_int), ("num", C.c_int), ("channels", C.c_int),
+                ("head_h", C.c_int * MAX_HEADS), ("head_w", C.c_int * MAX_HEADS),
+                ("field_w", C.c_float * MAX_HEADS), ("field_h", C.c_float * MAX_HEADS),
+                ("downsample_rate", C.c_float * MAX_HEADS),
+                ("fg_thr", C.c_float), ("iou_thr", C.c_float), ("nms_mode", C.c_int),
+                ("field_whr", C.c_float), ("field_xyr", C.c_float),
+                ("max_nms_num", C.c_int), ("max_post_nms_num", C.c_int), ("min_size", C.c_float),
+                ("do_bbox_norm", C.c_int), ("bbox_mean", C.c_float * 4), ("bbox_std", C.c_float * 4)]
+
+
+class DetectionsDesc(C.Structure):
+    _fields_ = [("ncls", C.c_int), ("cls_id", C.c_int), ("bbox_mean", C.c_float * 4), ("bbox_std", C.c_float * 4),
+                ("proposal_thr", C.c_float), ("ratio_h", C.c_double), ("ratio_w", C.c_double),
+                ("org_h", C.c_double), ("org_w", C.c_double), ("nms_overlap", C.c_double)]
+
+
+NMS_MODES = {"IOU": 0, "IOMU": 1, "IOFU": 2}
+
+
+def lib():
+    """Load libmscnn_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MscnnError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.mscnn_last_error.restype = C.c_char_p
+        L.mscnn_version.restype = C.c_char_p
+        L.mscnn_conv2d_plan_kernel.restype = C.c_char_p
+        L.mscnn_conv2d_plan_kernel.argtypes = [C.c_void_p]
+        L.mscnn_conv2d_plan_flops.restype = C.c_double
+        L.mscnn_conv2d_plan_flops.argtypes = [C.c_void_p]
+        for f in ("mscnn_conv2d_packed_weight_bytes", "mscnn_conv2d_workspace_bytes"):
+            getattr(L, f).restype = C.c_size_t
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.mscnn_conv2d_plan_destroy.argtypes = [C.c_void_p]
+        L.mscnn_conv2d_plan_destroy.restype = None
+        L.mscnn_conv2d_plan_set_batch.argtypes = [C.c_void_p, C.c_int]
+        L.mscnn_conv2d_pack_weights.argtypes = [C.c_void_p] * 4
+        L.mscnn_conv2d_fwd_f32.argtypes = [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]
+        L.mscnn_relu_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
+        L.mscnn_pool2d_fwd_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
+        L.mscnn_inner_product_fwd_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
+        L.mscnn_concat_channels_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+        L.mscnn_deconv_depthwise_fwd_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 10 + [C.c_void_p]
+        L.mscnn_softmax_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.mscnn_roipool_fwd_f32.argtypes = ([C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_float, C.c_float] + [C.c_int] * 2
+                                            + [C.c_void_p])
+        L.mscnn_boxoutput_workspace_bytes.restype = C.c_size_t
+        L.mscnn_boxoutput_workspace_bytes.argtypes = [C.c_void_p]
+        L.mscnn_boxoutput_max_rows.argtypes = [C.c_void_p]
+        L.mscnn_boxoutput_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.mscnn_nms_workspace_bytes.restype = C.c_size_t
+        L.mscnn_nms_workspace_bytes.argtypes = [C.c_int]
+        L.mscnn_nms_greedy_f32.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_void_p]
+        L.mscnn_decodebbox_fwd_f32.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mscnn_detections_workspace_bytes.restype = C.c_size_t
+        L.mscnn_detections_workspace_bytes.argtypes = [C.c_int]
+        L.mscnn_detections_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MscnnError(f"mscnn status {rc}: {lib().mscnn_last_error().decode()}")
+
+
+def _dev(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MscnnError("libmscnn_hip has no CPU path: tensor must live on the GPU")
+    if not t.is_contiguous():
+        raise MscnnError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class ConvPlan:
+    """Owns a mscnn_conv_plan plus its packed weights and stream-K workspace (device memory)."""
+
+    def __init__(self, N, Cin, H, W, Cout, Kh, Kw, pad=(0, 0), stride=(1, 1), group=1, relu=False, device="cuda"):
+        self.desc = ConvDesc(N, Cin, H, W, Cout, Kh, Kw, pad[0], pad[1], stride[0], stride[1], group, int(relu))
+        self._p = C.c_void_p()
+        _check(lib().mscnn_conv2d_plan_create(C.byref(self.desc), C.byref(self._p)))
+        self.device = device
+        self.packed = None
+        self.ws = None
+        self._alloc()
+
+    def _alloc(self):
+        pb = lib().mscnn_conv2d_packed_weight_bytes(self._p)
+        wb = lib().mscnn_conv2d_workspace_bytes(self._p)
+        if pb and (self.packed is None or self.packed.numel() * 4 < pb):
+            self.packed = torch.empty(pb // 4, dtype=torch.float32, device=self.device)
+        if wb and (self.ws is None or self.ws.numel() * 4 < wb):
+            self.ws = torch.empty(wb // 4, dtype=torch.float32, device=self.device)
+
+    @property
+    def kernel(self):
+        return lib().mscnn_conv2d_plan_kernel(self._p).decode()
+
+    @property
+    def flops(self):
+        return lib().mscnn_conv2d_plan_flops(self._p)
+
+    def out_shape(self):
+        d = self.desc
+        return (d.N, d.Cout, (d.H + 2 * d.pad_h - d.Kh) // d.stride_h + 1, (d.W + 2 * d.pad_w - d.Kw) // d.stride_w + 1)
+
+    def set_batch(self, N):
+        _check(lib().mscnn_conv2d_plan_set_batch(self._p, N))
+        self.desc.N = N
+        self._alloc()
+
+    def pack(self, w):
+        self.w = w
+        if self.packed is not None:
+            _check(lib().mscnn_conv2d_pack_weights(self._p, _dev(w), _dev(self.packed), _stream()))
+
+    def forward(self, x, bias=None, out=None):
+        if out is None:
+            out = torch.empty(self.out_shape(), dtype=torch.float32, device=x.device)
+        wsb = self.ws.numel() * 4 if self.ws is not None else 0
+        _check(lib().mscnn_conv2d_fwd_f32(self._p, _dev(x), _dev(self.w), _dev(self.packed), _dev(bias), _dev(out),
+                                          _dev(self.ws), wsb, _stream()))
+        return out
+
+    def __del__(self):
+        try:
+            if self._p:
+                lib().mscnn_conv2d_plan_destroy(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+
+def conv2d(x, w, bias=None, pad=(0, 0), stride=(1, 1), group=1, relu=False):
+    N, Cin, H, W = x.shape
+    Cout, _, Kh, Kw = w.shape
+    plan = ConvPlan(N, Cin, H, W, Cout, Kh, Kw, pad, stride, group, relu, device=x.device)
+    plan.pack(w)
+    y = plan.forward(x, bias)
+    torch.cuda.current_stream().synchronize()   # plan buffers die with the plan
+    return y
+
+
+def relu(x, slope=0.0, inplace=False):
+    y = x if inplace else torch.empty_like(x)
+    _check(lib().mscnn_relu_fwd_f32(_dev(x), _dev(y), x.numel(), slope, _stream()))
+    return y
+
+
+def pool_out_dim(i, k, p, s):
+    return lib().mscnn_pool_out_dim(i, k, p, s)
+
+
+def pool2d(x, kernel=(2, 2), pad=(0, 0), stride=(2, 2), method="MAX"):
+    N, Cc, H, W = x.shape
+    Ho, Wo = pool_out_dim(H, kernel[0], pad[0], stride[0]), pool_out_dim(W, kernel[1], pad[1], stride[1])
+    y = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
+    _check(lib().mscnn_pool2d_fwd_f32(_dev(x), _dev(y), N, Cc, H, W, kernel[0], kernel[1], pad[0], pad[1],
+                                      stride[0], stride[1], 0 if method == "MAX" else 1, _stream()))
+    return y
+
+
+def inner_product(x, w, bias=None, relu=False):
+    M = x.shape[0]
+    K = x.numel() // max(M, 1) if M else w.shape[1]
+    Nn = w.shape[0]
+    y = torch.empty((M, Nn), dtype=torch.float32, device=x.device)
+    _check(lib().mscnn_inner_product_fwd_f32(_dev(x), _dev(w), _dev(bias), _dev(y), M, Nn, K, int(relu), _stream()))
+    return y
+
+
+def concat_channels(xs):
+    N = xs[0].shape[0]
+    inner = xs[0][0, 0].numel()
+    ctot = sum(t.shape[1] for t in xs)
+    y = torch.empty((N, ctot) + tuple(xs[0].shape[2:]), dtype=torch.float32, device=xs[0].device)
+    off = 0
+    for t in xs:
+        _check(lib().mscnn_concat_channels_f32(_dev(t), _dev(y), N, t.shape[1], inner, ctot, off, _stream()))
+        off += t.shape[1]
+    return y
+
+
+def deconv_depthwise(x, w, bias=None, pad=(0, 0), stride=(1, 1)):
+    N, Cc, H, W = x.shape
+    Kh, Kw = w.shape[2], w.shape[3]
+    Ho, Wo = stride[0] * (H - 1) + Kh - 2 * pad[0], stride[1] * (W - 1) + Kw - 2 * pad[1]
+    y = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
+    _check(lib().mscnn_deconv_depthwise_fwd_f32(_dev(x), _dev(w), _dev(bias), _dev(y), N, Cc, H, W, Kh, Kw,
+                                                pad[0], pad[1], stride[0], stride[1], _stream()))
+    return y
+
+
+def softmax(x, axis=1):
+    outer = 1
+    for d in x.shape[:axis]:
+        outer *= d
+    inner = 1
+    for d in x.shape[axis + 1:]:
+        inner *= d
+    y = torch.empty_like(x)
+    _check(lib().mscnn_softmax_fwd_f32(_dev(x), _dev(y), outer, x.shape[axis], inner, _stream()))
+    return y
+
+
+def roipool(feat, rois, pooled_h, pooled_w, spatial_scale, pad_ratio=0.0, out=None, c_total=None, c_offset=0):
+    N, Cc, H, W = feat.shape
+    R = rois.shape[0]
+    c_total = c_total or Cc
+    if out is None:
+        out = torch.empty((R, c_total, pooled_h, pooled_w), dtype=torch.float32, device=feat.device)
+    _check(lib().mscnn_roipool_fwd_f32(_dev(feat), _dev(rois), _dev(out), R, N, Cc, H, W, pooled_h, pooled_w,
+                                       spatial_scale, pad_ratio, c_total, c_offset, _stream()))
+    return out
+
+
+def make_boxoutput_desc(head_shapes, num, channels, field_w, field_h, downsample, fg_thr=-5.0, iou_thr=0.65,
+                        nms_type="IOU", field_whr=2.0, field_xyr=2.0, max_nms_num=2000, max_post_nms_num=0,
+                        min_size=15.0, bbox_mean=None, bbox_std=None):
+    d = BoxOutputDesc()
+    d.num_heads = len(head_shapes); d.num = num; d.channels = channels
+    for j, (h, w) in enumerate(head_shapes):
+        d.head_h[j] = h; d.head_w[j] = w
+        d.field_w[j] = field_w[j]; d.field_h[j] = field_h[j]; d.downsample_rate[j] = downsample[j]
+    d.fg_thr = fg_thr; d.iou_thr = iou_thr; d.nms_mode = NMS_MODES[nms_type]
+    d.field_whr = field_whr; d.field_xyr = field_xyr
+    d.max_nms_num = max_nms_num; d.max_post_nms_num = max_post_nms_num; d.min_size = min_size
+    if bbox_mean is not None and bbox_std is not None and len(bbox_mean) and len(bbox_std):
+        d.do_bbox_norm = 1
+        for k in range(4):
+            d.bbox_mean[k] = bbox_mean[k]; d.bbox_std[k] = bbox_std[k]
+    return d
+
+
+class BoxOutput:
+    """Device-resident BoxOutput layer state: descriptor + workspace + output buffers."""
+
+    def __init__(self, desc, device="cuda"):
+        self.desc = desc
+        wb = lib().mscnn_boxoutput_workspace_bytes(C.byref(desc))
+        if wb == 0:
+            raise MscnnError(lib().mscnn_last_error().decode())
+        self.cap = lib().mscnn_boxoutput_max_rows(C.byref(desc))
+        self.ws = torch.empty(wb, dtype=torch.uint8, device=device)
+        self.rois = torch.empty((self.cap, 5), dtype=torch.float32, device=device)
+        self.props = torch.empty((self.cap, 6), dtype=torch.float32, device=device)
+        self.aids = torch.empty(self.cap, dtype=torch.int32, device=device)
+        self.count = torch.zeros(2, dtype=torch.int32, device=device)
+
+    def forward_async(self, heads):
+        n = self.desc.num_heads
+        ptrs = (C.c_void_p * n)(*[h.data_ptr() for h in heads])
+        for h in heads:
+            _dev(h)
+        _check(lib().mscnn_boxoutput_fwd_f32(C.byref(self.desc), ptrs, _dev(self.rois), _dev(self.props), _dev(self.aids),
+                                             self.cap, _dev(self.count), _dev(self.ws), self.ws.numel(), _stream()))
+
+    def forward(self, heads):
+        self.forward_async(heads)
+        R, nreal = self.count.tolist()      # the one small D2H of the layer (R drives the next Reshape)
+        return self.rois[:R], self.props[:R], self.aids[:R], nreal
+
+
+def nms_greedy(boxes_xywh, thr, mode="IOU"):
+    n = boxes_xywh.shape[0]
+    keep = torch.zeros(max(n, 1), dtype=torch.uint8, device=boxes_xywh.device)
+    wb = lib().mscnn_nms_workspace_bytes(n)
+    ws = torch.empty(wb, dtype=torch.uint8, device=boxes_xywh.device)
+    _check(lib().mscnn_nms_greedy_f32(_dev(boxes_xywh), n, thr, NMS_MODES[mode], _dev(keep), _dev(ws), wb, _stream()))
+    return keep[:n].bool()
+
+
+def decode_bbox(bbox, prior, mean=(0, 0, 0, 0), std=(1, 1, 1, 1)):
+    R = bbox.shape[0]
+    out = torch.empty((R, 5), dtype=torch.float32, device=bbox.device)
+    m = (C.c_float * 4)(*mean); s = (C.c_float * 4)(*std)
+    _check(lib().mscnn_decodebbox_fwd_f32(_dev(bbox), _dev(prior), _dev(out), R, bbox.shape[1], m, s, _stream()))
+    return out
+
+
+def detections(bbox_pred, cls_pred, props, cls_id, bbox_mean=(0, 0, 0, 0), bbox_std=(0.1, 0.1, 0.2, 0.2),
+               proposal_thr=-10.0, ratios=(1.0, 1.0), org_hw=(375, 1242), nms_overlap=0.5):
+    R = props.shape[0]
+    d = DetectionsDesc()
+    d.ncls = cls_pred.shape[1]; d.cls_id = cls_id
+    for k in range(4):
+        d.bbox_mean[k] = bbox_mean[k]; d.bbox_std[k] = bbox_std[k]
+    d.proposal_thr = proposal_thr
+    d.ratio_h, d.ratio_w = ratios
+    d.org_h, d.org_w = org_hw
+    d.nms_overlap = nms_overlap
+    dev = props.device
+    dets = torch.zeros((max(R, 1), 5), dtype=torch.float64, device=dev)
+    ids = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    wb = lib().mscnn_detections_workspace_bytes(R)
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    _check(lib().mscnn_detections_fwd(C.byref(d), _dev(bbox_pred), _dev(cls_pred), _dev(props), R, _dev(dets), _dev(ids),
+                                      _dev(count), _dev(ws), wb, _stream()))
+    D = int(count.item())
+    return dets[:D], ids[:D]

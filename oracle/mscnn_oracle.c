@@ -383,15 +383,17 @@ static int cmp_score_idx_desc(const void* a, const void* b) {
  * rois_out: capacity cap rows x 5, props_out: cap rows x 6 (may be NULL).
  * cand_idx_out (optional, cap ints): for every emitted row, the candidate insertion
  *   index (per image) of the kept box -- the "NMS index selection" the parity bar
- *   compares bit-exactly.
+ *   compares bit-exactly.  anchor_id_out (optional): the same selection expressed as the
+ *   global anchor id (sum of h*w of the preceding heads + id), which is what the device
+ *   path reports (bookkeeping added by this restatement; it does not alter any result).
  * Returns R (number of rows incl. the dummy row when nothing survives) or <0.
  * *num_real receives the number of real boxes (0 when the dummy row was emitted).
  */
 ORC_API int orc_boxoutput(const float* const* heads, const int* hs, const int* ws, int nheads,
                           int num, int channels, const float* field_w, const float* field_h,
                           const float* downsample, const orc_boxoutput_params* p,
-                          float* rois_out, float* props_out, int* cand_idx_out, int cap,
-                          int* num_real) {
+                          float* rois_out, float* props_out, int* cand_idx_out, int* anchor_id_out,
+                          int cap, int* num_real) {
   const int cls_num = channels - 4;
   const float field_whr = p->field_whr, field_xyr = p->field_xyr;
   const float min_whr = logf(1.f / field_whr), max_whr = logf(field_whr);
@@ -403,10 +405,12 @@ ORC_API int orc_boxoutput(const float* const* heads, const int* hs, const int* w
   score_idx* si = (score_idx*)malloc(sizeof(score_idx) * (size_t)ncand_max);
   float* sorted = (float*)malloc(sizeof(float) * 4 * (size_t)ncand_max);
   unsigned char* keep = (unsigned char*)malloc((size_t)ncand_max);
-  if (!boxes || !si || !sorted || !keep) return -2;
+  int* cand_aid = (int*)malloc(sizeof(int) * (size_t)ncand_max);
+  if (!boxes || !si || !sorted || !keep || !cand_aid) return -2;
 
   for (int i = 0; i < num; ++i) {
     int bb_count = 0;
+    int head_off = 0;
     for (int j = 0; j < nheads; ++j) {
       const float* bottom_data = heads[j];
       const int width = ws[j], height = hs[j];
@@ -441,10 +445,12 @@ ORC_API int orc_boxoutput(const float* const* heads, const int* hs, const int* w
             float* bb = boxes + 6 * (size_t)bb_count;
             bb[0] = (float)i; bb[1] = bbx; bb[2] = bby; bb[3] = bbw; bb[4] = bbh; bb[5] = fg_score;
             si[bb_count].score = fg_score; si[bb_count].idx = bb_count;
+            cand_aid[bb_count] = head_off + id;
             ++bb_count;
           }
         }
       }
+      head_off += spatial_dim;
     }
     if (bb_count <= 0) continue;
     qsort(si, (size_t)bb_count, sizeof(score_idx), cmp_score_idx_desc);
@@ -456,7 +462,7 @@ ORC_API int orc_boxoutput(const float* const* heads, const int* hs, const int* w
     for (int k = 0; k < n; ++k) {
       if (!keep[k]) continue;
       if (p->max_post_nms_num > 0 && emitted >= p->max_post_nms_num) break;
-      if (total >= cap) { free(boxes); free(si); free(sorted); free(keep); return -3; }
+      if (total >= cap) { free(boxes); free(si); free(sorted); free(keep); free(cand_aid); return -3; }
       const float* bb = boxes + 6 * (size_t)si[k].idx;
       float* r = rois_out + 5 * (size_t)total;
       r[0] = bb[0]; r[1] = bb[1]; r[2] = bb[2]; r[3] = bb[1] + bb[3]; r[4] = bb[2] + bb[4];
@@ -465,16 +471,18 @@ ORC_API int orc_boxoutput(const float* const* heads, const int* hs, const int* w
         q[0] = bb[0]; q[1] = bb[1]; q[2] = bb[2]; q[3] = bb[1] + bb[3]; q[4] = bb[2] + bb[4]; q[5] = bb[5];
       }
       if (cand_idx_out) cand_idx_out[total] = si[k].idx;
+      if (anchor_id_out) anchor_id_out[total] = cand_aid[si[k].idx];
       ++total; ++emitted;
     }
   }
-  free(boxes); free(si); free(sorted); free(keep);
+  free(boxes); free(si); free(sorted); free(keep); free(cand_aid);
   if (num_real) *num_real = total;
   if (total <= 0) {               /* special case, :195-199, :214-218 */
     if (cap < 1) return -3;
     rois_out[0] = 0; rois_out[1] = 1; rois_out[2] = 1; rois_out[3] = 10; rois_out[4] = 10;
     if (props_out) for (int k = 0; k < 6; ++k) props_out[k] = 0.f;
     if (cand_idx_out) cand_idx_out[0] = -1;
+    if (anchor_id_out) anchor_id_out[0] = -1;
     return 1;
   }
   return total;

@@ -156,7 +156,7 @@ def nms_greedy(boxes_xywh, thr, mode="IOU"):
 
 def boxoutput(heads, field_w, field_h, downsample, fg_thr=-5.0, iou_thr=0.65, nms_type="IOU",
               field_whr=2.0, field_xyr=2.0, max_nms_num=2000, max_post_nms_num=0, min_size=15.0,
-              bbox_mean=None, bbox_std=None):
+              bbox_mean=None, bbox_std=None, with_anchor_ids=False):
     """heads: list of (num, cls+4, h, w) arrays. Returns (rois[R,5], props[R,6], cand_idx[R], num_real)."""
     hs = [np.ascontiguousarray(h, np.float32) for h in heads]
     n = len(hs)
@@ -173,11 +173,13 @@ def boxoutput(heads, field_w, field_h, downsample, fg_thr=-5.0, iou_thr=0.65, nm
     if max_nms_num > 0:
         cap = max(1, min(cap, max_nms_num * num))
     rois = np.zeros((cap, 5), np.float32); props = np.zeros((cap, 6), np.float32)
-    cidx = np.zeros(cap, np.int32); nreal = C.c_int(0)
+    cidx = np.zeros(cap, np.int32); aids = np.zeros(cap, np.int32); nreal = C.c_int(0)
     R = lib().orc_boxoutput(ptrs, hh, ww, n, num, channels, fw, fh, ds, C.byref(p),
                             rois.ctypes.data_as(f32p), props.ctypes.data_as(f32p),
-                            cidx.ctypes.data_as(i32p), cap, C.byref(nreal))
+                            cidx.ctypes.data_as(i32p), aids.ctypes.data_as(i32p), cap, C.byref(nreal))
     assert R >= 1, R
+    if with_anchor_ids:
+        return rois[:R].copy(), props[:R].copy(), cidx[:R].copy(), nreal.value, aids[:R].copy()
     return rois[:R].copy(), props[:R].copy(), cidx[:R].copy(), nreal.value
 
 

@@ -1,0 +1,305 @@
+"""Parity of every HIP op (through the C ABI of libmscnn_hip.so) against the CPU oracle on the same
+seeded inputs.  Bars (north_star): bit-exact for index/selection and compare/select work (pool, ROI pool,
+NMS keep sets, BoxOutput selection); fp32 values within 1e-4 relative (|a-b| <= 1e-4 * max(1,|b|))."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a MI355X: torch.cuda.is_available() is False")
+    from mscnn_amd import hipapi
+    hipapi.lib()          # raises if libmscnn_hip.so is missing: no silent fallback
+    return hipapi
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(a, b, tol=1e-4):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert err.max() <= tol, f"max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+# ------------------------------------------------------------------ elementwise / pooling
+def test_relu(hip, orc):
+    rng = np.random.default_rng(1)
+    for n in (1, 7, 1024, 4099):
+        x = rng.standard_normal(n).astype(np.float32)
+        assert np.array_equal(hip.relu(dev(x)).cpu().numpy(), orc.relu(x))
+    x = rng.standard_normal(64).astype(np.float32)
+    close(hip.relu(dev(x), 0.1).cpu().numpy(), orc.relu(x, 0.1), 1e-6)
+    t = dev(x)
+    hip.relu(t, inplace=True)
+    assert np.array_equal(t.cpu().numpy(), orc.relu(x))
+
+
+@pytest.mark.parametrize("shape,k,p,s,m", [
+    ((1, 64, 32, 48), (2, 2), (0, 0), (2, 2), "MAX"),     # fast path
+    ((2, 3, 9, 15), (2, 2), (0, 0), (2, 2), "MAX"),       # ceil-mode edges (caltech pool6)
+    ((1, 2, 3, 5), (2, 2), (0, 0), (1, 1), "MAX"),
+    ((1, 1, 3, 3), (3, 3), (2, 2), (2, 2), "MAX"),        # test_pooling_layer.cpp:478-522
+    ((1, 4, 8, 8), (2, 2), (0, 0), (1, 1), "AVE"),        # widerface 2x2 s1 AVE after ROIAlign
+    ((1, 2, 7, 7), (3, 3), (1, 1), (2, 2), "AVE"),
+])
+def test_pool(hip, orc, shape, k, p, s, m):
+    x = np.random.default_rng(2).standard_normal(shape).astype(np.float32)
+    y = hip.pool2d(dev(x), k, p, s, m).cpu().numpy()
+    ref = orc.pool2d(x, k, p, s, m)
+    if m == "MAX":
+        assert np.array_equal(y, ref)
+    else:
+        close(y, ref, 1e-6)
+
+
+def test_pool_kat_on_device(hip):
+    plane = np.array([[1, 2, 5, 2, 3], [9, 4, 1, 4, 8], [1, 2, 5, 2, 3]], np.float32)
+    y = hip.pool2d(dev(np.tile(plane, (2, 2, 1, 1))), (2, 2), (0, 0), (1, 1)).cpu().numpy()
+    assert np.array_equal(y[1, 1], np.array([[9, 5, 5, 8], [9, 5, 5, 8]], np.float32))
+
+
+def test_concat_softmax_deconv(hip, orc):
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((5, 3, 7, 7)).astype(np.float32); b = rng.standard_normal((5, 4, 7, 7)).astype(np.float32)
+    assert np.array_equal(hip.concat_channels([dev(a), dev(b)]).cpu().numpy(), orc.concat_channels([a, b]))
+    x = rng.standard_normal((6, 5)).astype(np.float32)
+    close(hip.softmax(dev(x)).cpu().numpy(), orc.softmax(x), 1e-6)
+    x = rng.standard_normal((1, 8, 9, 11)).astype(np.float32)
+    w = orc.bilinear_filler((8, 1, 4, 4))
+    close(hip.deconv_depthwise(dev(x), dev(w), None, (1, 1), (2, 2)).cpu().numpy(),
+          orc.deconv2d(x, w, None, (1, 1), (2, 2), group=8), 1e-6)
+
+
+# ------------------------------------------------------------------ convolution
+CONV_CASES = [
+    # (N, Cin, H, W, Cout, k, pad, stride, group)          kernel family expected
+    (1, 3, 20, 33, 16, (3, 3), (1, 1), (1, 1), 1),          # conv1_1-like -> direct
+    (2, 6, 9, 7, 4, (3, 3), (0, 0), (2, 2), 2),             # stride/group -> direct
+    (1, 8, 16, 32, 128, (3, 3), (1, 1), (1, 1), 1),         # igemm 128x128, exact tiles
+    (1, 16, 13, 37, 64, (3, 3), (1, 1), (1, 1), 1),         # ragged H/W, Cout 64
+    (1, 24, 36, 120, 256, (3, 3), (1, 1), (1, 1), 1),       # conv5-shaped plane, 2 M tiles, stream-K splits
+    (2, 8, 10, 20, 130, (3, 3), (1, 1), (1, 1), 1),         # batch 2, Cout not a multiple of 32
+    (1, 32, 18, 60, 9, (5, 5), (2, 2), (1, 1), 1),          # proposal head 5x5
+    (1, 16, 9, 30, 9, (7, 7), (3, 3), (1, 1), 1),           # proposal head 7x7
+    (1, 16, 12, 20, 7, (3, 5), (1, 2), (1, 1), 1),          # ped/cyc head 3x5
+    (1, 8, 12, 20, 7, (5, 7), (2, 3), (1, 1), 1),           # ped/cyc head 5x7
+    (3, 16, 7, 7, 64, (3, 3), (0, 0), (1, 1), 1),           # roi_c1-shaped: R x (C,7,7) no pad -> 5x5
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv(hip, orc, case, relu):
+    N, Cin, H, W, Cout, k, pad, stride, group = case
+    rng = np.random.default_rng(1701)
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin // group, *k)) * np.sqrt(2.0 / (Cin // group * k[0] * k[1]))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    y = hip.conv2d(dev(x), dev(w), dev(b), pad, stride, group, relu).cpu().numpy()
+    ref = orc.conv2d(x, w, b, pad, stride, group)
+    if relu:
+        ref = orc.relu(ref)
+    close(y, ref)
+
+
+def test_conv_no_bias_and_kernel_selection(hip, orc):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 8, 8, 16)).astype(np.float32)
+    w = rng.standard_normal((32, 8, 3, 3)).astype(np.float32) * 0.1
+    plan = hip.ConvPlan(1, 8, 8, 16, 32, 3, 3, (1, 1))
+    assert plan.kernel.startswith("igemm_")
+    plan.pack(dev(w))
+    close(plan.forward(dev(x)).cpu().numpy(), orc.conv2d(x, w, None, (1, 1)))
+    assert hip.ConvPlan(1, 3, 8, 16, 32, 3, 3, (1, 1)).kernel == "direct_f32"
+    assert plan.flops == 2.0 * 32 * 8 * 16 * 8 * 9
+
+
+def test_conv_identity_asymmetric(hip):
+    # transpose-detecting check: delta weights must reproduce a shifted copy of the (asymmetric) input
+    Cin = Cout = 32
+    x = np.arange(Cin * 8 * 16, dtype=np.float32).reshape(1, Cin, 8, 16) / 100.0
+    w = np.zeros((Cout, Cin, 3, 3), np.float32)
+    for c in range(Cout):
+        w[c, (c + 1) % Cin, 0, 2] = 1.0          # y[c][h][w] = x[c+1][h-1][w+1]
+    y = hip.conv2d(dev(x), dev(w), None, (1, 1)).cpu().numpy()
+    exp = np.zeros_like(y)
+    xs = np.roll(x, -1, axis=1)
+    exp[0, :, 1:, :-1] = xs[0, :, :-1, 1:]
+    assert np.array_equal(y, exp)
+
+
+# ------------------------------------------------------------------ inner product
+@pytest.mark.parametrize("M,N,K", [(1, 5, 64), (7, 20, 4096), (3, 128, 256), (130, 192, 1000), (257, 4096, 800), (1, 4096, 12800)])
+def test_inner_product(hip, orc, M, N, K):
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    close(hip.inner_product(dev(x), dev(w), dev(b)).cpu().numpy(), orc.inner_product(x, w, b))
+    close(hip.inner_product(dev(x), dev(w), None, relu=True).cpu().numpy(), orc.relu(orc.inner_product(x, w, None)))
+
+
+# ------------------------------------------------------------------ ROI pooling (bit-exact)
+def _random_rois(rng, R, img_h, img_w, batch=1):
+    x1 = rng.uniform(-40, img_w, R); y1 = rng.uniform(-40, img_h, R)
+    w = rng.uniform(1, 500, R); h = rng.uniform(1, 400, R)
+    return np.stack([rng.integers(0, batch, R), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("ph,pw,scale,pad", [(7, 7, 0.125, 0.0), (7, 7, 0.125, 0.25), (7, 5, 0.25, 0.25), (8, 4, 0.125, 0.0)])
+def test_roipool_bitexact(hip, orc, ph, pw, scale, pad):
+    rng = np.random.default_rng(7)
+    feat = rng.standard_normal((2, 24, 36, 120)).astype(np.float32)
+    rois = _random_rois(rng, 97, 36 / scale, 120 / scale, batch=2)
+    rois[0] = [0, -500, -500, -300, -300]                      # fully outside -> zeros
+    rois[1] = [1, 0, 0, 120 / scale - 1, 36 / scale - 1]       # whole map
+    rois[2] = [0, 20, 20, 20, 20]                              # half-away-from-zero rounding case
+    y = hip.roipool(dev(feat), dev(rois), ph, pw, scale, pad).cpu().numpy()
+    assert np.array_equal(y, orc.roipool(feat, rois, ph, pw, scale, pad))
+
+
+def test_roipool_concat_window(hip, orc):
+    rng = np.random.default_rng(8)
+    feat = rng.standard_normal((1, 16, 18, 60)).astype(np.float32)
+    rois = _random_rois(rng, 10, 144, 480)
+    out = torch.zeros((10, 32, 7, 7), dtype=torch.float32, device="cuda")
+    hip.roipool(dev(feat), dev(rois), 7, 7, 0.125, 0.0, out=out, c_total=32, c_offset=0)
+    hip.roipool(dev(feat), dev(rois), 7, 7, 0.125, 0.25, out=out, c_total=32, c_offset=16)
+    ref = orc.concat_channels([orc.roipool(feat, rois, 7, 7, 0.125, 0.0), orc.roipool(feat, rois, 7, 7, 0.125, 0.25)])
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------ NMS / BoxOutput (index-exact)
+def _clustered_boxes(rng, n):
+    centers = rng.uniform(0, 1500, (max(1, n // 12), 2))
+    c = centers[rng.integers(0, len(centers), n)] + rng.normal(0, 12, (n, 2))
+    wh = rng.uniform(20, 200, (n, 2))
+    return np.concatenate([c, wh], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 500, 2000, 3000])
+@pytest.mark.parametrize("mode", ["IOU", "IOMU", "IOFU"])
+def test_nms_keep_set_bitexact(hip, orc, n, mode):
+    boxes = _clustered_boxes(np.random.default_rng(n), n)
+    boxes[0, 2] = 0.0 if n > 3 else boxes[0, 2]               # degenerate box: IoU 0 with everything
+    k = hip.nms_greedy(dev(boxes), 0.65, mode).cpu().numpy()
+    assert np.array_equal(k, orc.nms_greedy(boxes, 0.65, mode))
+
+
+def test_nms_threshold_strict_on_device(hip):
+    boxes = np.array([[0, 0, 10, 10], [0, 0, 10, 5], [100, 100, 5, 5]], np.float32)
+    assert hip.nms_greedy(dev(boxes), 0.5).cpu().tolist() == [True, True, True]
+    assert hip.nms_greedy(dev(boxes), 0.4999).cpu().tolist() == [True, False, True]
+
+
+KITTI_HEADS = dict(shapes=[(18, 60), (18, 60), (9, 30), (9, 30), (5, 15), (5, 15), (3, 8)],
+                   field=[60, 84, 120, 168, 240, 336, 480], ds=[8, 8, 16, 16, 32, 32, 64])
+
+
+def _heads(rng, shapes, num=1, cls=5, bg_bias=0.0, sigma=2.0):
+    out = []
+    for (h, w) in shapes:
+        t = rng.standard_normal((num, cls + 4, h, w)).astype(np.float32)
+        t[:, :cls] *= sigma
+        t[:, 0] += bg_bias
+        t[:, cls:] *= 0.5
+        out.append(t)
+    return out
+
+
+@pytest.mark.parametrize("regime,bg_bias,max_nms", [("dense", -8.0, 2000), ("sparse", 6.0, 2000), ("trunc", -8.0, 300),
+                                                    ("empty", 60.0, 2000)])
+def test_boxoutput_selection_bitexact(hip, orc, regime, bg_bias, max_nms):
+    rng = np.random.default_rng(1701)
+    heads = _heads(rng, KITTI_HEADS["shapes"], bg_bias=bg_bias)
+    kw = dict(fg_thr=-5.0, iou_thr=0.65, max_nms_num=max_nms, min_size=15.0)
+    rois_r, props_r, cidx, nreal_r, aids_r = orc.boxoutput(heads, KITTI_HEADS["field"], KITTI_HEADS["field"], KITTI_HEADS["ds"],
+                                                          with_anchor_ids=True, **kw)
+    d = hip.make_boxoutput_desc(KITTI_HEADS["shapes"], 1, 9, KITTI_HEADS["field"], KITTI_HEADS["field"], KITTI_HEADS["ds"], **kw)
+    layer = hip.BoxOutput(d)
+    rois, props, aids, nreal = layer.forward([dev(h) for h in heads])
+    assert nreal == nreal_r and rois.shape[0] == rois_r.shape[0]
+    assert np.array_equal(aids.cpu().numpy(), aids_r)                       # NMS index selection: bit-exact
+    close(rois.cpu().numpy(), rois_r)
+    close(props.cpu().numpy(), props_r)
+    if regime != "empty":
+        # the libm-expf restatement on the device makes the boxes themselves bit-identical too
+        assert np.array_equal(rois.cpu().numpy(), rois_r)
+        assert np.array_equal(props.cpu().numpy(), props_r)
+    else:
+        assert rois.cpu().tolist() == [[0, 1, 1, 10, 10]] and aids.cpu().tolist() == [-1]
+
+
+def test_boxoutput_batch2_bboxnorm_ties(hip, orc):
+    rng = np.random.default_rng(11)
+    shapes = [(12, 20), (6, 10)]
+    heads = _heads(rng, shapes, num=2, cls=3, bg_bias=-4.0)
+    heads[0][1] = heads[0][0]                                   # image 1 == image 0 on head 0
+    heads[0][:, 1:3, 4:8, :] = 1.5                              # plateaus of exactly equal scores (tie-break by index)
+    kw = dict(fg_thr=-7.0, iou_thr=0.65, max_nms_num=100, min_size=5.0, bbox_mean=[0, 0, 0, 0], bbox_std=[0.1, 0.1, 0.2, 0.2])
+    ref = orc.boxoutput(heads, [40, 80], [56, 112], [8, 16], with_anchor_ids=True, **kw)
+    d = hip.make_boxoutput_desc(shapes, 2, 7, [40, 80], [56, 112], [8, 16], **kw)
+    rois, props, aids, nreal = hip.BoxOutput(d).forward([dev(h) for h in heads])
+    assert nreal == ref[3]
+    assert np.array_equal(aids.cpu().numpy(), ref[4])
+    assert np.array_equal(rois.cpu().numpy(), ref[0])
+    assert set(rois[:, 0].cpu().tolist()) == {0.0, 1.0}
+
+
+def test_boxoutput_full_size_properties(hip):
+    """BASELINE config-2 size (45,630 anchors, dense): size-independent properties instead of the oracle."""
+    shapes = [(72, 240), (72, 240), (36, 120), (36, 120), (18, 60), (18, 60), (9, 30)]
+    rng = np.random.default_rng(3)
+    heads = [dev(h) for h in _heads(rng, shapes, bg_bias=-8.0)]
+    d = hip.make_boxoutput_desc(shapes, 1, 9, KITTI_HEADS["field"], KITTI_HEADS["field"], KITTI_HEADS["ds"])
+    rois, props, aids, nreal = hip.BoxOutput(d).forward(heads)
+    R = rois.shape[0]
+    assert 1 <= R <= 2000 and nreal == R
+    s = props[:, 5].cpu().numpy()
+    assert np.all(np.diff(s) <= 0)                                              # score order
+    r = rois.cpu().numpy()
+    assert np.all(r[:, 1] >= 0) and np.all(r[:, 2] >= 0) and np.all(r[:, 3] <= 1920) and np.all(r[:, 4] <= 576)
+    assert np.all(r[:, 3] - r[:, 1] >= 15 - 1e-3) and np.all(r[:, 4] - r[:, 2] >= 15 - 1e-3)
+    xywh = torch.stack([rois[:, 1], rois[:, 2], rois[:, 3] - rois[:, 1], rois[:, 4] - rois[:, 2]], 1).contiguous()
+    assert bool(hip.nms_greedy(xywh, 0.6501).all())                              # idempotence: nothing left to suppress
+    assert len(set(aids.cpu().tolist())) == R
+
+
+# ------------------------------------------------------------------ DecodeBBox / final detections
+def test_decode_bbox(hip, orc):
+    rng = np.random.default_rng(12)
+    prior = _random_rois(rng, 200, 576, 1920)
+    bbox = rng.standard_normal((200, 8)).astype(np.float32)
+    out = hip.decode_bbox(dev(bbox), dev(prior), (0, 0, 0, 0), (0.1, 0.1, 0.2, 0.2)).cpu().numpy()
+    assert np.array_equal(out, orc.decode_bbox(bbox, prior, (0, 0, 0, 0), (0.1, 0.1, 0.2, 0.2)))
+
+
+@pytest.mark.parametrize("R", [1, 37, 1000, 2000])
+def test_detections_stage(hip, orc, R):
+    rng = np.random.default_rng(R)
+    b = _clustered_boxes(rng, R)
+    props = np.concatenate([np.zeros((R, 1), np.float32), b[:, :2], b[:, :2] + b[:, 2:], rng.normal(0, 4, (R, 1)).astype(np.float32)], 1)
+    props[::17, 5] = -11.0                                        # below proposal_thr
+    props[5::29, 3] = props[5::29, 1]                             # zero width
+    bbox_pred = rng.standard_normal((R, 20)).astype(np.float32)
+    cls_pred = (rng.standard_normal((R, 5)) * 2).astype(np.float32)
+    cls_pred[3::7] = cls_pred[2::7][: len(cls_pred[3::7])]        # exact prob ties -> stable order
+    kw = dict(cls_id=2, ratios=(576 / 375, 1920 / 1242), org_hw=(375, 1242))
+    dets, ids = hip.detections(dev(bbox_pred), dev(cls_pred), dev(props), **kw)
+    dref, iref = orc.detections(bbox_pred, cls_pred, props, **kw)
+    assert np.array_equal(ids.cpu().numpy(), iref)               # selection + order: exact
+    close(dets.cpu().numpy(), dref)
+
+
+# ------------------------------------------------------------------ loud failure without a GPU tensor
+def test_no_cpu_fallback(hip):
+    with pytest.raises(hip.MscnnError):
+        hip.relu(torch.zeros(4))
