@@ -25,6 +25,8 @@ def dev(a):
 def close(a, b, tol=1e-4):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return
     err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
     assert err.max() <= tol, f"max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
 
