@@ -1,0 +1,99 @@
+/*
+ * mscnn_net.h -- C ABI of libmscnn_caffe.so: the Caffe-compatible host runtime (caffe::Net<float> and the
+ * caffe::Layer<float> subclasses in mscnn_amd/host) for foreign-language callers.  This is what a MATLAB MEX /
+ * Python wrapper binds instead of the reference's matcaffe (matlab/+caffe/private/caffe_.cpp:253 get_net,
+ * :300-306 net_forward, :57-107 blob get/set) or pycaffe (python/caffe/_caffe.cpp).
+ * C++ callers use the caffe:: classes directly (mscnn_amd/host/include/caffe/caffe.hpp).
+ *
+ * All functions return 0 on success; on failure the text is available from mscnn_net_last_error().
+ * A net and everything it owns lives on ONE device and must be used from ONE host thread (the reference's
+ * Caffe singleton is thread-local, src/caffe/common.cpp:12-20).
+ */
+#ifndef MSCNN_NET_H_
+#define MSCNN_NET_H_
+
+#include <stddef.h>
+
+#if defined(__GNUC__)
+#define MSCNN_NET_API __attribute__((visibility("default")))
+#else
+#define MSCNN_NET_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mscnn_net mscnn_net;
+
+MSCNN_NET_API const char* mscnn_net_last_error(void);
+
+/* caffe.Net(prototxt, 'test') -- Net::Net(file, TEST), src/caffe/net.cpp:31-46.  device: HIP device ordinal;
+ * device < 0 builds the graph without touching a device (shape / naming inspection only; forward then fails). */
+MSCNN_NET_API int mscnn_net_create_from_file(const char* prototxt_path, int device, mscnn_net** out);
+MSCNN_NET_API int mscnn_net_create_from_string(const char* prototxt_text, int device, mscnn_net** out);
+MSCNN_NET_API void mscnn_net_destroy(mscnn_net* net);
+/* net.copy_from(caffemodel) -- Net::CopyTrainedLayersFrom, net.cpp:750-803 (binary NetParameter). */
+MSCNN_NET_API int mscnn_net_load_caffemodel(mscnn_net* net, const char* path);
+/* HIP stream (hipStream_t as void*) for every subsequent call on this thread; NULL = default stream. */
+MSCNN_NET_API int mscnn_net_set_stream(void* stream);
+
+/* graph introspection (Net::layer_names / blob_names / layers()[i]->blobs()) */
+MSCNN_NET_API int mscnn_net_num_layers(const mscnn_net* net);
+MSCNN_NET_API const char* mscnn_net_layer_name(const mscnn_net* net, int layer);
+MSCNN_NET_API const char* mscnn_net_layer_type(const mscnn_net* net, int layer);
+MSCNN_NET_API int mscnn_net_layer_index(const mscnn_net* net, const char* name);           /* -1 if absent */
+MSCNN_NET_API int mscnn_net_layer_num_bottoms(const mscnn_net* net, int layer);
+MSCNN_NET_API int mscnn_net_layer_num_tops(const mscnn_net* net, int layer);
+MSCNN_NET_API const char* mscnn_net_layer_bottom(const mscnn_net* net, int layer, int i);  /* blob name */
+MSCNN_NET_API const char* mscnn_net_layer_top(const mscnn_net* net, int layer, int i);
+MSCNN_NET_API int mscnn_net_layer_num_params(const mscnn_net* net, int layer);
+MSCNN_NET_API int mscnn_net_layer_param_shape(const mscnn_net* net, int layer, int param, int* dims8, int* ndim);
+MSCNN_NET_API int mscnn_net_layer_fused_away(const mscnn_net* net, int layer);              /* 1: ReLU folded into its producer */
+MSCNN_NET_API const char* mscnn_net_layer_kernel(const mscnn_net* net, int layer);          /* conv kernel family, "" otherwise */
+MSCNN_NET_API double mscnn_net_layer_flops(const mscnn_net* net, int layer);                /* of the last forward */
+MSCNN_NET_API int mscnn_net_num_blobs(const mscnn_net* net);
+MSCNN_NET_API const char* mscnn_net_blob_name(const mscnn_net* net, int blob);
+MSCNN_NET_API int mscnn_net_blob_shape(const mscnn_net* net, const char* name, int* dims8, int* ndim);
+MSCNN_NET_API int mscnn_net_num_inputs(const mscnn_net* net);
+MSCNN_NET_API int mscnn_net_num_outputs(const mscnn_net* net);
+MSCNN_NET_API const char* mscnn_net_output_name(const mscnn_net* net, int i);               /* alphabetical, net.cpp:267-274 */
+
+/* weights: layer->blobs()[param]  (host fp32, Caffe layout).  The setter marks the layer's packed copy stale. */
+MSCNN_NET_API int mscnn_net_set_param(mscnn_net* net, int layer, int param, const float* host, size_t count);
+MSCNN_NET_API int mscnn_net_get_param(mscnn_net* net, int layer, int param, float* host, size_t count);
+
+/* blob.set_data / get_data.  *_device copy device->device on the net's stream (no PCIe). */
+MSCNN_NET_API int mscnn_net_set_blob(mscnn_net* net, const char* name, const float* host, size_t count);
+MSCNN_NET_API int mscnn_net_set_blob_device(mscnn_net* net, const char* name, const float* dev, size_t count);
+MSCNN_NET_API int mscnn_net_get_blob(mscnn_net* net, const char* name, float* host, size_t capacity, size_t* count);
+MSCNN_NET_API const float* mscnn_net_blob_device_ptr(mscnn_net* net, const char* name);
+
+/* net.forward_prefilled(): Net::ForwardFromTo(0, L-1), net.cpp:544-575.  from/to: layer range, (0, -1) = all. */
+MSCNN_NET_API int mscnn_net_forward(mscnn_net* net);
+MSCNN_NET_API int mscnn_net_forward_from_to(mscnn_net* net, int from, int to);
+MSCNN_NET_API int mscnn_net_reshape(mscnn_net* net);
+/* `caffe time`-style per-layer HIP-event timing (tools/caffe.cpp:380-400); serialises the layers. */
+MSCNN_NET_API int mscnn_net_set_layer_timing(mscnn_net* net, int on);
+MSCNN_NET_API float mscnn_net_layer_ms(const mscnn_net* net, int layer);
+
+/*
+ * Final detection stage on the net's own output blobs (bbox_pred, cls_pred, proposals_score), on the device:
+ * the MATLAB post-processing of run_mscnn_detection.m:75-120 + bbNms.m:112-126.  Only the detections
+ * (dets_host[cap][5] doubles [x y w h prob], ids_host[cap] ROI row per detection) cross PCIe.
+ */
+typedef struct {
+  int cls_id;                       /* 1-based class column (car = 2 for the KITTI car nets) */
+  float bbox_mean[4], bbox_std[4];  /* [0 0 0 0], [.1 .1 .2 .2] in the scripts */
+  float proposal_thr;               /* -10 */
+  double ratio_h, ratio_w;          /* net input size / original image size */
+  double org_h, org_w;              /* original image size (clip bounds) */
+  double nms_overlap;               /* 0.5 */
+} mscnn_detect_params;
+MSCNN_NET_API int mscnn_net_detect(mscnn_net* net, const mscnn_detect_params* p, double* dets_host, int* ids_host,
+                                   int cap, int* num_dets, int* num_rois);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

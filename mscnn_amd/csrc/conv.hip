@@ -327,8 +327,8 @@ const KernelEntry kTable[] = {
     // proposal heads (Cout = 4 + classes <= 32): kitti_car 5x5 / 7x7, ped-cyc + caltech 3x5 / 5x7
     ENTRY(32, 128, 1, 4, 5, 5, 8, 16),
     ENTRY(32, 128, 1, 4, 7, 7, 8, 16),
-    ENTRY(32, 128, 1, 4, 3, 5, 8, 16),
-    ENTRY(32, 128, 1, 4, 5, 7, 8, 16),
+    ENTRY(32, 128, 1, 4, 5, 3, 8, 16),   // "3x5" heads are kernel_w 3 x kernel_h 5
+    ENTRY(32, 128, 1, 4, 7, 5, 8, 16),   // "5x7": kernel_w 5 x kernel_h 7
 };
 constexpr int kTableN = sizeof(kTable) / sizeof(kTable[0]);
 

@@ -1,0 +1,261 @@
+// Layer classes of the MS-CNN deploy nets, same class names / prototxt type strings as the reference
+// (include/caffe/layers/*.hpp).  Every Forward_gpu is a call into the C ABI of libmscnn_hip.so
+// (include/mscnn_hip.h); there is no Forward_cpu implementation.
+#ifndef MSCNN_CAFFE_LAYERS_HPP_
+#define MSCNN_CAFFE_LAYERS_HPP_
+
+#include <string>
+#include <vector>
+
+#include "caffe/blob.hpp"
+#include "caffe/layer.hpp"
+
+struct mscnn_conv_plan;
+
+namespace caffe {
+
+// Device scratch owned by a layer (hipMalloc/hipFree), grown on demand.
+class DeviceBuffer {
+ public:
+  DeviceBuffer() : ptr_(nullptr), bytes_(0) {}
+  ~DeviceBuffer();
+  void* Reserve(size_t bytes);
+  void* get() const { return ptr_; }
+  size_t bytes() const { return bytes_; }
+ private:
+  void* ptr_;
+  size_t bytes_;
+  DISABLE_COPY_AND_ASSIGN(DeviceBuffer);
+};
+
+// include/caffe/layers/input_layer.hpp
+template <typename Dtype>
+class InputLayer : public Layer<Dtype> {
+ public:
+  explicit InputLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {}
+  virtual inline const char* type() const { return "Input"; }
+  virtual inline int ExactNumBottomBlobs() const { return 0; }
+  virtual inline int MinTopBlobs() const { return 1; }
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {}
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {}
+};
+
+// include/caffe/layers/split_layer.hpp -- zero copy fan-out (split_layer.cpp:26-31)
+template <typename Dtype>
+class SplitLayer : public Layer<Dtype> {
+ public:
+  explicit SplitLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "Split"; }
+  virtual inline int ExactNumBottomBlobs() const { return 1; }
+  virtual inline int MinTopBlobs() const { return 1; }
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) { Forward_cpu(bottom, top); }
+};
+
+// include/caffe/layers/base_conv_layer.hpp + conv_layer.hpp (2-D, dilation 1)
+template <typename Dtype>
+class ConvolutionLayer : public Layer<Dtype> {
+ public:
+  explicit ConvolutionLayer(const LayerParameter& param) : Layer<Dtype>(param), plan_(nullptr), relu_(false), weights_dirty_(true), planned_n_(-1) {}
+  virtual ~ConvolutionLayer();
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "Convolution"; }
+  virtual inline int MinBottomBlobs() const { return 1; }
+  virtual inline int MinTopBlobs() const { return 1; }
+  virtual void OnWeightsChanged() { weights_dirty_ = true; }
+  virtual bool FuseReLU(Dtype negative_slope);
+  virtual double ForwardFlops() const;
+  const char* kernel_name() const;
+ protected:
+  MSCNN_NO_CPU_PATH("Convolution")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  void Plan(int n, int h, int w);
+  int num_output_, channels_, group_, kernel_h_, kernel_w_, pad_h_, pad_w_, stride_h_, stride_w_;
+  bool bias_term_;
+  mscnn_conv_plan* plan_;
+  bool relu_, weights_dirty_;
+  int planned_n_, planned_h_, planned_w_;
+  DeviceBuffer packed_, workspace_;
+};
+
+// include/caffe/layers/deconv_layer.hpp -- depthwise (group == channels) transposed conv only
+template <typename Dtype>
+class DeconvolutionLayer : public Layer<Dtype> {
+ public:
+  explicit DeconvolutionLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "Deconvolution"; }
+  virtual inline int ExactNumBottomBlobs() const { return 1; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+ protected:
+  MSCNN_NO_CPU_PATH("Deconvolution")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  int num_output_, channels_, group_, kernel_h_, kernel_w_, pad_h_, pad_w_, stride_h_, stride_w_;
+  bool bias_term_;
+};
+
+// include/caffe/layers/pooling_layer.hpp
+template <typename Dtype>
+class PoolingLayer : public Layer<Dtype> {
+ public:
+  explicit PoolingLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "Pooling"; }
+  virtual inline int ExactNumBottomBlobs() const { return 1; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }   // the optional argmax-mask top is not produced
+ protected:
+  MSCNN_NO_CPU_PATH("Pooling")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  int kernel_h_, kernel_w_, stride_h_, stride_w_, pad_h_, pad_w_;
+  int channels_, height_, width_, pooled_height_, pooled_width_;
+  bool global_pooling_;
+  int method_;
+};
+
+// include/caffe/layers/relu_layer.hpp
+template <typename Dtype>
+class ReLULayer : public Layer<Dtype> {
+ public:
+  explicit ReLULayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) { top[0]->ReshapeLike(*bottom[0]); }
+  virtual inline const char* type() const { return "ReLU"; }
+  virtual inline int ExactNumBottomBlobs() const { return 1; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+ protected:
+  MSCNN_NO_CPU_PATH("ReLU")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+};
+
+// include/caffe/layers/inner_product_layer.hpp
+template <typename Dtype>
+class InnerProductLayer : public Layer<Dtype> {
+ public:
+  explicit InnerProductLayer(const LayerParameter& param) : Layer<Dtype>(param), relu_(false) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "InnerProduct"; }
+  virtual inline int ExactNumBottomBlobs() const { return 1; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+  virtual bool FuseReLU(Dtype negative_slope) { if (negative_slope != 0) return false; relu_ = true; return true; }
+  virtual double ForwardFlops() const { return 2.0 * M_ * N_ * K_; }
+ protected:
+  MSCNN_NO_CPU_PATH("InnerProduct")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  int M_, K_, N_;
+  bool bias_term_, relu_;
+};
+
+// include/caffe/layers/concat_layer.hpp (channel axis)
+template <typename Dtype>
+class ConcatLayer : public Layer<Dtype> {
+ public:
+  explicit ConcatLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "Concat"; }
+  virtual inline int MinBottomBlobs() const { return 1; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+ protected:
+  MSCNN_NO_CPU_PATH("Concat")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  int concat_axis_, num_concats_, concat_input_size_;
+};
+
+// include/caffe/layers/dropout_layer.hpp -- TEST phase: identity (dropout_layer.cpp:43-45)
+template <typename Dtype>
+class DropoutLayer : public Layer<Dtype> {
+ public:
+  explicit DropoutLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) { top[0]->ReshapeLike(*bottom[0]); }
+  virtual inline const char* type() const { return "Dropout"; }
+  virtual inline int ExactNumBottomBlobs() const { return 1; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+ protected:
+  MSCNN_NO_CPU_PATH("Dropout")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+};
+
+// include/caffe/layers/softmax_layer.hpp
+template <typename Dtype>
+class SoftmaxLayer : public Layer<Dtype> {
+ public:
+  explicit SoftmaxLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "Softmax"; }
+  virtual inline int ExactNumBottomBlobs() const { return 1; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+ protected:
+  MSCNN_NO_CPU_PATH("Softmax")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  int outer_num_, inner_num_, softmax_axis_;
+};
+
+// include/caffe/layers/roi_pooling_layer.hpp
+template <typename Dtype>
+class ROIPoolingLayer : public Layer<Dtype> {
+ public:
+  explicit ROIPoolingLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "ROIPooling"; }
+  virtual inline int MinBottomBlobs() const { return 2; }
+  virtual inline int MaxBottomBlobs() const { return 2; }
+  virtual inline int MinTopBlobs() const { return 1; }
+  virtual inline int MaxTopBlobs() const { return 1; }
+ protected:
+  MSCNN_NO_CPU_PATH("ROIPooling")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  int channels_, height_, width_, pooled_height_, pooled_width_;
+  Dtype spatial_scale_, pad_ratio_;
+};
+
+// include/caffe/layers/box_output_layer.hpp -- GPU implementation (the reference's is CPU only)
+template <typename Dtype>
+class BoxOutputLayer : public Layer<Dtype> {
+ public:
+  explicit BoxOutputLayer(const LayerParameter& param) : Layer<Dtype>(param), forwarded_(false) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "BoxOutput"; }
+  virtual inline int MinBottomBlobs() const { return 1; }
+  virtual inline int MinTopBlobs() const { return 1; }
+  virtual inline int MaxTopBlobs() const { return 2; }
+  int last_num_rois() const { return last_rows_; }
+ protected:
+  MSCNN_NO_CPU_PATH("BoxOutput")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  float fg_thr_, iou_thr_;
+  string nms_type_;
+  bool output_proposal_with_score_;
+  DeviceBuffer workspace_, rois_, props_, count_;
+  int cap_, last_rows_;
+  bool forwarded_;
+};
+
+// include/caffe/layers/decode_bbox_layer.hpp (TEST phase)
+template <typename Dtype>
+class DecodeBBoxLayer : public Layer<Dtype> {
+ public:
+  explicit DecodeBBoxLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "DecodeBBox"; }
+  virtual inline int MinBottomBlobs() const { return 2; }
+  virtual inline int MaxBottomBlobs() const { return 2; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+ protected:
+  MSCNN_NO_CPU_PATH("DecodeBBox")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  float bbox_mean_[4], bbox_std_[4];
+};
+
+}  // namespace caffe
+#endif

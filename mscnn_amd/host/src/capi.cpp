@@ -1,0 +1,220 @@
+// C ABI over caffe::Net<float> (include/mscnn_net.h).  Every entry point catches caffe::FatalError (the
+// CHECK-failure exception of this build) and returns it as an error string instead of aborting the host process.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <string>
+
+#include "../../../include/mscnn_hip.h"
+#include "../../../include/mscnn_net.h"
+#include "caffe/caffe.hpp"
+
+using caffe::Blob;
+using caffe::Caffe;
+using caffe::Net;
+
+struct mscnn_net {
+  std::unique_ptr<Net<float> > net;
+  int device;
+  caffe::DeviceBuffer det_ws, det_out, det_ids, det_cnt;
+};
+
+namespace {
+thread_local std::string g_err;
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
+void fill_shape(const Blob<float>& b, int* dims8, int* ndim) {
+  *ndim = b.num_axes();
+  for (int i = 0; i < 8; ++i) dims8[i] = i < b.num_axes() ? b.shape(i) : 1;
+}
+
+int create(caffe::NetParameter param, int device, mscnn_net** out) {
+  return guarded([&] {
+    CHECK(out != nullptr);
+    if (device >= 0) Caffe::SetDevice(device);   // device < 0: graph construction only (no HIP device touched)
+    Caffe::set_mode(Caffe::GPU);
+    std::unique_ptr<mscnn_net> h(new mscnn_net());
+    h->device = device;
+    h->net.reset(new Net<float>(param, caffe::TEST));
+    *out = h.release();
+  });
+}
+}  // namespace
+
+extern "C" {
+
+const char* mscnn_net_last_error(void) { return g_err.c_str(); }
+
+int mscnn_net_create_from_file(const char* path, int device, mscnn_net** out) {
+  caffe::NetParameter p;
+  int rc = guarded([&] { caffe::ReadNetParamsFromTextFileOrDie(path, &p); });
+  return rc ? rc : create(p, device, out);
+}
+
+int mscnn_net_create_from_string(const char* text, int device, mscnn_net** out) {
+  caffe::NetParameter p;
+  int rc = guarded([&] { p = caffe::NetParameterFromString(text); });
+  return rc ? rc : create(p, device, out);
+}
+
+void mscnn_net_destroy(mscnn_net* net) { delete net; }
+
+int mscnn_net_load_caffemodel(mscnn_net* net, const char* path) { return guarded([&] { net->net->CopyTrainedLayersFrom(path); }); }
+
+int mscnn_net_set_stream(void* stream) { Caffe::set_stream(stream); return 0; }
+
+int mscnn_net_num_layers(const mscnn_net* n) { return (int)n->net->layers().size(); }
+const char* mscnn_net_layer_name(const mscnn_net* n, int i) { return n->net->layer_names()[i].c_str(); }
+const char* mscnn_net_layer_type(const mscnn_net* n, int i) { return n->net->layers()[i]->type(); }
+int mscnn_net_layer_index(const mscnn_net* n, const char* name) {
+  const auto& v = n->net->layer_names();
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i] == name) return (int)i;
+  return -1;
+}
+int mscnn_net_layer_num_bottoms(const mscnn_net* n, int l) { return (int)n->net->bottom_vecs()[l].size(); }
+int mscnn_net_layer_num_tops(const mscnn_net* n, int l) { return (int)n->net->top_vecs()[l].size(); }
+static const char* blob_name_of(const mscnn_net* n, const Blob<float>* b) {
+  const auto& blobs = n->net->blobs();
+  for (size_t i = 0; i < blobs.size(); ++i)
+    if (blobs[i].get() == b) return n->net->blob_names()[i].c_str();
+  return "";
+}
+const char* mscnn_net_layer_bottom(const mscnn_net* n, int l, int i) { return blob_name_of(n, n->net->bottom_vecs()[l][i]); }
+const char* mscnn_net_layer_top(const mscnn_net* n, int l, int i) { return blob_name_of(n, n->net->top_vecs()[l][i]); }
+int mscnn_net_layer_num_params(const mscnn_net* n, int l) { return (int)n->net->layers()[l]->blobs().size(); }
+int mscnn_net_layer_param_shape(const mscnn_net* n, int l, int p, int* dims8, int* ndim) {
+  return guarded([&] {
+    CHECK_LT(p, (int)n->net->layers()[l]->blobs().size());
+    fill_shape(*n->net->layers()[l]->blobs()[p], dims8, ndim);
+  });
+}
+int mscnn_net_layer_fused_away(const mscnn_net* n, int l) { return n->net->layer_fused_away()[l] ? 1 : 0; }
+const char* mscnn_net_layer_kernel(const mscnn_net* n, int l) {
+  auto* c = dynamic_cast<caffe::ConvolutionLayer<float>*>(n->net->layers()[l].get());
+  return c ? c->kernel_name() : "";
+}
+double mscnn_net_layer_flops(const mscnn_net* n, int l) { return n->net->layers()[l]->ForwardFlops(); }
+int mscnn_net_num_blobs(const mscnn_net* n) { return (int)n->net->blobs().size(); }
+const char* mscnn_net_blob_name(const mscnn_net* n, int b) { return n->net->blob_names()[b].c_str(); }
+int mscnn_net_blob_shape(const mscnn_net* n, const char* name, int* dims8, int* ndim) {
+  return guarded([&] {
+    CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
+    fill_shape(*n->net->blob_by_name(name), dims8, ndim);
+  });
+}
+int mscnn_net_num_inputs(const mscnn_net* n) { return n->net->num_inputs(); }
+int mscnn_net_num_outputs(const mscnn_net* n) { return n->net->num_outputs(); }
+const char* mscnn_net_output_name(const mscnn_net* n, int i) { return n->net->blob_names()[n->net->output_blob_indices()[i]].c_str(); }
+
+int mscnn_net_set_param(mscnn_net* n, int l, int p, const float* host, size_t count) {
+  return guarded([&] {
+    auto& blobs = n->net->layers()[l]->blobs();
+    CHECK_LT(p, (int)blobs.size());
+    CHECK_EQ((size_t)blobs[p]->count(), count) << "param size mismatch for layer " << n->net->layer_names()[l];
+    std::memcpy(blobs[p]->mutable_cpu_data(), host, sizeof(float) * count);
+    n->net->layers()[l]->OnWeightsChanged();
+  });
+}
+int mscnn_net_get_param(mscnn_net* n, int l, int p, float* host, size_t count) {
+  return guarded([&] {
+    auto& blobs = n->net->layers()[l]->blobs();
+    CHECK_LT(p, (int)blobs.size());
+    CHECK_EQ((size_t)blobs[p]->count(), count);
+    std::memcpy(host, blobs[p]->cpu_data(), sizeof(float) * count);
+  });
+}
+
+int mscnn_net_set_blob(mscnn_net* n, const char* name, const float* host, size_t count) {
+  return guarded([&] {
+    CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
+    auto b = n->net->blob_by_name(name);
+    CHECK_EQ((size_t)b->count(), count) << "blob " << name << " has shape " << b->shape_string();
+    std::memcpy(b->mutable_cpu_data(), host, sizeof(float) * count);
+  });
+}
+int mscnn_net_set_blob_device(mscnn_net* n, const char* name, const float* dev, size_t count) {
+  return guarded([&] {
+    CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
+    auto b = n->net->blob_by_name(name);
+    CHECK_EQ((size_t)b->count(), count) << "blob " << name << " has shape " << b->shape_string();
+    HIP_CHECK(hipMemcpyAsync(b->mutable_gpu_data(), dev, sizeof(float) * count, hipMemcpyDeviceToDevice, (hipStream_t)Caffe::stream()));
+  });
+}
+int mscnn_net_get_blob(mscnn_net* n, const char* name, float* host, size_t capacity, size_t* count) {
+  return guarded([&] {
+    CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
+    auto b = n->net->blob_by_name(name);
+    if (count) *count = (size_t)b->count();
+    CHECK_LE((size_t)b->count(), capacity) << "buffer too small for blob " << name;
+    std::memcpy(host, b->cpu_data(), sizeof(float) * b->count());
+  });
+}
+const float* mscnn_net_blob_device_ptr(mscnn_net* n, const char* name) {
+  const float* p = nullptr;
+  guarded([&] {
+    CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
+    p = n->net->blob_by_name(name)->gpu_data();
+  });
+  return p;
+}
+
+int mscnn_net_forward(mscnn_net* n) { return guarded([&] { n->net->Forward(); }); }
+int mscnn_net_forward_from_to(mscnn_net* n, int from, int to) {
+  return guarded([&] { n->net->ForwardFromTo(from, to < 0 ? (int)n->net->layers().size() - 1 : to); });
+}
+int mscnn_net_reshape(mscnn_net* n) { return guarded([&] { n->net->Reshape(); }); }
+int mscnn_net_set_layer_timing(mscnn_net* n, int on) { n->net->set_layer_timing(on != 0); return 0; }
+float mscnn_net_layer_ms(const mscnn_net* n, int l) { return n->net->layer_ms()[l]; }
+
+int mscnn_net_detect(mscnn_net* n, const mscnn_detect_params* p, double* dets_host, int* ids_host, int cap, int* num_dets,
+                     int* num_rois) {
+  return guarded([&] {
+    CHECK(p && dets_host && num_dets);
+    CHECK(n->net->has_blob("bbox_pred") && n->net->has_blob("cls_pred") && n->net->has_blob("proposals_score"))
+        << "net has no bbox_pred / cls_pred / proposals_score outputs";
+    auto bbox = n->net->blob_by_name("bbox_pred");
+    auto cls = n->net->blob_by_name("cls_pred");
+    auto props = n->net->blob_by_name("proposals_score");
+    const int R = props->num();
+    CHECK_EQ(bbox->num(), R);
+    CHECK_EQ(cls->num(), R);
+    mscnn_detections_desc d;
+    d.ncls = cls->count() / R;
+    CHECK_EQ(bbox->count() / R, 4 * d.ncls);
+    d.cls_id = p->cls_id;
+    for (int k = 0; k < 4; ++k) { d.bbox_mean[k] = p->bbox_mean[k]; d.bbox_std[k] = p->bbox_std[k]; }
+    d.proposal_thr = p->proposal_thr;
+    d.ratio_h = p->ratio_h; d.ratio_w = p->ratio_w; d.org_h = p->org_h; d.org_w = p->org_w; d.nms_overlap = p->nms_overlap;
+    const size_t wb = mscnn_detections_workspace_bytes(R);
+    void* ws = n->det_ws.Reserve(wb);
+    double* dets = static_cast<double*>(n->det_out.Reserve(sizeof(double) * 5 * (size_t)(R > 0 ? R : 1)));
+    int* ids = static_cast<int*>(n->det_ids.Reserve(sizeof(int) * (size_t)(R > 0 ? R : 1)));
+    int* cnt = static_cast<int*>(n->det_cnt.Reserve(sizeof(int)));
+    hipStream_t st = (hipStream_t)Caffe::stream();
+    MSCNN_CHECK(mscnn_detections_fwd(&d, bbox->gpu_data(), cls->gpu_data(), props->gpu_data(), R, dets, ids, cnt, ws, wb, st));
+    int D = 0;
+    HIP_CHECK(hipMemcpyAsync(&D, cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    CHECK_LE(D, cap) << "detections buffer too small";
+    if (D > 0) {
+      HIP_CHECK(hipMemcpyAsync(dets_host, dets, sizeof(double) * 5 * D, hipMemcpyDeviceToHost, st));
+      if (ids_host) HIP_CHECK(hipMemcpyAsync(ids_host, ids, sizeof(int) * D, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
+    *num_dets = D;
+    if (num_rois) *num_rois = R;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,537 @@
+// Layer implementations: parameter parsing + shape logic restated from the reference's layer sources,
+// Forward_gpu = one call into libmscnn_hip.so (include/mscnn_hip.h).
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstring>
+#include <random>
+
+#include "../../../include/mscnn_hip.h"
+#include "caffe/layer_factory.hpp"
+#include "caffe/layers/mscnn_layers.hpp"
+
+namespace caffe {
+
+namespace {
+// Fillers that occur in the deploy files (include/caffe/filler.hpp): constant, gaussian, bilinear.
+// Deploy nets carry no fillers for conv/IP weights => constant 0 (caffe.proto:45-46); real weights come from
+// a .caffemodel or are injected through layer->blobs().
+void Fill(const FillerParameter& fp, Blob<float>* blob, unsigned seed) {
+  float* d = blob->mutable_cpu_data();
+  const string t = fp.type();
+  if (t == "constant") {
+    for (int i = 0; i < blob->count(); ++i) d[i] = fp.value();
+  } else if (t == "gaussian") {
+    std::mt19937 gen(seed);
+    std::normal_distribution<float> dist(fp.mean(), fp.std());
+    for (int i = 0; i < blob->count(); ++i) d[i] = dist(gen);
+  } else if (t == "bilinear") {   // filler.hpp:244-262
+    CHECK_EQ(blob->num_axes(), 4) << "Blob must be 4 dim.";
+    CHECK_EQ(blob->width(), blob->height()) << "Filter must be square";
+    const int f = (int)std::ceil(blob->width() / 2.);
+    const float c = (2 * f - 1 - f % 2) / (2. * f);
+    for (int i = 0; i < blob->count(); ++i) {
+      const float x = i % blob->width();
+      const float y = (i / blob->width()) % blob->height();
+      d[i] = (1 - std::fabs(x / f - c)) * (1 - std::fabs(y / f - c));
+    }
+  } else {
+    LOG(FATAL) << "Unknown filler name: " << t;
+  }
+}
+
+// base_conv_layer.cpp:12-183, 2-D / dilation-1 subset
+void ParseConvParam(const ConvolutionParameter& p, int* kh, int* kw, int* ph, int* pw, int* sh, int* sw) {
+  if (p.has_kernel_h() || p.has_kernel_w()) {
+    CHECK_EQ(0, p.kernel_size_size()) << "Either kernel_size or kernel_h/w should be specified; not both.";
+    *kh = p.kernel_h(); *kw = p.kernel_w();
+  } else {
+    const int n = p.kernel_size_size();
+    CHECK(n == 1 || n == 2) << "kernel_size must be specified once, or once per spatial dimension (kernel_size specified " << n << " times)";
+    *kh = p.kernel_size(0); *kw = p.kernel_size(n == 1 ? 0 : 1);
+  }
+  CHECK_GT(*kh, 0) << "Filter dimensions must be nonzero.";
+  CHECK_GT(*kw, 0) << "Filter dimensions must be nonzero.";
+  if (p.has_stride_h() || p.has_stride_w()) {
+    CHECK_EQ(0, p.stride_size()) << "Either stride or stride_h/w should be specified; not both.";
+    *sh = p.stride_h(); *sw = p.stride_w();
+  } else {
+    const int n = p.stride_size();
+    CHECK(n <= 2) << "stride must be specified at most once per spatial dimension";
+    *sh = n ? p.stride(0) : 1; *sw = n ? p.stride(n == 1 ? 0 : 1) : 1;
+  }
+  CHECK_GT(*sh, 0); CHECK_GT(*sw, 0);
+  if (p.has_pad_h() || p.has_pad_w()) {
+    CHECK_EQ(0, p.pad_size()) << "Either pad or pad_h/w should be specified; not both.";
+    *ph = p.pad_h(); *pw = p.pad_w();
+  } else {
+    const int n = p.pad_size();
+    CHECK(n <= 2) << "pad must be specified at most once per spatial dimension";
+    *ph = n ? p.pad(0) : 0; *pw = n ? p.pad(n == 1 ? 0 : 1) : 0;
+  }
+  for (int i = 0; i < p.dilation_size(); ++i) CHECK_EQ(p.dilation(i), 1u) << "dilated convolution is not part of the MS-CNN path";
+}
+
+inline void* S() { return Caffe::stream(); }
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ Input
+template <typename Dtype>
+void InputLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const InputParameter p = this->layer_param_.input_param();
+  const int num_shape = p.shape_size();
+  CHECK(num_shape == 0 || num_shape == 1 || num_shape == (int)top.size())
+      << "Must specify 'shape' once, once per top blob, or not at all: " << top.size() << " tops vs. " << num_shape << " shapes.";
+  for (size_t i = 0; i < top.size() && num_shape > 0; ++i) {
+    const BlobShape s = p.shape(num_shape == 1 ? 0 : (int)i);
+    vector<int> shape;
+    for (int d = 0; d < s.dim_size(); ++d) shape.push_back((int)s.dim(d));
+    top[i]->Reshape(shape);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Split
+template <typename Dtype>
+void SplitLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  for (size_t i = 0; i < top.size(); ++i) {
+    CHECK_NE(top[i], bottom[0]) << this->type() << " Layer does not allow in-place computation.";
+    top[i]->ReshapeLike(*bottom[0]);
+    top[i]->ShareData(*bottom[0]);
+  }
+}
+template <typename Dtype>
+void SplitLayer<Dtype>::Forward_cpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  for (size_t i = 0; i < top.size(); ++i) top[i]->ShareData(*bottom[0]);
+}
+
+// ------------------------------------------------------------------------------------------------ Convolution
+template <typename Dtype>
+ConvolutionLayer<Dtype>::~ConvolutionLayer() {
+  if (plan_) mscnn_conv2d_plan_destroy(plan_);
+}
+
+template <typename Dtype>
+void ConvolutionLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const ConvolutionParameter p = this->layer_param_.convolution_param();
+  CHECK_EQ(bottom[0]->num_axes(), 4) << "2-D convolution expects (N, C, H, W) bottoms";
+  CHECK_EQ(p.axis(), 1);
+  ParseConvParam(p, &kernel_h_, &kernel_w_, &pad_h_, &pad_w_, &stride_h_, &stride_w_);
+  channels_ = bottom[0]->channels();
+  num_output_ = p.num_output();
+  CHECK_GT(num_output_, 0);
+  group_ = p.group();
+  CHECK_EQ(channels_ % group_, 0);
+  CHECK_EQ(num_output_ % group_, 0) << "Number of output should be multiples of group.";
+  bias_term_ = p.bias_term();
+  // base_conv_layer.cpp:130-160: blobs_[0] = [Cout][Cin/g][Kh][Kw], blobs_[1] = [Cout]
+  if (this->blobs_.size() > 0) {
+    CHECK_EQ((size_t)(1 + bias_term_), this->blobs_.size()) << "Incorrect number of weight blobs.";
+  } else {
+    this->blobs_.resize(bias_term_ ? 2 : 1);
+    this->blobs_[0].reset(new Blob<Dtype>(num_output_, channels_ / group_, kernel_h_, kernel_w_));
+    Fill(p.weight_filler(), this->blobs_[0].get(), 1701);
+    if (bias_term_) {
+      this->blobs_[1].reset(new Blob<Dtype>(vector<int>(1, num_output_)));
+      Fill(p.bias_filler(), this->blobs_[1].get(), 1702);
+    }
+  }
+  weights_dirty_ = true;
+}
+
+template <typename Dtype>
+void ConvolutionLayer<Dtype>::Plan(int n, int h, int w) {
+  if (plan_ && planned_h_ == h && planned_w_ == w) {
+    if (planned_n_ != n) {
+      MSCNN_CHECK(mscnn_conv2d_plan_set_batch(plan_, n));
+      planned_n_ = n;
+    }
+    return;
+  }
+  if (plan_) mscnn_conv2d_plan_destroy(plan_);
+  plan_ = nullptr;
+  mscnn_conv_desc d;
+  d.N = n; d.Cin = channels_; d.H = h; d.W = w; d.Cout = num_output_; d.Kh = kernel_h_; d.Kw = kernel_w_;
+  d.pad_h = pad_h_; d.pad_w = pad_w_; d.stride_h = stride_h_; d.stride_w = stride_w_; d.group = group_; d.relu = relu_ ? 1 : 0;
+  MSCNN_CHECK(mscnn_conv2d_plan_create(&d, &plan_));
+  planned_n_ = n; planned_h_ = h; planned_w_ = w;
+  weights_dirty_ = true;
+}
+
+template <typename Dtype>
+bool ConvolutionLayer<Dtype>::FuseReLU(Dtype negative_slope) {
+  if (negative_slope != 0) return false;
+  relu_ = true;
+  if (plan_) { mscnn_conv2d_plan_destroy(plan_); plan_ = nullptr; }
+  return true;
+}
+
+template <typename Dtype>
+void ConvolutionLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  CHECK_EQ(bottom[0]->channels(), channels_) << "Input size incompatible with convolution kernel.";
+  CHECK_EQ(bottom.size(), 1u) << "one bottom per Convolution layer in this build";
+  const int h = bottom[0]->height(), w = bottom[0]->width();
+  // conv_layer.cpp:8-22
+  const int oh = (h + 2 * pad_h_ - kernel_h_) / stride_h_ + 1, ow = (w + 2 * pad_w_ - kernel_w_) / stride_w_ + 1;
+  top[0]->Reshape(bottom[0]->num(), num_output_, oh, ow);
+}
+
+template <typename Dtype>
+double ConvolutionLayer<Dtype>::ForwardFlops() const { return plan_ ? mscnn_conv2d_plan_flops(plan_) : 0; }
+template <typename Dtype>
+const char* ConvolutionLayer<Dtype>::kernel_name() const { return plan_ ? mscnn_conv2d_plan_kernel(plan_) : ""; }
+
+template <typename Dtype>
+void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  Plan(bottom[0]->num(), bottom[0]->height(), bottom[0]->width());
+  const float* w = this->blobs_[0]->gpu_data();
+  const size_t pbytes = mscnn_conv2d_packed_weight_bytes(plan_);
+  float* packed = pbytes ? static_cast<float*>(packed_.Reserve(pbytes)) : nullptr;
+  if (weights_dirty_) {
+    MSCNN_CHECK(mscnn_conv2d_pack_weights(plan_, w, packed, S()));
+    weights_dirty_ = false;
+  }
+  const size_t wbytes = mscnn_conv2d_workspace_bytes(plan_);
+  void* ws = wbytes ? workspace_.Reserve(wbytes) : nullptr;
+  const float* bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
+  MSCNN_CHECK(mscnn_conv2d_fwd_f32(plan_, bottom[0]->gpu_data(), w, packed, bias, top[0]->mutable_gpu_data(), ws, wbytes, S()));
+}
+
+// ------------------------------------------------------------------------------------------------ Deconvolution
+template <typename Dtype>
+void DeconvolutionLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const ConvolutionParameter p = this->layer_param_.convolution_param();
+  ParseConvParam(p, &kernel_h_, &kernel_w_, &pad_h_, &pad_w_, &stride_h_, &stride_w_);
+  channels_ = bottom[0]->channels();
+  num_output_ = p.num_output();
+  group_ = p.group();
+  CHECK(group_ == channels_ && num_output_ == channels_)
+      << "Deconvolution: only the depthwise case (group == channels == num_output) of the '-2x' deploy nets is built";
+  bias_term_ = p.bias_term();
+  if (this->blobs_.size() == 0) {
+    this->blobs_.resize(bias_term_ ? 2 : 1);
+    // reversed dims for deconv: [Cin][Cout/g][Kh][Kw] (base_conv_layer.cpp:135-140 with reverse_dimensions())
+    this->blobs_[0].reset(new Blob<Dtype>(channels_, num_output_ / group_, kernel_h_, kernel_w_));
+    Fill(p.weight_filler(), this->blobs_[0].get(), 1703);
+    if (bias_term_) {
+      this->blobs_[1].reset(new Blob<Dtype>(vector<int>(1, num_output_)));
+      Fill(p.bias_filler(), this->blobs_[1].get(), 1704);
+    }
+  }
+}
+template <typename Dtype>
+void DeconvolutionLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  // deconv_layer.cpp:8-23
+  const int oh = stride_h_ * (bottom[0]->height() - 1) + kernel_h_ - 2 * pad_h_;
+  const int ow = stride_w_ * (bottom[0]->width() - 1) + kernel_w_ - 2 * pad_w_;
+  top[0]->Reshape(bottom[0]->num(), num_output_, oh, ow);
+}
+template <typename Dtype>
+void DeconvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  MSCNN_CHECK(mscnn_deconv_depthwise_fwd_f32(bottom[0]->gpu_data(), this->blobs_[0]->gpu_data(),
+                                             bias_term_ ? this->blobs_[1]->gpu_data() : nullptr, top[0]->mutable_gpu_data(),
+                                             bottom[0]->num(), channels_, bottom[0]->height(), bottom[0]->width(), kernel_h_,
+                                             kernel_w_, pad_h_, pad_w_, stride_h_, stride_w_, S()));
+}
+
+// ------------------------------------------------------------------------------------------------ Pooling
+template <typename Dtype>
+void PoolingLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const PoolingParameter p = this->layer_param_.pooling_param();   // pooling_layer.cpp:17-76
+  global_pooling_ = p.global_pooling();
+  if (global_pooling_) {
+    CHECK(!(p.has_kernel_size() || p.has_kernel_h() || p.has_kernel_w())) << "With Global_pooling: true Filter size cannot specified";
+    kernel_h_ = bottom[0]->height(); kernel_w_ = bottom[0]->width();
+  } else {
+    CHECK(!p.has_kernel_size() != !(p.has_kernel_h() && p.has_kernel_w())) << "Filter size is kernel_size OR kernel_h and kernel_w; not both";
+    if (p.has_kernel_size()) kernel_h_ = kernel_w_ = p.kernel_size();
+    else { kernel_h_ = p.kernel_h(); kernel_w_ = p.kernel_w(); }
+  }
+  CHECK_GT(kernel_h_, 0); CHECK_GT(kernel_w_, 0);
+  if (!p.has_pad_h()) pad_h_ = pad_w_ = p.pad(); else { pad_h_ = p.pad_h(); pad_w_ = p.pad_w(); }
+  if (!p.has_stride_h()) stride_h_ = stride_w_ = p.stride(); else { stride_h_ = p.stride_h(); stride_w_ = p.stride_w(); }
+  if (pad_h_ != 0 || pad_w_ != 0) {
+    CHECK(p.pool() == PoolingParameter_PoolMethod_AVE || p.pool() == PoolingParameter_PoolMethod_MAX) << "Padding implemented only for average and max pooling.";
+    CHECK_LT(pad_h_, kernel_h_); CHECK_LT(pad_w_, kernel_w_);
+  }
+  CHECK(p.pool() != PoolingParameter_PoolMethod_STOCHASTIC) << "stochastic pooling is training-only";
+  method_ = p.pool() == PoolingParameter_PoolMethod_MAX ? 0 : 1;
+}
+template <typename Dtype>
+void PoolingLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  CHECK_EQ(4, bottom[0]->num_axes()) << "Input must have 4 axes, corresponding to (num, channels, height, width)";
+  channels_ = bottom[0]->channels(); height_ = bottom[0]->height(); width_ = bottom[0]->width();
+  if (global_pooling_) { kernel_h_ = height_; kernel_w_ = width_; }
+  pooled_height_ = mscnn_pool_out_dim(height_, kernel_h_, pad_h_, stride_h_);   // pooling_layer.cpp:90-107 (ceil)
+  pooled_width_ = mscnn_pool_out_dim(width_, kernel_w_, pad_w_, stride_w_);
+  top[0]->Reshape(bottom[0]->num(), channels_, pooled_height_, pooled_width_);
+}
+template <typename Dtype>
+void PoolingLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  MSCNN_CHECK(mscnn_pool2d_fwd_f32(bottom[0]->gpu_data(), top[0]->mutable_gpu_data(), bottom[0]->num(), channels_, height_, width_,
+                                   kernel_h_, kernel_w_, pad_h_, pad_w_, stride_h_, stride_w_, method_, S()));
+}
+
+// ------------------------------------------------------------------------------------------------ ReLU
+template <typename Dtype>
+void ReLULayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  MSCNN_CHECK(mscnn_relu_fwd_f32(bottom[0]->gpu_data(), top[0]->mutable_gpu_data(), (size_t)bottom[0]->count(),
+                                 this->layer_param_.relu_param().negative_slope(), S()));
+}
+
+// ------------------------------------------------------------------------------------------------ InnerProduct
+template <typename Dtype>
+void InnerProductLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const InnerProductParameter p = this->layer_param_.inner_product_param();   // inner_product_layer.cpp:10-55
+  N_ = p.num_output();
+  bias_term_ = p.bias_term();
+  CHECK(!p.transpose()) << "transpose: true is not used by the MS-CNN nets";
+  const int axis = bottom[0]->CanonicalAxisIndex(p.axis());
+  K_ = bottom[0]->count(axis);
+  if (this->blobs_.size() == 0) {
+    this->blobs_.resize(bias_term_ ? 2 : 1);
+    vector<int> ws(2); ws[0] = N_; ws[1] = K_;
+    this->blobs_[0].reset(new Blob<Dtype>(ws));
+    Fill(p.weight_filler(), this->blobs_[0].get(), 1705);
+    if (bias_term_) {
+      this->blobs_[1].reset(new Blob<Dtype>(vector<int>(1, N_)));
+      Fill(p.bias_filler(), this->blobs_[1].get(), 1706);
+    }
+  }
+}
+template <typename Dtype>
+void InnerProductLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const int axis = bottom[0]->CanonicalAxisIndex(this->layer_param_.inner_product_param().axis());
+  const int new_K = bottom[0]->count(axis);
+  CHECK_EQ(K_, new_K) << "Input size incompatible with inner product parameters.";
+  M_ = bottom[0]->count(0, axis);
+  vector<int> top_shape = bottom[0]->shape();
+  top_shape.resize(axis + 1);
+  top_shape[axis] = N_;
+  top[0]->Reshape(top_shape);
+}
+template <typename Dtype>
+void InnerProductLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  MSCNN_CHECK(mscnn_inner_product_fwd_f32(bottom[0]->gpu_data(), this->blobs_[0]->gpu_data(),
+                                          bias_term_ ? this->blobs_[1]->gpu_data() : nullptr, top[0]->mutable_gpu_data(), M_, N_, K_,
+                                          relu_ ? 1 : 0, S()));
+}
+
+// ------------------------------------------------------------------------------------------------ Concat
+template <typename Dtype>
+void ConcatLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const ConcatParameter p = this->layer_param_.concat_param();
+  CHECK(!(p.raw().has("axis") && p.has_concat_dim())) << "Either axis or concat_dim should be specified; not both.";
+}
+template <typename Dtype>
+void ConcatLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const ConcatParameter p = this->layer_param_.concat_param();   // concat_layer.cpp:17-55
+  const int num_axes = bottom[0]->num_axes();
+  concat_axis_ = p.has_concat_dim() ? (int)p.concat_dim() : bottom[0]->CanonicalAxisIndex(p.axis());
+  CHECK_LT(concat_axis_, num_axes) << "concat axis out of range.";
+  vector<int> top_shape = bottom[0]->shape();
+  num_concats_ = bottom[0]->count(0, concat_axis_);
+  concat_input_size_ = bottom[0]->count(concat_axis_ + 1);
+  for (size_t i = 1; i < bottom.size(); ++i) {
+    CHECK_EQ(num_axes, bottom[i]->num_axes()) << "All inputs must have the same #axes.";
+    for (int j = 0; j < num_axes; ++j) {
+      if (j == concat_axis_) continue;
+      CHECK_EQ(top_shape[j], bottom[i]->shape(j)) << "All inputs must have the same shape, except at concat_axis.";
+    }
+    top_shape[concat_axis_] += bottom[i]->shape(concat_axis_);
+  }
+  top[0]->Reshape(top_shape);
+  if (bottom.size() == 1) top[0]->ShareData(*bottom[0]);
+}
+template <typename Dtype>
+void ConcatLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  if (bottom.size() == 1) return;
+  Dtype* top_data = top[0]->mutable_gpu_data();
+  const int top_concat_axis = top[0]->shape(concat_axis_);
+  int offset = 0;
+  for (size_t i = 0; i < bottom.size(); ++i) {
+    const int c = bottom[i]->shape(concat_axis_);
+    MSCNN_CHECK(mscnn_concat_channels_f32(bottom[i]->gpu_data(), top_data, num_concats_, c, concat_input_size_, top_concat_axis, offset, S()));
+    offset += c;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Dropout (TEST)
+template <typename Dtype>
+void DropoutLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  CHECK(this->phase_ == TEST) << "Dropout: TRAIN phase is outside the inference path";
+  if (top[0] == bottom[0]) return;                                  // in place: identity (dropout_layer.cpp:43-45)
+  const Dtype* src = bottom[0]->gpu_data();
+  Dtype* dst = top[0]->mutable_gpu_data();
+  if (src != dst)
+    HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(Dtype) * bottom[0]->count(), hipMemcpyDeviceToDevice, (hipStream_t)S()));
+}
+
+// ------------------------------------------------------------------------------------------------ Softmax
+template <typename Dtype>
+void SoftmaxLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  softmax_axis_ = bottom[0]->CanonicalAxisIndex(this->layer_param_.softmax_param().axis());
+  top[0]->ReshapeLike(*bottom[0]);
+  outer_num_ = bottom[0]->count(0, softmax_axis_);
+  inner_num_ = bottom[0]->count(softmax_axis_ + 1);
+}
+template <typename Dtype>
+void SoftmaxLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  MSCNN_CHECK(mscnn_softmax_fwd_f32(bottom[0]->gpu_data(), top[0]->mutable_gpu_data(), outer_num_, bottom[0]->shape(softmax_axis_), inner_num_, S()));
+}
+
+// ------------------------------------------------------------------------------------------------ ROIPooling
+template <typename Dtype>
+void ROIPoolingLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const ROIPoolingParameter p = this->layer_param_.roi_pooling_param();   // roi_pooling_layer.cpp:22-35
+  CHECK_GT(p.pooled_h(), 0u) << "pooled_h must be > 0";
+  CHECK_GT(p.pooled_w(), 0u) << "pooled_w must be > 0";
+  pooled_height_ = p.pooled_h();
+  pooled_width_ = p.pooled_w();
+  spatial_scale_ = p.spatial_scale();
+  pad_ratio_ = p.pad_ratio();
+  LOG(INFO) << "Spatial scale: " << spatial_scale_;
+}
+template <typename Dtype>
+void ROIPoolingLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  channels_ = bottom[0]->channels(); height_ = bottom[0]->height(); width_ = bottom[0]->width();
+  top[0]->Reshape(bottom[1]->num(), channels_, pooled_height_, pooled_width_);   // :37-46
+}
+template <typename Dtype>
+void ROIPoolingLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  MSCNN_CHECK(mscnn_roipool_fwd_f32(bottom[0]->gpu_data(), bottom[1]->gpu_data(), top[0]->mutable_gpu_data(), bottom[1]->num(),
+                                    bottom[0]->num(), channels_, height_, width_, pooled_height_, pooled_width_, spatial_scale_,
+                                    pad_ratio_, channels_, 0, S()));
+}
+
+// ------------------------------------------------------------------------------------------------ BoxOutput
+template <typename Dtype>
+void BoxOutputLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const BoxOutputParameter p = this->layer_param_.box_output_param();   // box_output_layer.cpp:19-26
+  fg_thr_ = p.fg_thr();
+  iou_thr_ = p.iou_thr();
+  nms_type_ = p.nms_type();
+  output_proposal_with_score_ = (top.size() == 2);
+  cap_ = 0;
+  last_rows_ = 1;
+}
+template <typename Dtype>
+void BoxOutputLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  // The reference does a dummy (1,5)/(1,6) reshape here on EVERY Forward (box_output_layer.cpp:29-36) and the real
+  // one inside Forward_cpu.  Layer::Forward calls Reshape first (layer.hpp:451-456), so the observable shapes after
+  // Forward are identical; between Net::Reshape() and Forward the tops are (1,5)/(1,6) as in the reference.
+  top[0]->Reshape(1, 5, 1, 1);
+  if (output_proposal_with_score_) top[1]->Reshape(1, 6, 1, 1);
+}
+template <typename Dtype>
+void BoxOutputLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const BoxOutputParameter p = this->layer_param_.box_output_param();
+  const int n = (int)bottom.size();
+  CHECK_EQ(n, p.field_h_size());        // :80-82
+  CHECK_EQ(n, p.field_w_size());
+  CHECK_EQ(n, p.downsample_rate_size());
+  mscnn_boxoutput_desc d;
+  std::memset(&d, 0, sizeof(d));
+  CHECK_LE(n, MSCNN_BOXOUT_MAX_HEADS);
+  d.num_heads = n;
+  d.num = bottom[0]->num();
+  d.channels = bottom[0]->channels();
+  const float* heads[MSCNN_BOXOUT_MAX_HEADS];
+  for (int j = 0; j < n; ++j) {
+    CHECK_EQ(bottom[j]->num(), d.num);
+    CHECK_EQ(bottom[j]->channels(), d.channels);
+    d.head_h[j] = bottom[j]->height(); d.head_w[j] = bottom[j]->width();
+    d.field_w[j] = (float)p.field_w(j); d.field_h[j] = (float)p.field_h(j); d.downsample_rate[j] = (float)p.downsample_rate(j);
+    heads[j] = bottom[j]->gpu_data();
+  }
+  d.fg_thr = fg_thr_; d.iou_thr = iou_thr_;
+  d.nms_mode = nms_type_ == "IOMU" ? 1 : nms_type_ == "IOFU" ? 2 : 0;   // BoxIOU: anything else is IOU (math_functions.cpp:26-32)
+  d.field_whr = p.field_whr(); d.field_xyr = p.field_xyr();
+  d.max_nms_num = (int)p.max_nms_num(); d.max_post_nms_num = (int)p.max_post_nms_num();
+  d.min_size = p.min_size();
+  const BBoxRegParameter br = this->layer_param_.bbox_reg_param();
+  if (br.bbox_mean_size() > 0 && br.bbox_std_size() > 0) {   // :92-103
+    CHECK_EQ(br.bbox_mean_size(), 4); CHECK_EQ(br.bbox_std_size(), 4);
+    d.do_bbox_norm = 1;
+    for (int k = 0; k < 4; ++k) { d.bbox_mean[k] = br.bbox_mean(k); d.bbox_std[k] = br.bbox_std(k); }
+  }
+  const size_t wbytes = mscnn_boxoutput_workspace_bytes(&d);
+  CHECK_GT(wbytes, 0u) << mscnn_last_error();
+  void* ws = workspace_.Reserve(wbytes);
+  cap_ = mscnn_boxoutput_max_rows(&d);
+  float* rois = static_cast<float*>(rois_.Reserve((size_t)cap_ * 5 * sizeof(float)));
+  float* props = static_cast<float*>(props_.Reserve((size_t)cap_ * 6 * sizeof(float)));
+  int* count = static_cast<int*>(count_.Reserve(2 * sizeof(int)));
+  MSCNN_CHECK(mscnn_boxoutput_fwd_f32(&d, heads, rois, output_proposal_with_score_ ? props : nullptr, nullptr, cap_, count, ws, wbytes, S()));
+  // The only host round trip of the layer: R (4 bytes) is needed to Reshape the tops (layer.hpp:451-456 propagates it
+  // to ROIPooling and the detection sub-net).  The reference moves all 7 head blobs D2H and the ROIs H2D here.
+  int host_count[2];
+  HIP_CHECK(hipMemcpyAsync(host_count, count, sizeof(host_count), hipMemcpyDeviceToHost, (hipStream_t)S()));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)S()));
+  const int R = host_count[0];
+  CHECK_GE(R, 1); CHECK_LE(R, cap_);
+  last_rows_ = R;
+  top[0]->Reshape(R, 5, 1, 1);
+  HIP_CHECK(hipMemcpyAsync(top[0]->mutable_gpu_data(), rois, sizeof(float) * 5 * R, hipMemcpyDeviceToDevice, (hipStream_t)S()));
+  if (output_proposal_with_score_) {
+    top[1]->Reshape(R, 6, 1, 1);
+    HIP_CHECK(hipMemcpyAsync(top[1]->mutable_gpu_data(), props, sizeof(float) * 6 * R, hipMemcpyDeviceToDevice, (hipStream_t)S()));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ DecodeBBox
+template <typename Dtype>
+void DecodeBBoxLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const BBoxRegParameter p = this->layer_param_.bbox_reg_param();   // decode_bbox_layer.cpp:18-36
+  if (p.bbox_mean_size() > 0 && p.bbox_std_size() > 0) {
+    CHECK_EQ(p.bbox_mean_size(), 4); CHECK_EQ(p.bbox_std_size(), 4);
+    for (int i = 0; i < 4; ++i) {
+      bbox_mean_[i] = p.bbox_mean(i); bbox_std_[i] = p.bbox_std(i);
+      CHECK_GT(bbox_std_[i], 0);
+    }
+  } else {
+    for (int i = 0; i < 4; ++i) { bbox_mean_[i] = 0; bbox_std_[i] = 1; }
+  }
+}
+template <typename Dtype>
+void DecodeBBoxLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  CHECK_EQ(bottom[0]->num(), bottom[1]->num());   // :39-52
+  CHECK(this->phase_ == TEST) << "DecodeBBox: TRAIN-phase filtering is outside the inference path";
+  CHECK_EQ(bottom[0]->channels(), 8);
+  CHECK_EQ(bottom[1]->channels(), 5);
+  top[0]->ReshapeLike(*bottom[1]);
+}
+template <typename Dtype>
+void DecodeBBoxLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  MSCNN_CHECK(mscnn_decodebbox_fwd_f32(bottom[0]->gpu_data(), bottom[1]->gpu_data(), top[0]->mutable_gpu_data(), bottom[0]->num(),
+                                       bottom[0]->channels(), bbox_mean_, bbox_std_, S()));
+}
+
+INSTANTIATE_CLASS(InputLayer);
+INSTANTIATE_CLASS(SplitLayer);
+INSTANTIATE_CLASS(ConvolutionLayer);
+INSTANTIATE_CLASS(DeconvolutionLayer);
+INSTANTIATE_CLASS(PoolingLayer);
+INSTANTIATE_CLASS(ReLULayer);
+INSTANTIATE_CLASS(InnerProductLayer);
+INSTANTIATE_CLASS(ConcatLayer);
+INSTANTIATE_CLASS(DropoutLayer);
+INSTANTIATE_CLASS(SoftmaxLayer);
+INSTANTIATE_CLASS(ROIPoolingLayer);
+INSTANTIATE_CLASS(BoxOutputLayer);
+INSTANTIATE_CLASS(DecodeBBoxLayer);
+
+REGISTER_LAYER_CLASS(Input);
+REGISTER_LAYER_CLASS(Split);
+REGISTER_LAYER_CLASS(Convolution);
+REGISTER_LAYER_CLASS(Deconvolution);
+REGISTER_LAYER_CLASS(Pooling);
+REGISTER_LAYER_CLASS(ReLU);
+REGISTER_LAYER_CLASS(InnerProduct);
+REGISTER_LAYER_CLASS(Concat);
+REGISTER_LAYER_CLASS(Dropout);
+REGISTER_LAYER_CLASS(Softmax);
+REGISTER_LAYER_CLASS(ROIPooling);
+REGISTER_LAYER_CLASS(BoxOutput);
+REGISTER_LAYER_CLASS(DecodeBBox);
+
+}  // namespace caffe

@@ -1,0 +1,356 @@
+// Net<Dtype>: graph construction + sequential forward executor.
+// Reference behaviour restated from src/caffe/net.cpp:49-284 (Init), :544-575 (ForwardFromTo / Forward), :743-747
+// (Reshape), src/caffe/util/upgrade_proto.cpp:966-1003 (legacy input upgrade) and
+// src/caffe/util/insert_splits.cpp:14-126 (automatic Split layers, identical blob/layer naming).
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <set>
+#include <sstream>
+#include <utility>
+
+#include "caffe/layer_factory.hpp"
+#include "caffe/layers/mscnn_layers.hpp"
+#include "caffe/net.hpp"
+
+namespace caffe {
+
+using std::make_pair;
+using std::map;
+using std::pair;
+using std::set;
+
+void UpgradeNetInput(const NetParameter& in, vector<LayerParameter>* layers) {
+  layers->clear();
+  // legacy `input:` + 4 x `input_dim:` (or input_shape) becomes an Input layer named "input" at the front
+  const bool has_shape = in.input_shape_size() > 0;
+  const bool has_dim = in.input_dim_size() > 0;
+  if (in.input_size() > 0) {
+    LayerParameter lp;
+    lp.set_name("input");
+    lp.set_type("Input");
+    TextMessage* ip = lp.mutable_raw()->add_message("input_param");
+    for (int i = 0; i < in.input_size(); ++i) {
+      lp.add_top(in.input(i));
+      TextMessage* shape = ip->add_message("shape");
+      if (has_shape) {
+        const BlobShape s = in.input_shape(i);
+        for (int d = 0; d < s.dim_size(); ++d) shape->add_scalar("dim", std::to_string(s.dim(d)));
+      } else if (has_dim) {
+        CHECK_EQ(in.input_dim_size(), 4 * in.input_size()) << "input_dim must have 4 entries per input";
+        for (int d = 0; d < 4; ++d) shape->add_scalar("dim", std::to_string(in.input_dim(4 * i + d)));
+      }
+    }
+    layers->push_back(lp);
+  }
+  CHECK(!in.has_legacy_layers()) << "V1 'layers' prototxt is not supported; use 'layer'";
+  for (int i = 0; i < in.layer_size(); ++i) layers->push_back(in.layer(i).Clone());
+}
+
+static string SplitLayerName(const string& layer_name, const string& blob_name, const int blob_idx) {
+  std::ostringstream s;
+  s << blob_name << "_" << layer_name << "_" << blob_idx << "_split";
+  return s.str();
+}
+static string SplitBlobName(const string& layer_name, const string& blob_name, const int blob_idx, const int split_idx) {
+  std::ostringstream s;
+  s << blob_name << "_" << layer_name << "_" << blob_idx << "_split_" << split_idx;
+  return s.str();
+}
+
+void InsertSplits(const vector<LayerParameter>& in, vector<LayerParameter>* out) {
+  out->clear();
+  map<string, pair<int, int> > blob_name_to_last_top_idx;
+  map<pair<int, int>, pair<int, int> > bottom_idx_to_source_top_idx;
+  map<pair<int, int>, int> top_idx_to_bottom_count;
+  map<pair<int, int>, int> top_idx_to_bottom_split_idx;
+  for (size_t i = 0; i < in.size(); ++i) {
+    const LayerParameter& lp = in[i];
+    for (int j = 0; j < lp.bottom_size(); ++j) {
+      const string& blob_name = lp.bottom(j);
+      CHECK(blob_name_to_last_top_idx.count(blob_name)) << "Unknown bottom blob '" << blob_name << "' (layer '" << lp.name() << "', bottom index " << j << ")";
+      const pair<int, int> top_idx = blob_name_to_last_top_idx[blob_name];
+      bottom_idx_to_source_top_idx[make_pair((int)i, j)] = top_idx;
+      ++top_idx_to_bottom_count[top_idx];
+    }
+    for (int j = 0; j < lp.top_size(); ++j) blob_name_to_last_top_idx[lp.top(j)] = make_pair((int)i, j);
+  }
+  for (size_t i = 0; i < in.size(); ++i) {
+    LayerParameter lp = in[i].Clone();
+    for (int j = 0; j < lp.bottom_size(); ++j) {
+      const pair<int, int> top_idx = bottom_idx_to_source_top_idx[make_pair((int)i, j)];
+      if (top_idx_to_bottom_count[top_idx] > 1) {
+        const string layer_name = in[top_idx.first].name();
+        const string blob_name = lp.bottom(j);
+        lp.set_bottom(j, SplitBlobName(layer_name, blob_name, top_idx.second, top_idx_to_bottom_split_idx[top_idx]++));
+      }
+    }
+    out->push_back(lp);
+    for (int j = 0; j < lp.top_size(); ++j) {
+      const pair<int, int> top_idx = make_pair((int)i, j);
+      const int split_count = top_idx_to_bottom_count[top_idx];
+      if (split_count > 1) {
+        LayerParameter sp;
+        sp.add_bottom(lp.top(j));
+        sp.set_name(SplitLayerName(lp.name(), lp.top(j), j));
+        sp.set_type("Split");
+        for (int k = 0; k < split_count; ++k) sp.add_top(SplitBlobName(lp.name(), lp.top(j), j, k));
+        out->push_back(sp);
+      }
+    }
+  }
+}
+
+template <typename Dtype>
+Net<Dtype>::Net(const NetParameter& param, Phase phase) : phase_(phase), fusion_(true), timing_(false) { Init(param); }
+
+template <typename Dtype>
+Net<Dtype>::Net(const string& param_file, Phase phase) : phase_(phase), fusion_(true), timing_(false) {
+  NetParameter param;
+  ReadNetParamsFromTextFileOrDie(param_file, &param);
+  Init(param);
+}
+
+static bool StateMeetsRule(Phase phase, const NetStateRule& rule) { return !rule.has_phase() || rule.phase() == phase; }
+
+template <typename Dtype>
+void Net<Dtype>::Init(const NetParameter& in_param) {
+  const char* nofuse = std::getenv("MSCNN_NO_FUSE");
+  if (nofuse && *nofuse && *nofuse != '0') fusion_ = false;
+  name_ = in_param.name();
+  vector<LayerParameter> upgraded, filtered, layers;
+  UpgradeNetInput(in_param, &upgraded);
+  // FilterNet (net.cpp:286-318): include/exclude rules on phase
+  for (const LayerParameter& lp : upgraded) {
+    CHECK(lp.include_size() == 0 || lp.exclude_size() == 0) << "Specify either include rules or exclude rules; not both.";
+    bool included = (lp.include_size() == 0);
+    for (int j = 0; included && j < lp.exclude_size(); ++j)
+      if (StateMeetsRule(phase_, lp.exclude(j))) included = false;
+    for (int j = 0; !included && j < lp.include_size(); ++j)
+      if (StateMeetsRule(phase_, lp.include(j))) included = true;
+    if (included) filtered.push_back(lp);
+  }
+  InsertSplits(filtered, &layers);
+
+  map<string, int> blob_name_to_idx;
+  set<string> available_blobs;
+  bottom_vecs_.resize(layers.size());
+  top_vecs_.resize(layers.size());
+  bottom_id_vecs_.resize(layers.size());
+  top_id_vecs_.resize(layers.size());
+  for (size_t layer_id = 0; layer_id < layers.size(); ++layer_id) {
+    LayerParameter lp = layers[layer_id];
+    if (!lp.has_phase()) lp.set_phase(phase_);
+    layers_.push_back(LayerRegistry<Dtype>::CreateLayer(lp));
+    layer_names_.push_back(lp.name());
+    LOG(INFO) << "Creating Layer " << lp.name();
+    // AppendBottom (net.cpp:426-451)
+    for (int b = 0; b < lp.bottom_size(); ++b) {
+      const string& blob_name = lp.bottom(b);
+      CHECK(available_blobs.count(blob_name)) << "Unknown bottom blob '" << blob_name << "' (layer '" << lp.name() << "', bottom index " << b << ")";
+      const int blob_id = blob_name_to_idx[blob_name];
+      LOG(INFO) << lp.name() << " <- " << blob_name;
+      bottom_vecs_[layer_id].push_back(blobs_[blob_id].get());
+      bottom_id_vecs_[layer_id].push_back(blob_id);
+      available_blobs.erase(blob_name);
+    }
+    // AppendTop (net.cpp:376-423)
+    for (int t = 0; t < lp.top_size(); ++t) {
+      const string& blob_name = lp.top(t);
+      if (lp.bottom_size() > t && blob_name == lp.bottom(t)) {
+        LOG(INFO) << lp.name() << " -> " << blob_name << " (in-place)";
+        top_vecs_[layer_id].push_back(blobs_[blob_name_to_idx[blob_name]].get());
+        top_id_vecs_[layer_id].push_back(blob_name_to_idx[blob_name]);
+      } else {
+        CHECK(!blob_name_to_idx.count(blob_name)) << "Top blob '" << blob_name << "' produced by multiple sources.";
+        LOG(INFO) << lp.name() << " -> " << blob_name;
+        shared_ptr<Blob<Dtype> > blob_pointer(new Blob<Dtype>());
+        const int blob_id = (int)blobs_.size();
+        blobs_.push_back(blob_pointer);
+        blob_names_.push_back(blob_name);
+        blob_name_to_idx[blob_name] = blob_id;
+        top_id_vecs_[layer_id].push_back(blob_id);
+        top_vecs_[layer_id].push_back(blob_pointer.get());
+        if (lp.type() == "Input") {
+          net_input_blob_indices_.push_back(blob_id);
+          net_input_blobs_.push_back(blob_pointer.get());
+        }
+      }
+      available_blobs.insert(blob_name);
+    }
+    layers_[layer_id]->SetUp(bottom_vecs_[layer_id], top_vecs_[layer_id]);
+    for (size_t t = 0; t < top_vecs_[layer_id].size(); ++t)
+      LOG(INFO) << "Top shape: " << top_vecs_[layer_id][t]->shape_string();   // net.cpp:158
+  }
+  // remaining blobs are outputs, in std::set (alphabetical) order -- net.cpp:267-274
+  for (set<string>::iterator it = available_blobs.begin(); it != available_blobs.end(); ++it) {
+    LOG(INFO) << "This network produces output " << *it;
+    net_output_blobs_.push_back(blobs_[blob_name_to_idx[*it]].get());
+    net_output_blob_indices_.push_back(blob_name_to_idx[*it]);
+  }
+  for (size_t i = 0; i < blob_names_.size(); ++i) blob_names_index_[blob_names_[i]] = (int)i;
+  for (size_t i = 0; i < layer_names_.size(); ++i) layer_names_index_[layer_names_[i]] = (int)i;
+  fused_away_.assign(layers_.size(), false);
+  layer_ms_.assign(layers_.size(), 0.f);
+  if (fusion_) ApplyFusion();
+  LOG(INFO) << "Network initialization done.";
+}
+
+// Conv / InnerProduct followed by an in-place ReLU on its top (every trunk conv of the deploy nets): the ReLU is
+// applied in the producer's epilogue and the ReLU layer becomes a no-op.  Bit-identical to the unfused pair.
+template <typename Dtype>
+void Net<Dtype>::ApplyFusion() {
+  for (size_t i = 0; i + 1 < layers_.size(); ++i) {
+    const string t = layers_[i]->type();
+    if (t != "Convolution" && t != "InnerProduct") continue;
+    if (string(layers_[i + 1]->type()) != "ReLU") continue;
+    if (top_vecs_[i].size() != 1 || bottom_vecs_[i + 1].size() != 1) continue;
+    if (bottom_vecs_[i + 1][0] != top_vecs_[i][0] || top_vecs_[i + 1][0] != top_vecs_[i][0]) continue;   // in-place only
+    const Dtype slope = layers_[i + 1]->layer_param().relu_param().negative_slope();
+    if (layers_[i]->FuseReLU(slope)) fused_away_[i + 1] = true;
+  }
+}
+
+template <typename Dtype>
+Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
+  CHECK_GE(start, 0);
+  CHECK_LT(end, (int)layers_.size());
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timing_) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
+  for (int i = start; i <= end; ++i) {
+    if (fused_away_[i]) { layer_ms_[i] = 0.f; continue; }
+    if (timing_) HIP_CHECK(hipEventRecord(e0, (hipStream_t)Caffe::stream()));
+    layers_[i]->Forward(bottom_vecs_[i], top_vecs_[i]);
+    if (timing_) {
+      HIP_CHECK(hipEventRecord(e1, (hipStream_t)Caffe::stream()));
+      HIP_CHECK(hipEventSynchronize(e1));
+      HIP_CHECK(hipEventElapsedTime(&layer_ms_[i], e0, e1));
+    }
+  }
+  if (timing_) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+  return 0;
+}
+
+template <typename Dtype>
+const vector<Blob<Dtype>*>& Net<Dtype>::Forward(Dtype* loss) {
+  const Dtype l = ForwardFromTo(0, (int)layers_.size() - 1);
+  if (loss != NULL) *loss = l;
+  return net_output_blobs_;
+}
+
+template <typename Dtype>
+void Net<Dtype>::Reshape() {
+  for (size_t i = 0; i < layers_.size(); ++i) layers_[i]->Reshape(bottom_vecs_[i], top_vecs_[i]);
+}
+
+template <typename Dtype>
+void Net<Dtype>::MarkWeightsChanged() {
+  for (size_t i = 0; i < layers_.size(); ++i) layers_[i]->OnWeightsChanged();
+}
+
+template <typename Dtype>
+bool Net<Dtype>::has_blob(const string& blob_name) const { return blob_names_index_.find(blob_name) != blob_names_index_.end(); }
+
+template <typename Dtype>
+const shared_ptr<Blob<Dtype> > Net<Dtype>::blob_by_name(const string& blob_name) const {
+  shared_ptr<Blob<Dtype> > blob_ptr;
+  if (has_blob(blob_name)) blob_ptr = blobs_[blob_names_index_.find(blob_name)->second];
+  else LOG(WARNING) << "Unknown blob name " << blob_name;
+  return blob_ptr;
+}
+
+template <typename Dtype>
+bool Net<Dtype>::has_layer(const string& layer_name) const { return layer_names_index_.find(layer_name) != layer_names_index_.end(); }
+
+template <typename Dtype>
+const shared_ptr<Layer<Dtype> > Net<Dtype>::layer_by_name(const string& layer_name) const {
+  shared_ptr<Layer<Dtype> > layer_ptr;
+  if (has_layer(layer_name)) layer_ptr = layers_[layer_names_index_.find(layer_name)->second];
+  else LOG(WARNING) << "Unknown layer name " << layer_name;
+  return layer_ptr;
+}
+
+// ---- .caffemodel (binary NetParameter) reader: varint / length-delimited / packed float only ------------------
+// caffe.proto: NetParameter{ layer = 100 } ; LayerParameter{ name = 1, blobs = 7 } ;
+// BlobProto{ num=1 channels=2 height=3 width=4 data=5 (packed float) shape=7 } ; BlobShape{ dim=1 (packed int64) }
+namespace {
+struct Reader {
+  const unsigned char* p; const unsigned char* end;
+  bool ok() const { return p < end; }
+  unsigned long long varint() {
+    unsigned long long v = 0; int shift = 0;
+    while (p < end) { const unsigned char b = *p++; v |= (unsigned long long)(b & 0x7f) << shift; if (!(b & 0x80)) break; shift += 7; }
+    return v;
+  }
+  Reader sub() { const size_t n = (size_t)varint(); CHECK_LE(n, (size_t)(end - p)) << "truncated caffemodel"; Reader r{p, p + n}; p += n; return r; }
+  void skip(int wire) {
+    if (wire == 0) varint();
+    else if (wire == 1) p += 8;
+    else if (wire == 2) { const size_t n = (size_t)varint(); p += n; }
+    else if (wire == 5) p += 4;
+    else LOG(FATAL) << "unsupported wire type " << wire << " in caffemodel";
+  }
+};
+struct ParsedBlob { vector<int> shape; vector<float> data; int legacy[4] = {0, 0, 0, 0}; bool has_legacy = false; };
+}  // namespace
+
+template <typename Dtype>
+void Net<Dtype>::CopyTrainedLayersFrom(const string& trained_filename) {
+  string bytes;
+  CHECK(ReadFileToString(trained_filename, &bytes)) << "cannot read " << trained_filename;
+  Reader net{(const unsigned char*)bytes.data(), (const unsigned char*)bytes.data() + bytes.size()};
+  int copied = 0;
+  while (net.ok()) {
+    const unsigned long long key = net.varint();
+    const int field = (int)(key >> 3), wire = (int)(key & 7);
+    if (!(field == 100 && wire == 2)) { CHECK(!(field == 2 && wire == 2)) << "V1 caffemodel (layers = 2) is not supported"; net.skip(wire); continue; }
+    Reader lr = net.sub();
+    string lname;
+    vector<ParsedBlob> pblobs;
+    while (lr.ok()) {
+      const unsigned long long k = lr.varint();
+      const int f = (int)(k >> 3), w = (int)(k & 7);
+      if (f == 1 && w == 2) { Reader s = lr.sub(); lname.assign((const char*)s.p, (size_t)(s.end - s.p)); }
+      else if (f == 7 && w == 2) {
+        Reader br = lr.sub();
+        ParsedBlob pb;
+        while (br.ok()) {
+          const unsigned long long bk = br.varint();
+          const int bf = (int)(bk >> 3), bw = (int)(bk & 7);
+          if (bf >= 1 && bf <= 4 && bw == 0) { pb.legacy[bf - 1] = (int)br.varint(); pb.has_legacy = true; }
+          else if (bf == 5 && bw == 2) { Reader d = br.sub(); const size_t n = (size_t)(d.end - d.p) / 4; const size_t o = pb.data.size(); pb.data.resize(o + n); memcpy(pb.data.data() + o, d.p, n * 4); }
+          else if (bf == 5 && bw == 5) { float v; memcpy(&v, br.p, 4); br.p += 4; pb.data.push_back(v); }
+          else if (bf == 7 && bw == 2) {
+            Reader sr = br.sub();
+            while (sr.ok()) {
+              const unsigned long long sk = sr.varint();
+              if ((sk >> 3) == 1 && (sk & 7) == 2) { Reader dr = sr.sub(); while (dr.ok()) pb.shape.push_back((int)dr.varint()); }
+              else if ((sk >> 3) == 1 && (sk & 7) == 0) pb.shape.push_back((int)sr.varint());
+              else sr.skip((int)(sk & 7));
+            }
+          } else br.skip(bw);
+        }
+        pblobs.push_back(pb);
+      } else lr.skip(w);
+    }
+    if (!has_layer(lname)) { LOG(INFO) << "Ignoring source layer " << lname; continue; }   // net.cpp:760-764
+    shared_ptr<Layer<Dtype> > layer = layer_by_name(lname);
+    vector<shared_ptr<Blob<Dtype> > >& target = layer->blobs();
+    if (pblobs.empty()) continue;
+    CHECK_EQ(target.size(), pblobs.size()) << "Incompatible number of blobs for layer " << lname;
+    for (size_t j = 0; j < target.size(); ++j) {
+      CHECK_EQ((size_t)target[j]->count(), pblobs[j].data.size())
+          << "Cannot copy param " << j << " weights from layer '" << lname << "'; shape mismatch (target " << target[j]->shape_string() << ")";
+      memcpy(target[j]->mutable_cpu_data(), pblobs[j].data.data(), sizeof(float) * pblobs[j].data.size());   // blob.cpp:448-482
+    }
+    layer->OnWeightsChanged();
+    ++copied;
+  }
+  LOG(INFO) << "Copied weights of " << copied << " layers from " << trained_filename;
+}
+
+INSTANTIATE_CLASS(Net);
+
+}  // namespace caffe

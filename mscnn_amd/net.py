@@ -1,0 +1,181 @@
+"""ctypes binding of libmscnn_caffe.so (include/mscnn_net.h): the Caffe-compatible C++ runtime.
+
+Mirrors the slice of matcaffe / pycaffe the reference's drivers use (caffe.Net(prototxt, 'test'), net.forward,
+blob get/set; examples/kitti_car/run_mscnn_detection.m:24,72-79).  No CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmscnn_caffe.so")
+_lib = None
+
+
+class NetError(RuntimeError):
+    pass
+
+
+class DetectParams(C.Structure):
+    _fields_ = [("cls_id", C.c_int), ("bbox_mean", C.c_float * 4), ("bbox_std", C.c_float * 4), ("proposal_thr", C.c_float),
+                ("ratio_h", C.c_double), ("ratio_w", C.c_double), ("org_h", C.c_double), ("org_w", C.c_double),
+                ("nms_overlap", C.c_double)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NetError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        C.CDLL(os.path.join(_HERE, "libmscnn_hip.so"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(LIB_PATH)
+        for f in ("mscnn_net_last_error", "mscnn_net_layer_name", "mscnn_net_layer_type", "mscnn_net_layer_bottom",
+                  "mscnn_net_layer_top", "mscnn_net_layer_kernel", "mscnn_net_blob_name", "mscnn_net_output_name"):
+            getattr(L, f).restype = C.c_char_p
+        L.mscnn_net_layer_flops.restype = C.c_double
+        L.mscnn_net_layer_ms.restype = C.c_float
+        L.mscnn_net_blob_device_ptr.restype = C.c_void_p
+        L.mscnn_net_destroy.restype = None
+        vp, ci, cs = C.c_void_p, C.c_int, C.c_char_p
+        sig = {
+            "mscnn_net_create_from_file": [cs, ci, vp], "mscnn_net_create_from_string": [cs, ci, vp], "mscnn_net_destroy": [vp],
+            "mscnn_net_load_caffemodel": [vp, cs], "mscnn_net_set_stream": [vp], "mscnn_net_num_layers": [vp],
+            "mscnn_net_layer_name": [vp, ci], "mscnn_net_layer_type": [vp, ci], "mscnn_net_layer_index": [vp, cs],
+            "mscnn_net_layer_num_bottoms": [vp, ci], "mscnn_net_layer_num_tops": [vp, ci], "mscnn_net_layer_bottom": [vp, ci, ci],
+            "mscnn_net_layer_top": [vp, ci, ci], "mscnn_net_layer_num_params": [vp, ci], "mscnn_net_layer_param_shape": [vp, ci, ci, vp, vp],
+            "mscnn_net_layer_fused_away": [vp, ci], "mscnn_net_layer_kernel": [vp, ci], "mscnn_net_layer_flops": [vp, ci],
+            "mscnn_net_num_blobs": [vp], "mscnn_net_blob_name": [vp, ci], "mscnn_net_blob_shape": [vp, cs, vp, vp],
+            "mscnn_net_num_inputs": [vp], "mscnn_net_num_outputs": [vp], "mscnn_net_output_name": [vp, ci],
+            "mscnn_net_set_param": [vp, ci, ci, vp, C.c_size_t], "mscnn_net_get_param": [vp, ci, ci, vp, C.c_size_t],
+            "mscnn_net_set_blob": [vp, cs, vp, C.c_size_t], "mscnn_net_set_blob_device": [vp, cs, vp, C.c_size_t],
+            "mscnn_net_get_blob": [vp, cs, vp, C.c_size_t, vp], "mscnn_net_blob_device_ptr": [vp, cs],
+            "mscnn_net_forward": [vp], "mscnn_net_forward_from_to": [vp, ci, ci], "mscnn_net_reshape": [vp],
+            "mscnn_net_set_layer_timing": [vp, ci], "mscnn_net_layer_ms": [vp, ci],
+            "mscnn_net_detect": [vp, vp, vp, vp, ci, vp, vp],
+        }
+        for name, args in sig.items():
+            getattr(L, name).argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise NetError(lib().mscnn_net_last_error().decode())
+
+
+class Net:
+    """caffe.Net(prototxt, 'test') on one MI355X."""
+
+    def __init__(self, prototxt_path=None, prototxt_text=None, device=0):
+        self._h = C.c_void_p()
+        if prototxt_text is not None:
+            _check(lib().mscnn_net_create_from_string(prototxt_text.encode(), device, C.byref(self._h)))
+        else:
+            _check(lib().mscnn_net_create_from_file(str(prototxt_path).encode(), device, C.byref(self._h)))
+        L = lib()
+        n = L.mscnn_net_num_layers(self._h)
+        self.layer_names = [L.mscnn_net_layer_name(self._h, i).decode() for i in range(n)]
+        self.layer_types = [L.mscnn_net_layer_type(self._h, i).decode() for i in range(n)]
+        self.blob_names = [L.mscnn_net_blob_name(self._h, i).decode() for i in range(L.mscnn_net_num_blobs(self._h))]
+        self.outputs = [L.mscnn_net_output_name(self._h, i).decode() for i in range(L.mscnn_net_num_outputs(self._h))]
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().mscnn_net_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- graph ----
+    def layer_bottoms(self, i):
+        return [lib().mscnn_net_layer_bottom(self._h, i, k).decode() for k in range(lib().mscnn_net_layer_num_bottoms(self._h, i))]
+
+    def layer_tops(self, i):
+        return [lib().mscnn_net_layer_top(self._h, i, k).decode() for k in range(lib().mscnn_net_layer_num_tops(self._h, i))]
+
+    def param_shapes(self, i):
+        out = []
+        for p in range(lib().mscnn_net_layer_num_params(self._h, i)):
+            dims = (C.c_int * 8)(); nd = C.c_int()
+            _check(lib().mscnn_net_layer_param_shape(self._h, i, p, dims, C.byref(nd)))
+            out.append(tuple(dims[:nd.value]))
+        return out
+
+    def blob_shape(self, name):
+        dims = (C.c_int * 8)(); nd = C.c_int()
+        _check(lib().mscnn_net_blob_shape(self._h, name.encode(), dims, C.byref(nd)))
+        return tuple(dims[:nd.value])
+
+    def fused_away(self, i):
+        return bool(lib().mscnn_net_layer_fused_away(self._h, i))
+
+    def layer_kernel(self, i):
+        return lib().mscnn_net_layer_kernel(self._h, i).decode()
+
+    def layer_flops(self, i):
+        return lib().mscnn_net_layer_flops(self._h, i)
+
+    # ---- weights ----
+    def set_param(self, layer, p, arr):
+        i = layer if isinstance(layer, int) else self.layer_names.index(layer)
+        a = np.ascontiguousarray(arr, np.float32)
+        _check(lib().mscnn_net_set_param(self._h, i, p, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get_param(self, layer, p):
+        i = layer if isinstance(layer, int) else self.layer_names.index(layer)
+        shape = self.param_shapes(i)[p]
+        a = np.empty(shape, np.float32)
+        _check(lib().mscnn_net_get_param(self._h, i, p, a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
+    def load_caffemodel(self, path):
+        _check(lib().mscnn_net_load_caffemodel(self._h, str(path).encode()))
+
+    # ---- data ----
+    def set_blob(self, name, arr):
+        if hasattr(arr, "is_cuda"):   # torch CUDA tensor: device -> device
+            assert arr.is_cuda and arr.is_contiguous()
+            _check(lib().mscnn_net_set_blob_device(self._h, name.encode(), C.c_void_p(arr.data_ptr()), arr.numel()))
+            return
+        a = np.ascontiguousarray(arr, np.float32)
+        _check(lib().mscnn_net_set_blob(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get_blob(self, name):
+        a = np.empty(self.blob_shape(name), np.float32)
+        cnt = C.c_size_t()
+        _check(lib().mscnn_net_get_blob(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size, C.byref(cnt)))
+        return a
+
+    def forward(self, start=0, end=-1):
+        if start == 0 and end == -1:
+            _check(lib().mscnn_net_forward(self._h))
+        else:
+            _check(lib().mscnn_net_forward_from_to(self._h, start, end))
+
+    def reshape(self):
+        _check(lib().mscnn_net_reshape(self._h))
+
+    def set_layer_timing(self, on):
+        lib().mscnn_net_set_layer_timing(self._h, int(on))
+
+    def layer_ms(self):
+        return [lib().mscnn_net_layer_ms(self._h, i) for i in range(len(self.layer_names))]
+
+    def detect(self, cls_id, ratios, org_hw, bbox_mean=(0, 0, 0, 0), bbox_std=(0.1, 0.1, 0.2, 0.2), proposal_thr=-10.0,
+               nms_overlap=0.5, cap=4096):
+        """Final detection stage on the device; returns (dets[D,5] float64 [x y w h prob], roi ids[D], R)."""
+        p = DetectParams()
+        p.cls_id = cls_id
+        for k in range(4):
+            p.bbox_mean[k] = bbox_mean[k]; p.bbox_std[k] = bbox_std[k]
+        p.proposal_thr = proposal_thr
+        p.ratio_h, p.ratio_w = ratios
+        p.org_h, p.org_w = org_hw
+        p.nms_overlap = nms_overlap
+        dets = np.zeros((cap, 5), np.float64); ids = np.zeros(cap, np.int32)
+        D = C.c_int(); R = C.c_int()
+        _check(lib().mscnn_net_detect(self._h, C.byref(p), dets.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), cap,
+                                      C.byref(D), C.byref(R)))
+        return dets[:D.value].copy(), ids[:D.value].copy(), R.value

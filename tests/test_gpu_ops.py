@@ -91,8 +91,8 @@ CONV_CASES = [
     (2, 8, 10, 20, 130, (3, 3), (1, 1), (1, 1), 1),         # batch 2, Cout not a multiple of 32
     (1, 32, 18, 60, 9, (5, 5), (2, 2), (1, 1), 1),          # proposal head 5x5
     (1, 16, 9, 30, 9, (7, 7), (3, 3), (1, 1), 1),           # proposal head 7x7
-    (1, 16, 12, 20, 7, (3, 5), (1, 2), (1, 1), 1),          # ped/cyc head 3x5
-    (1, 8, 12, 20, 7, (5, 7), (2, 3), (1, 1), 1),           # ped/cyc head 5x7
+    (1, 16, 12, 20, 7, (5, 3), (2, 1), (1, 1), 1),          # ped/cyc head "3x5" (kernel_w 3, kernel_h 5)
+    (1, 8, 12, 20, 7, (7, 5), (3, 2), (1, 1), 1),           # ped/cyc head "5x7" (kernel_w 5, kernel_h 7)
     (3, 16, 7, 7, 64, (3, 3), (0, 0), (1, 1), 1),           # roi_c1-shaped: R x (C,7,7) no pad -> 5x5
 ]
 

@@ -1,0 +1,127 @@
+"""Boundary tests that need no GPU: the prototxt text-format parser, the generated model zoo against the reference's
+deploy files, and Net graph construction (legacy input upgrade, Split insertion + naming, in-place tops, alphabetical
+outputs, blob shapes) -- reference behaviour: src/caffe/net.cpp:49-284, util/insert_splits.cpp, util/upgrade_proto.cpp."""
+import glob
+import os
+
+import pytest
+
+from mscnn_amd import net as mnet
+from mscnn_amd import zoo
+
+REF = "/root/reference/examples"
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+
+
+def _device():
+    try:
+        import torch
+        return 0 if torch.cuda.is_available() else -1
+    except Exception:
+        return -1
+
+
+class Net(mnet.Net):
+    def __init__(self, path=None, prototxt_text=None):
+        super().__init__(path, prototxt_text=prototxt_text, device=_device())
+
+
+def graph(n):
+    return [(n.layer_names[i], n.layer_types[i], n.layer_bottoms(i), n.layer_tops(i), n.param_shapes(i)) for i in range(len(n.layer_names))]
+
+
+def test_parser_features():
+    txt = '''
+    name: "t"   # trailing comment
+    input: "data" input_dim: 1 input_dim: 3 input_dim: 8 input_dim: 8
+    layer { name: "c" type: "Convolution" bottom: "data" top: "c"
+            convolution_param: { num_output: 4 kernel_size: 3 pad: 1 bias_term: false weight_filler: { type: "bilinear" } } }
+    layer { name: 'r' type: "ReLU" bottom: "c" top: "c" relu_param { negative_slope: -0.5e-1 } }
+    layer { name: "p" type: "Pooling" bottom: "c" top: "p" pooling_param { pool: AVE kernel_size: 2 stride: 2 } }
+    '''
+    n = Net(prototxt_text=txt)
+    assert n.layer_names == ["input", "c", "r", "p"]
+    assert n.layer_types == ["Input", "Convolution", "ReLU", "Pooling"]
+    assert n.blob_shape("data") == (1, 3, 8, 8) and n.blob_shape("c") == (1, 4, 8, 8) and n.blob_shape("p") == (1, 4, 4, 4)
+    assert n.param_shapes(1) == [(4, 3, 3, 3)]                    # bias_term: false
+    assert n.outputs == ["p"]
+    assert not n.fused_away(2)                                     # negative slope != 0 is not fused
+
+
+def test_parse_errors_are_reported():
+    with pytest.raises(mnet.NetError, match="parse error"):
+        Net(prototxt_text='layer { name: "x" type: ')
+    with pytest.raises(mnet.NetError, match="Unknown layer type"):
+        Net(prototxt_text='input: "d" input_dim: 1 input_dim: 1 input_dim: 2 input_dim: 2 layer { name: "x" type: "Nope" bottom: "d" top: "x" }')
+    with pytest.raises(mnet.NetError, match="Unknown bottom blob"):
+        Net(prototxt_text='layer { name: "x" type: "ReLU" bottom: "missing" top: "x" }')
+
+
+def test_7s576_graph_splits_and_shapes():
+    n = Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576"))
+    assert n.blob_shape("data") == (1, 3, 576, 1920)
+    # conv4_3 has 4 consumers (loss1_conv1, pool4, roi_pool_org, roi_pool_ctx): split named after the LAST producer (relu4_3)
+    i = n.layer_names.index("conv4_3_relu4_3_0_split")
+    assert n.layer_types[i] == "Split" and n.layer_bottoms(i) == ["conv4_3"]
+    assert n.layer_tops(i) == [f"conv4_3_relu4_3_0_split_{k}" for k in range(4)]
+    assert n.layer_bottoms(n.layer_names.index("loss1_conv1")) == ["conv4_3_relu4_3_0_split_0"]
+    assert n.layer_bottoms(n.layer_names.index("pool4")) == ["conv4_3_relu4_3_0_split_1"]
+    assert n.layer_bottoms(n.layer_names.index("roi_pool_org")) == ["conv4_3_relu4_3_0_split_2", "proposals_proposals_0_split_0"]
+    assert n.blob_shape("conv4_3") == (1, 512, 72, 240)
+    assert n.blob_shape("conv5_3") == (1, 512, 36, 120) and n.blob_shape("conv6_1") == (1, 512, 18, 60)
+    assert n.blob_shape("pool6") == (1, 512, 9, 30)
+    assert n.blob_shape("LFCN_1_7x7") == (1, 9, 72, 240) and n.blob_shape("LFCN_4_5x5") == (1, 9, 9, 30)
+    assert n.blob_shape("proposals") == (1, 5, 1, 1) and n.blob_shape("proposals_score") == (1, 6, 1, 1)   # dummy reshape
+    assert n.blob_shape("roi_pool") == (1, 1024, 7, 7) and n.blob_shape("roi_c1") == (1, 512, 5, 5)
+    assert n.blob_shape("fc6") == (1, 4096) and n.blob_shape("bbox_pred") == (1, 20)
+    assert n.outputs == ["bbox_pred", "cls_pred", "proposals_score"]          # std::set order, net.cpp:267-274
+    assert n.param_shapes(n.layer_names.index("fc6")) == [(4096, 12800), (4096,)]
+    assert n.param_shapes(n.layer_names.index("LFCN_2_7x7")) == [(9, 512, 7, 7), (9,)]
+    # every in-place ReLU after a conv / fc is folded into its producer
+    for name in ("relu1_1", "relu4_3", "loss_relu1", "roi_c1_relu", "relu6"):
+        assert n.fused_away(n.layer_names.index(name))
+    assert sum(t == "Convolution" for t in n.layer_types) == 23 and sum(t == "Pooling" for t in n.layer_types) == 6
+
+
+def test_other_configs_shapes():
+    n = Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-8s-768-trainval"))
+    assert n.blob_shape("data") == (1, 3, 768, 2560) and n.blob_shape("LFCN_4_7x7") == (1, 9, 12, 40)
+    assert sum(t == "Convolution" for t in n.layer_types) == 24
+    n = Net(prototxt_text=zoo.prototxt("kitti_ped_cyc/mscnn-7s-576-2x"))
+    assert n.blob_shape("conv4_3_2x") == (1, 512, 144, 480) and n.blob_shape("roi_pool") == (1, 1024, 7, 5)
+    assert n.blob_shape("roi_c1") == (1, 512, 5, 3) and n.blob_shape("LFCN_1_5x7") == (1, 7, 72, 240)
+    assert n.param_shapes(n.layer_names.index("LFCN_1_3x5")) == [(7, 512, 5, 3), (7,)]     # kernel_h 5, kernel_w 3
+    assert n.param_shapes(n.layer_names.index("conv4_3_2x")) == [(512, 1, 4, 4)]
+    w = n.get_param("conv4_3_2x", 0)                                                         # bilinear filler
+    assert abs(w[0, 0, 0, 0] - 0.0625) < 1e-7 and abs(w[5, 0, 1, 2] - 0.5625) < 1e-7
+    n = Net(prototxt_text=zoo.prototxt("caltech/mscnn-7s-480"))
+    assert n.blob_shape("pool6") == (1, 512, 8, 10)                                          # ceil-mode pooling: 15 -> 8
+    assert n.blob_shape("roi_c1") == (1, 512, 8, 4) and n.blob_shape("bbox_pred") == (1, 8)
+
+
+@needs_ref
+@pytest.mark.parametrize("model", sorted(zoo.MODELS))
+def test_generated_net_equals_reference_file(model):
+    ref = Net(os.path.join(REF, zoo.MODELS[model][1]))
+    gen = Net(prototxt_text=zoo.prototxt(model))
+    assert graph(gen) == graph(ref)
+    assert gen.blob_names == ref.blob_names and gen.outputs == ref.outputs
+    for b in gen.blob_names:
+        assert gen.blob_shape(b) == ref.blob_shape(b)
+
+
+@needs_ref
+def test_all_reference_deploys_parse():
+    """Every shipped deploy file goes through the text parser; the ones whose layer types are all built (no ROIAlign /
+    Eltwise) also build their graph."""
+    files = sorted(glob.glob(os.path.join(REF, "*/*/mscnn_deploy.prototxt")))
+    assert len(files) == 23
+    built = 0
+    for f in files:
+        try:
+            n = Net(f)
+            assert n.outputs, f
+            built += 1
+        except mnet.NetError as e:
+            assert "Unknown layer type" in str(e), (f, str(e))
+    assert built >= 14
