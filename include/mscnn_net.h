@@ -49,6 +49,8 @@ MSCNN_NET_API const char* mscnn_net_layer_bottom(const mscnn_net* net, int layer
 MSCNN_NET_API const char* mscnn_net_layer_top(const mscnn_net* net, int layer, int i);
 MSCNN_NET_API int mscnn_net_layer_num_params(const mscnn_net* net, int layer);
 MSCNN_NET_API int mscnn_net_layer_param_shape(const mscnn_net* net, int layer, int param, int* dims8, int* ndim);
+/* The layer's LayerParameter in prototxt text form (valid until the next call on this thread). */
+MSCNN_NET_API const char* mscnn_net_layer_param_text(const mscnn_net* net, int layer);
 MSCNN_NET_API int mscnn_net_layer_fused_away(const mscnn_net* net, int layer);              /* 1: ReLU folded into its producer */
 MSCNN_NET_API const char* mscnn_net_layer_kernel(const mscnn_net* net, int layer);          /* conv kernel family, "" otherwise */
 MSCNN_NET_API double mscnn_net_layer_flops(const mscnn_net* net, int layer);                /* of the last forward */

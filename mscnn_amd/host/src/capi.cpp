@@ -99,6 +99,11 @@ int mscnn_net_layer_param_shape(const mscnn_net* n, int l, int p, int* dims8, in
     fill_shape(*n->net->layers()[l]->blobs()[p], dims8, ndim);
   });
 }
+const char* mscnn_net_layer_param_text(const mscnn_net* n, int l) {
+  static thread_local std::string text;
+  text = n->net->layers()[l]->layer_param().raw().DebugString();
+  return text.c_str();
+}
 int mscnn_net_layer_fused_away(const mscnn_net* n, int l) { return n->net->layer_fused_away()[l] ? 1 : 0; }
 const char* mscnn_net_layer_kernel(const mscnn_net* n, int l) {
   auto* c = dynamic_cast<caffe::ConvolutionLayer<float>*>(n->net->layers()[l].get());

@@ -30,7 +30,7 @@ def lib():
         C.CDLL(os.path.join(_HERE, "libmscnn_hip.so"), mode=C.RTLD_GLOBAL)
         L = C.CDLL(LIB_PATH)
         for f in ("mscnn_net_last_error", "mscnn_net_layer_name", "mscnn_net_layer_type", "mscnn_net_layer_bottom",
-                  "mscnn_net_layer_top", "mscnn_net_layer_kernel", "mscnn_net_blob_name", "mscnn_net_output_name"):
+                  "mscnn_net_layer_top", "mscnn_net_layer_kernel", "mscnn_net_layer_param_text", "mscnn_net_blob_name", "mscnn_net_output_name"):
             getattr(L, f).restype = C.c_char_p
         L.mscnn_net_layer_flops.restype = C.c_double
         L.mscnn_net_layer_ms.restype = C.c_float
@@ -43,7 +43,7 @@ def lib():
             "mscnn_net_layer_name": [vp, ci], "mscnn_net_layer_type": [vp, ci], "mscnn_net_layer_index": [vp, cs],
             "mscnn_net_layer_num_bottoms": [vp, ci], "mscnn_net_layer_num_tops": [vp, ci], "mscnn_net_layer_bottom": [vp, ci, ci],
             "mscnn_net_layer_top": [vp, ci, ci], "mscnn_net_layer_num_params": [vp, ci], "mscnn_net_layer_param_shape": [vp, ci, ci, vp, vp],
-            "mscnn_net_layer_fused_away": [vp, ci], "mscnn_net_layer_kernel": [vp, ci], "mscnn_net_layer_flops": [vp, ci],
+            "mscnn_net_layer_fused_away": [vp, ci], "mscnn_net_layer_param_text": [vp, ci], "mscnn_net_layer_kernel": [vp, ci], "mscnn_net_layer_flops": [vp, ci],
             "mscnn_net_num_blobs": [vp], "mscnn_net_blob_name": [vp, ci], "mscnn_net_blob_shape": [vp, cs, vp, vp],
             "mscnn_net_num_inputs": [vp], "mscnn_net_num_outputs": [vp], "mscnn_net_output_name": [vp, ci],
             "mscnn_net_set_param": [vp, ci, ci, vp, C.c_size_t], "mscnn_net_get_param": [vp, ci, ci, vp, C.c_size_t],
@@ -107,6 +107,9 @@ class Net:
         dims = (C.c_int * 8)(); nd = C.c_int()
         _check(lib().mscnn_net_blob_shape(self._h, name.encode(), dims, C.byref(nd)))
         return tuple(dims[:nd.value])
+
+    def layer_param_text(self, i):
+        return lib().mscnn_net_layer_param_text(self._h, i).decode()
 
     def fused_away(self, i):
         return bool(lib().mscnn_net_layer_fused_away(self._h, i))

@@ -221,19 +221,20 @@ ORC_API int orc_pool2d(const float* x, float* y, int* mask, int N, int C, int H,
 /* InnerProduct: src/caffe/layers/inner_product_layer.cpp:83-97          */
 /*   top[M,N] = bottom[M,K] * W[N,K]^T + 1 * bias                         */
 /* ------------------------------------------------------------------ */
-__attribute__((target_clones("avx2", "default")))
 ORC_API int orc_inner_product(const float* x, const float* w, const float* b, float* y,
                               int M, int N, int K) {
-#pragma omp parallel for collapse(2) schedule(static)
-  for (int m = 0; m < M; ++m)
-    for (int n = 0; n < N; ++n) {
-      const float* xr = x + (size_t)m * K;
-      const float* wr = w + (size_t)n * K;
-      float acc = 0.f;
-      for (int k = 0; k < K; ++k) acc += xr[k] * wr[k];
-      if (b) acc += 1.f * b[n];
-      y[(size_t)m * N + n] = acc;
-    }
+  /* cblas_sgemm(NoTrans, Trans) in the reference; here W is transposed once and the k-ascending GEMM above is
+   * used, which is bit-identical to the plain dot-product loop  acc += x[m][k] * w[n][k]. */
+  float* wt = (float*)malloc(sizeof(float) * (size_t)N * K);
+  if (!wt) return -2;
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) wt[(size_t)k * N + n] = w[(size_t)n * K + k];
+  sgemm_nn(M, N, K, x, wt, y, 0);
+  free(wt);
+  if (b)
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < N; ++n) y[(size_t)m * N + n] += 1.f * b[n];
   return 0;
 }
 
