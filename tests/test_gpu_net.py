@@ -73,7 +73,7 @@ def test_net_layerwise_and_end_to_end(model, size, regime, cls_id):
             out = pynet.forward([l], ws, {l[2][0]: n.get_blob(l[2][0]), l[2][1]: rois_dev})[l[3][0]]
             assert np.array_equal(n.get_blob(l[3][0]), out), l[0]
     # detection sub-net with identical inputs
-    sub = [l for l in layers if l[0] in ("roi_pool", "roi_c1", "roi_c1_relu", "fc6", "relu6", "drop6", "cls_pred", "bbox_pred")]
+    sub = layers[[l[0] for l in layers].index("roi_pool"):]            # Concat ... bbox_pred, incl. the auto-inserted Split
     feeds = {b: n.get_blob(b) for b in sub[0][2]}
     r3 = pynet.forward(sub, ws, feeds)
     for b in ("roi_c1", "fc6", "cls_pred", "bbox_pred"):
