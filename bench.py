@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""MS-CNN hot-path benchmark (BASELINE.json metric: images/sec, mscnn-7s-576 KITTI-car inference, fp32).
+
+A step = one synthetic KITTI-shaped frame (already resident in HBM as the 1x3x576x1920 net input) through the whole path:
+VGG-16 trunk + proposal heads (MFMA implicit-GEMM convs) -> BoxOutput (decode / top-2000 / NMS) -> 2 x ROIPooling ->
+roi_c1 + fc6 + cls/bbox heads -> final bbox transform + per-class NMS, with the detections delivered to the host.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+Multi-GPU: independent images per GPU (weak scaling, no data-path collective); the per-step detections of all ranks are
+gathered with one RCCL all_gather of a fixed-size padded buffer.
+
+Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel (the 128x128 implicit-GEMM MFMA conv over conv3_1..conv5_3,
+60 % of the trunk FLOPs) timed with HIP events on the stream the net launches on; `cpu_baseline` = the CPU oracle (or
+oracle/_ref when built) on a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MODEL = "kitti_car/mscnn-7s-576"
+H, W = 576, 1920
+ORG_HW = (375, 1242)
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+ROOFLINE_LAYERS = ["conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3"]
+MAX_DET = 512                           # padded rows per image in the RCCL gather (detections after final NMS)
+
+
+def cpu_baseline(R_gpu, regime):
+    """Bounded CPU sample: the oracle's im2col+GEMM path (the reference's CPU algorithm, conv_layer.cpp:25-40) on a
+    quarter-area frame (288x960) for trunk + heads + BoxOutput, plus the detection sub-net on 32 ROIs; scaled to the full
+    workload (x4 pixels, x R/32 ROIs).  Returns the cpu_baseline object."""
+    from mscnn_amd import net as mnet, synth, zoo
+    from oracle import pynet, pyoracle
+    pyoracle.lib()
+    h, w = H // 2, W // 2
+    n = mnet.Net(prototxt_text=zoo.prototxt(MODEL, height=h, width=w, max_nms_num=32), device=0)
+    layers = [(n.layer_names[i], n.layer_types[i], n.layer_bottoms(i), n.layer_tops(i), n.layer_param_text(i))
+              for i in range(len(n.layer_names))]
+    ws = synth.weights(n.layer_names, n.layer_types, [n.param_shapes(i) for i in range(len(n.layer_names))], regime)
+    x = synth.frame(h, w)
+    names = [l[0] for l in layers]
+    cut = names.index("proposals") + 1
+    t0 = time.perf_counter()
+    blobs = pynet.forward(layers[:cut], ws, {"data": x})
+    t_trunk = time.perf_counter() - t0
+    split = [l for l in layers[cut:]]
+    t0 = time.perf_counter()
+    blobs = pynet.forward(split, ws, blobs)
+    t_det = time.perf_counter() - t0
+    r_sample = blobs["proposals"].shape[0]
+    est = 4.0 * t_trunk + t_det * (R_gpu / max(r_sample, 1))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    return {"value": round(1.0 / est, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle (im2col + k-ordered GEMM, OpenMP) on a 288x960 frame for trunk+heads+BoxOutput ({t_trunk:.2f} s) "
+                      f"and the detection sub-net on {r_sample} ROIs ({t_det:.2f} s), scaled x4 pixels and x{R_gpu}/{r_sample} ROIs",
+            "seconds_per_image_est": round(est, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--regime", default="mid", choices=["dense", "mid", "sparse"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print the per-layer table (caffe time format) to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)       # "nccl" is RCCL on ROCm
+    else:
+        torch.cuda.set_device(local_rank)
+    assert torch.cuda.is_available(), "bench.py needs a MI355X"
+
+    from mscnn_amd import net as mnet, synth, zoo
+    net = mnet.Net(prototxt_text=zoo.prototxt(MODEL), device=local_rank)
+    synth.load_into(net, args.regime)
+    # a handful of distinct frames per rank, resident in HBM before the timed region
+    frames = [torch.from_numpy(synth.frame(H, W, seed=1701 + 97 * rank + i)).cuda() for i in range(4)]
+    kw = dict(cls_id=2, ratios=(H / ORG_HW[0], W / ORG_HW[1]), org_hw=ORG_HW)
+    gather_out = torch.zeros((world, MAX_DET + 1, 6), dtype=torch.float32, device="cuda") if world > 1 else None
+    pad = torch.zeros((MAX_DET + 1, 6), dtype=torch.float32, device="cuda") if world > 1 else None
+    stats = {"R": [], "D": []}
+
+    def step(i):
+        net.set_blob("data", frames[i % len(frames)])        # D2D: the frame is already in HBM
+        net.forward()
+        dets, ids, R = net.detect(**kw)                       # final stage on device; detections land on the host
+        stats["R"].append(R); stats["D"].append(len(dets))
+        if world > 1:                                         # the only collective of the path: detections -> every rank
+            d = min(len(dets), MAX_DET)
+            buf = np.zeros((MAX_DET + 1, 6), np.float32)
+            buf[0, 0] = d
+            buf[1:d + 1, :5] = dets[:d]
+            buf[1:d + 1, 5] = ids[:d]
+            pad.copy_(torch.from_numpy(buf), non_blocking=False)
+            dist.all_gather_into_tensor(gather_out, pad)
+        return dets
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    stats = {"R": [], "D": []}
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: per-layer HIP events on the net's stream, outside the timed region ----
+        net.set_layer_timing(True)
+        acc = np.zeros(len(net.layer_names)); reps = 5
+        for i in range(reps):
+            net.set_blob("data", frames[i % len(frames)])
+            net.forward()
+            acc += np.array(net.layer_ms())
+        net.set_layer_timing(False)
+        lay_ms = acc / reps
+        flops = np.array([net.layer_flops(i) for i in range(len(net.layer_names))])
+        idx = [net.layer_names.index(nm) for nm in ROOFLINE_LAYERS]
+        blk_flops, blk_ms = float(flops[idx].sum()), float(lay_ms[idx].sum())
+        achieved = blk_flops / (blk_ms * 1e-3) / 1e12
+        conv_idx = [i for i, t in enumerate(net.layer_types) if t == "Convolution"]
+        trunk_tf = float(flops[conv_idx].sum()) / (float(lay_ms[conv_idx].sum()) * 1e-3) / 1e12
+        if args.layers:
+            for i, nm in enumerate(net.layer_names):
+                if lay_ms[i] > 0:
+                    tf = flops[i] / (lay_ms[i] * 1e-3) / 1e12 if flops[i] else 0
+                    print(f"{nm:28s} {net.layer_types[i]:14s} {net.layer_kernel(i):30s} {lay_ms[i]*1e3:9.1f} us {tf:7.1f} TF", file=sys.stderr)
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "igemm_kernel<128x128, k3x3> (+ stream-K fix-up) over " + "..".join([ROOFLINE_LAYERS[0], ROOFLINE_LAYERS[-1]]),
+                    "algorithmic_gflop_per_image": round(blk_flops / 1e9, 2), "avg_ms_per_image": round(blk_ms, 4),
+                    "all_conv_tflops": round(trunk_tf, 2)}
+        Rm = float(np.mean(stats["R"]))
+        result = {"metric": "images/sec mscnn-7s-576 KITTI-car inference", "value": round(value, 3), "unit": "images/sec",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                  "config": {"workload": "mscnn-7s-576 KITTI-car fp32, batch=1 per GPU, 1x3x576x1920 frame resident in HBM -> "
+                                         "detections on host (trunk + heads + BoxOutput + ROI pool + det sub-net + final NMS)",
+                             "regime": args.regime, "mean_rois": round(Rm, 1), "mean_detections": round(float(np.mean(stats["D"])), 1),
+                             "parallelism": f"image-parallel x{world}, RCCL all_gather of detections"},
+                  "roofline": roofline}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(max(1, int(round(Rm))), args.regime)
+        stage = {}
+        for i, nm in enumerate(net.layer_names):
+            t = net.layer_types[i]
+            key = ("trunk_conv" if t == "Convolution" and not nm.startswith(("LFCN_", "roi_c1")) else
+                   "head_conv" if nm.startswith("LFCN_") else nm if nm in ("roi_c1", "fc6") else t)
+            stage[key] = stage.get(key, 0.0) + float(lay_ms[i])
+        result["stage_ms"] = {k: round(v, 3) for k, v in sorted(stage.items(), key=lambda kv: -kv[1]) if v > 0.0005}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()
