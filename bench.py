@@ -186,7 +186,13 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    # release every device object before interpreter teardown (HIP calls from destructors after the runtime has
+    # shut down can hang under rocprofv3)
+    del net, frames
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 if __name__ == "__main__":

@@ -32,26 +32,41 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct IgemmArgs {
   const float* x; const float* wp; const float* bias; float* y; float* ws;
-  int Cin, H, W, Cout, Ho, Wo, pad_h, pad_w;
+  int N, Cin, H, W, Cout, Ho, Wo, pad_h, pad_w;
   int MT, NTH, NTW, NT, KI, G, relu;
   long total_iters;
 };
 
-template <int BM_, int BN_, int WGM_, int WGN_, int KH_, int KW_, int CK_, int TW_>
+// Tile configuration.  Two geometries share one kernel:
+//   plane mode (RH == 0): the N side of a tile is a TH x TW patch of one image's output plane (trunk, heads);
+//   ROI mode   (RH  > 0): the images are tiny (RH x RW, e.g. the 7x7 ROI-pooled maps of roi_c1) and a tile packs
+//                         IPT whole images: N side = IPT * OH * OW output pixels.  The reference's CAFFE engine runs
+//                         one im2col+GEMM with N = 25 per ROI here (conv_layer.cu:14-21).
+template <int BM_, int BN_, int WGM_, int WGN_, int KH_, int KW_, int CK_, int TW_, int RH_ = 0, int RW_ = 0, int RP_ = 0>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, KH = KH_, KW = KW_, CK = CK_, TW = TW_;
+  static constexpr bool ROI = RH_ > 0;
+  static constexpr int RH = RH_, RW = RW_, RP = RP_;
   static constexpr int TH = BN / TW;
-  static constexpr int PH = TH + KH - 1, PW = TW + KW - 1, PS = PW;
+  // plane mode patch
+  static constexpr int PH = TH + KH - 1, PW = TW + KW - 1;
+  // ROI mode: padded image, output size, images per tile
+  static constexpr int IPH = RH + 2 * RP, IPW = RW + 2 * RP;
+  static constexpr int OH = ROI ? IPH - KH + 1 : 1, OW = ROI ? IPW - KW + 1 : 1, OPX = OH * OW;
+  static constexpr int IPT = ROI ? BN / OPX : 1;
+  static constexpr int ROWS = ROI ? IPW : PW;                           // LDS row stride of the patch
+  static constexpr int CH_STRIDE = ROI ? IPT * IPH * IPW : PH * PW;     // LDS floats per channel
   static constexpr int TAPS = KH * KW;
   static constexpr int A_ELEMS = TAPS * CK * BM;
   static constexpr int A_VEC4 = A_ELEMS / 4;
   static constexpr int A_PER_T = (A_VEC4 + 255) / 256;
-  static constexpr int B_ELEMS = CK * PH * PW;
+  static constexpr int B_ELEMS = CK * CH_STRIDE;
   static constexpr int B_PER_T = (B_ELEMS + 255) / 256;
-  static constexpr int B_LDS = CK * PH * PS;
   static constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
+  static constexpr int FIX_SPLIT = (BM * BN) / 4096;                    // fix-up workgroups per tile
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(WM % 32 == 0 && WN % 32 == 0 && BN % TW == 0 && CK % 2 == 0 && A_ELEMS % 4 == 0, "tile shape");
+  static_assert((BM * BN) % 4096 == 0, "fix-up split");
 };
 
 __device__ __forceinline__ void wg_range(long total, int G, int g, long& b, long& e) {
@@ -83,10 +98,72 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 }
 constexpr unsigned kOob = 0x80000000u;   // offset that is out of range for every tensor here (< 2 GiB each)
 
+// Where a tile sits: decoded once per stream-K segment (main kernel) / once per workgroup (fix-up kernel).
+template <class C>
+struct TileGeo {
+  int h0, w0, img;   // plane mode
+  int r0;            // ROI mode: first image of the tile
+
+  __device__ __forceinline__ void decode(const IgemmArgs& a, int nt) {
+    if (C::ROI) {
+      r0 = nt * C::IPT; h0 = w0 = img = 0;
+    } else {
+      const int tw = nt % a.NTW, th = (nt / a.NTW) % a.NTH;
+      img = nt / (a.NTW * a.NTH); h0 = th * C::TH; w0 = tw * C::TW; r0 = 0;
+    }
+  }
+  // x / y buffer windows the 32-bit offsets are relative to
+  __device__ __forceinline__ const float* x_base(const IgemmArgs& a) const { return C::ROI ? a.x : a.x + (long)img * a.Cin * a.H * a.W; }
+  __device__ __forceinline__ unsigned x_bytes(const IgemmArgs& a) const {
+    return (unsigned)(C::ROI ? a.N : 1) * (unsigned)a.Cin * (unsigned)(a.H * a.W) * 4u;
+  }
+  __device__ __forceinline__ float* y_base(const IgemmArgs& a) const { return C::ROI ? a.y : a.y + (long)img * a.Cout * a.Ho * a.Wo; }
+  __device__ __forceinline__ unsigned y_bytes(const IgemmArgs& a) const {
+    return (unsigned)(C::ROI ? a.N : 1) * (unsigned)a.Cout * (unsigned)(a.Ho * a.Wo) * 4u;
+  }
+  // float offset (inside x_base, channel-chunk term excluded) of staging element idx, or -1 for zero fill
+  __device__ __forceinline__ int in_off(const IgemmArgs& a, int idx) const {
+    const int ck = idx / C::CH_STRIDE, rem = idx % C::CH_STRIDE;
+    if (idx >= C::B_ELEMS) return -1;
+    if (C::ROI) {
+      const int rl = rem / (C::IPH * C::IPW), e = rem % (C::IPH * C::IPW);
+      const int ih = e / C::IPW - C::RP, iw = e % C::IPW - C::RP, r = r0 + rl;
+      if (r >= a.N || ih < 0 || ih >= C::RH || iw < 0 || iw >= C::RW) return -1;
+      return (r * a.Cin + ck) * (C::RH * C::RW) + ih * C::RW + iw;
+    }
+    const int ih = h0 - a.pad_h + rem / C::PW, iw = w0 - a.pad_w + rem % C::PW;
+    if (ih < 0 || ih >= a.H || iw < 0 || iw >= a.W) return -1;
+    return ck * (a.H * a.W) + ih * a.W + iw;
+  }
+  // float offset (inside y_base) of output pixel p of the tile for channel 0, or -1 when p is padding
+  __device__ __forceinline__ int out_off(const IgemmArgs& a, int p) const {
+    if (C::ROI) {
+      const int rl = p / C::OPX, q = p % C::OPX, r = r0 + rl;
+      if (rl >= C::IPT || r >= a.N) return -1;
+      return r * a.Cout * C::OPX + q;
+    }
+    const int oh = h0 + p / C::TW, ow = w0 + p % C::TW;
+    if (oh >= a.Ho || ow >= a.Wo) return -1;
+    return oh * a.Wo + ow;
+  }
+};
+
+// LDS float offset of output pixel p's top-left input sample inside one channel of the staged patch
+template <class C>
+__device__ __forceinline__ int lane_patch_off(int p) {
+  if (C::ROI) {
+    int rl = p / C::OPX;
+    const int q = p % C::OPX;
+    if (rl >= C::IPT) rl = 0;          // padding lanes read something valid; their results are dropped
+    return rl * (C::IPH * C::IPW) + (q / C::OW) * C::IPW + q % C::OW;
+  }
+  return (p / C::TW) * C::PW + p % C::TW;
+}
+
 template <class C>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   __shared__ __attribute__((aligned(16))) float ldsA[C::A_ELEMS];
-  __shared__ float ldsB[C::B_LDS];
+  __shared__ float ldsB[C::B_ELEMS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -100,36 +177,30 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   const float* aRd = ldsA + khalf * C::BM + wm * C::WM + l31;
   const float* bRd[C::NI];
 #pragma unroll
-  for (int ni = 0; ni < C::NI; ++ni) {
-    const int p = wn * C::WN + ni * 32 + l31;
-    bRd[ni] = ldsB + (khalf * C::PH + p / C::TW) * C::PS + (p % C::TW);
-  }
+  for (int ni = 0; ni < C::NI; ++ni) bRd[ni] = ldsB + khalf * C::CH_STRIDE + lane_patch_off<C>(wn * C::WN + ni * 32 + l31);
   float4* aWr = reinterpret_cast<float4*>(ldsA) + tid;
 
   const int plane = a.H * a.W;
-  const unsigned x_bytes = (unsigned)a.Cin * plane * 4u, y_bytes = (unsigned)a.Cout * a.Ho * a.Wo * 4u;
+  const bool ragged_c = (a.Cin % C::CK) != 0;    // last chunk has fewer than CK real channels (conv1_1: Cin = 3)
   const __amdgpu_buffer_rsrc_t wsrc = make_rsrc(a.wp, (unsigned)((long)a.MT * a.KI * C::A_ELEMS * 4));
   const __amdgpu_buffer_rsrc_t bias_rsrc = make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+  const int co_stride = a.Ho * a.Wo;
 
   while (it < it_end) {
     const int t = (int)(it / a.KI);
     const int k0 = (int)(it % a.KI);
     const int k1 = (int)min((long)a.KI, k0 + (it_end - it));
-    // tile decode: t = mt * NT + nt ; nt = (img * NTH + th) * NTW + tw
-    const int mt = t / a.NT, nt = t % a.NT;
-    const int tw = nt % a.NTW, th = (nt / a.NTW) % a.NTH, img = nt / (a.NTW * a.NTH);
-    const int h0 = th * C::TH, w0 = tw * C::TW;
-    const __amdgpu_buffer_rsrc_t xsrc = make_rsrc(a.x + (long)img * a.Cin * plane, x_bytes);
+    const int mt = t / a.NT, nt = t % a.NT;       // t = mt * NT + nt
+    TileGeo<C> geo;
+    geo.decode(a, nt);
+    const __amdgpu_buffer_rsrc_t xsrc = make_rsrc(geo.x_base(a), geo.x_bytes(a));
 
-    // byte offsets of this thread's patch elements inside the image (channel chunk term is the scalar offset)
+    // byte offsets of this thread's patch elements (the channel-chunk term is the scalar offset of the load)
     unsigned g_off[C::B_PER_T];
 #pragma unroll
     for (int i = 0; i < C::B_PER_T; ++i) {
-      const int idx = tid + i * 256;
-      const int ck = idx / (C::PH * C::PW), rem = idx % (C::PH * C::PW);
-      const int ih = h0 - a.pad_h + rem / C::PW, iw = w0 - a.pad_w + rem % C::PW;
-      const bool ok = (idx < C::B_ELEMS) && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-      g_off[i] = ok ? (unsigned)(ck * plane + ih * a.W + iw) * 4u : kOob;
+      const int o = geo.in_off(a, tid + i * 256);
+      g_off[i] = o >= 0 ? (unsigned)o * 4u : kOob;
     }
 
     f32x16 acc[C::MI][C::NI];
@@ -153,8 +224,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, vo, a_soff + i * 4096u, 0)); \
       }                                                                                                             \
       const unsigned b_soff = (unsigned)(kc) * (unsigned)(C::CK * 4) * (unsigned)plane;                             \
-      _Pragma("unroll") for (int i = 0; i < C::B_PER_T; ++i)                                                        \
-        rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, g_off[i], b_soff, 0));         \
+      const int c_left = a.Cin - (kc) * C::CK;                                                                      \
+      _Pragma("unroll") for (int i = 0; i < C::B_PER_T; ++i) {                                                      \
+        unsigned vo = g_off[i];                                                                                     \
+        if (ragged_c && (tid + i * 256) / C::CH_STRIDE >= c_left) vo = kOob;                                        \
+        rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, vo, b_soff, 0));               \
+      }                                                                                                             \
     }
 
     MSCNN_LOAD_CHUNK(k0);
@@ -164,11 +239,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       for (int i = 0; i < C::A_PER_T; ++i)
         if (C::A_VEC4 % 256 == 0 || tid + i * 256 < C::A_VEC4) aWr[i * 256] = ra[i];
 #pragma unroll
-      for (int i = 0; i < C::B_PER_T; ++i) {
-        const int idx = tid + i * 256;
-        const int ck = idx / (C::PH * C::PW), rem = idx % (C::PH * C::PW);
-        if (C::B_ELEMS % 256 == 0 || idx < C::B_ELEMS) ldsB[(ck * C::PH + rem / C::PW) * C::PS + rem % C::PW] = rb[i];
-      }
+      for (int i = 0; i < C::B_PER_T; ++i)
+        if (C::B_ELEMS % 256 == 0 || tid + i * 256 < C::B_ELEMS) ldsB[tid + i * 256] = rb[i];
       __syncthreads();
       if (kc + 1 < k1) MSCNN_LOAD_CHUNK(kc + 1);   // in flight while this chunk is multiplied
 #pragma unroll
@@ -181,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int mi = 0; mi < C::MI; ++mi) av[mi] = aRd[((kh * C::KW + kw) * C::CK + cp * 2) * C::BM + mi * 32];
 #pragma unroll
-            for (int ni = 0; ni < C::NI; ++ni) bv[ni] = bRd[ni][(cp * 2 * C::PH + kh) * C::PS + kw];
+            for (int ni = 0; ni < C::NI; ++ni) bv[ni] = bRd[ni][cp * 2 * C::CH_STRIDE + kh * C::ROWS + kw];
 #pragma unroll
             for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
@@ -195,8 +267,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 
     const bool full = (k0 == 0 && k1 == a.KI);
     if (full) {
-      const __amdgpu_buffer_rsrc_t ysrc = make_rsrc(a.y + (long)img * a.Cout * a.Ho * a.Wo, y_bytes);
-      const int HW = a.Ho * a.Wo;
+      const __amdgpu_buffer_rsrc_t ysrc = make_rsrc(geo.y_base(a), geo.y_bytes(a));
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi) {
         const int co0 = mt * C::BM + wm * C::WM + mi * 32 + 4 * khalf;
@@ -207,16 +278,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
                                                    bias_rsrc, (unsigned)co0 * 4u, ((r & 3) + 8 * (r >> 2)) * 4u, 0));
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni) {
-          const int p = wn * C::WN + ni * 32 + l31;
-          const int oh = h0 + p / C::TW, ow = w0 + p % C::TW;
-          const unsigned voff = (oh < a.Ho && ow < a.Wo) ? (unsigned)(co0 * HW + oh * a.Wo + ow) * 4u : kOob;
+          const int o = geo.out_off(a, wn * C::WN + ni * 32 + l31);
+          const unsigned voff = o >= 0 ? (unsigned)(co0 * co_stride + o) * 4u : kOob;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[mi][ni][r] + bvals[r];
             if (a.relu) v = v > 0.f ? v : 0.f;
             const unsigned vo = (co0 + (r & 3) + 8 * (r >> 2) < a.Cout) ? voff : kOob;   // Cout < BM (proposal heads)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, vo,
-                                                  (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)HW * 4u, 0);
+                                                  (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)co_stride * 4u, 0);
           }
         }
       }
@@ -237,38 +307,61 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   }
 }
 
-// Sums the partial slabs of every tile that was split across workgroups, in k order, + bias + ReLU.
+// Sums the partial slabs of every tile that was split across workgroups, in k order (deterministic), + bias + ReLU.
+// FIX_SPLIT workgroups per tile, each owning 4096 consecutive slab elements (16 per thread, float4 loads); the list of
+// contributing slabs is resolved once per workgroup (the 64-bit range arithmetic is kept out of the element loop).
 template <class C>
 __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
-  const int t = blockIdx.x;
-  const long its = (long)t * a.KI, ite = its + a.KI;
-  int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
-  long b, e;
-  wg_range(a.total_iters, a.G, gf, b, e);
-  while (e <= its) { ++gf; wg_range(a.total_iters, a.G, gf, b, e); }
-  while (b > its) { --gf; wg_range(a.total_iters, a.G, gf, b, e); }
-  wg_range(a.total_iters, a.G, gl, b, e);
-  while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
-  while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
-  if (gf == gl) return;   // the tile was computed whole by one workgroup
-
-  const int mt = t / a.NT, nt = t % a.NT;
-  const int tw = nt % a.NTW, th = (nt / a.NTW) % a.NTH, img = nt / (a.NTW * a.NTH);
-  const int h0 = th * C::TH, w0 = tw * C::TW;
-  float* yimg = a.y + (long)img * a.Cout * a.Ho * a.Wo;
-  for (int i = threadIdx.x; i < C::BM * C::BN; i += 256) {
-    const int m = i / C::BN, p = i % C::BN;
-    float v = 0.f;
-    for (int g = gf; g <= gl; ++g) {
-      wg_range(a.total_iters, a.G, g, b, e);
-      const float* slab = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * (C::BM * C::BN);
-      v += slab[i];
+  __shared__ const float* s_slab[64];
+  __shared__ int s_n;
+  const int t = blockIdx.x / C::FIX_SPLIT, part = blockIdx.x % C::FIX_SPLIT;
+  if (threadIdx.x == 0) {
+    const long its = (long)t * a.KI, ite = its + a.KI;
+    int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
+    long b, e;
+    wg_range(a.total_iters, a.G, gf, b, e);
+    while (e <= its) { ++gf; wg_range(a.total_iters, a.G, gf, b, e); }
+    while (b > its) { --gf; wg_range(a.total_iters, a.G, gf, b, e); }
+    wg_range(a.total_iters, a.G, gl, b, e);
+    while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
+    while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
+    int n = 0;
+    if (gf != gl) {           // gf == gl: the tile was computed whole by one workgroup and is already in y
+      for (int g = gf; g <= gl && n < 64; ++g) {
+        wg_range(a.total_iters, a.G, g, b, e);
+        s_slab[n++] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * (C::BM * C::BN);
+      }
     }
-    const int co = mt * C::BM + m, oh = h0 + p / C::TW, ow = w0 + p % C::TW;
-    if (co < a.Cout && oh < a.Ho && ow < a.Wo) {
-      if (a.bias) v += a.bias[co];
-      if (a.relu) v = v > 0.f ? v : 0.f;
-      yimg[((long)co * a.Ho + oh) * a.Wo + ow] = v;
+    s_n = n;
+  }
+  __syncthreads();
+  const int n = s_n;
+  if (n == 0) return;
+  const int mt = t / a.NT, nt = t % a.NT;
+  TileGeo<C> geo;
+  geo.decode(a, nt);
+  float* ybase = geo.y_base(a);
+  const int co_stride = a.Ho * a.Wo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = part * 4096 + (j * 256 + threadIdx.x) * 4;     // 4 consecutive pixels of one output channel row
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < n; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(s_slab[s] + i);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int m = i / C::BN, p = i % C::BN;
+    const int co = mt * C::BM + m;
+    if (co >= a.Cout) continue;
+    const float bv = a.bias ? a.bias[co] : 0.f;
+    const float vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = geo.out_off(a, p + q);
+      if (o < 0) continue;
+      float r = vals[q] + bv;
+      if (a.relu) r = r > 0.f ? r : 0.f;
+      ybase[(long)co * co_stride + o] = r;
     }
   }
 }
@@ -312,12 +405,19 @@ typedef void (*IgemmFn)(IgemmArgs);
 struct KernelEntry {
   const char* name;
   int BM, BN, KH, KW, CK, TW, TH;
+  int RH, RW, RP, IPT, fix_split;
   IgemmFn main_fn, fix_fn;
 };
 
-#define ENTRY(BM, BN, WGM, WGN, KH, KW, CK, TW)                                                        \
-  {"igemm_" #BM "x" #BN "_k" #KH "x" #KW "_tw" #TW, BM, BN, KH, KW, CK, TW, BN / TW,                  \
+#define ENTRY(BM, BN, WGM, WGN, KH, KW, CK, TW)                                                                     \
+  {"igemm_" #BM "x" #BN "_k" #KH "x" #KW "_tw" #TW, BM, BN, KH, KW, CK, TW, BN / TW, 0, 0, 0, 1, (BM * BN) / 4096,     \
    igemm_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW>>, igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW>>}
+// ROI mode entries: images of RH x RW with symmetric pad RP, IPT images per tile
+#define ROI_ENTRY(BM, BN, WGM, WGN, KH, KW, CK, RH, RW, RP)                                                             \
+  {"igemm_" #BM "x" #BN "_k" #KH "x" #KW "_roi" #RH "x" #RW "p" #RP, BM, BN, KH, KW, CK, 0, 0, RH, RW, RP,              \
+   Cfg<BM, BN, WGM, WGN, KH, KW, CK, 32, RH, RW, RP>::IPT, (BM * BN) / 4096,                                            \
+   igemm_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, 32, RH, RW, RP>>,                                                     \
+   igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, 32, RH, RW, RP>>}
 
 const KernelEntry kTable[] = {
     // trunk 3x3
@@ -329,6 +429,10 @@ const KernelEntry kTable[] = {
     ENTRY(32, 128, 1, 4, 7, 7, 8, 16),
     ENTRY(32, 128, 1, 4, 5, 3, 8, 16),   // "3x5" heads are kernel_w 3 x kernel_h 5
     ENTRY(32, 128, 1, 4, 7, 5, 8, 16),   // "5x7": kernel_w 5 x kernel_h 7
+    // detection sub-net roi_c1 (3x3 over the ROI-pooled maps): kitti_car 7x7 pad 0, ped/cyc 7x5 pad 0, caltech 8x4 pad 1
+    ROI_ENTRY(128, 128, 2, 2, 3, 3, 8, 7, 7, 0),
+    ROI_ENTRY(128, 128, 2, 2, 3, 3, 8, 7, 5, 0),
+    ROI_ENTRY(128, 128, 2, 2, 3, 3, 8, 8, 4, 1),
 };
 constexpr int kTableN = sizeof(kTable) / sizeof(kTable[0]);
 
@@ -352,24 +456,38 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->entry = -1;
   p->packed_bytes = 0;
   p->ws_bytes = 0;
-  if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.Cin % 8 != 0) return;   // CK = 8 channels per chunk
-  // choose the table entry with the least padded work
+  if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0) return;
+  // 32-bit buffer offsets: every tensor window the kernel addresses must stay below 2 GiB
+  const double win_x = (double)d.Cin * d.H * d.W * 4.0, win_y = (double)d.Cout * p->Ho * p->Wo * 4.0;
+  // choose the table entry with the least padded work; an ROI-mode entry wins whenever it matches the image shape
   double best = 1e300;
   for (int i = 0; i < kTableN; ++i) {
     const KernelEntry& k = kTable[i];
     if (k.KH != d.Kh || k.KW != d.Kw) continue;
-    const long mt = cdiv(d.Cout, k.BM), nth = cdiv(p->Ho, k.TH), ntw = cdiv(p->Wo, k.TW);
-    double cost = (double)mt * k.BM * nth * k.TH * ntw * k.TW;
-    // prefer larger M tiles at equal cost (less re-staging of the input patch)
-    cost *= (1.0 + 0.001 * (128.0 / k.BM));
+    double cost;
+    if (k.RH > 0) {
+      if (d.H != k.RH || d.W != k.RW || d.pad_h != k.RP || d.pad_w != k.RP) continue;
+      if (win_x * d.N >= 2.0e9 || win_y * d.N >= 2.0e9) continue;
+      cost = 0.0;
+    } else {
+      if (win_x >= 2.0e9 || win_y >= 2.0e9) continue;
+      const long mt = cdiv(d.Cout, k.BM), nth = cdiv(p->Ho, k.TH), ntw = cdiv(p->Wo, k.TW);
+      cost = (double)mt * k.BM * nth * k.TH * ntw * k.TW;
+      cost *= (1.0 + 0.001 * (128.0 / k.BM));   // prefer larger M tiles at equal cost (less re-staging of the patch)
+    }
     if (cost < best) { best = cost; p->entry = i; }
   }
   if (p->entry < 0) return;
   const KernelEntry& k = kTable[p->entry];
   p->MT = cdiv(d.Cout, k.BM);
-  p->NTH = cdiv(p->Ho, k.TH);
-  p->NTW = cdiv(p->Wo, k.TW);
-  p->NT = d.N * p->NTH * p->NTW;
+  if (k.RH > 0) {
+    p->NTH = p->NTW = 1;
+    p->NT = cdiv(d.N, k.IPT);
+  } else {
+    p->NTH = cdiv(p->Ho, k.TH);
+    p->NTW = cdiv(p->Wo, k.TW);
+    p->NT = d.N * p->NTH * p->NTW;
+  }
   p->KI = cdiv(d.Cin, k.CK);
   p->total_iters = (long)p->MT * p->NT * p->KI;
   // stream-K grid: two workgroups per CU, but never less than ~4 chunks per workgroup
@@ -461,13 +579,13 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
   }
   IgemmArgs a;
   a.x = x; a.wp = packed; a.bias = bias; a.y = y; a.ws = static_cast<float*>(workspace);
-  a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.Ho = p->Ho; a.Wo = p->Wo; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
+  a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.Ho = p->Ho; a.Wo = p->Wo; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
   a.MT = p->MT; a.NTH = p->NTH; a.NTW = p->NTW; a.NT = p->NT; a.KI = p->KI; a.G = p->G; a.relu = d.relu;
   a.total_iters = p->total_iters;
   k.main_fn<<<p->G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   if (split) {
-    k.fix_fn<<<(int)tiles, 256, 0, st>>>(a);
+    k.fix_fn<<<(int)tiles * k.fix_split, 256, 0, st>>>(a);
     MSCNN_POST_LAUNCH();
   }
   return MSCNN_OK;

@@ -133,31 +133,50 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
 }
 
 __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmArgs a) {
-  const int t = blockIdx.x;
-  const long its = (long)t * a.KI, ite = its + a.KI;
-  int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
-  long b, e;
-  wg_range(a.total_iters, a.G, gf, b, e);
-  while (e <= its) { ++gf; wg_range(a.total_iters, a.G, gf, b, e); }
-  while (b > its) { --gf; wg_range(a.total_iters, a.G, gf, b, e); }
-  wg_range(a.total_iters, a.G, gl, b, e);
-  while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
-  while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
-  if (gf == gl) return;
+  __shared__ const float* s_slab[64];
+  __shared__ int s_n;
+  const int t = blockIdx.x >> 2, part = blockIdx.x & 3;    // 4 workgroups per 128x128 tile
+  if (threadIdx.x == 0) {
+    const long its = (long)t * a.KI, ite = its + a.KI;
+    int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
+    long b, e;
+    wg_range(a.total_iters, a.G, gf, b, e);
+    while (e <= its) { ++gf; wg_range(a.total_iters, a.G, gf, b, e); }
+    while (b > its) { --gf; wg_range(a.total_iters, a.G, gf, b, e); }
+    wg_range(a.total_iters, a.G, gl, b, e);
+    while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
+    while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
+    int n = 0;
+    if (gf != gl)
+      for (int g = gf; g <= gl && n < 64; ++g) {
+        wg_range(a.total_iters, a.G, g, b, e);
+        s_slab[n++] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * (BM * BN);
+      }
+    s_n = n;
+  }
+  __syncthreads();
+  const int n = s_n;
+  if (n == 0) return;
   const int nt = t / a.MT, mt = t % a.MT;
   const int m0 = mt * BM, n0 = nt * BN;
-  for (int i = threadIdx.x; i < BM * BN; i += 256) {
-    const int ml = i / BN, nl = i % BN;
-    float v = 0.f;
-    for (int g = gf; g <= gl; ++g) {
-      wg_range(a.total_iters, a.G, g, b, e);
-      v += a.ws[((long)g * 2 + (b > its ? 0 : 1)) * (BM * BN) + i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = part * 4096 + (j * 256 + threadIdx.x) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < n; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(s_slab[s] + i);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
-    const int m = m0 + ml, n = n0 + nl;
-    if (m < a.M && n < a.N) {
-      if (a.bias) v += a.bias[n];
-      if (a.relu) v = v > 0.f ? v : 0.f;
-      a.y[(long)m * a.N + n] = v;
+    const int m = m0 + i / BN, nn = n0 + i % BN;
+    if (m >= a.M) continue;
+    const float vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (nn + q >= a.N) continue;
+      float r = vals[q];
+      if (a.bias) r += a.bias[nn + q];
+      if (a.relu) r = r > 0.f ? r : 0.f;
+      a.y[(long)m * a.N + nn + q] = r;
     }
   }
 }
@@ -227,7 +246,7 @@ extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const
   a.ws = g_ws;
   gemm_tn_kernel<<<a.G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
-  gemm_fixup_kernel<<<a.MT * a.NT, 256, 0, st>>>(a);
+  gemm_fixup_kernel<<<a.MT * a.NT * 4, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

@@ -83,7 +83,12 @@ def test_concat_softmax_deconv(hip, orc):
 # ------------------------------------------------------------------ convolution
 CONV_CASES = [
     # (N, Cin, H, W, Cout, k, pad, stride, group)          kernel family expected
-    (1, 3, 20, 33, 16, (3, 3), (1, 1), (1, 1), 1),          # conv1_1-like -> direct
+    (1, 3, 20, 33, 16, (3, 3), (1, 1), (1, 1), 1),          # conv1_1-like: Cin 3 zero-padded to one 8-channel chunk
+    (1, 12, 11, 19, 40, (3, 3), (1, 1), (1, 1), 1),         # Cin not a multiple of 8 over two chunks
+    (13, 16, 7, 7, 256, (3, 3), (0, 0), (1, 1), 1),         # roi_c1 (kitti car): ROI mode, 5 images per tile, ragged last tile
+    (9, 8, 7, 5, 130, (3, 3), (0, 0), (1, 1), 1),           # roi_c1 ped/cyc 7x5 -> 5x3
+    (6, 24, 8, 4, 64, (3, 3), (1, 1), (1, 1), 1),           # roi_c1 caltech 8x4 pad 1 -> 8x4
+    (2, 8, 5, 5, 16, (3, 3), (1, 1), (2, 2), 1),            # stride 2 -> direct
     (2, 6, 9, 7, 4, (3, 3), (0, 0), (2, 2), 2),             # stride/group -> direct
     (1, 8, 16, 32, 128, (3, 3), (1, 1), (1, 1), 1),         # igemm 128x128, exact tiles
     (1, 16, 13, 37, 64, (3, 3), (1, 1), (1, 1), 1),         # ragged H/W, Cout 64
@@ -120,7 +125,9 @@ def test_conv_no_bias_and_kernel_selection(hip, orc):
     assert plan.kernel.startswith("igemm_")
     plan.pack(dev(w))
     close(plan.forward(dev(x)).cpu().numpy(), orc.conv2d(x, w, None, (1, 1)))
-    assert hip.ConvPlan(1, 3, 8, 16, 32, 3, 3, (1, 1)).kernel == "direct_f32"
+    assert hip.ConvPlan(1, 3, 8, 16, 32, 3, 3, (1, 1)).kernel.startswith("igemm_")          # Cin 3 is zero-padded
+    assert hip.ConvPlan(1, 8, 8, 16, 32, 3, 3, (1, 1), stride=(2, 2)).kernel == "direct_f32"
+    assert "roi7x7p0" in hip.ConvPlan(50, 1024, 7, 7, 512, 3, 3).kernel
     assert plan.flops == 2.0 * 32 * 8 * 16 * 8 * 9
 
 
