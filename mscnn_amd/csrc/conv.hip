@@ -24,7 +24,9 @@
 //   * epilogue fuses bias and ReLU; stores are 128-B runs along W.
 // Shapes the MFMA path does not cover (stride > 1, groups, Cin < 8) use direct_conv_kernel.
 #include "common.h"
+#include <cstdlib>
 #include <new>
+#include <type_traits>
 
 namespace {
 
@@ -34,7 +36,8 @@ struct IgemmArgs {
   const float* x; const float* wp; const float* bias; float* y; float* ws;
   int N, Cin, H, W, Cout, Ho, Wo, pad_h, pad_w;
   int MT, NTH, NTW, NT, KI, G, relu;
-  long total_iters;
+  int full_q;          // whole tiles per workgroup in the data-parallel phase (tile t = g + j * G, j < full_q)
+  long total_iters;    // iterations (tile, chunk) of the stream-K phase: the remaining tiles [full_q * G, MT * NT)
 };
 
 // Tile configuration.  Two geometries share one kernel:
@@ -42,8 +45,9 @@ struct IgemmArgs {
 //   ROI mode   (RH  > 0): the images are tiny (RH x RW, e.g. the 7x7 ROI-pooled maps of roi_c1) and a tile packs
 //                         IPT whole images: N side = IPT * OH * OW output pixels.  The reference's CAFFE engine runs
 //                         one im2col+GEMM with N = 25 per ROI here (conv_layer.cu:14-21).
-template <int BM_, int BN_, int WGM_, int WGN_, int KH_, int KW_, int CK_, int TW_, int RH_ = 0, int RW_ = 0, int RP_ = 0>
+template <int BM_, int BN_, int WGM_, int WGN_, int KH_, int KW_, int CK_, int TW_, int RH_ = 0, int RW_ = 0, int RP_ = 0, int PF_ = 0>
 struct Cfg {
+  static constexpr int PF = PF_;   // 1: LDS operand reads software-pipelined one MFMA group ahead
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, KH = KH_, KW = KW_, CK = CK_, TW = TW_;
   static constexpr bool ROI = RH_ > 0;
   static constexpr int RH = RH_, RW = RW_, RP = RP_;
@@ -68,6 +72,14 @@ struct Cfg {
   static_assert(WM % 32 == 0 && WN % 32 == 0 && BN % TW == 0 && CK % 2 == 0 && A_ELEMS % 4 == 0, "tile shape");
   static_assert((BM * BN) % 4096 == 0, "fix-up split");
 };
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 __device__ __forceinline__ void wg_range(long total, int G, int g, long& b, long& e) {
   b = total * g / G;
@@ -170,8 +182,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   const int l31 = lane & 31, khalf = lane >> 5;
   const int wm = wave / C::WGN, wn = wave % C::WGN;
 
+  // Hybrid schedule: first full_q whole tiles per workgroup (no partial sums at all), then the remaining tiles are
+  // cut stream-K style into G equal (tile, chunk) ranges so that every CU finishes at the same time.
   long it, it_end;
   wg_range(a.total_iters, a.G, blockIdx.x, it, it_end);
+  int full_j = 0;
+  const int rem_tile0 = a.full_q * a.G;
 
   // per-lane LDS read bases (floats)
   const float* aRd = ldsA + khalf * C::BM + wm * C::WM + l31;
@@ -186,10 +202,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   const __amdgpu_buffer_rsrc_t bias_rsrc = make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
   const int co_stride = a.Ho * a.Wo;
 
-  while (it < it_end) {
-    const int t = (int)(it / a.KI);
-    const int k0 = (int)(it % a.KI);
-    const int k1 = (int)min((long)a.KI, k0 + (it_end - it));
+  for (;;) {
+    int t, k0, k1;
+    if (full_j < a.full_q) {
+      t = blockIdx.x + full_j * a.G; k0 = 0; k1 = a.KI;
+      ++full_j;
+    } else if (it < it_end) {
+      t = rem_tile0 + (int)(it / a.KI);
+      k0 = (int)(it % a.KI);
+      k1 = (int)min((long)a.KI, k0 + (it_end - it));
+      it += (k1 - k0);
+    } else {
+      break;
+    }
     const int mt = t / a.NT, nt = t % a.NT;       // t = mt * NT + nt
     TileGeo<C> geo;
     geo.decode(a, nt);
@@ -243,25 +268,51 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         if (C::B_ELEMS % 256 == 0 || tid + i * 256 < C::B_ELEMS) ldsB[tid + i * 256] = rb[i];
       __syncthreads();
       if (kc + 1 < k1) MSCNN_LOAD_CHUNK(kc + 1);   // in flight while this chunk is multiplied
+      if constexpr (C::PF == 0) {
 #pragma unroll
-      for (int kh = 0; kh < C::KH; ++kh)
+        for (int kh = 0; kh < C::KH; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < C::KW; ++kw)
+          for (int kw = 0; kw < C::KW; ++kw)
 #pragma unroll
-          for (int cp = 0; cp < C::CK / 2; ++cp) {
-            float av[C::MI], bv[C::NI];
+            for (int cp = 0; cp < C::CK / 2; ++cp) {
+              float av[C::MI], bv[C::NI];
 #pragma unroll
-            for (int mi = 0; mi < C::MI; ++mi) av[mi] = aRd[((kh * C::KW + kw) * C::CK + cp * 2) * C::BM + mi * 32];
+              for (int mi = 0; mi < C::MI; ++mi) av[mi] = aRd[((kh * C::KW + kw) * C::CK + cp * 2) * C::BM + mi * 32];
 #pragma unroll
-            for (int ni = 0; ni < C::NI; ++ni) bv[ni] = bRd[ni][cp * 2 * C::CH_STRIDE + kh * C::ROWS + kw];
+              for (int ni = 0; ni < C::NI; ++ni) bv[ni] = bRd[ni][cp * 2 * C::CH_STRIDE + kh * C::ROWS + kw];
 #pragma unroll
-            for (int mi = 0; mi < C::MI; ++mi)
+              for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-              for (int ni = 0; ni < C::NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
-            // keep the scheduler from hoisting every ds_read of the chunk to the top (register blow-up)
-            if (cp % 2 == 1) asm volatile("" ::: "memory");
-          }
+                for (int ni = 0; ni < C::NI; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+              // keep the scheduler from hoisting every ds_read of the chunk to the top (register blow-up)
+              if (cp % 2 == 1) asm volatile("" ::: "memory");
+            }
+      } else {
+        // software-pipelined operand reads: the ds_reads of MFMA group s+1 are issued before the MFMAs of group s,
+        // so a wave never sits on lgkmcnt(0) with an idle matrix pipe
+        constexpr int S = C::TAPS * (C::CK / 2);
+        float av[2][C::MI], bv[2][C::NI];
+#define MSCNN_LDS_GROUP(s, buf)                                                                                  \
+        {                                                                                                        \
+          constexpr int tap_ = (s) / (C::CK / 2), cp_ = (s) % (C::CK / 2), kh_ = tap_ / C::KW, kw_ = tap_ % C::KW; \
+          _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi) av[buf][mi] = aRd[(tap_ * C::CK + cp_ * 2) * C::BM + mi * 32]; \
+          _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni) bv[buf][ni] = bRd[ni][cp_ * 2 * C::CH_STRIDE + kh_ * C::ROWS + kw_]; \
+        }
+        MSCNN_LDS_GROUP(0, 0);
+        static_for<0, S>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if constexpr (s + 1 < S) MSCNN_LDS_GROUP(s + 1, (s + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);      // pin: next group's ds_reads are issued BEFORE this group's MFMAs
+#pragma unroll
+          for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][mi], bv[s & 1][ni], acc[mi][ni], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+#undef MSCNN_LDS_GROUP
+      }
     }
 #undef MSCNN_LOAD_CHUNK
 
@@ -302,7 +353,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
           for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2)) * C::BN] = acc[mi][ni][r];
         }
     }
-    it += (k1 - k0);
     __syncthreads();   // LDS is re-used by the next segment's first stores
   }
 }
@@ -312,11 +362,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 // contributing slabs is resolved once per workgroup (the 64-bit range arithmetic is kept out of the element loop).
 template <class C>
 __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
-  __shared__ const float* s_slab[64];
+  __shared__ const float* s_slab[256];   // a tile has at most KI <= 256 contributors
   __shared__ int s_n;
-  const int t = blockIdx.x / C::FIX_SPLIT, part = blockIdx.x % C::FIX_SPLIT;
+  const int tr = blockIdx.x / C::FIX_SPLIT, part = blockIdx.x % C::FIX_SPLIT;   // tr: index among the stream-K tiles
+  const int t = a.full_q * a.G + tr;
   if (threadIdx.x == 0) {
-    const long its = (long)t * a.KI, ite = its + a.KI;
+    const long its = (long)tr * a.KI, ite = its + a.KI;
     int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
     long b, e;
     wg_range(a.total_iters, a.G, gf, b, e);
@@ -327,8 +378,9 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
     while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
     int n = 0;
     if (gf != gl) {           // gf == gl: the tile was computed whole by one workgroup and is already in y
-      for (int g = gf; g <= gl && n < 64; ++g) {
+      for (int g = gf; g <= gl && n < 256; ++g) {
         wg_range(a.total_iters, a.G, g, b, e);
+        if (e <= b) continue;   // empty range: this workgroup contributed nothing
         s_slab[n++] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * (C::BM * C::BN);
       }
     }
@@ -405,17 +457,20 @@ typedef void (*IgemmFn)(IgemmArgs);
 struct KernelEntry {
   const char* name;
   int BM, BN, KH, KW, CK, TW, TH;
-  int RH, RW, RP, IPT, fix_split;
+  int RH, RW, RP, IPT, fix_split, variant;
   IgemmFn main_fn, fix_fn;
 };
 
 #define ENTRY(BM, BN, WGM, WGN, KH, KW, CK, TW)                                                                     \
-  {"igemm_" #BM "x" #BN "_k" #KH "x" #KW "_tw" #TW, BM, BN, KH, KW, CK, TW, BN / TW, 0, 0, 0, 1, (BM * BN) / 4096,     \
+  {"igemm_" #BM "x" #BN "_k" #KH "x" #KW "_tw" #TW, BM, BN, KH, KW, CK, TW, BN / TW, 0, 0, 0, 1, (BM * BN) / 4096, 0,  \
    igemm_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW>>, igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW>>}
+#define ENTRY_PF(BM, BN, WGM, WGN, KH, KW, CK, TW)                                                                  \
+  {"igemm_" #BM "x" #BN "_k" #KH "x" #KW "_tw" #TW "_pf", BM, BN, KH, KW, CK, TW, BN / TW, 0, 0, 0, 1, (BM * BN) / 4096, 1, \
+   igemm_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW, 0, 0, 0, 1>>, igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW, 0, 0, 0, 1>>}
 // ROI mode entries: images of RH x RW with symmetric pad RP, IPT images per tile
 #define ROI_ENTRY(BM, BN, WGM, WGN, KH, KW, CK, RH, RW, RP)                                                             \
   {"igemm_" #BM "x" #BN "_k" #KH "x" #KW "_roi" #RH "x" #RW "p" #RP, BM, BN, KH, KW, CK, 0, 0, RH, RW, RP,              \
-   Cfg<BM, BN, WGM, WGN, KH, KW, CK, 32, RH, RW, RP>::IPT, (BM * BN) / 4096,                                            \
+   Cfg<BM, BN, WGM, WGN, KH, KW, CK, 32, RH, RW, RP>::IPT, (BM * BN) / 4096, 0,                                         \
    igemm_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, 32, RH, RW, RP>>,                                                     \
    igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, 32, RH, RW, RP>>}
 
@@ -424,6 +479,10 @@ const KernelEntry kTable[] = {
     ENTRY(128, 128, 2, 2, 3, 3, 8, 16),
     ENTRY(128, 128, 2, 2, 3, 3, 8, 32),
     ENTRY(64, 256, 1, 4, 3, 3, 8, 32),
+    ENTRY_PF(128, 128, 2, 2, 3, 3, 8, 16),
+    ENTRY_PF(128, 128, 2, 2, 3, 3, 8, 32),
+    ENTRY_PF(64, 256, 1, 4, 3, 3, 8, 32),
+    ENTRY(128, 256, 2, 2, 3, 3, 8, 32),     // variant 2 (selected with MSCNN_IGEMM_VARIANT=2): 64x128 wave tiles
     // proposal heads (Cout = 4 + classes <= 32): kitti_car 5x5 / 7x7, ped-cyc + caltech 3x5 / 5x7
     ENTRY(32, 128, 1, 4, 5, 5, 8, 16),
     ENTRY(32, 128, 1, 4, 7, 7, 8, 16),
@@ -442,8 +501,8 @@ struct mscnn_conv_plan {
   mscnn_conv_desc d;
   int Ho, Wo;
   int entry;          // -1: direct
-  int MT, NTH, NTW, NT, KI, G;
-  long total_iters;
+  int MT, NTH, NTW, NT, KI, G, full_q;
+  long total_iters;      // stream-K phase iterations
   size_t packed_bytes, ws_bytes;
 };
 
@@ -456,14 +515,21 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->entry = -1;
   p->packed_bytes = 0;
   p->ws_bytes = 0;
-  if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0) return;
+  if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0 || d.Cin > 2048) return;   // KI <= 256
   // 32-bit buffer offsets: every tensor window the kernel addresses must stay below 2 GiB
   const double win_x = (double)d.Cin * d.H * d.W * 4.0, win_y = (double)d.Cout * p->Ho * p->Wo * 4.0;
   // choose the table entry with the least padded work; an ROI-mode entry wins whenever it matches the image shape
   double best = 1e300;
+  const char* venv = std::getenv("MSCNN_IGEMM_VARIANT");     // tuning knob: 0 baseline, 1 pipelined LDS reads, 2 128x256 tiles
+  const int want = venv ? std::atoi(venv) : 0;
   for (int i = 0; i < kTableN; ++i) {
     const KernelEntry& k = kTable[i];
     if (k.KH != d.Kh || k.KW != d.Kw) continue;
+    const bool is256 = (k.BM == 128 && k.BN == 256);
+    if (k.KH == 3 && k.KW == 3 && k.RH == 0) {
+      if (want == 2) { if (!is256 && d.Cout >= 128) continue; if (k.variant != 0) continue; }
+      else if (is256 || k.variant != want) continue;
+    }
     double cost;
     if (k.RH > 0) {
       if (d.H != k.RH || d.W != k.RW || d.pad_h != k.RP || d.pad_w != k.RP) continue;
@@ -489,15 +555,15 @@ static void plan_shape(mscnn_conv_plan* p) {
     p->NT = d.N * p->NTH * p->NTW;
   }
   p->KI = cdiv(d.Cin, k.CK);
-  p->total_iters = (long)p->MT * p->NT * p->KI;
-  // stream-K grid: two workgroups per CU, but never less than ~4 chunks per workgroup
-  long G = 512;
-  if (p->total_iters / 4 < G) G = p->total_iters / 4;
-  if (G < 1) G = 1;
-  // when the tile count already fills whole rounds of 512 slots, plain data-parallel is exact
   const long tiles = (long)p->MT * p->NT;
-  if (tiles % 512 == 0) G = tiles;
+  // grid: G workgroups (default 2 per CU; 3 for the 128x128 tiles whose 43 KB of LDS and 168 VGPRs allow it)
+  const char* genv = std::getenv("MSCNN_SK_WGS");            // tuning knob
+  long G = genv ? std::atol(genv) : ((k.BM == 128 && k.BN == 128) ? 768 : 512);
+  if (tiles * p->KI / 4 < G) G = tiles * p->KI / 4;         // never less than ~4 chunks per workgroup
+  if (G < 1) G = 1;
   p->G = (int)G;
+  p->full_q = (int)(tiles / G);                               // data-parallel phase
+  p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
   p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * sizeof(float);
   p->ws_bytes = (size_t)p->G * 2 * k.BM * k.BN * sizeof(float);
 }
@@ -569,8 +635,8 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
   }
   MSCNN_REQUIRE(packed, "conv: igemm kernel needs packed weights (mscnn_conv2d_pack_weights)");
   const KernelEntry& k = kTable[p->entry];
-  const long tiles = (long)p->MT * p->NT;
-  const bool split = (p->total_iters % p->G != 0) || ((p->total_iters / p->G) % p->KI != 0);
+  const long rem_tiles = (long)p->MT * p->NT - (long)p->full_q * p->G;
+  const bool split = rem_tiles > 0;
   if (split) {
     if (!workspace || workspace_bytes < p->ws_bytes) {
       set_error("conv: workspace %zu < %zu", workspace_bytes, p->ws_bytes);
@@ -581,11 +647,11 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
   a.x = x; a.wp = packed; a.bias = bias; a.y = y; a.ws = static_cast<float*>(workspace);
   a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.Ho = p->Ho; a.Wo = p->Wo; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
   a.MT = p->MT; a.NTH = p->NTH; a.NTW = p->NTW; a.NT = p->NT; a.KI = p->KI; a.G = p->G; a.relu = d.relu;
-  a.total_iters = p->total_iters;
+  a.total_iters = p->total_iters; a.full_q = p->full_q;
   k.main_fn<<<p->G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   if (split) {
-    k.fix_fn<<<(int)tiles * k.fix_split, 256, 0, st>>>(a);
+    k.fix_fn<<<(int)rem_tiles * k.fix_split, 256, 0, st>>>(a);
     MSCNN_POST_LAUNCH();
   }
   return MSCNN_OK;
