@@ -521,7 +521,8 @@ static void plan_shape(mscnn_conv_plan* p) {
   // choose the table entry with the least padded work; an ROI-mode entry wins whenever it matches the image shape
   double best = 1e300;
   const char* venv = std::getenv("MSCNN_IGEMM_VARIANT");     // tuning knob: 0 baseline, 1 pipelined LDS reads, 2 128x256 tiles
-  const int want = venv ? std::atoi(venv) : 0;
+  // default: pipelined LDS reads for the 128-row tiles (+1..3 % measured on conv2_2..conv4_3), baseline for Cout = 64
+  const int want = venv ? std::atoi(venv) : (d.Cout >= 128 ? 1 : 0);
   for (int i = 0; i < kTableN; ++i) {
     const KernelEntry& k = kTable[i];
     if (k.KH != d.Kh || k.KW != d.Kw) continue;
