@@ -35,33 +35,51 @@ ROOFLINE_LAYERS = ["conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4
 MAX_DET = 512                           # padded rows per image in the RCCL gather (detections after final NMS)
 
 
+def _layers_of(n):
+    return [(n.layer_names[i], n.layer_types[i], n.layer_bottoms(i), n.layer_tops(i), n.layer_param_text(i))
+            for i in range(len(n.layer_names))]
+
+
 def cpu_baseline(R_gpu, regime):
-    """Bounded CPU sample: the oracle's im2col+GEMM path (the reference's CPU algorithm, conv_layer.cpp:25-40) on a
-    quarter-area frame (288x960) for trunk + heads + BoxOutput, plus the detection sub-net on 32 ROIs; scaled to the full
-    workload (x4 pixels, x R/32 ROIs).  Returns the cpu_baseline object."""
+    """The reference's CPU forward path timed on this box's host cores (rank 0, N=1 only).
+
+    kind "reference": oracle/_ref -- the reference's OWN layer sources (im2col + cblas_sgemm through MKL, serial
+    BoxOutput / ROIPooling / pooling loops) on ONE full 576x1920 frame with the same weights; the scope is Net::Forward
+    only, like the reference's tic/toc (run_mscnn_detection.m:72).
+    kind "port" (when _ref is not built): the C restatement on a bounded quarter-area sample, scaled."""
     from mscnn_amd import net as mnet, synth, zoo
-    from oracle import pynet, pyoracle
+    from oracle import pynet, pyoracle, pyref
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    if pyref.available():
+        n = mnet.Net(prototxt_text=zoo.prototxt(MODEL), device=-1)
+        layers = _layers_of(n)
+        ws = synth.weights(n.layer_names, n.layer_types, [n.param_shapes(i) for i in range(len(n.layer_names))], regime)
+        x = synth.frame(H, W, seed=1701)
+        t0 = time.perf_counter()
+        blobs = pynet.forward(layers, ws, {"data": x}, backend=pyref)
+        dt = time.perf_counter() - t0
+        R = blobs["proposals"].shape[0]
+        return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "reference",
+                "sample": f"1 full frame (1x3x576x1920, R={R} ROIs) through the reference's own CPU layers "
+                          f"(oracle/_ref: im2col + MKL cblas_sgemm, {cores} threads available), Net::Forward scope, {dt:.2f} s",
+                "seconds_per_image": round(dt, 2)}
     pyoracle.lib()
     h, w = H // 2, W // 2
-    n = mnet.Net(prototxt_text=zoo.prototxt(MODEL, height=h, width=w, max_nms_num=32), device=0)
-    layers = [(n.layer_names[i], n.layer_types[i], n.layer_bottoms(i), n.layer_tops(i), n.layer_param_text(i))
-              for i in range(len(n.layer_names))]
+    n = mnet.Net(prototxt_text=zoo.prototxt(MODEL, height=h, width=w, max_nms_num=32), device=-1)
+    layers = _layers_of(n)
     ws = synth.weights(n.layer_names, n.layer_types, [n.param_shapes(i) for i in range(len(n.layer_names))], regime)
     x = synth.frame(h, w)
-    names = [l[0] for l in layers]
-    cut = names.index("proposals") + 1
+    cut = [l[0] for l in layers].index("proposals") + 1
     t0 = time.perf_counter()
     blobs = pynet.forward(layers[:cut], ws, {"data": x})
     t_trunk = time.perf_counter() - t0
-    split = [l for l in layers[cut:]]
     t0 = time.perf_counter()
-    blobs = pynet.forward(split, ws, blobs)
+    blobs = pynet.forward(layers[cut:], ws, blobs)
     t_det = time.perf_counter() - t0
     r_sample = blobs["proposals"].shape[0]
     est = 4.0 * t_trunk + t_det * (R_gpu / max(r_sample, 1))
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     return {"value": round(1.0 / est, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle (im2col + k-ordered GEMM, OpenMP) on a 288x960 frame for trunk+heads+BoxOutput ({t_trunk:.2f} s) "
+            "sample": f"oracle restatement (im2col + k-ordered GEMM, OpenMP) on a 288x960 frame for trunk+heads+BoxOutput ({t_trunk:.2f} s) "
                       f"and the detection sub-net on {r_sample} ROIs ({t_det:.2f} s), scaled x4 pixels and x{R_gpu}/{r_sample} ROIs",
             "seconds_per_image_est": round(est, 2)}
 

@@ -17,8 +17,10 @@
  *     test_deconvolution_layer.cpp:117-134) and against oracle/_ref (the
  *     reference's own .cpp files compiled against oracle/shim) when built.
  *   - BoxOutput / ROIPooling / DecodeBBox: the reference holds no tests or
- *     fixtures for them; they are pinned against oracle/_ref
- *     (reference sources compiled here) via tests/golden/ fixtures.
+ *     fixtures for them; they are pinned BIT-EXACTLY against
+ *     oracle/_ref -- the reference's own .cpp files compiled by oracle/ref.mk --
+ *     in tests/test_oracle_vs_ref.py, and against the outputs of that library
+ *     committed as tests/golden/reference_layers.npz (tests/test_golden.py).
  *   - final detection stage (MATLAB, run_mscnn_detection.m:75-120 + bbNms.m):
  *     PARITY UNPINNED -- MATLAB is not available; restated from source only.
  */

@@ -51,9 +51,21 @@ def _conv_geom(p):
     return kh, kw, ph, pw, sh, sw, int(_num(p, "group", 1))
 
 
-def forward(layers, weights, inputs, stop_after=None):
+def forward(layers, weights, inputs, stop_after=None, backend=None):
     """layers: list of (name, type, bottoms, tops, param_text).  weights: {layer: [w, b]}.  inputs: {blob: array}.
-    Returns {blob name: array} (in-place layers overwrite their blob, like the net) plus '__anchor_ids__'."""
+    Returns {blob name: array} (in-place layers overwrite their blob, like the net) plus '__anchor_ids__'.
+    backend: oracle.pyoracle (default, the C restatement) or oracle.pyref (the reference's own sources, oracle/_ref)."""
+    global orc
+    _saved = orc
+    if backend is not None:
+        orc = backend
+    try:
+        return _forward(layers, weights, inputs, stop_after)
+    finally:
+        orc = _saved
+
+
+def _forward(layers, weights, inputs, stop_after):
     blobs = dict(inputs)
     for name, typ, bottoms, tops, ptext in layers:
         P = parse_param_text(ptext)
@@ -69,7 +81,8 @@ def forward(layers, weights, inputs, stop_after=None):
             blobs[tops[0]] = orc.conv2d(x[0], w[0], w[1] if len(w) > 1 else None, (ph, pw), (sh, sw), g)
         elif typ == "Deconvolution":
             kh, kw, ph, pw, sh, sw, g = _conv_geom(P["convolution_param"][0])
-            w = weights.get(name) or [orc.bilinear_filler((x[0].shape[1], 1, kh, kw))]
+            from . import pyoracle as _po
+            w = weights.get(name) or [_po.bilinear_filler((x[0].shape[1], 1, kh, kw))]
             blobs[tops[0]] = orc.deconv2d(x[0], w[0], w[1] if len(w) > 1 else None, (ph, pw), (sh, sw), g)
         elif typ == "ReLU":
             slope = _num(P.get("relu_param", [{}])[0], "negative_slope", 0.0)
@@ -84,7 +97,7 @@ def forward(layers, weights, inputs, stop_after=None):
         elif typ == "Dropout":
             blobs[tops[0]] = x[0]
         elif typ == "Concat":
-            blobs[tops[0]] = orc.concat_channels(x)
+            blobs[tops[0]] = np.concatenate([np.asarray(v, np.float32) for v in x], axis=1)
         elif typ == "Softmax":
             blobs[tops[0]] = orc.softmax(x[0], 1)
         elif typ == "ROIPooling":
@@ -94,13 +107,16 @@ def forward(layers, weights, inputs, stop_after=None):
         elif typ == "BoxOutput":
             p = P["box_output_param"][0]
             br = P.get("bbox_reg_param", [{}])[0]
-            rois, props, cidx, nreal, aids = orc.boxoutput(
-                x, [float(v) for v in p["field_w"]], [float(v) for v in p["field_h"]], [float(v) for v in p["downsample_rate"]],
-                fg_thr=_num(p, "fg_thr", 0.0), iou_thr=_num(p, "iou_thr", 0.5), nms_type=p.get("nms_type", ["IOU"])[0],
-                field_whr=_num(p, "field_whr", 2.0), field_xyr=_num(p, "field_xyr", 2.0), max_nms_num=int(_num(p, "max_nms_num", 0)),
-                max_post_nms_num=int(_num(p, "max_post_nms_num", 0)), min_size=_num(p, "min_size", 15.0),
-                bbox_mean=[float(v) for v in br.get("bbox_mean", [])], bbox_std=[float(v) for v in br.get("bbox_std", [])],
-                with_anchor_ids=True)
+            kw = dict(fg_thr=_num(p, "fg_thr", 0.0), iou_thr=_num(p, "iou_thr", 0.5), nms_type=p.get("nms_type", ["IOU"])[0],
+                      field_whr=_num(p, "field_whr", 2.0), field_xyr=_num(p, "field_xyr", 2.0), max_nms_num=int(_num(p, "max_nms_num", 0)),
+                      max_post_nms_num=int(_num(p, "max_post_nms_num", 0)), min_size=_num(p, "min_size", 15.0),
+                      bbox_mean=[float(v) for v in br.get("bbox_mean", [])], bbox_std=[float(v) for v in br.get("bbox_std", [])])
+            geom = ([float(v) for v in p["field_w"]], [float(v) for v in p["field_h"]], [float(v) for v in p["downsample_rate"]])
+            if orc.__name__.endswith("pyref"):
+                rois, props = orc.boxoutput(x, *geom, **kw)
+                aids = None
+            else:
+                rois, props, cidx, nreal, aids = orc.boxoutput(x, *geom, with_anchor_ids=True, **kw)
             blobs[tops[0]] = rois.reshape(-1, 5, 1, 1)
             if len(tops) > 1:
                 blobs[tops[1]] = props.reshape(-1, 6, 1, 1)
