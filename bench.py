@@ -115,8 +115,10 @@ def main():
     # a handful of distinct frames per rank, resident in HBM before the timed region
     frames = [torch.from_numpy(synth.frame(H, W, seed=1701 + 97 * rank + i)).cuda() for i in range(4)]
     kw = dict(cls_id=2, ratios=(H / ORG_HW[0], W / ORG_HW[1]), org_hw=ORG_HW)
-    gather_out = torch.zeros((world, MAX_DET + 1, 6), dtype=torch.float32, device="cuda") if world > 1 else None
-    pad = torch.zeros((MAX_DET + 1, 6), dtype=torch.float32, device="cuda") if world > 1 else None
+    gather = None
+    if world > 1:
+        from mscnn_amd import dist as mdist
+        gather = mdist.DetectionGather(MAX_DET, "cuda")
     stats = {"R": [], "D": []}
 
     def step(i):
@@ -124,14 +126,8 @@ def main():
         net.forward()
         dets, ids, R = net.detect(**kw)                       # final stage on device; detections land on the host
         stats["R"].append(R); stats["D"].append(len(dets))
-        if world > 1:                                         # the only collective of the path: detections -> every rank
-            d = min(len(dets), MAX_DET)
-            buf = np.zeros((MAX_DET + 1, 6), np.float32)
-            buf[0, 0] = d
-            buf[1:d + 1, :5] = dets[:d]
-            buf[1:d + 1, 5] = ids[:d]
-            pad.copy_(torch.from_numpy(buf), non_blocking=False)
-            dist.all_gather_into_tensor(gather_out, pad)
+        if gather is not None:                                # the only collective of the path: detections -> every rank
+            gather(dets, ids)
         return dets
 
     def sync():
