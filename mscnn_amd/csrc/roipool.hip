@@ -10,6 +10,7 @@
 // (conv4_3 is 35 MB: L2 / Infinity-Cache resident across ROIs).
 #include "common.h"
 #include <cfloat>
+#include <cstdlib>
 
 namespace {
 
@@ -19,8 +20,8 @@ __global__ __launch_bounds__(kThreads) void roipool_kernel(const float* __restri
                                                            float* __restrict__ out, int C, int H, int W, int PH, int PW,
                                                            float spatial_scale, float pad_ratio, int C_total, int c_offset,
                                                            int chan_per_block) {
-  const int r = blockIdx.x;
-  const int c_begin = blockIdx.y * chan_per_block;
+  const int r = blockIdx.y;
+  const int c_begin = blockIdx.x * chan_per_block;
   const int c_end = min(C, c_begin + chan_per_block);
 
   const float* roi = rois + 5 * (size_t)r;
@@ -80,9 +81,9 @@ __global__ __launch_bounds__(256) void roipool_wave_kernel(const float* __restri
                                                            float spatial_scale, float pad_ratio, int C_total, int c_offset,
                                                            int chan_per_wave) {
   __shared__ float colmax[4][kMaxPH][64];
-  const int r = blockIdx.x;
+  const int r = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c_begin = (blockIdx.y * 4 + wave) * chan_per_wave;
+  const int c_begin = (blockIdx.x * 4 + wave) * chan_per_wave;
   const int c_end = min(C, c_begin + chan_per_wave);
 
   const float* roi = rois + 5 * (size_t)r;
@@ -161,19 +162,25 @@ extern "C" int mscnn_roipool_fwd_f32(const float* feat, const float* rois, float
   MSCNN_REQUIRE(pooled_h > 0 && pooled_w > 0, "roipool: pooled_h/pooled_w must be > 0");   // roi_pooling_layer.cpp:26-29
   MSCNN_REQUIRE(c_offset >= 0 && c_offset + C <= C_total, "roipool: channel window outside the output buffer");
   if (R == 0) return MSCNN_OK;
+  // XCD-aware launch geometry: the feature map (conv4_3: 35 MB) does not fit one XCD's 4 MB L2, but 1/8 of its channels
+  // does.  Workgroups are dispatched round-robin over the 8 XCDs by linear id, so with the CHANNEL GROUP on grid.x (a
+  // multiple of 8 groups) XCD j only ever touches channel groups == j (mod 8): its L2 keeps those planes hot across all
+  // ROIs instead of every XCD streaming the whole map from the Infinity Cache for every ROI.
   const int bins = pooled_h * pooled_w;
-  if (bins <= 64 && pooled_h <= kMaxPH) {
-    const int chan_per_wave = 8;
-    dim3 grid(R, cdiv(C, 4 * chan_per_wave));
+  static const bool use_wave = [] { const char* e = getenv("MSCNN_ROIPOOL_WAVE"); return e && *e == '1'; }();
+  if (use_wave && bins <= 64 && pooled_h <= kMaxPH) {
+    int chan_per_wave = 8;
+    while (chan_per_wave > 1 && (C % (32 * chan_per_wave)) != 0) chan_per_wave >>= 1;
+    dim3 grid(cdiv(C, 4 * chan_per_wave), R);
     roipool_wave_kernel<<<grid, 256, 0, as_stream(stream)>>>(feat, rois, out, C, H, W, pooled_h, pooled_w, spatial_scale,
                                                              pad_ratio, C_total, c_offset, chan_per_wave);
     MSCNN_POST_LAUNCH();
     return MSCNN_OK;
   }
-  // general shapes: one output element per lane
   int chan_per_block = max(1, (kThreads * 4) / bins);
   if (chan_per_block > C) chan_per_block = C;
-  dim3 grid(R, cdiv(C, chan_per_block));
+  if (C % 128 == 0) chan_per_block = 16;            // C/16 channel groups: a multiple of 8
+  dim3 grid(cdiv(C, chan_per_block), R);
   roipool_kernel<<<grid, kThreads, 0, as_stream(stream)>>>(feat, rois, out, C, H, W, pooled_h, pooled_w, spatial_scale,
                                                            pad_ratio, C_total, c_offset, chan_per_block);
   MSCNN_POST_LAUNCH();
