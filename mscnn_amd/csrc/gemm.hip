@@ -181,15 +181,52 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmArgs a) {
   }
 }
 
-// Small-N path: one workgroup per row m.
+// Small-N path (cls_pred N = 5, bbox_pred N = 20, K = 4096): one workgroup per row m.  The row of x is held in registers
+// (K / 256 values per thread), every output n is a register dot product + wave reduction, the 4 wave partials of all N
+// outputs are combined after ONE barrier.  W (N x K) is re-read by every workgroup out of L2.
+constexpr int kRowMaxN = 64, kRowMaxKPerThread = 32;
 __global__ __launch_bounds__(256) void ip_rowwise_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int M, int N,
+                                                         int K, int relu) {
+  __shared__ float red[4][kRowMaxN];
+  const int m = blockIdx.x;
+  const float* xr = x + (long)m * K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float xv[kRowMaxKPerThread];
+#pragma unroll
+  for (int i = 0; i < kRowMaxKPerThread; ++i) {
+    const int k = tid + i * 256;
+    xv[i] = k < K ? xr[k] : 0.f;
+  }
+  for (int n = 0; n < N; ++n) {
+    const float* wr = w + (long)n * K;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < kRowMaxKPerThread; ++i) {
+      const int k = tid + i * 256;
+      if (k < K) acc += xv[i] * wr[k];
+    }
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if (lane == 0) red[wave][n] = acc;
+  }
+  __syncthreads();
+  if (tid < N) {
+    float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (bias) v += bias[tid];
+    if (relu) v = v > 0.f ? v : 0.f;
+    y[(long)m * N + tid] = v;
+  }
+}
+
+// Fully general fallback (any N, K): one output per workgroup pass.
+__global__ __launch_bounds__(256) void ip_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int M, int N,
                                                          int K, int relu) {
   __shared__ float red[4];
   const int m = blockIdx.x;
   const float* xr = x + (long)m * K;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int n = 0; n < N; ++n) {
+  for (int n = blockIdx.y; n < N; n += gridDim.y) {
     const float* wr = w + (long)n * K;
     float acc = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) acc += xr[k] * wr[k];
@@ -223,7 +260,11 @@ extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const
   hipStream_t st = as_stream(stream);
   const bool aligned = (K % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(w) % 16 == 0);
   if (N < 64 || !aligned) {
-    ip_rowwise_kernel<<<M, 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+    if (N <= kRowMaxN && K <= 256 * kRowMaxKPerThread) {
+      ip_rowwise_kernel<<<M, 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+    } else {
+      ip_generic_kernel<<<dim3(M, N < 64 ? N : 64), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+    }
     MSCNN_POST_LAUNCH();
     return MSCNN_OK;
   }

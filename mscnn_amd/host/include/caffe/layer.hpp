@@ -56,6 +56,9 @@ class Layer {
   virtual void OnWeightsChanged() {}
   // Net-level operator fusion hooks (a fused layer must produce exactly what the pair produced).
   virtual bool FuseReLU(Dtype negative_slope) { return false; }
+  // A producer that can write its top straight into channels [c_offset, c_offset + C) of a wider blob (the top of the
+  // Concat that would otherwise copy it) returns true and does so from then on; its own top blob is then not written.
+  virtual bool SetOutputWindow(Blob<Dtype>* target, int c_total, int c_offset) { return false; }
   // Algorithmic FLOPs of the last Forward (0 for bandwidth layers), for roofline accounting.
   virtual double ForwardFlops() const { return 0; }
 

@@ -202,7 +202,11 @@ class SoftmaxLayer : public Layer<Dtype> {
 template <typename Dtype>
 class ROIPoolingLayer : public Layer<Dtype> {
  public:
-  explicit ROIPoolingLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  explicit ROIPoolingLayer(const LayerParameter& param) : Layer<Dtype>(param), window_(nullptr), window_c_total_(0), window_c_offset_(0) {}
+  virtual bool SetOutputWindow(Blob<Dtype>* target, int c_total, int c_offset) {
+    window_ = target; window_c_total_ = c_total; window_c_offset_ = c_offset;
+    return true;
+  }
   virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   virtual inline const char* type() const { return "ROIPooling"; }
@@ -215,6 +219,8 @@ class ROIPoolingLayer : public Layer<Dtype> {
   virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   int channels_, height_, width_, pooled_height_, pooled_width_;
   Dtype spatial_scale_, pad_ratio_;
+  Blob<Dtype>* window_;
+  int window_c_total_, window_c_offset_;
 };
 
 // include/caffe/layers/box_output_layer.hpp -- GPU implementation (the reference's is CPU only)

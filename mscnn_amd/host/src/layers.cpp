@@ -398,9 +398,15 @@ void ROIPoolingLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const v
 }
 template <typename Dtype>
 void ROIPoolingLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
-  MSCNN_CHECK(mscnn_roipool_fwd_f32(bottom[0]->gpu_data(), bottom[1]->gpu_data(), top[0]->mutable_gpu_data(), bottom[1]->num(),
-                                    bottom[0]->num(), channels_, height_, width_, pooled_height_, pooled_width_, spatial_scale_,
-                                    pad_ratio_, channels_, 0, S()));
+  Dtype* out = window_ ? nullptr : top[0]->mutable_gpu_data();
+  int c_total = channels_, c_offset = 0;
+  if (window_) {   // Net fused the following Concat away: write this layer's channels of the concatenated blob directly
+    window_->Reshape(bottom[1]->num(), window_c_total_, pooled_height_, pooled_width_);
+    out = window_->mutable_gpu_data();
+    c_total = window_c_total_; c_offset = window_c_offset_;
+  }
+  MSCNN_CHECK(mscnn_roipool_fwd_f32(bottom[0]->gpu_data(), bottom[1]->gpu_data(), out, bottom[1]->num(), bottom[0]->num(), channels_,
+                                    height_, width_, pooled_height_, pooled_width_, spatial_scale_, pad_ratio_, c_total, c_offset, S()));
 }
 
 // ------------------------------------------------------------------------------------------------ BoxOutput

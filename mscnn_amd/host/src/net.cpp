@@ -211,6 +211,34 @@ void Net<Dtype>::ApplyFusion() {
     const Dtype slope = layers_[i + 1]->layer_param().relu_param().negative_slope();
     if (layers_[i]->FuseReLU(slope)) fused_away_[i + 1] = true;
   }
+  // Channel Concat whose bottoms all come straight from ROIPooling layers (roi_pool_org + roi_pool_ctx -> roi_pool): the
+  // producers write their channel window of the concatenated blob and the copy layer disappears (concat_layer.cu:28-46
+  // moves R x 1024 x 49 floats per image otherwise).  The individual ROIPooling tops are then not materialised.
+  for (size_t i = 0; i < layers_.size(); ++i) {
+    if (string(layers_[i]->type()) != "Concat" || bottom_vecs_[i].size() < 2 || top_vecs_[i].size() != 1) continue;
+    const ConcatParameter cp = layers_[i]->layer_param().concat_param();
+    if ((cp.has_concat_dim() ? (int)cp.concat_dim() : cp.axis()) != 1) continue;
+    vector<int> producers;
+    int c_total = 0;
+    bool ok = true;
+    for (size_t b = 0; b < bottom_vecs_[i].size() && ok; ++b) {
+      int prod = -1, consumers = 0;
+      for (size_t l = 0; l < layers_.size(); ++l) {
+        for (Blob<Dtype>* t : top_vecs_[l]) if (t == bottom_vecs_[i][b]) prod = (int)l;
+        for (Blob<Dtype>* bb : bottom_vecs_[l]) if (bb == bottom_vecs_[i][b]) ++consumers;
+      }
+      ok = prod >= 0 && consumers == 1 && string(layers_[prod]->type()) == "ROIPooling" && top_vecs_[prod].size() == 1;
+      producers.push_back(prod);
+      if (ok) c_total += bottom_vecs_[i][b]->channels();
+    }
+    if (!ok) continue;
+    int off = 0;
+    for (size_t b = 0; b < producers.size(); ++b) {
+      CHECK(layers_[producers[b]]->SetOutputWindow(top_vecs_[i][0], c_total, off));
+      off += bottom_vecs_[i][b]->channels();
+    }
+    fused_away_[i] = true;
+  }
 }
 
 template <typename Dtype>

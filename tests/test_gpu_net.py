@@ -67,11 +67,14 @@ def test_net_layerwise_and_end_to_end(model, size, regime, cls_id):
     assert R == r2["proposals"].shape[0]
     assert np.array_equal(rois_dev, r2["proposals"])                      # bit-identical boxes and order
     assert np.array_equal(n.get_blob("proposals_score"), r2["proposals_score"])
-    # ROI pooling on the device's conv4_3 + ROIs: bit-exact
+    # ROI pooling on the device's conv4_3 + ROIs: bit-exact.  The two ROIPooling layers write straight into the Concat top
+    # (the Concat layer is fused away), so the check is made on the concatenated blob.
+    assert n.fused_away(n.layer_names.index("roi_pool"))
+    parts = []
     for l in layers:
         if l[1] == "ROIPooling":
-            out = pynet.forward([l], ws, {l[2][0]: n.get_blob(l[2][0]), l[2][1]: rois_dev})[l[3][0]]
-            assert np.array_equal(n.get_blob(l[3][0]), out), l[0]
+            parts.append(pynet.forward([l], ws, {l[2][0]: n.get_blob(l[2][0]), l[2][1]: rois_dev})[l[3][0]])
+    assert np.array_equal(n.get_blob("roi_pool"), np.concatenate(parts, axis=1))
     # detection sub-net with identical inputs
     sub = layers[[l[0] for l in layers].index("roi_pool"):]            # Concat ... bbox_pred, incl. the auto-inserted Split
     feeds = {b: n.get_blob(b) for b in sub[0][2]}
@@ -114,7 +117,8 @@ def test_unfused_equals_fused(monkeypatch):
         n.set_blob("data", x)
         n.forward()
         assert n.fused_away(n.layer_names.index("relu1_1")) == (nofuse == "0")
-        outs.append({b: n.get_blob(b) for b in ("conv4_3", "conv6_1", "proposals_score", "fc6", "bbox_pred")})
+        assert n.fused_away(n.layer_names.index("roi_pool")) == (nofuse == "0")
+        outs.append({b: n.get_blob(b) for b in ("conv4_3", "conv6_1", "proposals_score", "roi_pool", "fc6", "bbox_pred")})
     for b in outs[0]:
         assert np.array_equal(outs[0][b], outs[1][b]), b
 

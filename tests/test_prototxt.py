@@ -80,6 +80,7 @@ def test_7s576_graph_splits_and_shapes():
     # every in-place ReLU after a conv / fc is folded into its producer
     for name in ("relu1_1", "relu4_3", "loss_relu1", "roi_c1_relu", "relu6"):
         assert n.fused_away(n.layer_names.index(name))
+    assert n.fused_away(n.layer_names.index("roi_pool"))                     # ROIPooling x2 write the Concat top directly
     assert sum(t == "Convolution" for t in n.layer_types) == 23 and sum(t == "Pooling" for t in n.layer_types) == 6
 
 
