@@ -76,8 +76,8 @@ def test_net_layerwise_and_end_to_end(model, size, regime, cls_id):
             parts.append(pynet.forward([l], ws, {l[2][0]: n.get_blob(l[2][0]), l[2][1]: rois_dev})[l[3][0]])
     assert np.array_equal(n.get_blob("roi_pool"), np.concatenate(parts, axis=1))
     # detection sub-net with identical inputs
-    sub = layers[[l[0] for l in layers].index("roi_pool"):]            # Concat ... bbox_pred, incl. the auto-inserted Split
-    feeds = {b: n.get_blob(b) for b in sub[0][2]}
+    sub = layers[[l[0] for l in layers].index("roi_pool") + 1:]        # roi_c1 ... bbox_pred, incl. the auto-inserted Split
+    feeds = {"roi_pool": n.get_blob("roi_pool")}
     r3 = pynet.forward(sub, ws, feeds)
     for b in ("roi_c1", "fc6", "cls_pred", "bbox_pred"):
         assert rel_err(n.get_blob(b), r3[b]) < 1e-4, b
