@@ -184,37 +184,48 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmArgs a) {
 // Small-N path (cls_pred N = 5, bbox_pred N = 20, K = 4096): one workgroup per row m.  The row of x is held in registers
 // (K / 256 values per thread), every output n is a register dot product + wave reduction, the 4 wave partials of all N
 // outputs are combined after ONE barrier.  W (N x K) is re-read by every workgroup out of L2.
-constexpr int kRowMaxN = 64, kRowMaxKPerThread = 32;
+constexpr int kRowMaxN = 64, kRowMaxKPerThread = 16, kRowsPerBlock = 4;
 __global__ __launch_bounds__(256) void ip_rowwise_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int M, int N,
                                                          int K, int relu) {
-  __shared__ float red[4][kRowMaxN];
-  const int m = blockIdx.x;
-  const float* xr = x + (long)m * K;
+  __shared__ float red[kRowsPerBlock][4][kRowMaxN];
+  const int m0 = blockIdx.x * kRowsPerBlock;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float xv[kRowMaxKPerThread];
+  float xv[kRowsPerBlock][kRowMaxKPerThread];          // kRowsPerBlock rows share every load of W
 #pragma unroll
-  for (int i = 0; i < kRowMaxKPerThread; ++i) {
-    const int k = tid + i * 256;
-    xv[i] = k < K ? xr[k] : 0.f;
-  }
-  for (int n = 0; n < N; ++n) {
-    const float* wr = w + (long)n * K;
-    float acc = 0.f;
+  for (int r = 0; r < kRowsPerBlock; ++r)
 #pragma unroll
     for (int i = 0; i < kRowMaxKPerThread; ++i) {
       const int k = tid + i * 256;
-      if (k < K) acc += xv[i] * wr[k];
+      xv[r][i] = (k < K && m0 + r < M) ? x[(long)(m0 + r) * K + k] : 0.f;
     }
-    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
-    if (lane == 0) red[wave][n] = acc;
+  for (int n = 0; n < N; ++n) {
+    const float* wr = w + (long)n * K;
+    float acc[kRowsPerBlock];
+#pragma unroll
+    for (int r = 0; r < kRowsPerBlock; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kRowMaxKPerThread; ++i) {
+      const int k = tid + i * 256;
+      const float wv = k < K ? wr[k] : 0.f;
+#pragma unroll
+      for (int r = 0; r < kRowsPerBlock; ++r) acc[r] += xv[r][i] * wv;
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsPerBlock; ++r) {
+      float a = acc[r];
+      for (int d = 32; d > 0; d >>= 1) a += __shfl_down(a, d, 64);
+      if (lane == 0) red[r][wave][n] = a;
+    }
   }
   __syncthreads();
-  if (tid < N) {
-    float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    if (bias) v += bias[tid];
+  for (int i = tid; i < kRowsPerBlock * N; i += 256) {
+    const int r = i / N, n = i % N;
+    if (m0 + r >= M) continue;
+    float v = (red[r][0][n] + red[r][1][n]) + (red[r][2][n] + red[r][3][n]);
+    if (bias) v += bias[n];
     if (relu) v = v > 0.f ? v : 0.f;
-    y[(long)m * N + tid] = v;
+    y[(long)(m0 + r) * N + n] = v;
   }
 }
 
@@ -261,7 +272,7 @@ extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const
   const bool aligned = (K % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(w) % 16 == 0);
   if (N < 64 || !aligned) {
     if (N <= kRowMaxN && K <= 256 * kRowMaxKPerThread) {
-      ip_rowwise_kernel<<<M, 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+      ip_rowwise_kernel<<<cdiv(M, kRowsPerBlock), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
     } else {
       ip_generic_kernel<<<dim3(M, N < 64 ? N : 64), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
     }

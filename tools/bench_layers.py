@@ -14,7 +14,7 @@ LAYERS = [  # name, Cin, H, W, Cout, k, pad
     ("LFCN_1_5x5", 512, 72, 240, 9, 5, 2), ("LFCN_1_7x7", 512, 72, 240, 9, 7, 3),
     ("LFCN_2_7x7", 512, 36, 120, 9, 7, 3),
 ]
-ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=20); ap.add_argument("--only", default="")
+ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=20); ap.add_argument("--only", default=""); ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS probe)")
 a = ap.parse_args()
 torch.manual_seed(0)
 tot_f = tot_t = 0.0
@@ -22,6 +22,7 @@ for name, Cin, H, W, Cout, k, pad in LAYERS:
     if a.only and a.only not in name: continue
     x = torch.randn(1, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
     b = torch.randn(Cout, device="cuda")
+    if a.zero: x.zero_(); w.zero_()
     plan = hip.ConvPlan(1, Cin, H, W, Cout, k, k, (pad, pad), relu=True); plan.pack(w)
     y = plan.forward(x, b)
     for _ in range(3): plan.forward(x, b, out=y)
