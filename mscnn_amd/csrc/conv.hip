@@ -259,6 +259,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 
     MSCNN_LOAD_CHUNK(k0);
     for (int kc = k0; kc < k1; ++kc) {
+      if (C::PF == 2) __builtin_amdgcn_s_setprio(3);   // staging phase: get through the barriers quickly
+      if (C::PF < 12 || kc == k0) {      // (PF >= 11: timing ablations only, results are wrong by construction)
       __syncthreads();                 // everyone finished reading the previous chunk
 #pragma unroll
       for (int i = 0; i < C::A_PER_T; ++i)
@@ -267,7 +269,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       for (int i = 0; i < C::B_PER_T; ++i)
         if (C::B_ELEMS % 256 == 0 || tid + i * 256 < C::B_ELEMS) ldsB[tid + i * 256] = rb[i];
       __syncthreads();
-      if (kc + 1 < k1) MSCNN_LOAD_CHUNK(kc + 1);   // in flight while this chunk is multiplied
+      }
+      if (kc + 1 < k1 && C::PF < 11) MSCNN_LOAD_CHUNK(kc + 1);   // in flight while this chunk is multiplied
+      if (C::PF == 2) __builtin_amdgcn_s_setprio(0);
       if constexpr (C::PF == 0) {
 #pragma unroll
         for (int kh = 0; kh < C::KH; ++kh)
@@ -300,9 +304,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
           _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni) bv[buf][ni] = bRd[ni][cp_ * 2 * C::CH_STRIDE + kh_ * C::ROWS + kw_]; \
         }
         MSCNN_LDS_GROUP(0, 0);
+        if constexpr (C::PF == 13) MSCNN_LDS_GROUP(1, 1);   // ablation: operands loaded once, MFMA-only loop
         static_for<0, S>([&](auto sc) {
           constexpr int s = decltype(sc)::value;
-          if constexpr (s + 1 < S) MSCNN_LDS_GROUP(s + 1, (s + 1) & 1);
+          if constexpr (s + 1 < S && C::PF != 13) MSCNN_LDS_GROUP(s + 1, (s + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);      // pin: next group's ds_reads are issued BEFORE this group's MFMAs
 #pragma unroll
           for (int mi = 0; mi < C::MI; ++mi)
@@ -482,6 +487,13 @@ const KernelEntry kTable[] = {
     ENTRY_PF(128, 128, 2, 2, 3, 3, 8, 16),
     ENTRY_PF(128, 128, 2, 2, 3, 3, 8, 32),
     ENTRY_PF(64, 256, 1, 4, 3, 3, 8, 32),
+#ifdef MSCNN_ABLATIONS
+    {"ablate_noload", 128, 128, 3, 3, 8, 16, 8, 0, 0, 0, 1, 4, 11, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 11>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 11>>},
+    {"igemm_128x128_k3x3_tw16_pf_prio", 128, 128, 3, 3, 8, 16, 8, 0, 0, 0, 1, 4, 2, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 2>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 2>>},
+    {"igemm_128x256_k3x3_tw32_pf", 128, 256, 3, 3, 8, 32, 8, 0, 0, 0, 1, 8, 3, igemm_kernel<Cfg<128, 256, 2, 2, 3, 3, 8, 32, 0, 0, 0, 1>>, igemm_fixup_kernel<Cfg<128, 256, 2, 2, 3, 3, 8, 32, 0, 0, 0, 1>>},
+    {"ablate_mfmaonly", 128, 128, 3, 3, 8, 16, 8, 0, 0, 0, 1, 4, 13, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 13>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 13>>},
+    {"ablate_nostage", 128, 128, 3, 3, 8, 16, 8, 0, 0, 0, 1, 4, 12, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 12>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 12>>},
+#endif
     ENTRY(128, 256, 2, 2, 3, 3, 8, 32),     // variant 2 (selected with MSCNN_IGEMM_VARIANT=2): 64x128 wave tiles
     // proposal heads (Cout = 4 + classes <= 32): kitti_car 5x5 / 7x7, ped-cyc + caltech 3x5 / 5x7
     ENTRY(32, 128, 1, 4, 5, 5, 8, 16),
@@ -528,8 +540,8 @@ static void plan_shape(mscnn_conv_plan* p) {
     if (k.KH != d.Kh || k.KW != d.Kw) continue;
     const bool is256 = (k.BM == 128 && k.BN == 256);
     if (k.KH == 3 && k.KW == 3 && k.RH == 0) {
-      if (want == 2) { if (!is256 && d.Cout >= 128) continue; if (k.variant != 0) continue; }
-      else if (is256 || k.variant != want) continue;
+      if (is256 && k.variant == 0) continue;                  // (kept for reference; superseded by variant 3)
+      if (k.variant != want) continue;
     }
     double cost;
     if (k.RH > 0) {

@@ -126,3 +126,70 @@ def test_all_reference_deploys_parse():
         except mnet.NetError as e:
             assert "Unknown layer type" in str(e), (f, str(e))
     assert built >= 14
+
+
+# ---- .caffemodel (binary NetParameter) reader: Net::CopyTrainedLayersFrom, net.cpp:750-803 / blob.cpp:448-482 ----
+def _varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(field, payload):          # length-delimited field
+    return _varint((field << 3) | 2) + _varint(len(payload)) + payload
+
+
+def _blobproto(arr, legacy=False):
+    import numpy as np
+    a = np.ascontiguousarray(arr, np.float32)
+    body = b""
+    if legacy:                    # num/channels/height/width = fields 1..4 (varint)
+        dims = list(a.shape) + [1] * (4 - a.ndim) if a.ndim <= 4 else list(a.shape)
+        for f, d in enumerate(dims[:4], start=1):
+            body += _varint((f << 3) | 0) + _varint(d)
+    else:                         # shape = 7 { dim = 1 packed }
+        body += _ld(7, _ld(1, b"".join(_varint(d) for d in a.shape)))
+    body += _ld(5, a.tobytes())   # data = 5, packed floats
+    return body
+
+
+def _caffemodel(layers):
+    """layers: [(name, type, [arrays])] -> bytes of NetParameter{ name=1, layer=100{ name=1, type=2, blobs=7 } }"""
+    out = _ld(1, b"synthetic")
+    for i, (name, typ, blobs) in enumerate(layers):
+        lp = _ld(1, name.encode()) + _ld(2, typ.encode())
+        for b in blobs:
+            lp += _ld(7, _blobproto(b, legacy=(i % 2 == 1)))
+        lp += _varint((10 << 3) | 0) + _varint(1)      # an unrelated varint field (phase = 10) must be skipped
+        out += _ld(100, lp)
+    return out
+
+
+def test_caffemodel_reader(tmp_path):
+    import numpy as np
+    n = Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=64, width=128))
+    rng = np.random.default_rng(0)
+    want = {}
+    layers = []
+    for name in ("conv1_1", "conv4_3", "LFCN_2_7x7", "fc6", "bbox_pred"):
+        shapes = n.param_shapes(n.layer_names.index(name))
+        arrs = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+        want[name] = arrs
+        layers.append((name, "Convolution", arrs))
+    layers.append(("layer_not_in_net", "ReLU", []))           # ignored (net.cpp:760-764)
+    path = tmp_path / "w.caffemodel"
+    path.write_bytes(_caffemodel(layers))
+    n.load_caffemodel(path)
+    for name, arrs in want.items():
+        for p, a in enumerate(arrs):
+            assert np.array_equal(n.get_param(name, p), a), (name, p)
+    assert not np.any(n.get_param("conv2_1", 0))                # untouched layers keep their constant-0 filler
+    # shape mismatch is fatal, like the reference's CHECK in Blob::FromProto
+    bad = tmp_path / "bad.caffemodel"
+    bad.write_bytes(_caffemodel([("conv1_1", "Convolution", [np.zeros((3, 3), np.float32), np.zeros(64, np.float32)])]))
+    with pytest.raises(mnet.NetError, match="shape mismatch"):
+        n.load_caffemodel(bad)
