@@ -36,6 +36,7 @@ struct IgemmArgs {
   const float* x; const float* wp; const float* bias; float* y; float* ws;
   int N, Cin, H, W, Cout, Ho, Wo, pad_h, pad_w;
   int MT, NTH, NTW, NT, KI, G, relu;
+  int xcd_map;         // 1: XCD-aware workgroup -> range mapping
   int full_q;          // whole tiles per workgroup in the data-parallel phase (tile t = g + j * G, j < full_q)
   long total_iters;    // iterations (tile, chunk) of the stream-K phase: the remaining tiles [full_q * G, MT * NT)
 };
@@ -184,8 +185,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 
   // Hybrid schedule: first full_q whole tiles per workgroup (no partial sums at all), then the remaining tiles are
   // cut stream-K style into G equal (tile, chunk) ranges so that every CU finishes at the same time.
+  // XCD-aware workgroup -> range mapping: the dispatcher places workgroup b on XCD b % 8; giving XCD x the contiguous
+  // ranges [x * G/8, (x+1) * G/8) keeps one M-tile's packed weights (2.4 MB for conv4) resident in that XCD's 4 MB L2
+  // instead of every XCD cycling through all of them (speed only: any mapping is correct).
+  const int wg = (a.xcd_map && a.G % 8 == 0) ? (int)(blockIdx.x % 8) * (a.G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   long it, it_end;
-  wg_range(a.total_iters, a.G, blockIdx.x, it, it_end);
+  wg_range(a.total_iters, a.G, wg, it, it_end);
   int full_j = 0;
   const int rem_tile0 = a.full_q * a.G;
 
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   for (;;) {
     int t, k0, k1;
     if (full_j < a.full_q) {
-      t = blockIdx.x + full_j * a.G; k0 = 0; k1 = a.KI;
+      t = wg + full_j * a.G; k0 = 0; k1 = a.KI;
       ++full_j;
     } else if (it < it_end) {
       t = rem_tile0 + (int)(it / a.KI);
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         }
       }
     } else {
-      float* slab = a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (C::BM * C::BN);
+      float* slab = a.ws + ((long)wg * 2 + (k0 > 0 ? 0 : 1)) * (C::BM * C::BN);
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
@@ -661,6 +666,7 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
   a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.Ho = p->Ho; a.Wo = p->Wo; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
   a.MT = p->MT; a.NTH = p->NTH; a.NTW = p->NTW; a.NT = p->NT; a.KI = p->KI; a.G = p->G; a.relu = d.relu;
   a.total_iters = p->total_iters; a.full_q = p->full_q;
+  { static const bool noxcd = [] { const char* e = std::getenv("MSCNN_SK_NOXCD"); return e && *e == '1'; }(); a.xcd_map = noxcd ? 0 : 1; }
   k.main_fn<<<p->G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   if (split) {
