@@ -173,8 +173,13 @@ def main():
                 if lay_ms[i] > 0:
                     tf = flops[i] / (lay_ms[i] * 1e-3) / 1e12 if flops[i] else 0
                     print(f"{nm:28s} {net.layer_types[i]:14s} {net.layer_kernel(i):30s} {lay_ms[i]*1e3:9.1f} us {tf:7.1f} TF", file=sys.stderr)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_conv4_2.json")
+        if os.path.exists(tpath):      # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs), per conv4_2 launch
+            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": "fabric-side bytes (incl. Infinity-Cache hits) of one conv4_2 launch, profiles/r01_traffic_conv4_2.json",
                     "kernel": "igemm_kernel<128x128, k3x3> (+ stream-K fix-up) over " + "..".join([ROOFLINE_LAYERS[0], ROOFLINE_LAYERS[-1]]),
                     "algorithmic_gflop_per_image": round(blk_flops / 1e9, 2), "avg_ms_per_image": round(blk_ms, 4),
                     "all_conv_tflops": round(trunk_tf, 2)}
