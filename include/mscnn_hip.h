@@ -117,6 +117,16 @@ MSCNN_API int mscnn_roipool_fwd_f32(const float* feat, const float* rois, float*
                           int pooled_h, int pooled_w, float spatial_scale, float pad_ratio,
                           int C_total, int c_offset, void* stream);
 
+/* ROIAlign -- ROIAlignLayer<Dtype>::Forward_gpu (roi_align_layer.cu:21-112): out[R][C][pooled_h+1][pooled_w+1] bilinear
+ * samples on the grid of the (context-padded) roi; the WiderFace cascade deploy follows it with a 2x2 stride-1 AVE Pooling. */
+MSCNN_API int mscnn_roialign_fwd_f32(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W,
+                                     int pooled_h, int pooled_w, float spatial_scale, float pad_ratio, void* stream);
+
+/* Eltwise -- EltwiseLayer<Dtype>::Forward_gpu (eltwise_layer.cu): op 0 PROD, 1 SUM (coeffs_host[num_bottoms], NULL = all 1),
+ * 2 MAX.  bottoms_host: host array of num_bottoms (2..8) device pointers of `count` floats each. */
+MSCNN_API int mscnn_eltwise_fwd_f32(const float* const* bottoms_host, int num_bottoms, const float* coeffs_host, float* y,
+                                    size_t count, int op, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * BoxOutput -- BoxOutputLayer<Dtype>::Forward_cpu (box_output_layer.cpp:66-234; the reference has
  * no GPU version, box_output_layer.hpp:39-40): per-anchor decode + filter, descending sort on

@@ -170,9 +170,46 @@ __global__ __launch_bounds__(kThreads) void softmax_kernel(const float* __restri
   }
 }
 
+// ---- Eltwise: eltwise_layer.cu (PROD / SUM with coefficients / MAX), up to 8 bottoms ----------------------------
+struct EltArgs { const float* x[8]; float coeff[8]; int nb, op; };
+__global__ __launch_bounds__(kThreads) void eltwise_kernel(EltArgs a, float* __restrict__ y, long count) {
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < count; i += (long)gridDim.x * kThreads) {
+    float v;
+    if (a.op == 0) {
+      v = a.x[0][i] * a.x[1][i];
+      for (int b = 2; b < a.nb; ++b) v = v * a.x[b][i];
+    } else if (a.op == 1) {
+      v = 0.f;
+      for (int b = 0; b < a.nb; ++b) v = a.coeff[b] * a.x[b][i] + v;     // caffe_axpy per bottom, in order
+    } else {
+      v = a.x[0][i] > a.x[1][i] ? a.x[0][i] : a.x[1][i];
+      for (int b = 2; b < a.nb; ++b) if (a.x[b][i] > v) v = a.x[b][i];
+    }
+    y[i] = v;
+  }
+}
+
 }  // namespace
 
 using namespace mscnn;
+
+extern "C" int mscnn_eltwise_fwd_f32(const float* const* bottoms_host, int num_bottoms, const float* coeffs_host, float* y,
+                                     size_t count, int op, void* stream) {
+  MSCNN_REQUIRE(bottoms_host && y && num_bottoms >= 2 && num_bottoms <= 8, "eltwise: 2..8 bottoms");
+  MSCNN_REQUIRE(op >= 0 && op <= 2, "eltwise: op must be 0 PROD, 1 SUM, 2 MAX");
+  if (count == 0) return MSCNN_OK;
+  EltArgs a;
+  a.nb = num_bottoms; a.op = op;
+  for (int b = 0; b < num_bottoms; ++b) {
+    MSCNN_REQUIRE(bottoms_host[b], "eltwise: null bottom");
+    a.x[b] = bottoms_host[b];
+    a.coeff[b] = coeffs_host ? coeffs_host[b] : 1.f;
+  }
+  eltwise_kernel<<<grid_for((long)count), kThreads, 0, as_stream(stream)>>>(a, y, (long)count);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
 
 extern "C" int mscnn_relu_fwd_f32(const float* x, float* y, size_t count, float negative_slope, void* stream) {
   if (count == 0) return MSCNN_OK;

@@ -69,9 +69,66 @@ __global__ __launch_bounds__(kThreads) void roipool_kernel(const float* __restri
 }
 
 
+// ROIAlign: (PH+1) x (PW+1) bilinear samples per (roi, channel) -- roi_align_layer.cu:21-98, same operation order.
+__global__ __launch_bounds__(kThreads) void roialign_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
+                                                            float* __restrict__ out, int C, int H, int W, int PH, int PW,
+                                                            float spatial_scale, float pad_ratio, int chan_per_block) {
+  const int r = blockIdx.y;
+  const int c_begin = blockIdx.x * chan_per_block;
+  const int c_end = min(C, c_begin + chan_per_block);
+  const int GH = PH + 1, GW = PW + 1, pts = GH * GW;
+  const float* roi = rois + 5 * (size_t)r;
+  const int b = (int)roi[0];
+  const float pad_w = (roi[3] - roi[1] + 1) * pad_ratio, pad_h = (roi[4] - roi[2] + 1) * pad_ratio;
+  float roi_start_w = (roi[1] - pad_w) * spatial_scale, roi_start_h = (roi[2] - pad_h) * spatial_scale;
+  float roi_end_w = (roi[3] + pad_w) * spatial_scale, roi_end_h = (roi[4] + pad_h) * spatial_scale;
+  roi_start_w -= 0.5f; roi_start_h -= 0.5f; roi_end_w -= 0.5f; roi_end_h -= 0.5f;
+  const float roi_height = roi_end_h - roi_start_h, roi_width = roi_end_w - roi_start_w;
+  const float bin_size_h = roi_height / (float)PH, bin_size_w = roi_width / (float)PW;
+  const float* fbase = feat + (size_t)b * C * H * W;
+  float* obase = out + (size_t)r * C * pts;
+  const int work = (c_end - c_begin) * pts;
+  for (int i = threadIdx.x; i < work; i += kThreads) {
+    const int c = c_begin + i / pts, g = i % pts;
+    const int ph = g / GW, pw = g % GW;
+    float val = 0.f;
+    if (!(roi_height <= 0 || roi_width <= 0)) {
+      float hfloat = roi_start_h + (float)ph * bin_size_h, wfloat = roi_start_w + (float)pw * bin_size_w;
+      if (!(hfloat < -0.5f || hfloat > (H - 0.5f) || wfloat < -0.5f || wfloat > (W - 0.5f))) {
+        int hfloor = (int)floorf(hfloat), wfloor = (int)floorf(wfloat);
+        int hceil = hfloor + 1, wceil = wfloor + 1;
+        hfloat = fminf(fmaxf(hfloat, 0.f), (float)(H - 1)); wfloat = fminf(fmaxf(wfloat, 0.f), (float)(W - 1));
+        hfloor = min(max(hfloor, 0), H - 1); wfloor = min(max(wfloor, 0), W - 1);
+        hceil = min(max(hceil, 0), H - 1); wceil = min(max(wceil, 0), W - 1);
+        const float lh = hfloat - hfloor, lw = wfloat - wfloor, hh = 1 - lh, hw = 1 - lw;
+        const float w00 = hw * hh, w10 = lw * hh, w01 = hw * lh, w11 = lw * lh;
+        const float* plane = fbase + (size_t)c * H * W;
+        const float v00 = plane[hfloor * W + wfloor], v10 = plane[hfloor * W + wceil];
+        const float v01 = plane[hceil * W + wfloor], v11 = plane[hceil * W + wceil];
+        val = w00 * v00 + w10 * v10 + w01 * v01 + w11 * v11;
+      }
+    }
+    obase[(size_t)c * pts + g] = val;
+  }
+}
+
 }  // namespace
 
 using namespace mscnn;
+
+extern "C" int mscnn_roialign_fwd_f32(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W,
+                                      int pooled_h, int pooled_w, float spatial_scale, float pad_ratio, void* stream) {
+  MSCNN_REQUIRE(feat && rois && out, "roialign: null pointer");
+  MSCNN_REQUIRE(R >= 0 && N > 0 && C > 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0, "roialign: bad shape");
+  if (R == 0) return MSCNN_OK;
+  const int chan_per_block = (C % 128 == 0) ? 16 : max(1, min(C, 16));
+  dim3 grid(cdiv(C, chan_per_block), R);   // channel group on grid.x: XCD-local feature planes, as in ROIPooling
+  roialign_kernel<<<grid, kThreads, 0, as_stream(stream)>>>(feat, rois, out, C, H, W, pooled_h, pooled_w, spatial_scale,
+                                                            pad_ratio, chan_per_block);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
 
 extern "C" int mscnn_roipool_fwd_f32(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W,
                                      int pooled_h, int pooled_w, float spatial_scale, float pad_ratio, int C_total,

@@ -75,6 +75,8 @@ def lib():
         L.mscnn_softmax_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.mscnn_roipool_fwd_f32.argtypes = ([C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_float, C.c_float] + [C.c_int] * 2
                                             + [C.c_void_p])
+        L.mscnn_roialign_fwd_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_void_p]
+        L.mscnn_eltwise_fwd_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.mscnn_boxoutput_workspace_bytes.restype = C.c_size_t
         L.mscnn_boxoutput_workspace_bytes.argtypes = [C.c_void_p]
         L.mscnn_boxoutput_max_rows.argtypes = [C.c_void_p]
@@ -251,6 +253,26 @@ def roipool(feat, rois, pooled_h, pooled_w, spatial_scale, pad_ratio=0.0, out=No
     _check(lib().mscnn_roipool_fwd_f32(_dev(feat), _dev(rois), _dev(out), R, N, Cc, H, W, pooled_h, pooled_w,
                                        spatial_scale, pad_ratio, c_total, c_offset, _stream()))
     return out
+
+
+def roialign(feat, rois, pooled_h, pooled_w, spatial_scale, pad_ratio=0.0):
+    N, Cc, H, W = feat.shape
+    R = rois.shape[0]
+    out = torch.empty((R, Cc, pooled_h + 1, pooled_w + 1), dtype=torch.float32, device=feat.device)
+    _check(lib().mscnn_roialign_fwd_f32(_dev(feat), _dev(rois), _dev(out), R, N, Cc, H, W, pooled_h, pooled_w, spatial_scale,
+                                        pad_ratio, _stream()))
+    return out
+
+
+def eltwise(xs, op="SUM", coeffs=None):
+    n = len(xs)
+    for t in xs:
+        _dev(t)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
+    cf = (C.c_float * n)(*coeffs) if coeffs is not None and len(coeffs) else None
+    y = torch.empty_like(xs[0])
+    _check(lib().mscnn_eltwise_fwd_f32(ptrs, n, cf, _dev(y), y.numel(), {"PROD": 0, "SUM": 1, "MAX": 2}[op], _stream()))
+    return y
 
 
 def make_boxoutput_desc(head_shapes, num, channels, field_w, field_h, downsample, fg_thr=-5.0, iou_thr=0.65,

@@ -223,6 +223,41 @@ class ROIPoolingLayer : public Layer<Dtype> {
   int window_c_total_, window_c_offset_;
 };
 
+// include/caffe/layers/roi_align_layer.hpp -- tops are (R, C, pooled_h + 1, pooled_w + 1) grid samples
+template <typename Dtype>
+class ROIAlignLayer : public Layer<Dtype> {
+ public:
+  explicit ROIAlignLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "ROIAlign"; }
+  virtual inline int MinBottomBlobs() const { return 2; }
+  virtual inline int MaxBottomBlobs() const { return 2; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+ protected:
+  MSCNN_NO_CPU_PATH("ROIAlign")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  int channels_, height_, width_, pooled_height_, pooled_width_;
+  Dtype spatial_scale_, pad_ratio_;
+};
+
+// include/caffe/layers/eltwise_layer.hpp
+template <typename Dtype>
+class EltwiseLayer : public Layer<Dtype> {
+ public:
+  explicit EltwiseLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  virtual inline const char* type() const { return "Eltwise"; }
+  virtual inline int MinBottomBlobs() const { return 2; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+ protected:
+  MSCNN_NO_CPU_PATH("Eltwise")
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  int op_;
+  vector<float> coeffs_;
+};
+
 // include/caffe/layers/box_output_layer.hpp -- GPU implementation (the reference's is CPU only)
 template <typename Dtype>
 class BoxOutputLayer : public Layer<Dtype> {

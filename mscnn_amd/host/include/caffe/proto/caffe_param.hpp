@@ -167,6 +167,21 @@ class SoftmaxParameter {
   int axis() const { return (int)m_->num("axis", 0, 1); }
 };
 
+enum EltwiseParameter_EltwiseOp { EltwiseParameter_EltwiseOp_PROD = 0, EltwiseParameter_EltwiseOp_SUM = 1, EltwiseParameter_EltwiseOp_MAX = 2 };
+
+class EltwiseParameter {
+  MSCNN_PARAM_CLASS(EltwiseParameter)
+  EltwiseParameter_EltwiseOp operation() const {
+    const std::string o = m_->str_or("operation", "SUM");
+    if (o == "PROD" || o == "0") return EltwiseParameter_EltwiseOp_PROD;
+    if (o == "SUM" || o == "1") return EltwiseParameter_EltwiseOp_SUM;
+    if (o == "MAX" || o == "2") return EltwiseParameter_EltwiseOp_MAX;
+    LOG(FATAL) << "Unknown elementwise operation " << o;
+  }
+  int coeff_size() const { return m_->count("coeff"); }
+  float coeff(int i) const { return (float)m_->num("coeff", i, 1); }
+};
+
 class ROIPoolingParameter {   // caffe.proto:1257-1266
   MSCNN_PARAM_CLASS(ROIPoolingParameter)
   unsigned pooled_h() const { return (unsigned)m_->num("pooled_h", 0, 0); }
@@ -262,6 +277,7 @@ class LayerParameter {
   DropoutParameter dropout_param() const { return DropoutParameter(m_->sub("dropout_param")); }
   ConcatParameter concat_param() const { return ConcatParameter(m_->sub("concat_param")); }
   SoftmaxParameter softmax_param() const { return SoftmaxParameter(m_->sub("softmax_param")); }
+  EltwiseParameter eltwise_param() const { return EltwiseParameter(m_->sub("eltwise_param")); }
   ROIPoolingParameter roi_pooling_param() const { return ROIPoolingParameter(m_->sub("roi_pooling_param")); }
   BoxOutputParameter box_output_param() const { return BoxOutputParameter(m_->sub("box_output_param")); }
   BBoxRegParameter bbox_reg_param() const { return BBoxRegParameter(m_->sub("bbox_reg_param")); }

@@ -20,7 +20,8 @@ void Fill(const FillerParameter& fp, Blob<float>* blob, unsigned seed) {
   float* d = blob->mutable_cpu_data();
   const string t = fp.type();
   if (t == "constant") {
-    for (int i = 0; i < blob->count(); ++i) d[i] = fp.value();
+    if (fp.value() != 0.f)                      // freshly allocated host memory is already zero (SyncedMemory::to_cpu)
+      for (int i = 0; i < blob->count(); ++i) d[i] = fp.value();
   } else if (t == "gaussian") {
     std::mt19937 gen(seed);
     std::normal_distribution<float> dist(fp.mean(), fp.std());
@@ -409,6 +410,50 @@ void ROIPoolingLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, con
                                     height_, width_, pooled_height_, pooled_width_, spatial_scale_, pad_ratio_, c_total, c_offset, S()));
 }
 
+// ------------------------------------------------------------------------------------------------ ROIAlign
+template <typename Dtype>
+void ROIAlignLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const ROIPoolingParameter p = this->layer_param_.roi_pooling_param();   // roi_align_layer.cpp:22-37 (same message)
+  CHECK_GT(p.pooled_h(), 0u) << "pooled_h must be > 0";
+  CHECK_GT(p.pooled_w(), 0u) << "pooled_w must be > 0";
+  pooled_height_ = p.pooled_h(); pooled_width_ = p.pooled_w();
+  spatial_scale_ = p.spatial_scale(); pad_ratio_ = p.pad_ratio();
+}
+template <typename Dtype>
+void ROIAlignLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  channels_ = bottom[0]->channels(); height_ = bottom[0]->height(); width_ = bottom[0]->width();
+  top[0]->Reshape(bottom[1]->num(), channels_, pooled_height_ + 1, pooled_width_ + 1);   // :40-46 grid_height_/grid_width_
+}
+template <typename Dtype>
+void ROIAlignLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  MSCNN_CHECK(mscnn_roialign_fwd_f32(bottom[0]->gpu_data(), bottom[1]->gpu_data(), top[0]->mutable_gpu_data(), bottom[1]->num(),
+                                     bottom[0]->num(), channels_, height_, width_, pooled_height_, pooled_width_, spatial_scale_,
+                                     pad_ratio_, S()));
+}
+
+// ------------------------------------------------------------------------------------------------ Eltwise
+template <typename Dtype>
+void EltwiseLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const EltwiseParameter p = this->layer_param_.eltwise_param();   // eltwise_layer.cpp:9-27
+  CHECK(p.coeff_size() == 0 || p.coeff_size() == (int)bottom.size()) << "Eltwise Layer takes one coefficient per bottom blob.";
+  CHECK(!(p.operation() == EltwiseParameter_EltwiseOp_PROD && p.coeff_size())) << "Eltwise layer only takes coefficients for summation.";
+  op_ = (int)p.operation();
+  coeffs_.assign(bottom.size(), 1.f);
+  for (int i = 0; i < p.coeff_size(); ++i) coeffs_[i] = p.coeff(i);
+  CHECK_LE(bottom.size(), 8u) << "Eltwise: at most 8 bottoms in this build";
+}
+template <typename Dtype>
+void EltwiseLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  for (size_t i = 1; i < bottom.size(); ++i) CHECK(bottom[i]->shape() == bottom[0]->shape());
+  top[0]->ReshapeLike(*bottom[0]);
+}
+template <typename Dtype>
+void EltwiseLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const float* ptrs[8];
+  for (size_t i = 0; i < bottom.size(); ++i) ptrs[i] = bottom[i]->gpu_data();
+  MSCNN_CHECK(mscnn_eltwise_fwd_f32(ptrs, (int)bottom.size(), coeffs_.data(), top[0]->mutable_gpu_data(), (size_t)top[0]->count(), op_, S()));
+}
+
 // ------------------------------------------------------------------------------------------------ BoxOutput
 template <typename Dtype>
 void BoxOutputLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
@@ -523,6 +568,8 @@ INSTANTIATE_CLASS(ConcatLayer);
 INSTANTIATE_CLASS(DropoutLayer);
 INSTANTIATE_CLASS(SoftmaxLayer);
 INSTANTIATE_CLASS(ROIPoolingLayer);
+INSTANTIATE_CLASS(ROIAlignLayer);
+INSTANTIATE_CLASS(EltwiseLayer);
 INSTANTIATE_CLASS(BoxOutputLayer);
 INSTANTIATE_CLASS(DecodeBBoxLayer);
 
@@ -537,6 +584,8 @@ REGISTER_LAYER_CLASS(Concat);
 REGISTER_LAYER_CLASS(Dropout);
 REGISTER_LAYER_CLASS(Softmax);
 REGISTER_LAYER_CLASS(ROIPooling);
+REGISTER_LAYER_CLASS(ROIAlign);
+REGISTER_LAYER_CLASS(Eltwise);
 REGISTER_LAYER_CLASS(BoxOutput);
 REGISTER_LAYER_CLASS(DecodeBBox);
 

@@ -649,6 +649,65 @@ ORC_API int orc_detections(const float* bbox_pred, const float* cls_pred, const 
   return D;
 }
 
+/* ------------------------------------------------------------------ */
+/* ROIAlign: src/caffe/layers/roi_align_layer.cpp:48-147 (CPU) /         */
+/* roi_align_layer.cu:21-98.  out (R, C, PH+1, PW+1): bilinear samples on  */
+/* the (PH+1)x(PW+1) grid of the padded ROI; the deploy nets follow it with */
+/* a 2x2 stride-1 AVE Pooling.                                              */
+/* ------------------------------------------------------------------ */
+ORC_API int orc_roialign(const float* feat, const float* rois, float* out, int R, int batch, int C, int H, int W,
+                         int PH, int PW, float spatial_scale, float pad_ratio) {
+  const int GH = PH + 1, GW = PW + 1;
+  for (int n = 0; n < R; ++n) {
+    const float* roi = rois + 5 * (size_t)n;
+    const int b = (int)roi[0];
+    if (b < 0 || b >= batch) return -1;
+    const float pad_w = (roi[3] - roi[1] + 1) * pad_ratio, pad_h = (roi[4] - roi[2] + 1) * pad_ratio;
+    float roi_start_w = (roi[1] - pad_w) * spatial_scale, roi_start_h = (roi[2] - pad_h) * spatial_scale;
+    float roi_end_w = (roi[3] + pad_w) * spatial_scale, roi_end_h = (roi[4] + pad_h) * spatial_scale;
+    roi_start_w -= 0.5; roi_start_h -= 0.5; roi_end_w -= 0.5; roi_end_h -= 0.5;
+    const float roi_height = roi_end_h - roi_start_h, roi_width = roi_end_w - roi_start_w;
+    const float bin_size_h = roi_height / (float)PH, bin_size_w = roi_width / (float)PW;
+    for (int c = 0; c < C; ++c) {
+      const float* bd = feat + ((size_t)b * C + c) * H * W;
+      float* top = out + ((size_t)n * C + c) * GH * GW;
+      for (int ph = 0; ph <= PH; ++ph)
+        for (int pw = 0; pw <= PW; ++pw) {
+          float* o = top + ph * GW + pw;
+          if (roi_height <= 0 || roi_width <= 0) { *o = 0.f; continue; }
+          float hfloat = roi_start_h + (float)ph * bin_size_h, wfloat = roi_start_w + (float)pw * bin_size_w;
+          if (hfloat < -0.5 || hfloat > (H - 0.5) || wfloat < -0.5 || wfloat > (W - 0.5)) { *o = 0.f; continue; }
+          int hfloor = (int)floorf(hfloat), wfloor = (int)floorf(wfloat);
+          int hceil = hfloor + 1, wceil = wfloor + 1;
+          hfloat = fminf(fmaxf(hfloat, 0.f), (float)(H - 1)); wfloat = fminf(fmaxf(wfloat, 0.f), (float)(W - 1));
+          hfloor = imin(imax(hfloor, 0), H - 1); wfloor = imin(imax(wfloor, 0), W - 1);
+          hceil = imin(imax(hceil, 0), H - 1); wceil = imin(imax(wceil, 0), W - 1);
+          const float lh = hfloat - hfloor, lw = wfloat - wfloor, hh = 1 - lh, hw = 1 - lw;
+          const float w00 = hw * hh, w10 = lw * hh, w01 = hw * lh, w11 = lw * lh;
+          const float v00 = bd[hfloor * W + wfloor], v10 = bd[hfloor * W + wceil], v01 = bd[hceil * W + wfloor], v11 = bd[hceil * W + wceil];
+          *o = w00 * v00 + w10 * v10 + w01 * v01 + w11 * v11;
+        }
+    }
+  }
+  return 0;
+}
+
+/* Eltwise: src/caffe/layers/eltwise_layer.cpp:44-100.  op: 0 PROD, 1 SUM (coeffs), 2 MAX */
+ORC_API int orc_eltwise(const float* const* xs, int nb, const float* coeffs, float* y, long count, int op) {
+  if (nb < 2) return -1;
+  for (long i = 0; i < count; ++i) {
+    float v;
+    if (op == 0) { v = xs[0][i] * xs[1][i]; for (int b = 2; b < nb; ++b) v = v * xs[b][i]; }
+    else if (op == 1) { v = 0.f; for (int b = 0; b < nb; ++b) v = coeffs[b] * xs[b][i] + v; }   /* axpy: y = a*x + y */
+    else {                                      /* MAX: a > b ? a : b, then strict '>' for bottoms 2.. (:72-92) */
+      v = xs[0][i] > xs[1][i] ? xs[0][i] : xs[1][i];
+      for (int b = 2; b < nb; ++b) if (xs[b][i] > v) v = xs[b][i];
+    }
+    y[i] = v;
+  }
+  return 0;
+}
+
 /* Concat along channels: src/caffe/layers/concat_layer.cpp:57-74 */
 ORC_API int orc_concat_channels(const float* const* xs, const int* cs, int nb, float* y, int N, int inner) {
   int ctot = 0;

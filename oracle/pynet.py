@@ -104,6 +104,13 @@ def _forward(layers, weights, inputs, stop_after):
             p = P["roi_pooling_param"][0]
             blobs[tops[0]] = orc.roipool(x[0], x[1].reshape(-1, 5), int(_num(p, "pooled_h", 0)), int(_num(p, "pooled_w", 0)),
                                          _num(p, "spatial_scale", 1.0), _num(p, "pad_ratio", 0.0))
+        elif typ == "ROIAlign":
+            p = P["roi_pooling_param"][0]
+            blobs[tops[0]] = orc.roialign(x[0], x[1].reshape(-1, 5), int(_num(p, "pooled_h", 0)), int(_num(p, "pooled_w", 0)),
+                                          _num(p, "spatial_scale", 1.0), _num(p, "pad_ratio", 0.0))
+        elif typ == "Eltwise":
+            p = P.get("eltwise_param", [{}])[0]
+            blobs[tops[0]] = orc.eltwise(x, p.get("operation", ["SUM"])[0], [float(v) for v in p.get("coeff", [])])
         elif typ == "BoxOutput":
             p = P["box_output_param"][0]
             br = P.get("bbox_reg_param", [{}])[0]

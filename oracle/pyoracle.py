@@ -195,6 +195,30 @@ def roipool(feat, rois, pooled_h, pooled_w, spatial_scale, pad_ratio=0.0, with_a
     return (out, am) if with_argmax else out
 
 
+def roialign(feat, rois, pooled_h, pooled_w, spatial_scale, pad_ratio=0.0):
+    feat, fp = _f(feat); rois, rp = _f(rois)
+    N, Cc, H, W = feat.shape
+    R = rois.shape[0]
+    out = np.empty((R, Cc, pooled_h + 1, pooled_w + 1), np.float32)
+    rc = lib().orc_roialign(fp, rp, out.ctypes.data_as(f32p), R, N, Cc, H, W, pooled_h, pooled_w, C.c_float(spatial_scale), C.c_float(pad_ratio))
+    assert rc == 0, rc
+    return out
+
+
+ELTWISE_OPS = {"PROD": 0, "SUM": 1, "MAX": 2}
+
+
+def eltwise(xs, op="SUM", coeffs=None):
+    arrs = [np.ascontiguousarray(x, np.float32) for x in xs]
+    n = len(arrs)
+    ptrs = (f32p * n)(*[a.ctypes.data_as(f32p) for a in arrs])
+    cf = (C.c_float * n)(*(coeffs if coeffs is not None and len(coeffs) else [1.0] * n))
+    y = np.empty_like(arrs[0])
+    rc = lib().orc_eltwise(ptrs, n, cf, y.ctypes.data_as(f32p), C.c_long(y.size), ELTWISE_OPS[op])
+    assert rc == 0
+    return y
+
+
 def decode_bbox(bbox, prior, mean=(0, 0, 0, 0), std=(1, 1, 1, 1)):
     bbox, bp = _f(bbox); prior, pp = _f(prior)
     R = bbox.shape[0]

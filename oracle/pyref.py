@@ -120,6 +120,25 @@ def roipool(feat, rois, pooled_h, pooled_w, spatial_scale, pad_ratio=0.0):
     return out
 
 
+def roialign(feat, rois, pooled_h, pooled_w, spatial_scale, pad_ratio=0.0):
+    feat, fp = _f(feat); rois, rp = _f(rois)
+    N, Cc, H, W = feat.shape
+    R = rois.shape[0]
+    out = np.empty((R, Cc, pooled_h + 1, pooled_w + 1), np.float32)
+    _ck(lib().ref_roialign(fp, rp, out.ctypes.data_as(f32p), R, N, Cc, H, W, pooled_h, pooled_w, C.c_float(spatial_scale), C.c_float(pad_ratio)))
+    return out
+
+
+def eltwise(xs, op="SUM", coeffs=None):
+    arrs = [np.ascontiguousarray(x, np.float32) for x in xs]
+    n = len(arrs)
+    ptrs = (f32p * n)(*[a.ctypes.data_as(f32p) for a in arrs])
+    cf = (C.c_float * n)(*coeffs) if coeffs is not None and len(coeffs) else None
+    y = np.empty_like(arrs[0])
+    _ck(lib().ref_eltwise(ptrs, n, cf, y.ctypes.data_as(f32p), y.size, {"PROD": 0, "SUM": 1, "MAX": 2}[op]))
+    return y
+
+
 def boxoutput(heads, field_w, field_h, downsample, fg_thr=-5.0, iou_thr=0.65, nms_type="IOU", field_whr=2.0, field_xyr=2.0,
               max_nms_num=2000, max_post_nms_num=0, min_size=15.0, bbox_mean=None, bbox_std=None):
     hs = [np.ascontiguousarray(h, np.float32) for h in heads]

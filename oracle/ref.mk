@@ -2,7 +2,7 @@
 # (glog / gflags / boost / protobuf / cblas stand-ins), plus oracle/ref_harness.cpp (C entry points for the tests).
 # Nothing from $(REF) is copied into this repository; outputs go to oracle/_ref/ only (git-ignored).
 REF_SRCS := blob.cpp syncedmem.cpp layer.cpp common.cpp util/math_functions.cpp util/im2col.cpp \
-            layers/box_output_layer.cpp layers/roi_pooling_layer.cpp layers/decode_bbox_layer.cpp \
+            layers/box_output_layer.cpp layers/roi_pooling_layer.cpp layers/roi_align_layer.cpp layers/eltwise_layer.cpp layers/decode_bbox_layer.cpp \
             layers/conv_layer.cpp layers/base_conv_layer.cpp layers/deconv_layer.cpp layers/pooling_layer.cpp \
             layers/relu_layer.cpp layers/neuron_layer.cpp layers/inner_product_layer.cpp layers/concat_layer.cpp \
             layers/softmax_layer.cpp layers/split_layer.cpp
@@ -12,14 +12,16 @@ REF_CXXFLAGS := -O2 -ffp-contract=off -fPIC -std=c++11 -DCPU_ONLY -Ishim -I$(REF
 
 ref: _ref/libmscnn_ref.so
 
+SHIM_HDRS := $(shell find shim -name '*.h' -o -name '*.hpp')
+
 define REF_RULE
-_ref/obj/$(subst /,_,$(1:.cpp=.o)): $(REF)/src/caffe/$(1)
+_ref/obj/$(subst /,_,$(1:.cpp=.o)): $(REF)/src/caffe/$(1) $(SHIM_HDRS)
 	@mkdir -p _ref/obj
 	$(CXX) $(REF_CXXFLAGS) -c $$< -o $$@
 endef
 $(foreach s,$(REF_SRCS),$(eval $(call REF_RULE,$(s))))
 
-_ref/obj/harness.o: ref_harness.cpp
+_ref/obj/harness.o: ref_harness.cpp $(SHIM_HDRS)
 	@mkdir -p _ref/obj
 	$(CXX) $(REF_CXXFLAGS) -c $< -o $@
 

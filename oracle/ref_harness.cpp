@@ -15,6 +15,8 @@
 #include "caffe/layers/inner_product_layer.hpp"
 #include "caffe/layers/pooling_layer.hpp"
 #include "caffe/layers/relu_layer.hpp"
+#include "caffe/layers/eltwise_layer.hpp"
+#include "caffe/layers/roi_align_layer.hpp"
 #include "caffe/layers/roi_pooling_layer.hpp"
 #include "caffe/layers/softmax_layer.hpp"
 #include "caffe/util/math_functions.hpp"
@@ -145,6 +147,44 @@ REF_API int ref_roipool(const float* feat, const float* rois, float* out, int R,
     layer.SetUp(bv, tv);
     layer.Forward(bv, tv);
     take(top, out);
+  })
+}
+
+REF_API int ref_roialign(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W, int PH, int PW,
+                         float spatial_scale, float pad_ratio) {
+  GUARD({
+    LayerParameter lp;
+    ROIPoolingParameter* p = lp.mutable_roi_pooling_param();
+    p->set_pooled_h(PH); p->set_pooled_w(PW); p->set_spatial_scale(spatial_scale); p->set_pad_ratio(pad_ratio);
+    ROIAlignLayer<float> layer(lp);
+    Blob<float> bottom(N, C, H, W), broi(R, 5, 1, 1), top;
+    fill(&bottom, feat); fill(&broi, rois);
+    BV bv; bv.push_back(&bottom); bv.push_back(&broi);
+    BV tv(1, &top);
+    layer.SetUp(bv, tv);
+    layer.Forward(bv, tv);
+    take(top, out);
+  })
+}
+
+REF_API int ref_eltwise(const float* const* xs, int nb, const float* coeffs, float* y, int count, int op) {
+  GUARD({
+    LayerParameter lp;
+    lp.mutable_eltwise_param()->set_operation((EltwiseParameter_EltwiseOp)op);
+    if (coeffs && op == 1) for (int b = 0; b < nb; ++b) lp.mutable_eltwise_param()->add_coeff(coeffs[b]);
+    EltwiseLayer<float> layer(lp);
+    std::vector<shared_ptr<Blob<float> > > hold;
+    BV bv;
+    for (int b = 0; b < nb; ++b) {
+      hold.push_back(shared_ptr<Blob<float> >(new Blob<float>(1, 1, 1, count)));
+      fill(hold.back().get(), xs[b]);
+      bv.push_back(hold.back().get());
+    }
+    Blob<float> top;
+    BV tv(1, &top);
+    layer.SetUp(bv, tv);
+    layer.Forward(bv, tv);
+    take(top, y);
   })
 }
 

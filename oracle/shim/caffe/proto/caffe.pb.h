@@ -124,6 +124,12 @@ class ConcatParameter {
   PB_OPT(unsigned, concat_dim, 1)
 };
 class DropoutParameter { PB_OPT(float, dropout_ratio, 0.5f) };
+enum EltwiseParameter_EltwiseOp { EltwiseParameter_EltwiseOp_PROD = 0, EltwiseParameter_EltwiseOp_SUM = 1, EltwiseParameter_EltwiseOp_MAX = 2 };
+class EltwiseParameter {
+  PB_OPT(EltwiseParameter_EltwiseOp, operation, EltwiseParameter_EltwiseOp_SUM)
+  PB_REP(float, coeff)
+  PB_OPT(bool, stable_prod_grad, true)
+};
 
 class ROIPoolingParameter {      // caffe.proto:1257-1266
   PB_OPT(unsigned, pooled_h, 0)
@@ -177,6 +183,7 @@ class LayerParameter {
   PB_MSG(SoftmaxParameter, softmax_param)
   PB_MSG(ConcatParameter, concat_param)
   PB_MSG(DropoutParameter, dropout_param)
+  PB_MSG(EltwiseParameter, eltwise_param)
   PB_MSG(ROIPoolingParameter, roi_pooling_param)
   PB_MSG(BoxOutputParameter, box_output_param)
   PB_MSG(BBoxRegParameter, bbox_reg_param)

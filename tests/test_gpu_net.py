@@ -137,3 +137,69 @@ def test_dynamic_roi_count_across_forwards():
     n.set_blob("data", np.zeros((1, 3, 128, 256), np.float32))   # nothing like an object -> may hit few/no proposals
     n.forward()
     assert n.blob_shape("cls_pred")[0] == n.blob_shape("proposals")[0] >= 1
+
+
+MINI_CASCADE = """
+name: "mini_cascade"
+input: "data" input_dim: 1 input_dim: 3 input_dim: 96 input_dim: 160
+layer { name: "conv1_1" type: "Convolution" bottom: "data" top: "conv1_1" convolution_param { num_output: 16 pad: 1 kernel_size: 3 } }
+layer { name: "relu1_1" type: "ReLU" bottom: "conv1_1" top: "conv1_1" }
+layer { name: "pool1" type: "Pooling" bottom: "conv1_1" top: "pool1" pooling_param { pool: MAX kernel_size: 2 stride: 2 } }
+layer { name: "conv2_1" type: "Convolution" bottom: "pool1" top: "conv2_1" convolution_param { num_output: 32 pad: 1 kernel_size: 3 } }
+layer { name: "relu2_1" type: "ReLU" bottom: "conv2_1" top: "conv2_1" }
+layer { name: "pool2" type: "Pooling" bottom: "conv2_1" top: "pool2" pooling_param { pool: MAX kernel_size: 2 stride: 2 } }
+layer { name: "conv3_1" type: "Convolution" bottom: "pool2" top: "conv3_1" convolution_param { num_output: 32 pad: 1 kernel_size: 3 } }
+layer { name: "relu3_1" type: "ReLU" bottom: "conv3_1" top: "conv3_1" }
+layer { name: "LFCN_1_5x5" type: "Convolution" bottom: "conv3_1" top: "LFCN_1_5x5" convolution_param { num_output: 6 pad: 2 kernel_size: 5 } }
+layer { name: "proposals" type: "BoxOutput" bottom: "LFCN_1_5x5" top: "proposals" top: "proposals_score"
+        box_output_param { fg_thr: -3 iou_thr: 0.65 nms_type: "IOU" field_w: 24 field_h: 24 downsample_rate: 4 max_nms_num: 60 min_size: 4 } }
+layer { name: "roi_align" type: "ROIAlign" bottom: "conv3_1" bottom: "proposals" top: "roi_align"
+        roi_pooling_param { pooled_w: 6 pooled_h: 6 spatial_scale: 0.25 pad_ratio: 0 } }
+layer { name: "roi_align_ave" type: "Pooling" bottom: "roi_align" top: "roi_align_ave" pooling_param { pool: AVE kernel_size: 2 stride: 1 } }
+layer { name: "fc_a" type: "InnerProduct" bottom: "roi_align_ave" top: "fc_a" inner_product_param { num_output: 64 } }
+layer { name: "relu_a" type: "ReLU" bottom: "fc_a" top: "fc_a" }
+layer { name: "cls_1st" type: "InnerProduct" bottom: "fc_a" top: "cls_1st" inner_product_param { num_output: 2 } }
+layer { name: "bbox_1st" type: "InnerProduct" bottom: "fc_a" top: "bbox_1st" inner_product_param { num_output: 8 } }
+layer { name: "proposals_2nd" type: "DecodeBBox" bottom: "bbox_1st" bottom: "proposals" top: "proposals_2nd"
+        bbox_reg_param { bbox_mean: 0 bbox_mean: 0 bbox_mean: 0 bbox_mean: 0 bbox_std: 0.1 bbox_std: 0.1 bbox_std: 0.2 bbox_std: 0.2 } }
+layer { name: "roi_pool_2nd" type: "ROIPooling" bottom: "conv3_1" bottom: "proposals_2nd" top: "roi_pool_2nd"
+        roi_pooling_param { pooled_w: 4 pooled_h: 4 spatial_scale: 0.25 pad_ratio: 0.25 } }
+layer { name: "fc_b" type: "InnerProduct" bottom: "roi_pool_2nd" top: "fc_b" inner_product_param { num_output: 64 } }
+layer { name: "relu_b" type: "ReLU" bottom: "fc_b" top: "fc_b" }
+layer { name: "cls_2nd" type: "InnerProduct" bottom: "fc_b" top: "cls_2nd" inner_product_param { num_output: 2 } }
+layer { name: "cls_prob_1st" type: "Softmax" bottom: "cls_1st" top: "cls_prob_1st" }
+layer { name: "cls_prob_2nd" type: "Softmax" bottom: "cls_2nd" top: "cls_prob_2nd" }
+layer { name: "cls_prob_avg" type: "Eltwise" bottom: "cls_prob_1st" bottom: "cls_prob_2nd" top: "cls_prob_avg"
+        eltwise_param { operation: SUM coeff: 0.5 coeff: 0.5 } }
+"""
+
+
+def test_cascade_style_net():
+    """The layer chain of the cascade / WiderFace deploys (DecodeBBox -> re-pooling, ROIAlign + 2x2 AVE pooling, Softmax,
+    Eltwise) on a small hand-written net: per-layer parity with identical inputs."""
+    from oracle import pynet
+    n = mnet.Net(prototxt_text=MINI_CASCADE)
+    ws = synth.load_into(n, "dense")
+    x = synth.frame(96, 160)
+    n.set_blob("data", x)
+    n.forward()
+    layers = layer_list(n)
+    assert n.outputs == ["cls_prob_avg", "proposals_score"]
+    R = n.blob_shape("proposals")[0]
+    assert R > 3 and n.blob_shape("roi_align") == (R, 32, 7, 7) and n.blob_shape("roi_align_ave") == (R, 32, 6, 6)
+    names = [l[0] for l in layers]
+    # every layer after the trunk: feed the oracle with the device's own bottoms, compare the top
+    for l in layers[names.index("proposals"):]:
+        if l[1] in ("Split",):
+            continue
+        feeds = {b: n.get_blob(b) for b in l[2]}
+        ref = pynet.forward([l], ws, feeds)
+        for t in l[3]:
+            a, b = n.get_blob(t), ref[t].reshape(n.blob_shape(t))
+            if l[1] in ("BoxOutput", "ROIAlign", "ROIPooling", "DecodeBBox", "Eltwise", "ReLU"):
+                assert np.array_equal(a, b), (l[0], t)
+            else:
+                assert rel_err(a, b) < 1e-4, (l[0], t)
+    # and the trunk end to end
+    ref = pynet.forward(layers[:names.index("proposals")], ws, {"data": x})
+    assert rel_err(n.get_blob("LFCN_1_5x5"), ref["LFCN_1_5x5"]) < 1e-4

@@ -187,6 +187,23 @@ def test_roipool_concat_window(hip, orc):
     assert np.array_equal(out.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("ph,pw,scale,pad", [(7, 7, 0.125, 0.0), (7, 7, 0.125, 0.25), (4, 6, 0.25, 0.5)])
+def test_roialign(hip, orc, ph, pw, scale, pad):
+    rng = np.random.default_rng(17)
+    feat = rng.standard_normal((2, 24, 36, 120)).astype(np.float32)
+    rois = _random_rois(rng, 97, 36 / scale, 120 / scale, batch=2)
+    rois[0] = [0, -500, -500, -300, -300]; rois[1, 3] = rois[1, 1] - 3
+    y = hip.roialign(dev(feat), dev(rois), ph, pw, scale, pad).cpu().numpy()
+    assert np.array_equal(y, orc.roialign(feat, rois, ph, pw, scale, pad))       # same op order, contraction off: bit-exact
+
+
+def test_eltwise(hip, orc):
+    rng = np.random.default_rng(18)
+    xs = [rng.standard_normal((37, 5)).astype(np.float32) for _ in range(3)]
+    for op, cf in (("SUM", [0.33333333] * 3), ("SUM", None), ("PROD", None), ("MAX", None)):
+        assert np.array_equal(hip.eltwise([dev(x) for x in xs], op, cf).cpu().numpy(), orc.eltwise(xs, op, cf)), op
+
+
 # ------------------------------------------------------------------ NMS / BoxOutput (index-exact)
 def _clustered_boxes(rng, n):
     centers = rng.uniform(0, 1500, (max(1, n // 12), 2))

@@ -57,6 +57,25 @@ def test_roipool_bitexact(orc, ph, pw, scale, pad):
     assert np.array_equal(orc.roipool(feat, rois, ph, pw, scale, pad), pyref.roipool(feat, rois, ph, pw, scale, pad))
 
 
+@pytest.mark.parametrize("ph,pw,scale,pad", [(7, 7, 0.125, 0.0), (7, 7, 0.125, 0.25), (4, 4, 0.25, 0.5)])
+def test_roialign_bitexact(orc, ph, pw, scale, pad):
+    rng = np.random.default_rng(13)
+    feat = rng.standard_normal((2, 5, 36, 120)).astype(np.float32)
+    rois = _rois(rng, 150, 36 / scale, 120 / scale, 2)
+    rois[:10, 3] = rois[:10, 1] - 5                     # malformed (negative width) -> zeros
+    assert np.array_equal(orc.roialign(feat, rois, ph, pw, scale, pad), pyref.roialign(feat, rois, ph, pw, scale, pad))
+
+
+def test_eltwise(orc):
+    rng = np.random.default_rng(14)
+    xs = [rng.standard_normal((7, 5)).astype(np.float32) for _ in range(3)]
+    for op in ("PROD", "MAX"):
+        assert np.array_equal(orc.eltwise(xs, op), pyref.eltwise(xs, op))
+    assert np.array_equal(orc.eltwise(xs[:2], "MAX"), pyref.eltwise(xs[:2], "MAX"))
+    assert np.allclose(orc.eltwise(xs, "SUM", [0.33333333] * 3), pyref.eltwise(xs, "SUM", [0.33333333] * 3), atol=1e-6)   # saxpy may fuse
+    assert np.array_equal(orc.eltwise(xs, "SUM"), pyref.eltwise(xs, "SUM"))
+
+
 def test_decode_bbox_bitexact(orc):
     rng = np.random.default_rng(4)
     prior = _rois(rng, 300, 576, 1920)

@@ -112,20 +112,18 @@ def test_generated_net_equals_reference_file(model):
 
 
 @needs_ref
-def test_all_reference_deploys_parse():
-    """Every shipped deploy file goes through the text parser; the ones whose layer types are all built (no ROIAlign /
-    Eltwise) also build their graph."""
+def test_all_reference_deploys_build():
+    """Every shipped deploy file (23: KITTI car / ped-cyc, Caltech, CityPersons, cascade-*, WiderFace ROIAlign) goes through
+    the text parser AND builds its graph: all 15 layer types they use are registered."""
     files = sorted(glob.glob(os.path.join(REF, "*/*/mscnn_deploy.prototxt")))
     assert len(files) == 23
-    built = 0
+    types = set()
     for f in files:
-        try:
-            n = Net(f)
-            assert n.outputs, f
-            built += 1
-        except mnet.NetError as e:
-            assert "Unknown layer type" in str(e), (f, str(e))
-    assert built >= 14
+        n = Net(f)
+        assert n.outputs, f
+        types.update(n.layer_types)
+    assert types == {"Input", "Split", "Convolution", "Deconvolution", "Pooling", "ReLU", "InnerProduct", "Concat", "Dropout",
+                     "Softmax", "Eltwise", "ROIPooling", "ROIAlign", "BoxOutput", "DecodeBBox"}
 
 
 # ---- .caffemodel (binary NetParameter) reader: Net::CopyTrainedLayersFrom, net.cpp:750-803 / blob.cpp:448-482 ----
