@@ -69,6 +69,152 @@ __global__ __launch_bounds__(kThreads) void roipool_kernel(const float* __restri
 }
 
 
+// ---- row-coalesced ROI max pooling -----------------------------------------------------------------------------------
+// The per-output kernel above makes every lane of a wave walk its own window: 64 different cache lines per load
+// instruction and one dependent load chain per lane.  Here a SLOT of Wp lanes (Wp = the ROI's clipped width rounded up to a
+// power of two, 8..128) owns one channel of the workgroup's ROI: the lanes read the ROI's feature rows as contiguous row
+// segments (64/Wp channels per wave instruction), 16 independent row loads in flight per lane (4 bin-rows x 4 rows),
+// reduce them to per-column maxima of every bin-row ph, park those PH x Wp values in LDS, and then finish the PH x PW bins
+// of the channel with a short max over each bin's columns, written as one contiguous run of out[r][c][:][:].
+// max is exact and order independent (inputs are post-ReLU: no -0/+0 or NaN ordering question arises), so the result is
+// bit-identical to the reference's scan order (roi_pooling_layer.cu:60-76).  Bin edges are computed with the reference's
+// float expressions, once per workgroup.
+constexpr int kMaxP = 16;        // pooled_h / pooled_w limit of this kernel
+constexpr int kMaxSpan = 128;    // widest clipped ROI (feature columns) it handles; wider ROIs take the per-bin loop
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(kThreads) void roipool_rows_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
+                                                                float* __restrict__ out, int C, int H, int W, int PH, int PW,
+                                                                float spatial_scale, float pad_ratio, int C_total,
+                                                                int c_offset, int chan_per_block) {
+  __shared__ int s_h0[kMaxP], s_h1[kMaxP], s_w0[kMaxP], s_w1[kMaxP];
+  __shared__ unsigned char s_ph[kMaxP * kMaxP], s_pw[kMaxP * kMaxP];
+  extern __shared__ float s_col[];            // 512 * PH floats: [slot][ph][Wp]
+  const int tid = threadIdx.x;
+  const int r = blockIdx.y;
+  const int c_begin = blockIdx.x * chan_per_block;
+  const int nchan = min(C, c_begin + chan_per_block) - c_begin;
+  const int bins = PH * PW;
+
+  const float* roi = rois + 5 * (size_t)r;
+  const int b = (int)roi[0];
+  const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+  const float pad_w = (x2 - x1 + 1) * pad_ratio;
+  const float pad_h = (y2 - y1 + 1) * pad_ratio;
+  const int roi_start_w = (int)roundf((x1 - pad_w) * spatial_scale);
+  const int roi_start_h = (int)roundf((y1 - pad_h) * spatial_scale);
+  const int roi_end_w = (int)roundf((x2 + pad_w) * spatial_scale);
+  const int roi_end_h = (int)roundf((y2 + pad_h) * spatial_scale);
+  const int roi_width = max(roi_end_w - roi_start_w + 1, 1);
+  const int roi_height = max(roi_end_h - roi_start_h + 1, 1);
+  const float bin_size_h = (float)roi_height / (float)PH;
+  const float bin_size_w = (float)roi_width / (float)PW;
+  if (tid < PH) {
+    s_h0[tid] = min(max((int)floorf((float)tid * bin_size_h) + roi_start_h, 0), H);
+    s_h1[tid] = min(max((int)ceilf((float)(tid + 1) * bin_size_h) + roi_start_h, 0), H);
+  } else if (tid >= 64 && tid < 64 + PW) {
+    const int pw = tid - 64;
+    s_w0[pw] = min(max((int)floorf((float)pw * bin_size_w) + roi_start_w, 0), W);
+    s_w1[pw] = min(max((int)ceilf((float)(pw + 1) * bin_size_w) + roi_start_w, 0), W);
+  }
+  if (tid < bins) { s_ph[tid] = (unsigned char)(tid / PW); s_pw[tid] = (unsigned char)(tid % PW); }
+  __syncthreads();
+  const int x_lo = s_w0[0], x_hi = s_w1[PW - 1];     // both edge sequences are non-decreasing in pw
+  const int span = x_hi - x_lo;
+  const int HW = H * W;
+  const float* fbase = feat + (size_t)b * C * HW + (size_t)c_begin * HW;
+  float* obase = out + ((size_t)r * C_total + c_offset + c_begin) * bins;
+
+  if (span <= 0 || span > kMaxSpan) {
+    // nothing inside the map (all bins empty -> 0), or an ROI wider than the LDS column buffer: per-bin loop
+    for (int i = tid; i < nchan * bins; i += kThreads) {
+      const int c = i / bins, bin = i % bins, ph = s_ph[bin], pw = s_pw[bin];
+      const int hs = s_h0[ph], he = s_h1[ph], ws = s_w0[pw], we = s_w1[pw];
+      float m = (he <= hs || we <= ws) ? 0.f : -FLT_MAX;
+      const float* plane = fbase + c * HW;
+      for (int h = hs; h < he; ++h)
+        for (int w = ws; w < we; ++w) { const float v = plane[h * W + w]; if (v > m) m = v; }
+      obase[i] = m;
+    }
+    return;
+  }
+
+  int Wp = 8;
+  while (Wp < span) Wp <<= 1;
+  const int lanes = min(Wp, 64);              // lanes of one slot; a slot never straddles a wave
+  const int xper = Wp / lanes;                // columns per lane (2 when the ROI is 65..128 columns wide)
+  const int slots = kThreads / lanes;
+  const int slot = tid / lanes, lx = tid % lanes;
+  float* col = s_col + slot * (Wp * PH);
+  const int Hm1 = H - 1;
+
+  for (int c0 = 0; c0 < nchan; c0 += slots) {
+    const int c = c0 + slot;
+    const bool live = c < nchan;
+    if (live) {
+      for (int xi = 0; xi < xper; ++xi) {
+        const int xcol = lx + xi * 64;
+        const float* p = fbase + c * HW + min(x_lo + xcol, x_hi - 1);   // re-reading the last column never changes a max
+        for (int ph0 = 0; ph0 < PH; ph0 += 4) {
+          float m[4];
+          int hs[4], he[4];
+          float v[4][4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ph = min(ph0 + j, PH - 1);
+            hs[j] = s_h0[ph]; he[j] = s_h1[ph];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)       // rows past the bin re-read its last row (clamped into the map for empty bins)
+              v[j][i] = p[min(max(min(hs[j] + i, he[j] - 1), 0), Hm1) * W];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            m[j] = -FLT_MAX;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (v[j][i] > m[j]) m[j] = v[j][i];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            for (int h = hs[j] + 4; h < he[j]; h += 4) {     // bins taller than 4 rows (ROIs taller than ~28 feature rows)
+              const float u0 = p[h * W], u1 = p[min(h + 1, he[j] - 1) * W];
+              const float u2 = p[min(h + 2, he[j] - 1) * W], u3 = p[min(h + 3, he[j] - 1) * W];
+              if (u0 > m[j]) m[j] = u0;
+              if (u1 > m[j]) m[j] = u1;
+              if (u2 > m[j]) m[j] = u2;
+              if (u3 > m[j]) m[j] = u3;
+            }
+            if (ph0 + j < PH) col[(ph0 + j) * Wp + xcol] = m[j];
+          }
+        }
+      }
+    }
+    wave_lds_sync();
+    if (live) {
+      for (int o = lx; o < bins; o += lanes) {
+        const int ph = s_ph[o], pw = s_pw[o];
+        const int ws = s_w0[pw] - x_lo, we = s_w1[pw] - x_lo;
+        const bool empty = (s_h1[ph] <= s_h0[ph]) || (we <= ws);
+        const float* cr = col + ph * Wp;
+        const int last = max(we - 1, 0);
+        const float a0 = cr[min(ws, last)], a1 = cr[min(ws + 1, last)], a2 = cr[min(ws + 2, last)], a3 = cr[min(ws + 3, last)];
+        float m = -FLT_MAX;
+        if (a0 > m) m = a0;
+        if (a1 > m) m = a1;
+        if (a2 > m) m = a2;
+        if (a3 > m) m = a3;
+        for (int x = ws + 4; x < we; ++x) { const float u = cr[x]; if (u > m) m = u; }
+        obase[c * bins + o] = empty ? 0.f : m;
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
 // ROIAlign: (PH+1) x (PW+1) bilinear samples per (roi, channel) -- roi_align_layer.cu:21-98, same operation order.
 __global__ __launch_bounds__(kThreads) void roialign_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
                                                             float* __restrict__ out, int C, int H, int W, int PH, int PW,
@@ -147,8 +293,13 @@ extern "C" int mscnn_roipool_fwd_f32(const float* feat, const float* rois, float
   if (chan_per_block > C) chan_per_block = C;
   if (C % 128 == 0) chan_per_block = 16;            // C/16 channel groups: a multiple of 8
   dim3 grid(cdiv(C, chan_per_block), R);
-  roipool_kernel<<<grid, kThreads, 0, as_stream(stream)>>>(feat, rois, out, C, H, W, pooled_h, pooled_w, spatial_scale,
-                                                           pad_ratio, C_total, c_offset, chan_per_block);
+  static const bool per_bin = getenv("MSCNN_ROIPOOL_PERBIN") != nullptr;      // A/B switch for profiling
+  if (!per_bin && pooled_h <= kMaxP && pooled_w <= kMaxP && (size_t)C * H * W < (1u << 30))
+    roipool_rows_kernel<<<grid, kThreads, 512 * pooled_h * sizeof(float), as_stream(stream)>>>(
+        feat, rois, out, C, H, W, pooled_h, pooled_w, spatial_scale, pad_ratio, C_total, c_offset, chan_per_block);
+  else
+    roipool_kernel<<<grid, kThreads, 0, as_stream(stream)>>>(feat, rois, out, C, H, W, pooled_h, pooled_w, spatial_scale,
+                                                             pad_ratio, C_total, c_offset, chan_per_block);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

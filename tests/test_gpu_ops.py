@@ -176,6 +176,18 @@ def test_roipool_bitexact(hip, orc, ph, pw, scale, pad):
     assert np.array_equal(y, orc.roipool(feat, rois, ph, pw, scale, pad))
 
 
+def test_roipool_wide_rois(hip, orc):
+    """ROIs wider than one wave (64 columns) and wider than the kernel's LDS column buffer (512 columns)."""
+    rng = np.random.default_rng(9)
+    feat = np.maximum(rng.standard_normal((1, 16, 20, 700)), 0).astype(np.float32)
+    rois = _random_rois(rng, 40, 80, 2800)
+    rois[:, 3] = rois[:, 1] + rng.uniform(200, 2790, 40)       # 50 .. 700 feature columns at scale 0.25
+    rois[0] = [0, 0, 0, 2799, 79]; rois[1] = [0, -300, 5, 2500, 60]
+    for pad in (0.0, 0.25):
+        y = hip.roipool(dev(feat), dev(rois), 7, 7, 0.25, pad).cpu().numpy()
+        assert np.array_equal(y, orc.roipool(feat, rois, 7, 7, 0.25, pad))
+
+
 def test_roipool_concat_window(hip, orc):
     rng = np.random.default_rng(8)
     feat = rng.standard_normal((1, 16, 18, 60)).astype(np.float32)
