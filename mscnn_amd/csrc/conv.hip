@@ -24,6 +24,7 @@
 //   * epilogue fuses bias and ReLU; stores are 128-B runs along W.
 // Shapes the MFMA path does not cover (stride > 1, groups, Cin < 8) use direct_conv_kernel.
 #include "common.h"
+#include "headconv.h"
 #include <cstdlib>
 #include <new>
 #include <type_traits>
@@ -521,6 +522,7 @@ struct mscnn_conv_plan {
   int MT, NTH, NTW, NT, KI, G, full_q;
   long total_iters;      // stream-K phase iterations
   size_t packed_bytes, ws_bytes;
+  mscnn::HeadPlan head;  // head.entry >= 0: the small-Cout kernel family of headconv.hip runs this layer
 };
 
 using namespace mscnn;
@@ -532,6 +534,12 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->entry = -1;
   p->packed_bytes = 0;
   p->ws_bytes = 0;
+  p->head.entry = -1;
+  if (head_plan(d, p->Ho, p->Wo, &p->head)) {
+    p->packed_bytes = p->head.packed_bytes;
+    p->ws_bytes = p->head.ws_bytes;
+    return;
+  }
   if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0 || d.Cin > 2048) return;   // KI <= 256
   // 32-bit buffer offsets: every tensor window the kernel addresses must stay below 2 GiB
   const double win_x = (double)d.Cin * d.H * d.W * 4.0, win_y = (double)d.Cout * p->Ho * p->Wo * 4.0;
@@ -606,6 +614,7 @@ extern "C" size_t mscnn_conv2d_packed_weight_bytes(const mscnn_conv_plan* p) { r
 extern "C" size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* p) { return p ? p->ws_bytes : 0; }
 extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (!p) return "";
+  if (p->head.entry >= 0) return head_kernel_name(p->head);
   return p->entry < 0 ? "direct_f32" : kTable[p->entry].name;
 }
 extern "C" double mscnn_conv2d_plan_flops(const mscnn_conv_plan* p) {
@@ -622,6 +631,10 @@ extern "C" int mscnn_conv2d_plan_set_batch(mscnn_conv_plan* p, int N) {
 
 extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* w, float* packed, void* stream) {
   MSCNN_REQUIRE(p, "conv pack: null plan");
+  if (p->head.entry >= 0) {
+    MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
+    return head_pack(p->d, p->head, w, packed, as_stream(stream));
+  }
   if (p->entry < 0) return MSCNN_OK;   // direct kernel reads the Caffe layout
   MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
   const KernelEntry& k = kTable[p->entry];
@@ -641,6 +654,10 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
   if (d.N == 0) return MSCNN_OK;
   MSCNN_REQUIRE(x && y, "conv: null pointer");
   hipStream_t st = as_stream(stream);
+  if (p->head.entry >= 0) {
+    MSCNN_REQUIRE(packed, "conv: head kernel needs packed weights (mscnn_conv2d_pack_weights)");
+    return head_forward(d, p->head, p->Ho, p->Wo, x, packed, bias, y, workspace, workspace_bytes, st);
+  }
   if (p->entry < 0) {
     MSCNN_REQUIRE(w, "conv: direct kernel needs the Caffe-layout weights");
     const long total = (long)d.N * d.Cout * p->Ho * p->Wo;

@@ -98,6 +98,9 @@ CONV_CASES = [
     (1, 16, 9, 30, 9, (7, 7), (3, 3), (1, 1), 1),           # proposal head 7x7
     (1, 16, 12, 20, 7, (5, 3), (2, 1), (1, 1), 1),          # ped/cyc head "3x5" (kernel_w 3, kernel_h 5)
     (1, 8, 12, 20, 7, (7, 5), (3, 2), (1, 1), 1),           # ped/cyc head "5x7" (kernel_w 5, kernel_h 7)
+    (2, 20, 40, 70, 6, (5, 3), (2, 1), (1, 1), 1),          # caltech head: 6 channels, ragged Cin, batch 2, several tiles
+    (1, 64, 36, 120, 9, (7, 7), (3, 3), (1, 1), 1),         # conv5_3-sized head plane: stream-K splits + fix-up
+    (1, 12, 20, 40, 12, (5, 5), (2, 2), (1, 1), 1),         # 12 channels (3 quads all live)
     (3, 16, 7, 7, 64, (3, 3), (0, 0), (1, 1), 1),           # roi_c1-shaped: R x (C,7,7) no pad -> 5x5
 ]
 
@@ -128,6 +131,8 @@ def test_conv_no_bias_and_kernel_selection(hip, orc):
     assert hip.ConvPlan(1, 3, 8, 16, 32, 3, 3, (1, 1)).kernel.startswith("igemm_")          # Cin 3 is zero-padded
     assert hip.ConvPlan(1, 8, 8, 16, 32, 3, 3, (1, 1), stride=(2, 2)).kernel == "direct_f32"
     assert "roi7x7p0" in hip.ConvPlan(50, 1024, 7, 7, 512, 3, 3).kernel
+    assert hip.ConvPlan(1, 512, 72, 240, 9, 7, 7, (3, 3)).kernel == "head4x4_k7x7_m3x4"     # proposal heads: M = 4 MFMA
+    assert hip.ConvPlan(1, 512, 72, 240, 6, 5, 3, (2, 1)).kernel == "head4x4_k5x3_m2x4"
     assert plan.flops == 2.0 * 32 * 8 * 16 * 8 * 9
 
 
