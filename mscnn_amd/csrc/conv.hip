@@ -25,6 +25,7 @@
 // Shapes the MFMA path does not cover (stride > 1, groups, Cin < 8) use direct_conv_kernel.
 #include "common.h"
 #include "headconv.h"
+#include "winograd.h"
 #include <cstdlib>
 #include <new>
 #include <type_traits>
@@ -38,6 +39,8 @@ struct IgemmArgs {
   int N, Cin, H, W, Cout, Ho, Wo, pad_h, pad_w;
   int MT, NTH, NTW, NT, KI, G, relu;
   int xcd_map;         // 1: XCD-aware workgroup -> range mapping
+  int nt_major;        // 1: tile index t = nt * MT + mt (the M tiles of one pixel tile run together; Winograd GEMM)
+  unsigned w_img_bytes;  // per-image weight stride in bytes (0: one weight set; Winograd GEMM: one U matrix per "image")
   int full_q;          // whole tiles per workgroup in the data-parallel phase (tile t = g + j * G, j < full_q)
   long total_iters;    // iterations (tile, chunk) of the stream-K phase: the remaining tiles [full_q * G, MT * NT)
 };
@@ -47,8 +50,12 @@ struct IgemmArgs {
 //   ROI mode   (RH  > 0): the images are tiny (RH x RW, e.g. the 7x7 ROI-pooled maps of roi_c1) and a tile packs
 //                         IPT whole images: N side = IPT * OH * OW output pixels.  The reference's CAFFE engine runs
 //                         one im2col+GEMM with N = 25 per ROI here (conv_layer.cu:14-21).
-template <int BM_, int BN_, int WGM_, int WGN_, int KH_, int KW_, int CK_, int TW_, int RH_ = 0, int RW_ = 0, int RP_ = 0, int PF_ = 0>
+template <int BM_, int BN_, int WGM_, int WGN_, int KH_, int KW_, int CK_, int TW_, int RH_ = 0, int RW_ = 0, int RP_ = 0, int PF_ = 0, int VEC_ = 0>
 struct Cfg {
+  // VEC: 1x1 kernel over planes of exactly 128-pixel rows (the Winograd GEMM operands): the B tile is CK contiguous
+  // 512-byte rows, staged with b128 loads / ds_write_b128 and no per-element offset table
+  static constexpr int VEC = VEC_;
+  static constexpr int BV_PER_T = CK_ * 32 / 256;
   static constexpr int PF = PF_;   // 1: LDS operand reads software-pipelined one MFMA group ahead
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, KH = KH_, KW = KW_, CK = CK_, TW = TW_;
   static constexpr bool ROI = RH_ > 0;
@@ -70,6 +77,7 @@ struct Cfg {
   static constexpr int B_PER_T = (B_ELEMS + 255) / 256;
   static constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
   static constexpr int FIX_SPLIT = (BM * BN) / 4096;                    // fix-up workgroups per tile
+  static_assert(!VEC_ || (KH_ == 1 && KW_ == 1 && TW_ == 128 && BN_ == 128 && RH_ == 0 && CK_ % 8 == 0), "VEC: 1x1, one 128-pixel row per tile");
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(WM % 32 == 0 && WN % 32 == 0 && BN % TW == 0 && CK % 2 == 0 && A_ELEMS % 4 == 0, "tile shape");
   static_assert((BM * BN) % 4096 == 0, "fix-up split");
@@ -177,7 +185,7 @@ __device__ __forceinline__ int lane_patch_off(int p) {
 template <class C>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   __shared__ __attribute__((aligned(16))) float ldsA[C::A_ELEMS];
-  __shared__ float ldsB[C::B_ELEMS];
+  __shared__ __attribute__((aligned(16))) float ldsB[C::B_ELEMS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -204,7 +212,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 
   const int plane = a.H * a.W;
   const bool ragged_c = (a.Cin % C::CK) != 0;    // last chunk has fewer than CK real channels (conv1_1: Cin = 3)
-  const __amdgpu_buffer_rsrc_t wsrc = make_rsrc(a.wp, (unsigned)((long)a.MT * a.KI * C::A_ELEMS * 4));
+  const __amdgpu_buffer_rsrc_t wsrc =
+      make_rsrc(a.wp, (unsigned)((long)a.MT * a.KI * C::A_ELEMS * 4) + (a.w_img_bytes ? (unsigned)(a.N - 1) * a.w_img_bytes : 0u));
   const __amdgpu_buffer_rsrc_t bias_rsrc = make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
   const int co_stride = a.Ho * a.Wo;
 
@@ -221,18 +230,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     } else {
       break;
     }
-    const int mt = t / a.NT, nt = t % a.NT;       // t = mt * NT + nt
+    const int mt = a.nt_major ? t % a.MT : t / a.NT;
+    const int nt = a.nt_major ? t / a.MT : t % a.NT;
     TileGeo<C> geo;
     geo.decode(a, nt);
     const __amdgpu_buffer_rsrc_t xsrc = make_rsrc(geo.x_base(a), geo.x_bytes(a));
 
     // byte offsets of this thread's patch elements (the channel-chunk term is the scalar offset of the load)
     unsigned g_off[C::B_PER_T];
+    if constexpr (!C::VEC) {
 #pragma unroll
-    for (int i = 0; i < C::B_PER_T; ++i) {
-      const int o = geo.in_off(a, tid + i * 256);
-      g_off[i] = o >= 0 ? (unsigned)o * 4u : kOob;
+      for (int i = 0; i < C::B_PER_T; ++i) {
+        const int o = geo.in_off(a, tid + i * 256);
+        g_off[i] = o >= 0 ? (unsigned)o * 4u : kOob;
+      }
     }
+    // VEC: float4 number tid + i*256 of the tile = channel (tid >> 5) + 8 i, pixels 4 (tid & 31) .. +3 of row h0
+    const unsigned bv_voff = ((unsigned)(tid >> 5) * (unsigned)plane + (unsigned)geo.h0 * 128u + (unsigned)(tid & 31) * 4u) * 4u;
 
     f32x16 acc[C::MI][C::NI];
 #pragma unroll
@@ -244,8 +258,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 
     float4 ra[C::A_PER_T];
     float rb[C::B_PER_T];
+    float4 rbv[C::VEC ? C::BV_PER_T : 1];
     const unsigned a_voff = (unsigned)tid * 16u;
-    const unsigned a_tile = (unsigned)(mt * a.KI) * (C::A_ELEMS * 4u);
+    const unsigned a_tile = (unsigned)(mt * a.KI) * (C::A_ELEMS * 4u) + (unsigned)geo.img * a.w_img_bytes;
 
 #define MSCNN_LOAD_CHUNK(kc)                                                                                        \
     {                                                                                                               \
@@ -256,10 +271,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       }                                                                                                             \
       const unsigned b_soff = (unsigned)(kc) * (unsigned)(C::CK * 4) * (unsigned)plane;                             \
       const int c_left = a.Cin - (kc) * C::CK;                                                                      \
-      _Pragma("unroll") for (int i = 0; i < C::B_PER_T; ++i) {                                                      \
-        unsigned vo = g_off[i];                                                                                     \
-        if (ragged_c && (tid + i * 256) / C::CH_STRIDE >= c_left) vo = kOob;                                        \
-        rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, vo, b_soff, 0));               \
+      if constexpr (C::VEC) {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < C::BV_PER_T; ++i) {                                                   \
+          const unsigned vo = (ragged_c && (tid >> 5) + 8 * i >= c_left) ? kOob : bv_voff;                          \
+          rbv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(                                \
+                                                  xsrc, vo, b_soff + (unsigned)(8 * i) * (unsigned)plane * 4u, 0)); \
+        }                                                                                                           \
+      } else {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < C::B_PER_T; ++i) {                                                    \
+          unsigned vo = g_off[i];                                                                                   \
+          if (ragged_c && (tid + i * 256) / C::CH_STRIDE >= c_left) vo = kOob;                                      \
+          rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, vo, b_soff, 0));             \
+        }                                                                                                           \
       }                                                                                                             \
     }
 
@@ -271,9 +294,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
       for (int i = 0; i < C::A_PER_T; ++i)
         if (C::A_VEC4 % 256 == 0 || tid + i * 256 < C::A_VEC4) aWr[i * 256] = ra[i];
+      if constexpr (C::VEC) {
 #pragma unroll
-      for (int i = 0; i < C::B_PER_T; ++i)
-        if (C::B_ELEMS % 256 == 0 || tid + i * 256 < C::B_ELEMS) ldsB[tid + i * 256] = rb[i];
+        for (int i = 0; i < C::BV_PER_T; ++i) reinterpret_cast<float4*>(ldsB)[tid + i * 256] = rbv[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < C::B_PER_T; ++i)
+          if (C::B_ELEMS % 256 == 0 || tid + i * 256 < C::B_ELEMS) ldsB[tid + i * 256] = rb[i];
+      }
       __syncthreads();
       }
       if (kc + 1 < k1 && C::PF < 11) MSCNN_LOAD_CHUNK(kc + 1);   // in flight while this chunk is multiplied
@@ -400,7 +428,8 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
   __syncthreads();
   const int n = s_n;
   if (n == 0) return;
-  const int mt = t / a.NT, nt = t % a.NT;
+  const int mt = a.nt_major ? t % a.MT : t / a.NT;
+  const int nt = a.nt_major ? t / a.MT : t % a.NT;
   TileGeo<C> geo;
   geo.decode(a, nt);
   float* ybase = geo.y_base(a);
@@ -500,6 +529,14 @@ const KernelEntry kTable[] = {
     {"ablate_mfmaonly", 128, 128, 3, 3, 8, 16, 8, 0, 0, 0, 1, 4, 13, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 13>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 13>>},
     {"ablate_nostage", 128, 128, 3, 3, 8, 16, 8, 0, 0, 0, 1, 4, 12, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 12>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 12>>},
 #endif
+    // 1x1 (the 16 batched GEMMs of the Winograd path; plane = [rows][128] so a tile is one 128-pixel row)
+    {"igemm_128x128_k1x1_ck32_pf", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 0, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1>>,
+     igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1>>},
+    // variants 101 / 102: vectorised staging, planes of exactly 128-pixel rows only (Winograd GEMM)
+    {"igemm_128x128_k1x1_ck32_vec", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 101, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>,
+     igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>},
+    {"igemm_128x128_k1x1_ck64_vec", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 102, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>,
+     igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>},
     ENTRY(128, 256, 2, 2, 3, 3, 8, 32),     // variant 2 (selected with MSCNN_IGEMM_VARIANT=2): 64x128 wave tiles
     // proposal heads (Cout = 4 + classes <= 32): kitti_car 5x5 / 7x7, ped-cyc + caltech 3x5 / 5x7
     ENTRY(32, 128, 1, 4, 5, 5, 8, 16),
@@ -523,9 +560,46 @@ struct mscnn_conv_plan {
   long total_iters;      // stream-K phase iterations
   size_t packed_bytes, ws_bytes;
   mscnn::HeadPlan head;  // head.entry >= 0: the small-Cout kernel family of headconv.hip runs this layer
+  // Winograd F(2x2, 3x3) path (wino != nullptr): input transform -> 16 batched 1x1 GEMMs (the nested igemm plan) ->
+  // output transform.  Workspace layout: [V: 16 x Cin x T_pad][M: 16 x Cout x T_pad][nested plan's stream-K slabs].
+  mscnn_conv_plan* wino = nullptr;
+  int tiles_h = 0, tiles_w = 0, T_pad = 0;
+  ~mscnn_conv_plan() { delete wino; }
 };
 
 using namespace mscnn;
+
+static void plan_shape(mscnn_conv_plan* p);
+
+// Winograd F(2x2, 3x3) is chosen where the 2.25x cut in multiplies outweighs the extra HBM traffic of the transforms
+// (V and M are 4x the input / output and are written and read once each): GEMM FLOPs per transform byte grow with
+// Cin * Cout / (Cin + Cout).  Measured on MI355X: conv2_2 (64) 706 vs 640 us direct, conv3_1 (85) 329 vs 332, conv3_2 (128) 503 vs 614, conv4_1 (171) 250 vs 346,
+// conv4_2 (256) 407 vs 617 -> threshold 100.
+// MSCNN_WINOGRAD=0 disables the path, =2 forces it wherever it is legal (tests).
+static bool wino_plan(mscnn_conv_plan* p) {
+  const mscnn_conv_desc& d = p->d;
+  const char* menv = std::getenv("MSCNN_WINOGRAD");      // read per plan: the tests switch it
+  const int mode = menv ? std::atoi(menv) : 1;
+  if (mode == 0 || d.Kh != 3 || d.Kw != 3 || d.stride_h != 1 || d.stride_w != 1 || d.group != 1) return false;
+  if (p->Ho < 2 || p->Wo < 2) return false;
+  const double intensity = (double)d.Cin * d.Cout / (d.Cin + d.Cout);
+  if (mode != 2 && (intensity < 100.0 || d.H * d.W < 256 || (d.H <= 8 && d.W <= 8))) return false;   // ROI maps stay on the ROI-mode igemm
+  const int th = cdiv(p->Ho, 2), tw = cdiv(p->Wo, 2);
+  const long T = (long)d.N * th * tw;
+  const long T_pad = (T + 127) / 128 * 128;
+  if ((double)T_pad * (d.Cin > d.Cout ? d.Cin : d.Cout) * 4.0 >= 2.0e9) return false;   // one transform plane per 32-bit window
+  mscnn_conv_plan* g = new (std::nothrow) mscnn_conv_plan();
+  if (!g) return false;
+  g->d = d;
+  g->d.N = 16; g->d.H = (int)(T_pad / 128); g->d.W = 128; g->d.Kh = g->d.Kw = 1; g->d.pad_h = g->d.pad_w = 0; g->d.relu = 0;
+  plan_shape(g);
+  if (g->entry < 0 || g->wino || g->head.entry >= 0) { delete g; return false; }
+  p->wino = g;
+  p->tiles_h = th; p->tiles_w = tw; p->T_pad = (int)T_pad;
+  p->packed_bytes = 16 * g->packed_bytes;
+  p->ws_bytes = (size_t)16 * ((size_t)d.Cin + d.Cout) * T_pad * sizeof(float) + g->ws_bytes;
+  return true;
+}
 
 static void plan_shape(mscnn_conv_plan* p) {
   const mscnn_conv_desc& d = p->d;
@@ -540,7 +614,10 @@ static void plan_shape(mscnn_conv_plan* p) {
     p->ws_bytes = p->head.ws_bytes;
     return;
   }
+  delete p->wino;
+  p->wino = nullptr;
   if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0 || d.Cin > 2048) return;   // KI <= 256
+  if (wino_plan(p)) return;
   // 32-bit buffer offsets: every tensor window the kernel addresses must stay below 2 GiB
   const double win_x = (double)d.Cin * d.H * d.W * 4.0, win_y = (double)d.Cout * p->Ho * p->Wo * 4.0;
   // choose the table entry with the least padded work; an ROI-mode entry wins whenever it matches the image shape
@@ -555,6 +632,12 @@ static void plan_shape(mscnn_conv_plan* p) {
     if (k.KH == 3 && k.KW == 3 && k.RH == 0) {
       if (is256 && k.variant == 0) continue;                  // (kept for reference; superseded by variant 3)
       if (k.variant != want) continue;
+    }
+    if (k.KH == 1 && k.KW == 1) {
+      const bool rows128 = d.W == 128 && d.pad_h == 0 && d.pad_w == 0;        // Winograd GEMM operand planes
+      const char* e1 = std::getenv("MSCNN_GEMM1X1_VARIANT");                  // tuning knob: 0 generic, 101 / 102 vectorised
+      const int want1 = !rows128 ? 0 : (e1 ? std::atoi(e1) : 102);
+      if (k.variant != want1) continue;
     }
     double cost;
     if (k.RH > 0) {
@@ -584,7 +667,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   const long tiles = (long)p->MT * p->NT;
   // grid: G workgroups (default 2 per CU; 3 for the 128x128 tiles whose 43 KB of LDS and 168 VGPRs allow it)
   const char* genv = std::getenv("MSCNN_SK_WGS");            // tuning knob
-  long G = genv ? std::atol(genv) : ((k.BM == 128 && k.BN == 128) ? 768 : 512);
+  long G = genv ? std::atol(genv) : ((k.BM == 128 && k.BN == 128 && k.CK < 64) ? 768 : 512);   // CK = 64: 64 KB of LDS, 2 per CU
   if (tiles * p->KI / 4 < G) G = tiles * p->KI / 4;         // never less than ~4 chunks per workgroup
   if (G < 1) G = 1;
   p->G = (int)G;
@@ -615,6 +698,7 @@ extern "C" size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* p) { retur
 extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (!p) return "";
   if (p->head.entry >= 0) return head_kernel_name(p->head);
+  if (p->wino) return "winograd_f2x2_3x3";
   return p->entry < 0 ? "direct_f32" : kTable[p->entry].name;
 }
 extern "C" double mscnn_conv2d_plan_flops(const mscnn_conv_plan* p) {
@@ -635,6 +719,11 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
     MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
     return head_pack(p->d, p->head, w, packed, as_stream(stream));
   }
+  if (p->wino) {
+    MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
+    const KernelEntry& k = kTable[p->wino->entry];
+    return wino_pack_weights(w, packed, p->d.Cout, p->d.Cin, k.BM, k.CK, p->wino->MT, p->wino->KI, as_stream(stream));
+  }
   if (p->entry < 0) return MSCNN_OK;   // direct kernel reads the Caffe layout
   MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
   const KernelEntry& k = kTable[p->entry];
@@ -647,28 +736,10 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   return MSCNN_OK;
 }
 
-extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, const float* w, const float* packed,
-                                    const float* bias, float* y, void* workspace, size_t workspace_bytes, void* stream) {
-  MSCNN_REQUIRE(p, "conv: null plan");
+// igemm launch (main kernel + fix-up).  w_img_bytes / nt_major: see IgemmArgs (non-zero only for the Winograd GEMM).
+static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* packed, const float* bias, float* y,
+                        void* workspace, size_t workspace_bytes, hipStream_t st, unsigned w_img_bytes, int nt_major) {
   const mscnn_conv_desc& d = p->d;
-  if (d.N == 0) return MSCNN_OK;
-  MSCNN_REQUIRE(x && y, "conv: null pointer");
-  hipStream_t st = as_stream(stream);
-  if (p->head.entry >= 0) {
-    MSCNN_REQUIRE(packed, "conv: head kernel needs packed weights (mscnn_conv2d_pack_weights)");
-    return head_forward(d, p->head, p->Ho, p->Wo, x, packed, bias, y, workspace, workspace_bytes, st);
-  }
-  if (p->entry < 0) {
-    MSCNN_REQUIRE(w, "conv: direct kernel needs the Caffe-layout weights");
-    const long total = (long)d.N * d.Cout * p->Ho * p->Wo;
-    long blocks = (total + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    direct_conv_kernel<<<(int)blocks, 256, 0, st>>>(x, w, bias, y, d.N, d.Cin, d.H, d.W, d.Cout, d.Kh, d.Kw, d.pad_h, d.pad_w,
-                                                    d.stride_h, d.stride_w, d.group, p->Ho, p->Wo, d.relu);
-    MSCNN_POST_LAUNCH();
-    return MSCNN_OK;
-  }
-  MSCNN_REQUIRE(packed, "conv: igemm kernel needs packed weights (mscnn_conv2d_pack_weights)");
   const KernelEntry& k = kTable[p->entry];
   const long rem_tiles = (long)p->MT * p->NT - (long)p->full_q * p->G;
   const bool split = rem_tiles > 0;
@@ -683,6 +754,7 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
   a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.Ho = p->Ho; a.Wo = p->Wo; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
   a.MT = p->MT; a.NTH = p->NTH; a.NTW = p->NTW; a.NT = p->NT; a.KI = p->KI; a.G = p->G; a.relu = d.relu;
   a.total_iters = p->total_iters; a.full_q = p->full_q;
+  a.w_img_bytes = w_img_bytes; a.nt_major = nt_major;
   { static const bool noxcd = [] { const char* e = std::getenv("MSCNN_SK_NOXCD"); return e && *e == '1'; }(); a.xcd_map = noxcd ? 0 : 1; }
   k.main_fn<<<p->G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
@@ -691,4 +763,45 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
     MSCNN_POST_LAUNCH();
   }
   return MSCNN_OK;
+}
+
+extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, const float* w, const float* packed,
+                                    const float* bias, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+  MSCNN_REQUIRE(p, "conv: null plan");
+  const mscnn_conv_desc& d = p->d;
+  if (d.N == 0) return MSCNN_OK;
+  MSCNN_REQUIRE(x && y, "conv: null pointer");
+  hipStream_t st = as_stream(stream);
+  if (p->head.entry >= 0) {
+    MSCNN_REQUIRE(packed, "conv: head kernel needs packed weights (mscnn_conv2d_pack_weights)");
+    return head_forward(d, p->head, p->Ho, p->Wo, x, packed, bias, y, workspace, workspace_bytes, st);
+  }
+  if (p->wino) {
+    MSCNN_REQUIRE(packed, "conv: Winograd path needs packed weights (mscnn_conv2d_pack_weights)");
+    if (!workspace || workspace_bytes < p->ws_bytes) {
+      set_error("conv(winograd): workspace %zu < %zu", workspace_bytes, p->ws_bytes);
+      return MSCNN_ERR_WORKSPACE;
+    }
+    const mscnn_conv_plan* g = p->wino;
+    float* V = static_cast<float*>(workspace);
+    float* M = V + (size_t)16 * d.Cin * p->T_pad;
+    float* gws = M + (size_t)16 * d.Cout * p->T_pad;
+    int rc = wino_input_transform(x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st);
+    if (rc != MSCNN_OK) return rc;
+    rc = launch_igemm(g, V, packed, nullptr, M, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
+    if (rc != MSCNN_OK) return rc;
+    return wino_output_transform(M, bias, y, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st);
+  }
+  if (p->entry < 0) {
+    MSCNN_REQUIRE(w, "conv: direct kernel needs the Caffe-layout weights");
+    const long total = (long)d.N * d.Cout * p->Ho * p->Wo;
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    direct_conv_kernel<<<(int)blocks, 256, 0, st>>>(x, w, bias, y, d.N, d.Cin, d.H, d.W, d.Cout, d.Kh, d.Kw, d.pad_h, d.pad_w,
+                                                    d.stride_h, d.stride_w, d.group, p->Ho, p->Wo, d.relu);
+    MSCNN_POST_LAUNCH();
+    return MSCNN_OK;
+  }
+  MSCNN_REQUIRE(packed, "conv: igemm kernel needs packed weights (mscnn_conv2d_pack_weights)");
+  return launch_igemm(p, x, packed, bias, y, workspace, workspace_bytes, st, 0u, 0);
 }

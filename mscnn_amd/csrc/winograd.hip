@@ -1,0 +1,172 @@
+// Winograd F(2x2, 3x3) data transforms for gfx950 (the batched GEMM between them is the 1x1 igemm kernel of conv.hip).
+//
+// Used for the 3x3 / stride 1 trunk layers whose channel counts make the transforms cheap next to the multiply
+// (conv4_*, loss1_conv1, conv5_*, conv6_1 of the mscnn-7s nets): y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 output tile,
+// i.e. 16 multiplies instead of 36 per tile and channel pair -- 2.25x fewer MFMA FLOPs than the direct form that the
+// reference computes (conv_layer.cu:8-23 im2col + SGEMM).  Result differs from the direct form only by fp32 rounding
+// (different but equally short summation trees); the parity tests hold it to the same 1e-4 bound.
+//
+//   B^T = | 1  0 -1  0 |     G = | 1    0    0  |     A^T = | 1  1  1  0 |
+//         | 0  1  1  0 |         | 1/2  1/2  1/2|           | 0  1 -1 -1 |
+//         | 0 -1  1  0 |         | 1/2 -1/2  1/2|
+//         | 0  1  0 -1 |         | 0    0    1  |
+//
+// All three kernels are HBM-bound streaming kernels: one thread per (channel, tile), tiles fastest, so every one of the 16
+// transform planes is read / written as contiguous runs.
+#include "winograd.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                                          int BM, int CK, int MT, int KI) {
+  const long img_stride = (long)MT * KI * CK * BM;
+  const long total = (long)MT * BM * KI * CK;           // padded (co, ci) pairs
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i % BM);
+    long r = i / BM;
+    const int ck = (int)(r % CK); r /= CK;
+    const int kc = (int)(r % KI);
+    const int mt = (int)(r / KI);
+    const int co = mt * BM + m, ci = kc * CK + ck;
+    float g[3][3];
+    const bool live = co < Cout && ci < Cin;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[a][b] = live ? w[((long)co * Cin + ci) * 9 + a * 3 + b] : 0.f;
+    float t[4][3];   // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      t[0][b] = g[0][b];
+      t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+      t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+      t[3][b] = g[2][b];
+    }
+    float* dst = wp + (((long)mt * KI + kc) * CK + ck) * BM + m;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
+      dst[(a * 4 + 0) * img_stride] = u0;
+      dst[(a * 4 + 1) * img_stride] = u1;
+      dst[(a * 4 + 2) * img_stride] = u2;
+      dst[(a * 4 + 3) * img_stride] = u3;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int Cin, int H,
+                                                         int W, int pad_h, int pad_w, int tiles_h, int tiles_w, int T, int T_pad) {
+  const int t = blockIdx.x * 256 + threadIdx.x;          // tile index (n, ty, tx), tx fastest
+  const int ci = blockIdx.y;
+  if (t >= T_pad) return;
+  const long plane_stride = (long)Cin * T_pad;            // between the 16 transform planes
+  float* dst = V + (long)ci * T_pad + t;
+  float d[4][4];
+  if (t < T) {
+    const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
+    const float* src = x + ((long)n * Cin + ci) * H * W;
+    const int h0 = 2 * ty - pad_h, w0 = 2 * tx - pad_w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int h = h0 + i;
+      const bool hok = h >= 0 && h < H;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int wv = w0 + j;
+        d[i][j] = (hok && wv >= 0 && wv < W) ? src[h * W + wv] : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j] = 0.f;
+  }
+  float r[4][4];   // B^T d
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r[0][j] = d[0][j] - d[2][j];
+    r[1][j] = d[1][j] + d[2][j];
+    r[2][j] = d[2][j] - d[1][j];
+    r[3][j] = d[1][j] - d[3][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dst[(i * 4 + 0) * plane_stride] = r[i][0] - r[i][2];
+    dst[(i * 4 + 1) * plane_stride] = r[i][1] + r[i][2];
+    dst[(i * 4 + 2) * plane_stride] = r[i][2] - r[i][1];
+    dst[(i * 4 + 3) * plane_stride] = r[i][1] - r[i][3];
+  }
+}
+
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int N, int Cout, int Ho, int Wo, int tiles_h,
+                                                          int tiles_w, int T, int T_pad, int relu) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int co = blockIdx.y;
+  if (t >= T) return;
+  const long plane_stride = (long)Cout * T_pad;
+  const float* src = M + (long)co * T_pad + t;
+  float m[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[i][j] = src[(i * 4 + j) * plane_stride];
+  float r[2][4];   // A^T m
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r[0][j] = m[0][j] + m[1][j] + m[2][j];
+    r[1][j] = m[1][j] - m[2][j] - m[3][j];
+  }
+  const float b = bias ? bias[co] : 0.f;
+  const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
+  float* dst = y + ((long)n * Cout + co) * Ho * Wo;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oh = 2 * ty + i;
+    if (oh >= Ho) continue;
+    float v0 = r[i][0] + r[i][1] + r[i][2] + b;
+    float v1 = r[i][1] - r[i][2] - r[i][3] + b;
+    if (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+    const int ow = 2 * tx;
+    if (ow + 1 < Wo && (Wo % 2 == 0)) {
+      *reinterpret_cast<float2*>(dst + oh * Wo + ow) = make_float2(v0, v1);     // 8-byte aligned when Wo is even
+    } else {
+      if (ow < Wo) dst[oh * Wo + ow] = v0;
+      if (ow + 1 < Wo) dst[oh * Wo + ow + 1] = v1;
+    }
+  }
+}
+
+}  // namespace
+
+namespace mscnn {
+
+int wino_pack_weights(const float* w, float* packed, int Cout, int Cin, int BM, int CK, int MT, int KI, hipStream_t st) {
+  const long total = (long)MT * BM * KI * CK;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  wino_weight_kernel<<<(int)blocks, 256, 0, st>>>(w, packed, Cout, Cin, BM, CK, MT, KI);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+int wino_input_transform(const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
+                         int tiles_w, int T_pad, hipStream_t st) {
+  const int T = N * tiles_h * tiles_w;
+  dim3 grid(cdiv(T_pad, 256), Cin);
+  wino_input_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+int wino_output_transform(const float* M, const float* bias, float* y, int N, int Cout, int Ho, int Wo, int tiles_h,
+                          int tiles_w, int T_pad, int relu, hipStream_t st) {
+  const int T = N * tiles_h * tiles_w;
+  dim3 grid(cdiv(T, 256), Cout);
+  wino_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+}  // namespace mscnn

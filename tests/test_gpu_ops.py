@@ -101,6 +101,7 @@ CONV_CASES = [
     (2, 20, 40, 70, 6, (5, 3), (2, 1), (1, 1), 1),          # caltech head: 6 channels, ragged Cin, batch 2, several tiles
     (1, 64, 36, 120, 9, (7, 7), (3, 3), (1, 1), 1),         # conv5_3-sized head plane: stream-K splits + fix-up
     (1, 12, 20, 40, 12, (5, 5), (2, 2), (1, 1), 1),         # 12 channels (3 quads all live)
+    (1, 64, 10, 20, 96, (1, 1), (0, 0), (1, 1), 1),         # 1x1 (igemm_128x128_k1x1)
     (3, 16, 7, 7, 64, (3, 3), (0, 0), (1, 1), 1),           # roi_c1-shaped: R x (C,7,7) no pad -> 5x5
 ]
 
@@ -118,6 +119,38 @@ def test_conv(hip, orc, case, relu):
     if relu:
         ref = orc.relu(ref)
     close(y, ref)
+
+
+WINO_CASES = [   # N, Cin, H, W, Cout, pad
+    (1, 16, 8, 12, 24, 1),        # exact 2x2 tiles
+    (1, 40, 13, 21, 130, 1),      # odd H and W: partial tiles at the bottom / right edge, Cout ragged
+    (2, 24, 10, 14, 32, 1),       # batch 2
+    (1, 8, 9, 16, 16, 0),         # pad 0 (Ho = H - 2)
+    (1, 320, 18, 60, 320, 1),     # chosen by the default heuristic (conv6_1-like plane), stream-K split of the 1x1 GEMM
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv_winograd(hip, orc, case, relu, monkeypatch):
+    """Winograd F(2x2,3x3) path (input transform -> 16 batched 1x1 igemm GEMMs -> output transform) against the oracle's
+    direct convolution: same 1e-4 bound as every other fp32 layer."""
+    N, Cin, H, W, Cout, pad = case
+    monkeypatch.setenv("MSCNN_WINOGRAD", "2")
+    rng = np.random.default_rng(4242)
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), relu=relu)
+    assert plan.kernel.startswith("winograd_f2x2_3x3")
+    plan.pack(dev(w))
+    y = plan.forward(dev(x), dev(b)).cpu().numpy()
+    ref = orc.conv2d(x, w, b, (pad, pad))
+    if relu:
+        ref = orc.relu(ref)
+    close(y, ref)
+    monkeypatch.setenv("MSCNN_WINOGRAD", "0")
+    assert not hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad)).kernel.startswith("winograd")
 
 
 def test_conv_no_bias_and_kernel_selection(hip, orc):

@@ -9,7 +9,7 @@ from mscnn_amd import hipapi as hip
 LAYERS = [  # name, Cin, H, W, Cout, k, pad
     ("conv1_2", 64, 576, 1920, 64, 3, 1), ("conv2_1", 64, 288, 960, 128, 3, 1), ("conv2_2", 128, 288, 960, 128, 3, 1),
     ("conv3_1", 128, 144, 480, 256, 3, 1), ("conv3_2", 256, 144, 480, 256, 3, 1),
-    ("conv4_1", 256, 72, 240, 512, 3, 1), ("conv4_2", 512, 72, 240, 512, 3, 1),
+    ("conv4_1", 256, 72, 240, 512, 3, 1), ("conv4_2", 512, 72, 240, 512, 3, 1), ("conv4_3", 512, 72, 240, 512, 3, 1),
     ("conv5_1", 512, 36, 120, 512, 3, 1), ("conv6_1", 512, 18, 60, 512, 3, 1),
     ("LFCN_1_5x5", 512, 72, 240, 9, 5, 2), ("LFCN_1_7x7", 512, 72, 240, 9, 7, 3),
     ("LFCN_2_7x7", 512, 36, 120, 9, 7, 3),
