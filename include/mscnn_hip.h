@@ -76,6 +76,14 @@ MSCNN_API int mscnn_conv2d_plan_set_batch(mscnn_conv_plan* plan, int N);
 MSCNN_API int mscnn_conv2d_pack_weights(const mscnn_conv_plan* plan, const float* w, float* packed, void* stream);
 MSCNN_API int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* plan, const float* x, const float* w, const float* packed,
                          const float* bias, float* y, void* workspace, size_t workspace_bytes, void* stream);
+/* Convolution (+ the plan's ReLU) with the following PoolingLayer (MAX, kernel 2, stride 2, pad 0, ceil mode:
+ * pooling_layer.cu:11-47, pooling_layer.cpp:90-107) fused into the epilogue: y as above AND
+ * y_pool[N][Cout][ceil(Ho/2)][ceil(Wo/2)].  Only for plans where mscnn_conv2d_plan_can_pool() is 1 (the trunk
+ * kernels); bit-identical to mscnn_conv2d_fwd_f32 followed by mscnn_pool2d_fwd_f32.  y_pool == NULL: plain forward. */
+MSCNN_API int mscnn_conv2d_plan_can_pool(const mscnn_conv_plan* plan);
+MSCNN_API int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* plan, const float* x, const float* w, const float* packed,
+                              const float* bias, float* y, float* y_pool, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* ReLU -- ReLULayer::Forward_gpu (relu_layer.cu:9-26); in place allowed (y == x). */
 MSCNN_API int mscnn_relu_fwd_f32(const float* x, float* y, size_t count, float negative_slope, void* stream);

@@ -39,6 +39,8 @@ struct IgemmArgs {
   int N, Cin, H, W, Cout, Ho, Wo, pad_h, pad_w;
   int MT, NTH, NTW, NT, KI, G, relu;
   int xcd_map;         // 1: XCD-aware workgroup -> range mapping
+  float* yp;           // != nullptr: also write the 2x2 / stride-2 max-pooled output [N][Cout][Hp][Wp] (fused PoolingLayer)
+  int Hp, Wp;
   int nt_major;        // 1: tile index t = nt * MT + mt (the M tiles of one pixel tile run together; Winograd GEMM)
   unsigned w_img_bytes;  // per-image weight stride in bytes (0: one weight set; Winograd GEMM: one U matrix per "image")
   int full_q;          // whole tiles per workgroup in the data-parallel phase (tile t = g + j * G, j < full_q)
@@ -77,6 +79,9 @@ struct Cfg {
   static constexpr int B_PER_T = (B_ELEMS + 255) / 256;
   static constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
   static constexpr int FIX_SPLIT = (BM * BN) / 4096;                    // fix-up workgroups per tile
+  // fused 2x2 max pooling in the epilogue: a 32-pixel MFMA block is two 16-pixel rows (TW 16) or one row whose partner
+  // row is the next block of the same lane (TW 32); tiles start on even rows / columns
+  static constexpr bool CAN_POOL = !ROI && (BN / TW) % 2 == 0 && (TW_ == 16 || (TW_ == 32 && (BN / WGN / 32) % 2 == 0));
   static_assert(!VEC_ || (KH_ == 1 && KW_ == 1 && TW_ == 128 && BN_ == 128 && RH_ == 0 && CK_ % 8 == 0), "VEC: 1x1, one 128-pixel row per tile");
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(WM % 32 == 0 && WN % 32 == 0 && BN % TW == 0 && CK % 2 == 0 && A_ELEMS % 4 == 0, "tile shape");
@@ -181,6 +186,15 @@ __device__ __forceinline__ int lane_patch_off(int p) {
   }
   return (p / C::TW) * C::PW + p % C::TW;
 }
+
+__device__ __forceinline__ float lane_xor1(float v) {      // DPP quad_perm [1,0,3,2]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_xor16(float v) {     // ds_swizzle bit mode: and 0x1f, or 0, xor 0x10
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+__device__ __forceinline__ float max2(float a, float b) { return b > a ? b : a; }
+constexpr float kNegMax = -3.402823466e+38f;
 
 template <class C>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
@@ -377,6 +391,37 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
             const unsigned vo = (co0 + (r & 3) + 8 * (r >> 2) < a.Cout) ? voff : kOob;   // Cout < BM (proposal heads)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, vo,
                                                   (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)co_stride * 4u, 0);
+            if constexpr (C::CAN_POOL) acc[mi][ni][r] = o >= 0 ? v : kNegMax;     // kept for the pooling pass below
+          }
+        }
+      }
+      if constexpr (C::CAN_POOL) {
+        if (a.yp) {
+          // fused PoolingLayer (MAX, 2x2, stride 2, pooling_layer.cu:11-47): window = rows {2i, 2i+1} x cols {2j, 2j+1};
+          // pixels outside the plane were set to -FLT_MAX above (ceil-mode windows at odd edges are clipped)
+          const int pstride = a.Hp * a.Wp;
+          const __amdgpu_buffer_rsrc_t psrc =
+              make_rsrc(a.yp + (long)geo.img * a.Cout * pstride, (unsigned)a.Cout * (unsigned)pstride * 4u);
+#pragma unroll
+          for (int mi = 0; mi < C::MI; ++mi) {
+            const int co0 = mt * C::BM + wm * C::WM + mi * 32 + 4 * khalf;
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ni += (C::TW == 32 ? 2 : 1)) {
+              const int p = wn * C::WN + ni * 32 + l31;
+              const int oh = geo.h0 + p / C::TW, ow = geo.w0 + p % C::TW;
+              const bool owner = C::TW == 32 ? (l31 & 1) == 0 : (l31 & 17) == 0;
+              const unsigned voff = (owner && oh < a.Ho && ow < a.Wo) ? (unsigned)(co0 * pstride + (oh >> 1) * a.Wp + (ow >> 1)) * 4u : kOob;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                float m;
+                if constexpr (C::TW == 32) m = max2(acc[mi][ni][r], acc[mi][ni + 1][r]);
+                else m = max2(acc[mi][ni][r], lane_xor16(acc[mi][ni][r]));
+                m = max2(m, lane_xor1(m));
+                const unsigned vo = (co0 + (r & 3) + 8 * (r >> 2) < a.Cout) ? voff : kOob;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), psrc, vo,
+                                                      (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)pstride * 4u, 0);
+              }
+            }
           }
         }
       }
@@ -458,6 +503,77 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
   }
 }
 
+// Fix-up with fused 2x2 max pooling: a thread owns one pooling window (4 pixels of one channel) of a split tile.
+template <class C>
+__global__ __launch_bounds__(256) void igemm_fixup_pool_kernel(IgemmArgs a) {
+  __shared__ const float* s_slab[256];
+  __shared__ int s_n;
+  const int tr = blockIdx.x / C::FIX_SPLIT, part = blockIdx.x % C::FIX_SPLIT;
+  const int t = a.full_q * a.G + tr;
+  if (threadIdx.x == 0) {
+    const long its = (long)tr * a.KI, ite = its + a.KI;
+    int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
+    long b, e;
+    wg_range(a.total_iters, a.G, gf, b, e);
+    while (e <= its) { ++gf; wg_range(a.total_iters, a.G, gf, b, e); }
+    while (b > its) { --gf; wg_range(a.total_iters, a.G, gf, b, e); }
+    wg_range(a.total_iters, a.G, gl, b, e);
+    while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
+    while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
+    int n = 0;
+    if (gf != gl) {
+      for (int g = gf; g <= gl && n < 256; ++g) {
+        wg_range(a.total_iters, a.G, g, b, e);
+        if (e <= b) continue;
+        s_slab[n++] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * (C::BM * C::BN);
+      }
+    }
+    s_n = n;
+  }
+  __syncthreads();
+  const int n = s_n;
+  if (n == 0) return;      // computed whole by one workgroup: y and the pooled output are already written
+  if constexpr (C::CAN_POOL) {
+    const int mt = a.nt_major ? t % a.MT : t / a.NT;
+    const int nt = a.nt_major ? t / a.MT : t % a.NT;
+    TileGeo<C> geo;
+    geo.decode(a, nt);
+    float* ybase = geo.y_base(a);
+    const int co_stride = a.Ho * a.Wo, pstride = a.Hp * a.Wp;
+    float* pbase = a.yp + (long)geo.img * a.Cout * pstride;
+    constexpr int WPT = C::BN / 4;                        // pooling windows per channel row of the tile
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = j * 256 + threadIdx.x;                // window index inside this workgroup's 4096-element part
+      const int m = part * (4096 / C::BN) + q / WPT, pp = q % WPT;
+      const int prow = pp / (C::TW / 2), pcol = pp % (C::TW / 2);
+      const int i0 = m * C::BN + (2 * prow) * C::TW + 2 * pcol;
+      float2 u0 = make_float2(0.f, 0.f), u1 = make_float2(0.f, 0.f);
+      for (int s = 0; s < n; ++s) {
+        const float2 w0 = *reinterpret_cast<const float2*>(s_slab[s] + i0);
+        const float2 w1 = *reinterpret_cast<const float2*>(s_slab[s] + i0 + C::TW);
+        u0.x += w0.x; u0.y += w0.y; u1.x += w1.x; u1.y += w1.y;
+      }
+      const int co = mt * C::BM + m;
+      if (co >= a.Cout) continue;
+      const float bv = a.bias ? a.bias[co] : 0.f;
+      const int oh = geo.h0 + 2 * prow, ow = geo.w0 + 2 * pcol;
+      float vals[4] = {u0.x + bv, u0.y + bv, u1.x + bv, u1.y + bv};
+      float mx = kNegMax;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int h = oh + (e >> 1), w = ow + (e & 1);
+        if (h >= a.Ho || w >= a.Wo) continue;
+        float r = vals[e];
+        if (a.relu) r = r > 0.f ? r : 0.f;
+        ybase[(long)co * co_stride + h * a.Wo + w] = r;
+        mx = max2(mx, r);
+      }
+      if (oh < a.Ho && ow < a.Wo) pbase[(long)co * pstride + (oh >> 1) * a.Wp + (ow >> 1)] = mx;
+    }
+  }
+}
+
 // Generic fallback: one output element per lane; any stride / pad / group.  Same (c, kh, kw) summation
 // order as the definitional loop (test_convolution_layer.cpp:84-107).
 __global__ __launch_bounds__(256) void direct_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -499,14 +615,17 @@ struct KernelEntry {
   int BM, BN, KH, KW, CK, TW, TH;
   int RH, RW, RP, IPT, fix_split, variant;
   IgemmFn main_fn, fix_fn;
+  IgemmFn fix_pool_fn;     // nullptr: this tile geometry has no fused 2x2 max-pooling epilogue
 };
 
 #define ENTRY(BM, BN, WGM, WGN, KH, KW, CK, TW)                                                                     \
   {"igemm_" #BM "x" #BN "_k" #KH "x" #KW "_tw" #TW, BM, BN, KH, KW, CK, TW, BN / TW, 0, 0, 0, 1, (BM * BN) / 4096, 0,  \
-   igemm_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW>>, igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW>>}
+   igemm_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW>>, igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW>>,                  \
+   Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW>::CAN_POOL ? igemm_fixup_pool_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW>> : nullptr}
 #define ENTRY_PF(BM, BN, WGM, WGN, KH, KW, CK, TW)                                                                  \
   {"igemm_" #BM "x" #BN "_k" #KH "x" #KW "_tw" #TW "_pf", BM, BN, KH, KW, CK, TW, BN / TW, 0, 0, 0, 1, (BM * BN) / 4096, 1, \
-   igemm_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW, 0, 0, 0, 1>>, igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW, 0, 0, 0, 1>>}
+   igemm_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW, 0, 0, 0, 1>>, igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW, 0, 0, 0, 1>>, \
+   Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW, 0, 0, 0, 1>::CAN_POOL ? igemm_fixup_pool_kernel<Cfg<BM, BN, WGM, WGN, KH, KW, CK, TW, 0, 0, 0, 1>> : nullptr}
 // ROI mode entries: images of RH x RW with symmetric pad RP, IPT images per tile
 #define ROI_ENTRY(BM, BN, WGM, WGN, KH, KW, CK, RH, RW, RP)                                                             \
   {"igemm_" #BM "x" #BN "_k" #KH "x" #KW "_roi" #RH "x" #RW "p" #RP, BM, BN, KH, KW, CK, 0, 0, RH, RW, RP,              \
@@ -537,6 +656,11 @@ const KernelEntry kTable[] = {
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>},
     {"igemm_128x128_k1x1_ck64_vec", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 102, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>},
+#ifdef MSCNN_ABLATIONS
+    {"abl1x1_noload", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 111, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 11, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 11, 1>>},
+    {"abl1x1_nostage", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 112, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 12, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 12, 1>>},
+    {"abl1x1_mfmaonly", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 113, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 13, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 13, 1>>},
+#endif
     ENTRY(128, 256, 2, 2, 3, 3, 8, 32),     // variant 2 (selected with MSCNN_IGEMM_VARIANT=2): 64x128 wave tiles
     // proposal heads (Cout = 4 + classes <= 32): kitti_car 5x5 / 7x7, ped-cyc + caltech 3x5 / 5x7
     ENTRY(32, 128, 1, 4, 5, 5, 8, 16),
@@ -738,7 +862,8 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
 
 // igemm launch (main kernel + fix-up).  w_img_bytes / nt_major: see IgemmArgs (non-zero only for the Winograd GEMM).
 static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* packed, const float* bias, float* y,
-                        void* workspace, size_t workspace_bytes, hipStream_t st, unsigned w_img_bytes, int nt_major) {
+                        float* y_pool, void* workspace, size_t workspace_bytes, hipStream_t st, unsigned w_img_bytes,
+                        int nt_major) {
   const mscnn_conv_desc& d = p->d;
   const KernelEntry& k = kTable[p->entry];
   const long rem_tiles = (long)p->MT * p->NT - (long)p->full_q * p->G;
@@ -755,19 +880,37 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
   a.MT = p->MT; a.NTH = p->NTH; a.NTW = p->NTW; a.NT = p->NT; a.KI = p->KI; a.G = p->G; a.relu = d.relu;
   a.total_iters = p->total_iters; a.full_q = p->full_q;
   a.w_img_bytes = w_img_bytes; a.nt_major = nt_major;
+  a.yp = y_pool; a.Hp = (p->Ho + 1) / 2; a.Wp = (p->Wo + 1) / 2;
+  if (y_pool && !k.fix_pool_fn) {
+    set_error("conv: kernel %s has no fused pooling epilogue", k.name);
+    return MSCNN_ERR_BAD_ARG;
+  }
   { static const bool noxcd = [] { const char* e = std::getenv("MSCNN_SK_NOXCD"); return e && *e == '1'; }(); a.xcd_map = noxcd ? 0 : 1; }
   k.main_fn<<<p->G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   if (split) {
-    k.fix_fn<<<(int)rem_tiles * k.fix_split, 256, 0, st>>>(a);
+    (y_pool ? k.fix_pool_fn : k.fix_fn)<<<(int)rem_tiles * k.fix_split, 256, 0, st>>>(a);
     MSCNN_POST_LAUNCH();
   }
   return MSCNN_OK;
 }
 
+extern "C" int mscnn_conv2d_plan_can_pool(const mscnn_conv_plan* p) {
+  if (!p || p->head.entry >= 0) return 0;
+  if (p->wino) return 1;
+  return p->entry >= 0 && kTable[p->entry].fix_pool_fn != nullptr;
+}
+
 extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, const float* w, const float* packed,
                                     const float* bias, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+  return mscnn_conv2d_fwd_pool_f32(p, x, w, packed, bias, y, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* x, const float* w, const float* packed,
+                                         const float* bias, float* y, float* y_pool, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
   MSCNN_REQUIRE(p, "conv: null plan");
+  MSCNN_REQUIRE(!y_pool || mscnn_conv2d_plan_can_pool(p), "conv: this plan has no fused 2x2 max-pooling epilogue");
   const mscnn_conv_desc& d = p->d;
   if (d.N == 0) return MSCNN_OK;
   MSCNN_REQUIRE(x && y, "conv: null pointer");
@@ -788,9 +931,9 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
     float* gws = M + (size_t)16 * d.Cout * p->T_pad;
     int rc = wino_input_transform(x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st);
     if (rc != MSCNN_OK) return rc;
-    rc = launch_igemm(g, V, packed, nullptr, M, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
+    rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
     if (rc != MSCNN_OK) return rc;
-    return wino_output_transform(M, bias, y, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st);
+    return wino_output_transform(M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st);
   }
   if (p->entry < 0) {
     MSCNN_REQUIRE(w, "conv: direct kernel needs the Caffe-layout weights");
@@ -803,5 +946,5 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
     return MSCNN_OK;
   }
   MSCNN_REQUIRE(packed, "conv: igemm kernel needs packed weights (mscnn_conv2d_pack_weights)");
-  return launch_igemm(p, x, packed, bias, y, workspace, workspace_bytes, st, 0u, 0);
+  return launch_igemm(p, x, packed, bias, y, y_pool, workspace, workspace_bytes, st, 0u, 0);
 }

@@ -14,7 +14,8 @@ int wino_input_transform(const float* x, float* V, int N, int Cin, int H, int W,
                          int tiles_w, int T_pad, hipStream_t st);
 
 // y[n][co][2ty + i][2tx + j] = (A^T m A)[i][j] + bias[co], optional ReLU;  m[xi][nu] = M[xinu][co][t].
-int wino_output_transform(const float* M, const float* bias, float* y, int N, int Cout, int Ho, int Wo, int tiles_h,
-                          int tiles_w, int T_pad, int relu, hipStream_t st);
+// y_pool != nullptr: also write max over the tile's (in-plane) outputs to y_pool[n][co][ty][tx] (fused 2x2/2 max pooling).
+int wino_output_transform(const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
+                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st);
 
 }  // namespace mscnn

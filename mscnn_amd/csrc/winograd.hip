@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
-                                                          float* __restrict__ y, int N, int Cout, int Ho, int Wo, int tiles_h,
-                                                          int tiles_w, int T, int T_pad, int relu) {
+                                                          float* __restrict__ y, float* __restrict__ yp, int N, int Cout, int Ho,
+                                                          int Wo, int tiles_h, int tiles_w, int T, int T_pad, int relu) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int co = blockIdx.y;
   if (t >= T) return;
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   const float b = bias ? bias[co] : 0.f;
   const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
   float* dst = y + ((long)n * Cout + co) * Ho * Wo;
+  float pooled = -3.402823466e+38f;      // fused PoolingLayer (MAX 2x2 stride 2): the tile IS the pooling window
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int oh = 2 * ty + i;
@@ -129,6 +130,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     float v1 = r[i][1] - r[i][2] - r[i][3] + b;
     if (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
     const int ow = 2 * tx;
+    if (ow < Wo && v0 > pooled) pooled = v0;
+    if (ow + 1 < Wo && v1 > pooled) pooled = v1;
     if (ow + 1 < Wo && (Wo % 2 == 0)) {
       *reinterpret_cast<float2*>(dst + oh * Wo + ow) = make_float2(v0, v1);     // 8-byte aligned when Wo is even
     } else {
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
       if (ow + 1 < Wo) dst[oh * Wo + ow + 1] = v1;
     }
   }
+  if (yp) yp[(((long)n * Cout + co) * tiles_h + ty) * tiles_w + tx] = pooled;
 }
 
 }  // namespace
@@ -160,11 +164,11 @@ int wino_input_transform(const float* x, float* V, int N, int Cin, int H, int W,
   return MSCNN_OK;
 }
 
-int wino_output_transform(const float* M, const float* bias, float* y, int N, int Cout, int Ho, int Wo, int tiles_h,
-                          int tiles_w, int T_pad, int relu, hipStream_t st) {
+int wino_output_transform(const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
+                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st) {
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T, 256), Cout);
-  wino_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu);
+  wino_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

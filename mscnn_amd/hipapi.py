@@ -67,6 +67,8 @@ def lib():
         L.mscnn_conv2d_plan_set_batch.argtypes = [C.c_void_p, C.c_int]
         L.mscnn_conv2d_pack_weights.argtypes = [C.c_void_p] * 4
         L.mscnn_conv2d_fwd_f32.argtypes = [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]
+        L.mscnn_conv2d_fwd_pool_f32.argtypes = [C.c_void_p] * 8 + [C.c_size_t, C.c_void_p]
+        L.mscnn_conv2d_plan_can_pool.argtypes = [C.c_void_p]
         L.mscnn_relu_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
         L.mscnn_pool2d_fwd_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
         L.mscnn_inner_product_fwd_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
@@ -155,12 +157,17 @@ class ConvPlan:
         if self.packed is not None:
             _check(lib().mscnn_conv2d_pack_weights(self._p, _dev(w), _dev(self.packed), _stream()))
 
-    def forward(self, x, bias=None, out=None):
+    @property
+    def can_pool(self):
+        return bool(lib().mscnn_conv2d_plan_can_pool(self._p))
+
+    def forward(self, x, bias=None, out=None, pool_out=None):
+        """pool_out: tensor [N, Cout, ceil(Ho/2), ceil(Wo/2)] that receives the fused MAX 2x2 / stride 2 pooling."""
         if out is None:
             out = torch.empty(self.out_shape(), dtype=torch.float32, device=x.device)
         wsb = self.ws.numel() * 4 if self.ws is not None else 0
-        _check(lib().mscnn_conv2d_fwd_f32(self._p, _dev(x), _dev(self.w), _dev(self.packed), _dev(bias), _dev(out),
-                                          _dev(self.ws), wsb, _stream()))
+        _check(lib().mscnn_conv2d_fwd_pool_f32(self._p, _dev(x), _dev(self.w), _dev(self.packed), _dev(bias), _dev(out),
+                                               _dev(pool_out), _dev(self.ws), wsb, _stream()))
         return out
 
     def __del__(self):

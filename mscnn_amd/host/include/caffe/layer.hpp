@@ -56,6 +56,11 @@ class Layer {
   virtual void OnWeightsChanged() {}
   // Net-level operator fusion hooks (a fused layer must produce exactly what the pair produced).
   virtual bool FuseReLU(Dtype negative_slope) { return false; }
+  // A producer that can also emit the output of the MAX 2x2 / stride 2 / pad 0 Pooling layer that consumes its top writes
+  // it into `pooled_top` (already shaped by that Pooling layer) from then on and returns true.
+  virtual bool FusePool2x2(Blob<Dtype>* pooled_top) { return false; }
+  // Pooling layers only: true when the layer is exactly MAX, kernel 2, stride 2, pad 0.
+  virtual bool IsMaxPool2x2() const { return false; }
   // A producer that can write its top straight into channels [c_offset, c_offset + C) of a wider blob (the top of the
   // Concat that would otherwise copy it) returns true and does so from then on; its own top blob is then not written.
   virtual bool SetOutputWindow(Blob<Dtype>* target, int c_total, int c_offset) { return false; }

@@ -70,6 +70,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   virtual inline int MinTopBlobs() const { return 1; }
   virtual void OnWeightsChanged() { weights_dirty_ = true; }
   virtual bool FuseReLU(Dtype negative_slope);
+  virtual bool FusePool2x2(Blob<Dtype>* pooled_top);
   virtual double ForwardFlops() const;
   const char* kernel_name() const;
  protected:
@@ -81,6 +82,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   mscnn_conv_plan* plan_;
   bool relu_, weights_dirty_;
   int planned_n_, planned_h_, planned_w_;
+  Blob<Dtype>* pooled_top_ = nullptr;     // fused Pooling layer's top (FusePool2x2)
   DeviceBuffer packed_, workspace_;
 };
 
@@ -111,6 +113,9 @@ class PoolingLayer : public Layer<Dtype> {
   virtual inline const char* type() const { return "Pooling"; }
   virtual inline int ExactNumBottomBlobs() const { return 1; }
   virtual inline int ExactNumTopBlobs() const { return 1; }   // the optional argmax-mask top is not produced
+  virtual bool IsMaxPool2x2() const {
+    return method_ == 0 && !global_pooling_ && kernel_h_ == 2 && kernel_w_ == 2 && stride_h_ == 2 && stride_w_ == 2 && pad_h_ == 0 && pad_w_ == 0;
+  }
  protected:
   MSCNN_NO_CPU_PATH("Pooling")
   virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);

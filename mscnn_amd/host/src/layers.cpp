@@ -194,7 +194,27 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
   const size_t wbytes = mscnn_conv2d_workspace_bytes(plan_);
   void* ws = wbytes ? workspace_.Reserve(wbytes) : nullptr;
   const float* bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
-  MSCNN_CHECK(mscnn_conv2d_fwd_f32(plan_, bottom[0]->gpu_data(), w, packed, bias, top[0]->mutable_gpu_data(), ws, wbytes, S()));
+  float* pooled = nullptr;
+  if (pooled_top_ && mscnn_conv2d_plan_can_pool(plan_)) {
+    CHECK_EQ(pooled_top_->num(), top[0]->num());
+    CHECK_EQ(pooled_top_->channels(), top[0]->channels());
+    CHECK_EQ(pooled_top_->height(), (top[0]->height() + 1) / 2);
+    CHECK_EQ(pooled_top_->width(), (top[0]->width() + 1) / 2);
+    pooled = pooled_top_->mutable_gpu_data();
+  }
+  MSCNN_CHECK(mscnn_conv2d_fwd_pool_f32(plan_, bottom[0]->gpu_data(), w, packed, bias, top[0]->mutable_gpu_data(), pooled, ws,
+                                        wbytes, S()));
+  if (pooled_top_ && !pooled) {
+    // the planned kernel has no pooling epilogue (e.g. a direct-kernel shape): run the pooling the fused-away layer would have
+    MSCNN_CHECK(mscnn_pool2d_fwd_f32(top[0]->gpu_data(), pooled_top_->mutable_gpu_data(), top[0]->num(), top[0]->channels(),
+                                     top[0]->height(), top[0]->width(), 2, 2, 0, 0, 2, 2, 0, S()));
+  }
+}
+
+template <typename Dtype>
+bool ConvolutionLayer<Dtype>::FusePool2x2(Blob<Dtype>* pooled_top) {
+  pooled_top_ = pooled_top;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------ Deconvolution

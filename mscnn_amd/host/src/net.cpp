@@ -211,6 +211,31 @@ void Net<Dtype>::ApplyFusion() {
     const Dtype slope = layers_[i + 1]->layer_param().relu_param().negative_slope();
     if (layers_[i]->FuseReLU(slope)) fused_away_[i + 1] = true;
   }
+  // Convolution (+ fused ReLU) -> [Split ->] Pooling(MAX 2x2 / 2): the convolution's epilogue also writes the pooled blob
+  // (pool1..pool6 of the VGG trunk); the Pooling layer becomes a no-op.  The convolution's own top is still written.
+  for (size_t i = 0; i < layers_.size(); ++i) {
+    if (string(layers_[i]->type()) != "Pooling" || !layers_[i]->IsMaxPool2x2()) continue;
+    if (bottom_vecs_[i].size() != 1 || top_vecs_[i].size() != 1) continue;
+    Blob<Dtype>* src = bottom_vecs_[i][0];
+    int prod = -1;
+    for (int hop = 0; hop < 2 && prod < 0; ++hop) {          // look through one Split
+      int l = -1;
+      for (size_t k = 0; k < i; ++k)
+        for (Blob<Dtype>* t : top_vecs_[k]) if (t == src) l = (int)k;      // last writer before the pooling layer
+      if (l < 0) break;
+      while (l > 0 && fused_away_[l]) --l;                                  // an in-place ReLU that was fused away
+      if (string(layers_[l]->type()) == "Split") { src = bottom_vecs_[l][0]; continue; }
+      if (string(layers_[l]->type()) == "Convolution" && top_vecs_[l].size() == 1 && top_vecs_[l][0] == src) prod = l;
+      break;
+    }
+    if (prod < 0) continue;
+    // nothing between the convolution and the pooling layer may rewrite the blob (only its fused in-place ReLU does)
+    bool clean = true;
+    for (size_t k = prod + 1; k < i && clean; ++k)
+      for (Blob<Dtype>* t : top_vecs_[k]) if (t == top_vecs_[prod][0] && !fused_away_[k]) clean = false;
+    if (!clean) continue;
+    if (layers_[prod]->FusePool2x2(top_vecs_[i][0])) fused_away_[i] = true;
+  }
   // Channel Concat whose bottoms all come straight from ROIPooling layers (roi_pool_org + roi_pool_ctx -> roi_pool): the
   // producers write their channel window of the concatenated blob and the copy layer disappears (concat_layer.cu:28-46
   // moves R x 1024 x 49 floats per image otherwise).  The individual ROIPooling tops are then not materialised.

@@ -153,6 +153,40 @@ def test_conv_winograd(hip, orc, case, relu, monkeypatch):
     assert not hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad)).kernel.startswith("winograd")
 
 
+POOL_CASES = [   # N, Cin, H, W, Cout, winograd
+    (1, 16, 16, 32, 128, 0),      # igemm 128x128 tw16: exact tiles
+    (1, 8, 13, 37, 64, 0),        # igemm 64x256 tw32: odd H and W (clipped ceil-mode windows at the edges)
+    (2, 24, 36, 120, 256, 0),     # conv5-shaped plane: stream-K split tiles go through the pooled fix-up kernel
+    (1, 16, 11, 18, 130, 0),      # Cout ragged
+    (1, 40, 13, 21, 130, 2),      # Winograd path, odd sizes
+    (2, 24, 10, 14, 32, 2),       # Winograd path, batch 2
+]
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_conv_fused_pool(hip, orc, case, monkeypatch):
+    """Conv + ReLU with the following MAX 2x2/2 PoolingLayer fused into the epilogue: y unchanged, pooled output
+    bit-identical to the stand-alone pooling kernel on y, and equal to the oracle's pooling of y."""
+    N, Cin, H, W, Cout, wino = case
+    monkeypatch.setenv("MSCNN_WINOGRAD", str(wino))
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True)
+    assert plan.can_pool and plan.kernel.startswith("winograd") == (wino == 2)
+    plan.pack(dev(w))
+    y0 = plan.forward(dev(x), dev(b)).clone()
+    yp = torch.full((N, Cout, (H + 1) // 2, (W + 1) // 2), float("nan"), device="cuda")
+    y1 = plan.forward(dev(x), dev(b), pool_out=yp)
+    assert torch.equal(y0, y1)
+    ref = hip.pool2d(y0, (2, 2), (0, 0), (2, 2))
+    assert torch.equal(yp, ref)
+    assert np.array_equal(yp.cpu().numpy(), orc.pool2d(y0.cpu().numpy(), (2, 2), (0, 0), (2, 2), "MAX"))
+    close(y0.cpu().numpy(), orc.relu(orc.conv2d(x, w, b, (1, 1))))
+    assert not hip.ConvPlan(1, 512, 72, 240, 9, 5, 5, (2, 2)).can_pool       # proposal-head kernel: no pooling epilogue
+
+
 def test_conv_no_bias_and_kernel_selection(hip, orc):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((1, 8, 8, 16)).astype(np.float32)
