@@ -57,7 +57,9 @@ struct Cfg {
   // VEC: 1x1 kernel over planes of exactly 128-pixel rows (the Winograd GEMM operands): the B tile is CK contiguous
   // 512-byte rows, staged with b128 loads / ds_write_b128 and no per-element offset table
   static constexpr int VEC = VEC_;
-  static constexpr int BV_PER_T = CK_ * 32 / 256;
+  static constexpr int F4_PER_CH = BN_ / 4;                 // float4s per channel row of the B tile (tile = BN contiguous pixels)
+  static constexpr int CH_PER_PASS = 256 / F4_PER_CH;       // channels staged per pass of the 256 threads
+  static constexpr int BV_PER_T = CK_ * F4_PER_CH / 256;
   static constexpr int PF = PF_;   // 1: LDS operand reads software-pipelined one MFMA group ahead
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, KH = KH_, KW = KW_, CK = CK_, TW = TW_;
   static constexpr bool ROI = RH_ > 0;
@@ -82,7 +84,8 @@ struct Cfg {
   // fused 2x2 max pooling in the epilogue: a 32-pixel MFMA block is two 16-pixel rows (TW 16) or one row whose partner
   // row is the next block of the same lane (TW 32); tiles start on even rows / columns
   static constexpr bool CAN_POOL = !ROI && (BN / TW) % 2 == 0 && (TW_ == 16 || (TW_ == 32 && (BN / WGN / 32) % 2 == 0));
-  static_assert(!VEC_ || (KH_ == 1 && KW_ == 1 && TW_ == 128 && BN_ == 128 && RH_ == 0 && CK_ % 8 == 0), "VEC: 1x1, one 128-pixel row per tile");
+  static_assert(!VEC_ || (KH_ == 1 && KW_ == 1 && TW_ == 128 && (BN_ == 128 || BN_ == 256) && RH_ == 0 && CK_ % 8 == 0),
+                "VEC: 1x1, tiles of one or two whole 128-pixel rows");
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(WM % 32 == 0 && WN % 32 == 0 && BN % TW == 0 && CK % 2 == 0 && A_ELEMS % 4 == 0, "tile shape");
   static_assert((BM * BN) % 4096 == 0, "fix-up split");
@@ -259,8 +262,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         g_off[i] = o >= 0 ? (unsigned)o * 4u : kOob;
       }
     }
-    // VEC: float4 number tid + i*256 of the tile = channel (tid >> 5) + 8 i, pixels 4 (tid & 31) .. +3 of row h0
-    const unsigned bv_voff = ((unsigned)(tid >> 5) * (unsigned)plane + (unsigned)geo.h0 * 128u + (unsigned)(tid & 31) * 4u) * 4u;
+    // VEC: float4 number tid + i*256 of the tile = channel tid / F4_PER_CH + CH_PER_PASS * i, pixels 4 (tid % F4_PER_CH) .. +3
+    // of the tile's BN contiguous pixels (rows of 128 are contiguous in the plane)
+    const unsigned bv_voff =
+        ((unsigned)(tid / C::F4_PER_CH) * (unsigned)plane + (unsigned)geo.h0 * 128u + (unsigned)(tid % C::F4_PER_CH) * 4u) * 4u;
 
     f32x16 acc[C::MI][C::NI];
 #pragma unroll
@@ -287,9 +292,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       const int c_left = a.Cin - (kc) * C::CK;                                                                      \
       if constexpr (C::VEC) {                                                                                       \
         _Pragma("unroll") for (int i = 0; i < C::BV_PER_T; ++i) {                                                   \
-          const unsigned vo = (ragged_c && (tid >> 5) + 8 * i >= c_left) ? kOob : bv_voff;                          \
+          const unsigned vo = (ragged_c && tid / C::F4_PER_CH + C::CH_PER_PASS * i >= c_left) ? kOob : bv_voff;     \
           rbv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(                                \
-                                                  xsrc, vo, b_soff + (unsigned)(8 * i) * (unsigned)plane * 4u, 0)); \
+                                         xsrc, vo, b_soff + (unsigned)(C::CH_PER_PASS * i) * (unsigned)plane * 4u, 0)); \
         }                                                                                                           \
       } else {                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < C::B_PER_T; ++i) {                                                    \
@@ -656,6 +661,8 @@ const KernelEntry kTable[] = {
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>},
     {"igemm_128x128_k1x1_ck64_vec", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 102, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>},
+    {"igemm_128x256_k1x1_ck32_vec", 128, 256, 1, 1, 32, 128, 2, 0, 0, 0, 1, 8, 103, igemm_kernel<Cfg<128, 256, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>,
+     igemm_fixup_kernel<Cfg<128, 256, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>},
 #ifdef MSCNN_ABLATIONS
     {"abl1x1_noload", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 111, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 11, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 11, 1>>},
     {"abl1x1_nostage", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 112, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 12, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 12, 1>>},
@@ -760,7 +767,9 @@ static void plan_shape(mscnn_conv_plan* p) {
     if (k.KH == 1 && k.KW == 1) {
       const bool rows128 = d.W == 128 && d.pad_h == 0 && d.pad_w == 0;        // Winograd GEMM operand planes
       const char* e1 = std::getenv("MSCNN_GEMM1X1_VARIANT");                  // tuning knob: 0 generic, 101 / 102 vectorised
-      const int want1 = !rows128 ? 0 : (e1 ? std::atoi(e1) : 102);
+      // measured (Winograd GEMMs of mscnn-7s-576): 128x256 tiles win on the large planes (conv3: 135 rows -17 us, conv4: 34
+      // rows -8 us), 128x128 / CK 64 on the small ones (conv5: 9 rows, conv6: 3 rows)
+      const int want1 = !rows128 ? 0 : (e1 ? std::atoi(e1) : (d.H >= 32 ? 103 : 102));
       if (k.variant != want1) continue;
     }
     double cost;
