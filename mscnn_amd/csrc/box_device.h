@@ -58,48 +58,69 @@ __device__ __forceinline__ u64 readlane64(u64 v, int lane) {
 }
 
 // Greedy scan over the upper-triangular bit matrix (nmsMax, box_output_layer.cpp:38-63) by one 256-thread
-// workgroup.  Wave 0 owns the removed-bitmap (lane w = boxes [64w, 64w+64)) and walks the boxes in chunks of
-// 64: a 64-step register-only pass over the diagonal word of each row (v_readlane broadcasts), then an OR of
-// the kept rows.  Waves 1-3 stream the NEXT chunk's 64 mask rows from L2 into the other half of a double
-// buffer in LDS meanwhile (one barrier per chunk).  W = words per row actually used (<= 64).
-// `buf` = dynamic LDS of 2 * 64 * W u64.  Result: lane c of wave 0 returns the keep-word of chunk c.
+// workgroup.  Wave 0 owns the removed-bitmap (lane w = boxes [64w, 64w+64)) and walks the boxes in chunks of 64:
+//   * diagonal pass, all scalar: the next surviving box is s_ff1 of the live word; its diagonal mask word comes from a
+//     v_readlane with a scalar lane index -- one iteration per KEPT box, not per box;
+//   * the kept rows' words (w >= c) are OR-ed into the removed-bitmap from LDS, four independent reads at a time.
+// Waves 1-3 stream the NEXT chunk's 64 mask rows (words c+1.. only) from L2 into the other half of a double buffer in LDS
+// meanwhile: lane = word, one row per load instruction (coalesced), all of a thread's rows in flight at once.
+// W = words per row actually used (<= 64).  `buf` = dynamic LDS of 2 * 64 * W u64.  Result: lane c of wave 0 returns the
+// keep-word of chunk c.
 __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, int wpr, int W, u64* buf) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunks = (n + 63) >> 6;
-  auto fill = [&](int c, int b, int t0, int stride) {
+  // rows r = r0, r0 + rstep, ... of chunk c -> buffer b; this thread moves word `lane` of each
+  auto fill = [&](int c, int b, int r0, int rstep) {
     u64* dst = buf + (size_t)b * 64 * W;
-    for (int idx = t0; idx < 64 * W; idx += stride) {
-      const int i = idx / W, w = idx - i * W;
-      const int row = c * 64 + i;
-      dst[idx] = (row < n && w >= c && w < wpr) ? mask[(size_t)row * wpr + w] : 0ull;
+    if (lane >= W) return;
+    const bool need = lane >= c && lane < wpr;           // words left of the diagonal are never read
+    constexpr int kBatch = 22;                           // ceil(64 / 3): every row of a producer wave in one batch
+    for (int rb = r0; rb < 64; rb += rstep * kBatch) {
+      u64 v[kBatch];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        const int r = rb + j * rstep, row = c * 64 + r;
+        v[j] = (need && r < 64 && row < n) ? mask[(size_t)row * wpr + lane] : 0ull;
+      }
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        const int r = rb + j * rstep;
+        if (r < 64) dst[r * W + lane] = v[j];
+      }
     }
   };
-  fill(0, 0, tid, 256);
+  fill(0, 0, wave, 4);
   __syncthreads();
   u64 removed = 0, mykeep = 0;
   for (int c = 0; c < nchunks; ++c) {
     const u64* cur_rows = buf + (size_t)(c & 1) * 64 * W;
     if (wave != 0) {
-      if (c + 1 < nchunks) fill(c + 1, (c + 1) & 1, tid - 64, 192);
+      if (c + 1 < nchunks) fill(c + 1, (c + 1) & 1, wave - 1, 3);
     } else {
       const int valid = min(64, n - c * 64);
-      const u64 dg = cur_rows[lane * W + c];            // diagonal word of row (c*64 + lane)
-      u64 cur = readlane64(removed, c);
+      const u64 dg = cur_rows[min(lane, 63) * W + c];    // diagonal word of row (c*64 + lane): bits j > lane it suppresses
+      u64 live = ~readlane64(removed, c);
+      if (valid < 64) live &= (1ull << valid) - 1ull;
       u64 keep = 0;
-#pragma unroll 8
-      for (int i = 0; i < 64; ++i) {
-        const u64 di = readlane64(dg, i);                // uniform
-        const bool alive = (i < valid) && !((cur >> i) & 1ull);
-        if (alive) { keep |= 1ull << i; cur |= di; }
+      while (live) {                                     // wave-uniform: scalar loop over the KEPT boxes of the chunk
+        const int i = __ffsll((long long)live) - 1;
+        keep |= 1ull << i;
+        live &= ~readlane64(dg, i);                      // boxes it suppresses
+        live &= ~((2ull << i) - 1ull);                   // boxes up to and including i are decided
       }
       if (lane == c) mykeep = keep;
       if (lane < W) {
-        u64 kk = keep;
-        while (kk) {                                     // uniform loop over kept rows
-          const int i = __ffsll((long long)kk) - 1;
-          kk &= kk - 1;
-          removed |= cur_rows[i * W + lane];
+        u64 kk = keep, acc = 0;
+        while (kk) {                                     // uniform loop over kept rows, four LDS reads in flight
+          const int i0 = __ffsll((long long)kk) - 1; kk &= kk - 1;
+          const int i1 = kk ? __ffsll((long long)kk) - 1 : i0; kk &= kk - 1;     // (kk & (kk - 1) of 0 is 0)
+          const int i2 = kk ? __ffsll((long long)kk) - 1 : i0; kk &= kk - 1;
+          const int i3 = kk ? __ffsll((long long)kk) - 1 : i0; kk &= kk - 1;
+          const u64 r0 = cur_rows[i0 * W + lane], r1 = cur_rows[i1 * W + lane];
+          const u64 r2 = cur_rows[i2 * W + lane], r3 = cur_rows[i3 * W + lane];
+          acc |= (r0 | r1) | (r2 | r3);
         }
+        removed |= acc;
       }
     }
     __syncthreads();

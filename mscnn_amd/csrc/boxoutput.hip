@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   __shared__ u64 sk[kSortCap];
   __shared__ unsigned hist[256];
   __shared__ u64 s_prefix;
-  __shared__ int s_need, s_fill;
+  __shared__ int s_need, s_fill, s_done;
   const int tid = threadIdx.x;
   const int n = cnt[CNT_CAND];
   int K = n;
@@ -126,8 +126,10 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
 
   u64 thresh = 0;             // keep keys >= thresh
   if (n > K) {
-    // radix select, MSB first, 8 bits per pass: find the K-th largest key
-    if (tid == 0) { s_prefix = 0; s_need = K; }
+    // radix select, MSB first, 8 bits per pass: find the K-th largest key.  The bucket walk is a 64-lane suffix scan
+    // (4 buckets per lane); the passes stop as soon as a bucket holds exactly the keys still needed (with the score in the
+    // upper 32 bits that is normally after 3-4 passes: the anchor-id passes only separate equal scores).
+    if (tid == 0) { s_prefix = 0; s_need = K; s_done = 0; }
     __syncthreads();
     for (int pass = 0; pass < 8; ++pass) {
       const int shift = 56 - 8 * pass;
@@ -140,18 +142,35 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
         if ((k & himask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        int need = s_need;
-        int b = 255;
-        for (; b > 0; --b) {
-          const int c = (int)hist[b];
-          if (c >= need) break;
-          need -= c;
+      if (tid < 64) {
+        // lane l owns buckets 255-4l .. 252-4l (descending key order)
+        unsigned c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = hist[255 - (4 * tid + j)];
+        const int mine = (int)(c[0] + c[1] + c[2] + c[3]);
+        int incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+          const int v = __shfl_up(incl, d, 64);
+          if (tid >= d) incl += v;
         }
-        s_need = need;
-        s_prefix = prefix | ((u64)b << shift);
+        const int need = s_need;
+        const u64 ball = __ballot(incl >= need);
+        const int first = __ffsll((long long)ball) - 1;      // ball != 0: the buckets hold at least `need` keys
+        if (tid == first) {
+          int rem = need - (incl - mine);
+          int j = 0;
+          for (; j < 3; ++j) {
+            if ((int)c[j] >= rem) break;
+            rem -= (int)c[j];
+          }
+          const int b = 255 - (4 * tid + j);
+          s_need = rem;
+          s_prefix = prefix | ((u64)b << shift);
+          if ((int)c[j] == rem) s_done = 1;                  // the whole bucket is taken: lower bits of the threshold are 0
+        }
       }
       __syncthreads();
+      if (s_done) break;
     }
     thresh = s_prefix;        // exactly K keys are >= thresh (keys are unique)
   }
