@@ -73,6 +73,10 @@ MSCNN_API const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* plan);
 MSCNN_API double mscnn_conv2d_plan_flops(const mscnn_conv_plan* plan);
 /* Re-shape a plan for a new batch size N (ROI count changes per image, layer.hpp:451-456). */
 MSCNN_API int mscnn_conv2d_plan_set_batch(mscnn_conv_plan* plan, int N);
+/* Identifies the packed-weight layout the plan currently expects (0: none, the kernel reads the Caffe layout).
+ * mscnn_conv2d_plan_set_batch may select a different kernel family for the new batch (e.g. ROI count crossing the
+ * Winograd threshold): when this value changes, call mscnn_conv2d_pack_weights again before the next forward. */
+MSCNN_API unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_plan* plan);
 MSCNN_API int mscnn_conv2d_pack_weights(const mscnn_conv_plan* plan, const float* w, float* packed, void* stream);
 MSCNN_API int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* plan, const float* x, const float* w, const float* packed,
                          const float* bias, float* y, void* workspace, size_t workspace_bytes, void* stream);

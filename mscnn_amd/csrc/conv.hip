@@ -643,6 +643,9 @@ const KernelEntry kTable[] = {
     ENTRY(128, 128, 2, 2, 3, 3, 8, 16),
     ENTRY(128, 128, 2, 2, 3, 3, 8, 32),
     ENTRY(64, 256, 1, 4, 3, 3, 8, 32),
+    // conv1_1 (Cin = 3): channel chunk of 4 instead of 8 halves the zero-padded K (36 instead of 72 for 27 real taps)
+    {"igemm_64x256_k3x3_tw32_ck4", 64, 256, 3, 3, 4, 32, 8, 0, 0, 0, 1, 4, 50, igemm_kernel<Cfg<64, 256, 1, 4, 3, 3, 4, 32>>,
+     igemm_fixup_kernel<Cfg<64, 256, 1, 4, 3, 3, 4, 32>>, igemm_fixup_pool_kernel<Cfg<64, 256, 1, 4, 3, 3, 4, 32>>},
     ENTRY_PF(128, 128, 2, 2, 3, 3, 8, 16),
     ENTRY_PF(128, 128, 2, 2, 3, 3, 8, 32),
     ENTRY_PF(64, 256, 1, 4, 3, 3, 8, 32),
@@ -694,6 +697,7 @@ struct mscnn_conv_plan {
   // Winograd F(2x2, 3x3) path (wino != nullptr): input transform -> 16 batched 1x1 GEMMs (the nested igemm plan) ->
   // output transform.  Workspace layout: [V: 16 x Cin x T_pad][M: 16 x Cout x T_pad][nested plan's stream-K slabs].
   mscnn_conv_plan* wino = nullptr;
+  int wino_m = 2;        // output tile edge: 2 = F(2x2,3x3) (16 planes), 3 = F(3x3,3x3) (25 planes; small ROI maps)
   int tiles_h = 0, tiles_w = 0, T_pad = 0;
   ~mscnn_conv_plan() { delete wino; }
 };
@@ -714,21 +718,27 @@ static bool wino_plan(mscnn_conv_plan* p) {
   if (mode == 0 || d.Kh != 3 || d.Kw != 3 || d.stride_h != 1 || d.stride_w != 1 || d.group != 1) return false;
   if (p->Ho < 2 || p->Wo < 2) return false;
   const double intensity = (double)d.Cin * d.Cout / (d.Cin + d.Cout);
-  if (mode != 2 && (intensity < 100.0 || d.H * d.W < 256 || (d.H <= 8 && d.W <= 8))) return false;   // ROI maps stay on the ROI-mode igemm
-  const int th = cdiv(p->Ho, 2), tw = cdiv(p->Wo, 2);
+  // small maps (the ROI-pooled 7x7 / 7x5 / 8x4 inputs of roi_c1): F(3x3,3x3) -- a 5x5 output is 2x2 tiles x 25 multiplies
+  // instead of 225 (measured 1293 -> see DESIGN.md); larger planes: F(2x2,3x3)
+  const bool roi_map = d.H <= 8 && d.W <= 8;
+  const int m = roi_map ? 3 : 2, planes = roi_map ? 25 : 16;
+  if (mode != 2 && (intensity < 100.0 || (!roi_map && d.H * d.W < 256))) return false;
+  if (roi_map && (mode == 3 || d.N < 8)) return false;          // MSCNN_WINOGRAD=3: F(2x2,3x3) layers only
+  const int th = cdiv(p->Ho, m), tw = cdiv(p->Wo, m);
   const long T = (long)d.N * th * tw;
   const long T_pad = (T + 127) / 128 * 128;
   if ((double)T_pad * (d.Cin > d.Cout ? d.Cin : d.Cout) * 4.0 >= 2.0e9) return false;   // one transform plane per 32-bit window
   mscnn_conv_plan* g = new (std::nothrow) mscnn_conv_plan();
   if (!g) return false;
   g->d = d;
-  g->d.N = 16; g->d.H = (int)(T_pad / 128); g->d.W = 128; g->d.Kh = g->d.Kw = 1; g->d.pad_h = g->d.pad_w = 0; g->d.relu = 0;
+  g->d.N = planes; g->d.H = (int)(T_pad / 128); g->d.W = 128; g->d.Kh = g->d.Kw = 1; g->d.pad_h = g->d.pad_w = 0; g->d.relu = 0;
   plan_shape(g);
   if (g->entry < 0 || g->wino || g->head.entry >= 0) { delete g; return false; }
+  p->wino_m = m;
   p->wino = g;
   p->tiles_h = th; p->tiles_w = tw; p->T_pad = (int)T_pad;
-  p->packed_bytes = 16 * g->packed_bytes;
-  p->ws_bytes = (size_t)16 * ((size_t)d.Cin + d.Cout) * T_pad * sizeof(float) + g->ws_bytes;
+  p->packed_bytes = (size_t)planes * g->packed_bytes;
+  p->ws_bytes = (size_t)planes * ((size_t)d.Cin + d.Cout) * T_pad * sizeof(float) + g->ws_bytes;
   return true;
 }
 
@@ -762,7 +772,7 @@ static void plan_shape(mscnn_conv_plan* p) {
     const bool is256 = (k.BM == 128 && k.BN == 256);
     if (k.KH == 3 && k.KW == 3 && k.RH == 0) {
       if (is256 && k.variant == 0) continue;                  // (kept for reference; superseded by variant 3)
-      if (k.variant != want) continue;
+      if (k.variant != ((d.Cin <= 4 && d.Cout <= 64 && !venv) ? 50 : want)) continue;
     }
     if (k.KH == 1 && k.KW == 1) {
       const bool rows128 = d.W == 128 && d.pad_h == 0 && d.pad_w == 0;        // Winograd GEMM operand planes
@@ -831,8 +841,17 @@ extern "C" size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* p) { retur
 extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (!p) return "";
   if (p->head.entry >= 0) return head_kernel_name(p->head);
-  if (p->wino) return "winograd_f2x2_3x3";
+  if (p->wino) return p->wino_m == 3 ? "winograd_f3x3_3x3" : "winograd_f2x2_3x3";
   return p->entry < 0 ? "direct_f32" : kTable[p->entry].name;
+}
+extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_plan* p) {
+  if (!p) return 0;
+  unsigned long long kind, e, mt, ki;
+  if (p->head.entry >= 0) { kind = 2; e = (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
+  else if (p->wino) { kind = 2 + (unsigned)p->wino_m; e = (unsigned)p->wino->entry; mt = (unsigned)p->wino->MT; ki = (unsigned)p->wino->KI; }
+  else if (p->entry >= 0) { kind = 1; e = (unsigned)p->entry; mt = (unsigned)p->MT; ki = (unsigned)p->KI; }
+  else return 0;   // direct kernel: reads the Caffe layout
+  return kind | (e << 8) | (mt << 24) | (ki << 44);
 }
 extern "C" double mscnn_conv2d_plan_flops(const mscnn_conv_plan* p) {
   if (!p) return 0;
@@ -855,7 +874,7 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   if (p->wino) {
     MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
     const KernelEntry& k = kTable[p->wino->entry];
-    return wino_pack_weights(w, packed, p->d.Cout, p->d.Cin, k.BM, k.CK, p->wino->MT, p->wino->KI, as_stream(stream));
+    return wino_pack_weights(p->wino_m, w, packed, p->d.Cout, p->d.Cin, k.BM, k.CK, p->wino->MT, p->wino->KI, as_stream(stream));
   }
   if (p->entry < 0) return MSCNN_OK;   // direct kernel reads the Caffe layout
   MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
@@ -906,7 +925,7 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
 
 extern "C" int mscnn_conv2d_plan_can_pool(const mscnn_conv_plan* p) {
   if (!p || p->head.entry >= 0) return 0;
-  if (p->wino) return 1;
+  if (p->wino) return p->wino_m == 2;
   return p->entry >= 0 && kTable[p->entry].fix_pool_fn != nullptr;
 }
 
@@ -935,14 +954,15 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
       return MSCNN_ERR_WORKSPACE;
     }
     const mscnn_conv_plan* g = p->wino;
+    const size_t planes = p->wino_m == 3 ? 25 : 16;
     float* V = static_cast<float*>(workspace);
-    float* M = V + (size_t)16 * d.Cin * p->T_pad;
-    float* gws = M + (size_t)16 * d.Cout * p->T_pad;
-    int rc = wino_input_transform(x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st);
+    float* M = V + planes * d.Cin * p->T_pad;
+    float* gws = M + planes * d.Cout * p->T_pad;
+    int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st);
     if (rc != MSCNN_OK) return rc;
     rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
     if (rc != MSCNN_OK) return rc;
-    return wino_output_transform(M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st);
+    return wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st);
   }
   if (p->entry < 0) {
     MSCNN_REQUIRE(w, "conv: direct kernel needs the Caffe-layout weights");

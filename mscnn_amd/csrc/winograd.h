@@ -1,4 +1,5 @@
-// Internal interface of winograd.hip: the three data transforms of the Winograd F(2x2, 3x3) convolution path.
+// Internal interface of winograd.hip: the three data transforms of the Winograd convolution paths.
+// m = output tile edge: 2 -> F(2x2, 3x3) (4x4 input tiles, 16 transform planes), 3 -> F(3x3, 3x3) (5x5 tiles, 25 planes).
 #pragma once
 #include "common.h"
 
@@ -6,16 +7,16 @@ namespace mscnn {
 
 // U[xi*4+nu] = (G g G^T)[xi][nu] for every (co, ci), written in the igemm packed layout of a 1x1 convolution with
 // per-"image" weights:  wp[xinu][mt][kc][ck][BM]  (zero padded in Cout and Cin).
-int wino_pack_weights(const float* w, float* packed, int Cout, int Cin, int BM, int CK, int MT, int KI, hipStream_t st);
+int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, int BM, int CK, int MT, int KI, hipStream_t st);
 
 // V[xinu][ci][t] = (B^T d B)[xi][nu],  d = the 4x4 input patch of output tile t = (n, ty, tx) (zero outside the image);
 // t < T real tiles, row stride T_pad (columns T..T_pad are written as zeros).
-int wino_input_transform(const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
+int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
                          int tiles_w, int T_pad, hipStream_t st);
 
 // y[n][co][2ty + i][2tx + j] = (A^T m A)[i][j] + bias[co], optional ReLU;  m[xi][nu] = M[xinu][co][t].
 // y_pool != nullptr: also write max over the tile's (in-plane) outputs to y_pool[n][co][ty][tx] (fused 2x2/2 max pooling).
-int wino_output_transform(const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
+int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
                           int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st);
 
 }  // namespace mscnn

@@ -69,6 +69,8 @@ def lib():
         L.mscnn_conv2d_fwd_f32.argtypes = [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]
         L.mscnn_conv2d_fwd_pool_f32.argtypes = [C.c_void_p] * 8 + [C.c_size_t, C.c_void_p]
         L.mscnn_conv2d_plan_can_pool.argtypes = [C.c_void_p]
+        L.mscnn_conv2d_plan_weight_layout.argtypes = [C.c_void_p]
+        L.mscnn_conv2d_plan_weight_layout.restype = C.c_ulonglong
         L.mscnn_relu_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
         L.mscnn_pool2d_fwd_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
         L.mscnn_inner_product_fwd_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
@@ -125,6 +127,7 @@ class ConvPlan:
         self.device = device
         self.packed = None
         self.ws = None
+        self.w = None
         self._alloc()
 
     def _alloc(self):
@@ -148,9 +151,13 @@ class ConvPlan:
         return (d.N, d.Cout, (d.H + 2 * d.pad_h - d.Kh) // d.stride_h + 1, (d.W + 2 * d.pad_w - d.Kw) // d.stride_w + 1)
 
     def set_batch(self, N):
+        before, had = lib().mscnn_conv2d_plan_weight_layout(self._p), self.packed
         _check(lib().mscnn_conv2d_plan_set_batch(self._p, N))
         self.desc.N = N
         self._alloc()
+        if getattr(self, "w", None) is not None and self.packed is not None and \
+                (lib().mscnn_conv2d_plan_weight_layout(self._p) != before or self.packed is not had):
+            self.pack(self.w)      # another kernel family (or a new buffer): the packed weights must be rebuilt
 
     def pack(self, w):
         self.w = w

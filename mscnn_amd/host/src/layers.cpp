@@ -143,8 +143,10 @@ template <typename Dtype>
 void ConvolutionLayer<Dtype>::Plan(int n, int h, int w) {
   if (plan_ && planned_h_ == h && planned_w_ == w) {
     if (planned_n_ != n) {
+      const unsigned long long before = mscnn_conv2d_plan_weight_layout(plan_);
       MSCNN_CHECK(mscnn_conv2d_plan_set_batch(plan_, n));
       planned_n_ = n;
+      if (mscnn_conv2d_plan_weight_layout(plan_) != before) weights_dirty_ = true;   // another kernel family: re-pack
     }
     return;
   }

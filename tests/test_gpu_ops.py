@@ -1,6 +1,7 @@
 """Parity of every HIP op (through the C ABI of libmscnn_hip.so) against the CPU oracle on the same
 seeded inputs.  Bars (north_star): bit-exact for index/selection and compare/select work (pool, ROI pool,
 NMS keep sets, BoxOutput selection); fp32 values within 1e-4 relative (|a-b| <= 1e-4 * max(1,|b|))."""
+import os
 import numpy as np
 import pytest
 
@@ -153,6 +154,35 @@ def test_conv_winograd(hip, orc, case, relu, monkeypatch):
     assert not hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad)).kernel.startswith("winograd")
 
 
+WINO33_CASES = [   # R, Cin, H, W, Cout, pad  (ROI-pooled maps -> roi_c1)
+    (20, 64, 7, 7, 48, 0),        # kitti_car: 7x7 -> 5x5 (2x2 tiles of 3x3, last row / column dropped)
+    (33, 40, 7, 5, 130, 0),       # ped/cyc: 7x5 -> 5x3
+    (16, 24, 8, 4, 32, 1),        # caltech: 8x4 pad 1 -> 8x4
+    (50, 1024, 7, 7, 512, 0),     # roi_c1 channel counts (default heuristic picks the path)
+]
+
+
+@pytest.mark.parametrize("case", WINO33_CASES)
+def test_conv_winograd_f3x3(hip, orc, case, monkeypatch):
+    """Winograd F(3x3,3x3) on the small ROI maps against the oracle's direct convolution, 1e-4 bound, inputs post-ReLU
+    like the ROI-pooled features."""
+    R, Cin, H, W, Cout, pad = case
+    monkeypatch.setenv("MSCNN_WINOGRAD", "2")
+    rng = np.random.default_rng(99)
+    x = np.maximum(rng.standard_normal((R, Cin, H, W)), 0).astype(np.float32) * 2.0
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    plan = hip.ConvPlan(R, Cin, H, W, Cout, 3, 3, (pad, pad), relu=True)
+    assert plan.kernel == "winograd_f3x3_3x3" and not plan.can_pool
+    plan.pack(dev(w))
+    y = plan.forward(dev(x), dev(b)).cpu().numpy()
+    ref = orc.relu(orc.conv2d(x, w, b, (pad, pad)))
+    close(y, ref)
+    plan.set_batch(R + 7)                                  # ROI count changes from frame to frame
+    x2 = np.concatenate([x, x[:7]], 0)
+    close(plan.forward(dev(x2), dev(b)).cpu().numpy(), np.concatenate([ref, ref[:7]], 0))
+
+
 POOL_CASES = [   # N, Cin, H, W, Cout, winograd
     (1, 16, 16, 32, 128, 0),      # igemm 128x128 tw16: exact tiles
     (1, 8, 13, 37, 64, 0),        # igemm 64x256 tw32: odd H and W (clipped ceil-mode windows at the edges)
@@ -197,7 +227,12 @@ def test_conv_no_bias_and_kernel_selection(hip, orc):
     close(plan.forward(dev(x)).cpu().numpy(), orc.conv2d(x, w, None, (1, 1)))
     assert hip.ConvPlan(1, 3, 8, 16, 32, 3, 3, (1, 1)).kernel.startswith("igemm_")          # Cin 3 is zero-padded
     assert hip.ConvPlan(1, 8, 8, 16, 32, 3, 3, (1, 1), stride=(2, 2)).kernel == "direct_f32"
-    assert "roi7x7p0" in hip.ConvPlan(50, 1024, 7, 7, 512, 3, 3).kernel
+    assert hip.ConvPlan(50, 1024, 7, 7, 512, 3, 3).kernel == "winograd_f3x3_3x3"             # roi_c1: F(3x3,3x3)
+    os.environ["MSCNN_WINOGRAD"] = "0"
+    try:
+        assert "roi7x7p0" in hip.ConvPlan(50, 1024, 7, 7, 512, 3, 3).kernel                # direct ROI-mode igemm
+    finally:
+        del os.environ["MSCNN_WINOGRAD"]
     assert hip.ConvPlan(1, 512, 72, 240, 9, 7, 7, (3, 3)).kernel == "head4x4_k7x7_m3x4"     # proposal heads: M = 4 MFMA
     assert hip.ConvPlan(1, 512, 72, 240, 6, 5, 3, (2, 1)).kernel == "head4x4_k5x3_m2x4"
     assert plan.flops == 2.0 * 32 * 8 * 16 * 8 * 9
