@@ -203,18 +203,47 @@ __global__ __launch_bounds__(256) void wino33_weight_kernel(const float* __restr
   }
 }
 
+// Input transform of the ROI maps.  x is [roi][channel][H*W] with H*W <= 64 floats per map: for a fixed ROI, 16 consecutive
+// channels are one contiguous run (3136 B for 7x7), while one channel of consecutive ROIs is 200 KB apart.  A workgroup
+// therefore stages (8 ROIs x 16 channels) through LDS with coalesced float4 loads and then lets thread = (channel, tile)
+// with tiles fastest do the 5x5 transform, so every one of the 25 planes V[xinu][ci][t] is written as 128-byte runs
+// (8 ROIs x tiles-per-ROI consecutive t).  157 -> see DESIGN.md (the per-(channel, tile) gather form read 64 cache lines per
+// load instruction).
+constexpr int kW33Rois = 8, kW33Ch = 16, kW33MaxHW = 64;
+
 __global__ __launch_bounds__(256) void wino33_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int Cin, int H,
                                                            int W, int pad_h, int pad_w, int tiles_h, int tiles_w, int T, int T_pad) {
-  const int t = blockIdx.x * 256 + threadIdx.x;          // tile index (n, ty, tx), tx fastest
-  const int ci = blockIdx.y;
-  if (t >= T_pad) return;
+  __shared__ __attribute__((aligned(16))) float sm[kW33Rois * kW33Ch * kW33MaxHW];
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * kW33Rois, c0 = blockIdx.y * kW33Ch;
+  const int HW = H * W, tpr = tiles_h * tiles_w;
+  const int nch = min(kW33Ch, Cin - c0);
+  const int run = nch * HW;                              // contiguous floats per ROI
+  // ---- stage: float4 where the run allows it (16 channels x 49 floats = 196 float4), scalars otherwise
+  for (int rl = 0; rl < kW33Rois; ++rl) {
+    const int r = r0 + rl;
+    if (r >= N) break;
+    const float* src = x + ((long)r * Cin + c0) * HW;
+    float* dst = sm + rl * (kW33Ch * HW);
+    if ((run & 3) == 0 && ((((long)r * Cin + c0) * HW) & 3) == 0) {
+      for (int i = tid; i < run / 4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+      for (int i = tid; i < run; i += 256) dst[i] = src[i];
+    }
+  }
+  __syncthreads();
+  // ---- transform: item = (channel, roi, tile) with (roi, tile) fastest
+  const int per_ch = kW33Rois * tpr;
   const long plane_stride = (long)Cin * T_pad;
-  float* dst = V + (long)ci * T_pad + t;
-  float d[5][5];
-  if (t < T) {
-    const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
-    const float* src = x + ((long)n * Cin + ci) * H * W;
+  for (int it = tid; it < nch * per_ch; it += 256) {
+    const int c = it / per_ch, q = it % per_ch;
+    const int rl = q / tpr, tl = q % tpr;
+    const int r = r0 + rl;
+    if (r >= N) continue;
+    const int ty = tl / tiles_w, tx = tl % tiles_w;
+    const float* map = sm + (rl * kW33Ch + c) * HW;
     const int h0 = 3 * ty - pad_h, w0 = 3 * tx - pad_w;
+    float d[5][5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int h = h0 + i;
@@ -222,30 +251,34 @@ __global__ __launch_bounds__(256) void wino33_input_kernel(const float* __restri
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         const int wv = w0 + j;
-        d[i][j] = (hok && wv >= 0 && wv < W) ? src[h * W + wv] : 0.f;
+        d[i][j] = (hok && wv >= 0 && wv < W) ? map[h * W + wv] : 0.f;
       }
     }
-  } else {
+    float rr[5][5];   // B^T d (columns of d)
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) {
+      const float col[5] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j]};
+      float o[5];
+      bt5(col, o);
 #pragma unroll
-      for (int j = 0; j < 5; ++j) d[i][j] = 0.f;
+      for (int i = 0; i < 5; ++i) rr[i][j] = o[i];
+    }
+    float* dst = V + (long)(c0 + c) * T_pad + (long)r * tpr + tl;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      float o[5];
+      bt5(rr[i], o);     // (B^T d) B: the same combination along the row
+#pragma unroll
+      for (int j = 0; j < 5; ++j) dst[(i * 5 + j) * plane_stride] = o[j];
+    }
   }
-  float r[5][5];   // B^T d (columns of d)
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const float col[5] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j]};
-    float o[5];
-    bt5(col, o);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) r[i][j] = o[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    float o[5];
-    bt5(r[i], o);     // (B^T d) B: the same combination along the row
-#pragma unroll
-    for (int j = 0; j < 5; ++j) dst[(i * 5 + j) * plane_stride] = o[j];
+  // columns T .. T_pad of every plane (GEMM padding) must be zero: the last ROI block writes them
+  if (blockIdx.x == gridDim.x - 1) {
+    for (int i = tid; i < nch * (T_pad - T); i += 256) {
+      const int c = i / (T_pad - T), t = T + i % (T_pad - T);
+#pragma unroll 1
+      for (int pl = 0; pl < 25; ++pl) V[pl * plane_stride + (long)(c0 + c) * T_pad + t] = 0.f;
+    }
   }
 }
 
@@ -306,8 +339,11 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
                          int tiles_w, int T_pad, hipStream_t st) {
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T_pad, 256), Cin);
-  if (m == 3) wino33_input_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
-  else wino_input_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
+  if (m == 3) {
+    MSCNN_REQUIRE(H * W <= kW33MaxHW, "winograd F(3x3,3x3): maps of at most 64 pixels");
+    dim3 g3(cdiv(N, kW33Rois), cdiv(Cin, kW33Ch));
+    wino33_input_kernel<<<g3, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
+  } else wino_input_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }
