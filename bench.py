@@ -13,7 +13,7 @@ gathered with one RCCL all_gather of a fixed-size padded buffer.
 
 Rank 0 prints ONE JSON line.  `roofline` = the conv3_1..conv5_3 block (60 % of the trunk FLOPs; BASELINE.json's north
 star names it) timed per layer with HIP events on the stream the net launches on.  `achieved` counts ALGORITHMIC FLOPs (the
-reference's direct convolution: 2*MACs); conv3_2..conv5_3 run the Winograd F(2x2,3x3) path, which executes 2.25x fewer
+reference's direct convolution: 2*MACs); conv3_1..conv5_3 run the Winograd F(3x3,3x3) path, which executes 3.24x fewer
 multiplies, so `frac` can exceed 1 -- `executed_tflops` / `executed_frac` give what the MFMA pipe really does.
 `cpu_baseline` = oracle/_ref (the reference's own CPU layers) when built, else the CPU oracle, on a bounded sample of the
 same workload on this box's host cores.
@@ -170,7 +170,10 @@ def main():
         blk_flops, blk_ms = float(flops[idx].sum()), float(lay_ms[idx].sum())
         achieved = blk_flops / (blk_ms * 1e-3) / 1e12
         wino = [nm for nm in ROOFLINE_LAYERS if net.layer_kernel(net.layer_names.index(nm)).startswith("winograd")]
-        exec_flops = sum(float(flops[net.layer_names.index(nm)]) / (2.25 if nm in wino else 1.0) for nm in ROOFLINE_LAYERS)
+        def _cut(nm):       # multiplies executed per algorithmic multiply: F(3x3,3x3) 25/81, F(2x2,3x3) 16/36
+            k = net.layer_kernel(net.layer_names.index(nm))
+            return 3.24 if k.startswith("winograd_f3x3") else 2.25 if k.startswith("winograd_f2x2") else 1.0
+        exec_flops = sum(float(flops[net.layer_names.index(nm)]) / _cut(nm) for nm in ROOFLINE_LAYERS)
         executed = exec_flops / (blk_ms * 1e-3) / 1e12
         conv_idx = [i for i, t in enumerate(net.layer_types) if t == "Convolution"]
         trunk_tf = float(flops[conv_idx].sum()) / (float(lay_ms[conv_idx].sum()) * 1e-3) / 1e12
@@ -187,11 +190,11 @@ def main():
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_note": "fabric-side bytes (incl. Infinity-Cache hits) of one conv4_2 layer (Winograd: transforms + GEMM + fix-up), "
                                     "profiles/r01_traffic_conv4_2_v4.json; algorithmic 80 MB -- the Winograd planes V, M account for 570 MB",
-                    "kernel": "conv3_1..conv5_3: igemm_kernel<128x128,k3x3> (direct) on " + ",".join(n for n in ROOFLINE_LAYERS if n not in wino)
-                              + "; Winograd F(2x2,3x3) = wino_input_kernel + igemm_kernel<128x128,k1x1,ck64> (16 batched GEMMs, + stream-K fix-up)"
-                                " + wino_output_kernel on " + ",".join(wino),
-                    "flops_note": "achieved = algorithmic (direct-convolution) FLOPs / time; the Winograd layers execute 2.25x fewer, "
-                                  "see executed_tflops",
+                    "kernel": "conv3_1..conv5_3: " + "; ".join(f"{nm}={net.layer_kernel(net.layer_names.index(nm))}" for nm in ROOFLINE_LAYERS)
+                              + " (winograd_* = input transform + igemm_kernel<k1x1> batched GEMMs (+ stream-K fix-up) + output transform;"
+                                " others = igemm_kernel<128x128,k3x3> direct)",
+                    "flops_note": "achieved = algorithmic (direct-convolution) FLOPs / time; Winograd F(3x3,3x3) / F(2x2,3x3) layers execute "
+                                  "3.24x / 2.25x fewer multiplies, see executed_tflops",
                     "executed_tflops": round(executed, 2), "executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
                     "algorithmic_gflop_per_image": round(blk_flops / 1e9, 2), "avg_ms_per_image": round(blk_ms, 4),
                     "all_conv_tflops": round(trunk_tf, 2)}

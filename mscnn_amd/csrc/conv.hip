@@ -706,9 +706,9 @@ using namespace mscnn;
 
 static void plan_shape(mscnn_conv_plan* p);
 
-// Winograd F(2x2, 3x3) is chosen where the 2.25x cut in multiplies outweighs the extra HBM traffic of the transforms
-// (V and M are 4x the input / output and are written and read once each): GEMM FLOPs per transform byte grow with
-// Cin * Cout / (Cin + Cout).  Measured on MI355X: conv2_2 (64) 706 vs 640 us direct, conv3_1 (85) 329 vs 332, conv3_2 (128) 503 vs 614, conv4_1 (171) 250 vs 346,
+// Winograd is chosen where the cut in multiplies (2.25x for F(2x2,3x3), 3.24x for F(3x3,3x3)) outweighs the extra HBM traffic
+// of the transforms (V and M are 4x / 2.78x the input / output and are written and read once each): GEMM FLOPs per transform
+// byte grow with Cin * Cout / (Cin + Cout).  F(2x2,3x3) numbers:  Measured on MI355X: conv2_2 (64) 706 vs 640 us direct, conv3_1 (85) 329 vs 332, conv3_2 (128) 503 vs 614, conv4_1 (171) 250 vs 346,
 // conv4_2 (256) 407 vs 617 -> threshold 100.
 // MSCNN_WINOGRAD=0 disables the path, =2 forces it wherever it is legal (tests).
 static bool wino_plan(mscnn_conv_plan* p) {
@@ -721,8 +721,12 @@ static bool wino_plan(mscnn_conv_plan* p) {
   // small maps (the ROI-pooled 7x7 / 7x5 / 8x4 inputs of roi_c1): F(3x3,3x3) -- a 5x5 output is 2x2 tiles x 25 multiplies
   // instead of 225 (measured 1293 -> see DESIGN.md); larger planes: F(2x2,3x3)
   const bool roi_map = d.H <= 8 && d.W <= 8;
-  const int m = roi_map ? 3 : 2, planes = roi_map ? 25 : 16;
-  if (mode != 2 && (intensity < 100.0 || (!roi_map && d.H * d.W < 256))) return false;
+  // whole planes: F(3x3,3x3) as well (3.24x fewer multiplies, planes 2.78x the tensor instead of 4x; measured conv3_2 380 vs
+  // 481 us with F(2x2,3x3), conv4_2 304 vs 389, conv5_1 107 vs 125, and the same end-to-end error, 3e-5).
+  // MSCNN_WINOGRAD_PLANE_M=2 selects F(2x2,3x3) (which has the fused 2x2 max-pooling epilogue) for A/B runs and tests.
+  const char* m3env = std::getenv("MSCNN_WINOGRAD_PLANE_M");
+  const int m = (roi_map || !(m3env && std::atoi(m3env) == 2)) ? 3 : 2, planes = m == 3 ? 25 : 16;
+  if (mode != 2 && (intensity < (m == 3 ? 80.0 : 100.0) || (!roi_map && d.H * d.W < 256))) return false;
   if (roi_map && (mode == 3 || d.N < 8)) return false;          // MSCNN_WINOGRAD=3: F(2x2,3x3) layers only
   const int th = cdiv(p->Ho, m), tw = cdiv(p->Wo, m);
   const long T = (long)d.N * th * tw;

@@ -282,6 +282,54 @@ __global__ __launch_bounds__(256) void wino33_input_kernel(const float* __restri
   }
 }
 
+// F(3x3,3x3) input transform for whole image planes (one thread per (channel, tile), tiles fastest), as wino_input_kernel.
+__global__ __launch_bounds__(256) void wino33_input_plane_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int Cin,
+                                                                 int H, int W, int pad_h, int pad_w, int tiles_h, int tiles_w,
+                                                                 int T, int T_pad) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int ci = blockIdx.y;
+  if (t >= T_pad) return;
+  const long plane_stride = (long)Cin * T_pad;
+  float* dst = V + (long)ci * T_pad + t;
+  float d[5][5];
+  if (t < T) {
+    const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
+    const float* src = x + ((long)n * Cin + ci) * H * W;
+    const int h0 = 3 * ty - pad_h, w0 = 3 * tx - pad_w;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int h = h0 + i;
+      const bool hok = h >= 0 && h < H;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int wv = w0 + j;
+        d[i][j] = (hok && wv >= 0 && wv < W) ? src[h * W + wv] : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) d[i][j] = 0.f;
+  }
+  float r[5][5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float col[5] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j]};
+    float o[5];
+    bt5(col, o);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r[i][j] = o[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    float o[5];
+    bt5(r[i], o);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dst[(i * 5 + j) * plane_stride] = o[j];
+  }
+}
+
 __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                             float* __restrict__ y, int N, int Cout, int Ho, int Wo, int tiles_h,
                                                             int tiles_w, int T, int T_pad, int relu) {
@@ -339,10 +387,11 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
                          int tiles_w, int T_pad, hipStream_t st) {
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T_pad, 256), Cin);
-  if (m == 3) {
-    MSCNN_REQUIRE(H * W <= kW33MaxHW, "winograd F(3x3,3x3): maps of at most 64 pixels");
+  if (m == 3 && H * W <= kW33MaxHW) {
     dim3 g3(cdiv(N, kW33Rois), cdiv(Cin, kW33Ch));
     wino33_input_kernel<<<g3, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
+  } else if (m == 3) {
+    wino33_input_plane_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
   } else wino_input_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;

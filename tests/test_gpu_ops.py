@@ -133,17 +133,20 @@ WINO_CASES = [   # N, Cin, H, W, Cout, pad
 
 @pytest.mark.parametrize("case", WINO_CASES)
 @pytest.mark.parametrize("relu", [False, True])
-def test_conv_winograd(hip, orc, case, relu, monkeypatch):
-    """Winograd F(2x2,3x3) path (input transform -> 16 batched 1x1 igemm GEMMs -> output transform) against the oracle's
-    direct convolution: same 1e-4 bound as every other fp32 layer."""
+@pytest.mark.parametrize("m", [2, 3])
+def test_conv_winograd(hip, orc, case, relu, m, monkeypatch):
+    """Winograd paths on whole planes -- F(2x2,3x3) (16 planes) and F(3x3,3x3) (25 planes, the default): input transform ->
+    batched 1x1 igemm GEMMs -> output transform, against the oracle's direct convolution: same 1e-4 bound as every other fp32
+    layer."""
     N, Cin, H, W, Cout, pad = case
     monkeypatch.setenv("MSCNN_WINOGRAD", "2")
+    monkeypatch.setenv("MSCNN_WINOGRAD_PLANE_M", str(m))
     rng = np.random.default_rng(4242)
     x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
     plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), relu=relu)
-    assert plan.kernel.startswith("winograd_f2x2_3x3")
+    assert plan.kernel == f"winograd_f{m}x{m}_3x3"
     plan.pack(dev(w))
     y = plan.forward(dev(x), dev(b)).cpu().numpy()
     ref = orc.conv2d(x, w, b, (pad, pad))
@@ -199,6 +202,7 @@ def test_conv_fused_pool(hip, orc, case, monkeypatch):
     bit-identical to the stand-alone pooling kernel on y, and equal to the oracle's pooling of y."""
     N, Cin, H, W, Cout, wino = case
     monkeypatch.setenv("MSCNN_WINOGRAD", str(wino))
+    monkeypatch.setenv("MSCNN_WINOGRAD_PLANE_M", "2")          # the pooling epilogue belongs to the F(2x2,3x3) output transform
     rng = np.random.default_rng(77)
     x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
@@ -215,6 +219,10 @@ def test_conv_fused_pool(hip, orc, case, monkeypatch):
     assert np.array_equal(yp.cpu().numpy(), orc.pool2d(y0.cpu().numpy(), (2, 2), (0, 0), (2, 2), "MAX"))
     close(y0.cpu().numpy(), orc.relu(orc.conv2d(x, w, b, (1, 1))))
     assert not hip.ConvPlan(1, 512, 72, 240, 9, 5, 5, (2, 2)).can_pool       # proposal-head kernel: no pooling epilogue
+    monkeypatch.delenv("MSCNN_WINOGRAD_PLANE_M")
+    monkeypatch.setenv("MSCNN_WINOGRAD", "1")
+    p3 = hip.ConvPlan(1, 512, 72, 240, 512, 3, 3, (1, 1))
+    assert p3.kernel == "winograd_f3x3_3x3" and not p3.can_pool                # default plane path: callers pool separately
 
 
 def test_conv_no_bias_and_kernel_selection(hip, orc):
