@@ -781,9 +781,9 @@ static void plan_shape(mscnn_conv_plan* p) {
     if (k.KH == 1 && k.KW == 1) {
       const bool rows128 = d.W == 128 && d.pad_h == 0 && d.pad_w == 0;        // Winograd GEMM operand planes
       const char* e1 = std::getenv("MSCNN_GEMM1X1_VARIANT");                  // tuning knob: 0 generic, 101 / 102 vectorised
-      // measured (Winograd GEMMs of mscnn-7s-576): 128x256 tiles win on the large planes (conv3: 135 rows -17 us, conv4: 34
-      // rows -8 us), 128x128 / CK 64 on the small ones (conv5: 9 rows, conv6: 3 rows)
-      const int want1 = !rows128 ? 0 : (e1 ? std::atoi(e1) : (d.H >= 32 ? 103 : 102));
+      // measured on the F(3x3,3x3) GEMMs of mscnn-7s-576 (25 planes; conv3_2 / conv4_2 / conv5_1, us per layer, G = 512):
+      // 128x128 CK 32 (101): 362 / 292 / 100;  128x128 CK 64 (102): 377 / 307 / 107;  128x256 CK 32 (103): 381 / 324 / 105
+      const int want1 = !rows128 ? 0 : (e1 ? std::atoi(e1) : 101);
       if (k.variant != want1) continue;
     }
     double cost;
@@ -814,7 +814,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   const long tiles = (long)p->MT * p->NT;
   // grid: G workgroups (default 2 per CU; 3 for the 128x128 tiles whose 43 KB of LDS and 168 VGPRs allow it)
   const char* genv = std::getenv("MSCNN_SK_WGS");            // tuning knob
-  long G = genv ? std::atol(genv) : ((k.BM == 128 && k.BN == 128 && k.CK < 64) ? 768 : 512);   // CK = 64: 64 KB of LDS, 2 per CU
+  long G = genv ? std::atol(genv) : ((k.BM == 128 && k.BN == 128 && k.KH == 3) ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
   if (tiles * p->KI / 4 < G) G = tiles * p->KI / 4;         // never less than ~4 chunks per workgroup
   if (G < 1) G = 1;
   p->G = (int)G;
