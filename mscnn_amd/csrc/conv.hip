@@ -723,10 +723,11 @@ static bool wino_plan(mscnn_conv_plan* p) {
   const bool roi_map = d.H <= 8 && d.W <= 8;
   // whole planes: F(3x3,3x3) as well (3.24x fewer multiplies, planes 2.78x the tensor instead of 4x; measured conv3_2 380 vs
   // 481 us with F(2x2,3x3), conv4_2 304 vs 389, conv5_1 107 vs 125, and the same end-to-end error, 3e-5).
-  // MSCNN_WINOGRAD_PLANE_M=2 selects F(2x2,3x3) (which has the fused 2x2 max-pooling epilogue) for A/B runs and tests.
+  // Threshold for F(3x3,3x3): conv2_2 (intensity 64) 523 vs 642 us direct, conv2_1 (43) 375 vs 383 (tie -> direct), conv1_2
+  // (32) 1175 vs 762.  MSCNN_WINOGRAD_PLANE_M=2 selects F(2x2,3x3) for A/B runs and tests.
   const char* m3env = std::getenv("MSCNN_WINOGRAD_PLANE_M");
   const int m = (roi_map || !(m3env && std::atoi(m3env) == 2)) ? 3 : 2, planes = m == 3 ? 25 : 16;
-  if (mode != 2 && (intensity < (m == 3 ? 80.0 : 100.0) || (!roi_map && d.H * d.W < 256))) return false;
+  if (mode != 2 && (intensity < (m == 3 ? 60.0 : 100.0) || (!roi_map && d.H * d.W < 256))) return false;
   if (roi_map && (mode == 3 || d.N < 8)) return false;          // MSCNN_WINOGRAD=3: F(2x2,3x3) layers only
   const int th = cdiv(p->Ho, m), tw = cdiv(p->Wo, m);
   const long T = (long)d.N * th * tw;
@@ -929,7 +930,7 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
 
 extern "C" int mscnn_conv2d_plan_can_pool(const mscnn_conv_plan* p) {
   if (!p || p->head.entry >= 0) return 0;
-  if (p->wino) return p->wino_m == 2;
+  if (p->wino) return p->wino_m == 2 || (p->tiles_h % 2 == 0 && p->tiles_w % 2 == 0 && p->d.H > 8);
   return p->entry >= 0 && kTable[p->entry].fix_pool_fn != nullptr;
 }
 

@@ -369,6 +369,91 @@ __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restr
   }
 }
 
+
+// F(3x3,3x3) output transform with the fused MAX 2x2 / stride 2 pooling: 3x3 tiles and 2x2 windows meet every 6 pixels, so a
+// thread owns a 2x2 group of tiles (= 6x6 outputs = 3x3 pooling windows).  Tiles t and t+1 are neighbours in a plane, so the
+// 25 x 2 M reads per tile row are float2 loads; the six output rows are written as three float2 each.  Needs an even number
+// of tile rows and columns (true for every pooled layer of the deploy nets at their native input sizes).
+__device__ __forceinline__ void at5(const float m[5], float o[3]) {
+  o[0] = m[0] + m[1] + m[2] + m[3];
+  o[1] = m[1] - m[2] + 2.f * m[3];
+  o[2] = m[1] + m[2] + 4.f * m[3] + m[4];
+}
+
+__global__ __launch_bounds__(256) void wino33_output_pool_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, float* __restrict__ yp, int N, int Cout,
+                                                                 int Ho, int Wo, int tiles_h, int tiles_w, int T_pad, int relu) {
+  const int sw = tiles_w / 2, sh = tiles_h / 2;
+  const int S = N * sh * sw;
+  const int sidx = blockIdx.x * 256 + threadIdx.x;
+  const int co = blockIdx.y;
+  if (sidx >= S) return;
+  const int sx = sidx % sw, sy = (sidx / sw) % sh, n = sidx / (sw * sh);
+  const long plane_stride = (long)Cout * T_pad;
+  const float b = bias ? bias[co] : 0.f;
+  float out[6][6];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {                  // upper / lower pair of tiles
+    const long t0 = ((long)n * tiles_h + 2 * sy + half) * tiles_w + 2 * sx;
+    const float* src = M + (long)co * T_pad + t0;
+    float ra[3][5], rb[3][5];                             // A^T m of the left / right tile
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float ca[5], cb[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const float2 v = *reinterpret_cast<const float2*>(src + (i * 5 + j) * plane_stride);
+        ca[i] = v.x; cb[i] = v.y;
+      }
+      float oa[3], ob[3];
+      at5(ca, oa); at5(cb, ob);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { ra[i][j] = oa[i]; rb[i][j] = ob[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float oa[3], ob[3];
+      at5(ra[i], oa); at5(rb[i], ob);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { out[half * 3 + i][j] = oa[j] + b; out[half * 3 + i][3 + j] = ob[j] + b; }
+    }
+  }
+  float* dst = y + ((long)n * Cout + co) * Ho * Wo;
+  const int oh0 = 6 * sy, ow0 = 6 * sx;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float v = out[i][j];
+      if (relu) v = v > 0.f ? v : 0.f;
+      out[i][j] = (oh0 + i < Ho && ow0 + j < Wo) ? v : -3.402823466e+38f;
+    }
+    const int oh = oh0 + i;
+    if (oh >= Ho) continue;
+    if ((Wo & 1) == 0 && ow0 + 5 < Wo) {
+#pragma unroll
+      for (int j = 0; j < 6; j += 2) *reinterpret_cast<float2*>(dst + oh * Wo + ow0 + j) = make_float2(out[i][j], out[i][j + 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) if (ow0 + j < Wo) dst[oh * Wo + ow0 + j] = out[i][j];
+    }
+  }
+  const int Hp = (Ho + 1) / 2, Wp = (Wo + 1) / 2;
+  float* pd = yp + ((long)n * Cout + co) * Hp * Wp;
+#pragma unroll
+  for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+    for (int pj = 0; pj < 3; ++pj) {
+      const int ph = 3 * sy + pi, pw = 3 * sx + pj;
+      if (ph >= Hp || pw >= Wp) continue;
+      float m = out[2 * pi][2 * pj];
+      if (out[2 * pi][2 * pj + 1] > m) m = out[2 * pi][2 * pj + 1];
+      if (out[2 * pi + 1][2 * pj] > m) m = out[2 * pi + 1][2 * pj];
+      if (out[2 * pi + 1][2 * pj + 1] > m) m = out[2 * pi + 1][2 * pj + 1];
+      pd[ph * Wp + pw] = m;
+    }
+}
+
 }  // namespace
 
 namespace mscnn {
@@ -401,8 +486,11 @@ int wino_output_transform(int m, const float* M, const float* bias, float* y, fl
                           int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st) {
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T, 256), Cout);
-  if (m == 3) {
-    MSCNN_REQUIRE(!y_pool, "winograd F(3x3,3x3): no fused pooling");
+  if (m == 3 && y_pool) {
+    MSCNN_REQUIRE(tiles_h % 2 == 0 && tiles_w % 2 == 0, "winograd F(3x3,3x3): fused pooling needs even tile counts");
+    dim3 gp(cdiv((long)N * (tiles_h / 2) * (tiles_w / 2), 256), Cout);
+    wino33_output_pool_kernel<<<gp, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T_pad, relu);
+  } else if (m == 3) {
     wino33_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu);
   } else {
     wino_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu);

@@ -186,7 +186,9 @@ def test_conv_winograd_f3x3(hip, orc, case, monkeypatch):
     close(plan.forward(dev(x2), dev(b)).cpu().numpy(), np.concatenate([ref, ref[:7]], 0))
 
 
-POOL_CASES = [   # N, Cin, H, W, Cout, winograd
+POOL_CASES = [   # N, Cin, H, W, Cout, winograd (0: direct igemm, 2: F(2x2,3x3), 3: F(3x3,3x3))
+    (1, 40, 12, 24, 130, 3),      # F(3x3,3x3): 4 x 8 tiles -> 2 x 4 groups of 6x6 outputs
+    (2, 24, 18, 36, 32, 3),       # F(3x3,3x3), batch 2
     (1, 16, 16, 32, 128, 0),      # igemm 128x128 tw16: exact tiles
     (1, 8, 13, 37, 64, 0),        # igemm 64x256 tw32: odd H and W (clipped ceil-mode windows at the edges)
     (2, 24, 36, 120, 256, 0),     # conv5-shaped plane: stream-K split tiles go through the pooled fix-up kernel
@@ -201,14 +203,15 @@ def test_conv_fused_pool(hip, orc, case, monkeypatch):
     """Conv + ReLU with the following MAX 2x2/2 PoolingLayer fused into the epilogue: y unchanged, pooled output
     bit-identical to the stand-alone pooling kernel on y, and equal to the oracle's pooling of y."""
     N, Cin, H, W, Cout, wino = case
-    monkeypatch.setenv("MSCNN_WINOGRAD", str(wino))
-    monkeypatch.setenv("MSCNN_WINOGRAD_PLANE_M", "2")          # the pooling epilogue belongs to the F(2x2,3x3) output transform
+    monkeypatch.setenv("MSCNN_WINOGRAD", "2" if wino else "0")
+    monkeypatch.setenv("MSCNN_WINOGRAD_PLANE_M", "2" if wino == 2 else "3")
     rng = np.random.default_rng(77)
     x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
     plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True)
-    assert plan.can_pool and plan.kernel.startswith("winograd") == (wino == 2)
+    assert plan.can_pool and plan.kernel == {0: plan.kernel, 2: "winograd_f2x2_3x3", 3: "winograd_f3x3_3x3"}[wino]
+    assert plan.kernel.startswith("winograd") == (wino != 0)
     plan.pack(dev(w))
     y0 = plan.forward(dev(x), dev(b)).clone()
     yp = torch.full((N, Cout, (H + 1) // 2, (W + 1) // 2), float("nan"), device="cuda")
@@ -222,7 +225,8 @@ def test_conv_fused_pool(hip, orc, case, monkeypatch):
     monkeypatch.delenv("MSCNN_WINOGRAD_PLANE_M")
     monkeypatch.setenv("MSCNN_WINOGRAD", "1")
     p3 = hip.ConvPlan(1, 512, 72, 240, 512, 3, 3, (1, 1))
-    assert p3.kernel == "winograd_f3x3_3x3" and not p3.can_pool                # default plane path: callers pool separately
+    assert p3.kernel == "winograd_f3x3_3x3" and p3.can_pool                    # 24 x 80 tiles: even -> fused pooling
+    assert not hip.ConvPlan(1, 512, 75, 240, 512, 3, 3, (1, 1)).can_pool       # 25 tile rows: the caller pools separately
 
 
 def test_conv_no_bias_and_kernel_selection(hip, orc):
