@@ -214,7 +214,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   // XCD-aware workgroup -> range mapping: the dispatcher places workgroup b on XCD b % 8; giving XCD x the contiguous
   // ranges [x * G/8, (x+1) * G/8) keeps one M-tile's packed weights (2.4 MB for conv4) resident in that XCD's 4 MB L2
   // instead of every XCD cycling through all of them (speed only: any mapping is correct).
-  const int wg = (a.xcd_map && a.G % 8 == 0) ? (int)(blockIdx.x % 8) * (a.G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  // (XCD x holds the workgroups b == x mod 8: G/8 of them, one more for x < G % 8)
+  const int xcd = (int)(blockIdx.x % 8), gq = a.G / 8, gr = a.G % 8;
+  const int wg = a.xcd_map ? xcd * gq + min(xcd, gr) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   long it, it_end;
   wg_range(a.total_iters, a.G, wg, it, it_end);
   int full_j = 0;
@@ -818,6 +820,12 @@ static void plan_shape(mscnn_conv_plan* p) {
   long G = genv ? std::atol(genv) : ((k.BM == 128 && k.BN == 128 && k.KH == 3) ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
   if (tiles * p->KI / 4 < G) G = tiles * p->KI / 4;         // never less than ~4 chunks per workgroup
   if (G < 1) G = 1;
+  // A slightly smaller grid that divides the tile count exactly needs no stream-K phase and no fix-up launch at all (the 25
+  // plane GEMMs of conv2_2..conv4_3 have 1500 / 3000 / 6000 tiles: G = 500 instead of 512 saves the 18 us fix-up and the
+  // slab traffic for 2 % idle workgroup slots).
+  if (!genv && tiles >= 2 * G)
+    for (long g2 = G; g2 >= G - G / 16; --g2)
+      if (tiles % g2 == 0) { G = g2; break; }
   p->G = (int)G;
   p->full_q = (int)(tiles / G);                               // data-parallel phase
   p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
