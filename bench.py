@@ -183,13 +183,13 @@ def main():
                     tf = flops[i] / (lay_ms[i] * 1e-3) / 1e12 if flops[i] else 0
                     print(f"{nm:28s} {net.layer_types[i]:14s} {net.layer_kernel(i):30s} {lay_ms[i]*1e3:9.1f} us {tf:7.1f} TF", file=sys.stderr)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_conv4_2_v4.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_conv4_2_v5.json")
         if os.path.exists(tpath):      # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs), per conv4_2 launch
             traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_note": "fabric-side bytes (incl. Infinity-Cache hits) of one conv4_2 layer (Winograd: transforms + GEMM + fix-up), "
-                                    "profiles/r01_traffic_conv4_2_v4.json; algorithmic 80 MB -- the Winograd planes V, M account for 570 MB",
+                                    "profiles/r01_traffic_conv4_2_v5.json; algorithmic 80 MB -- the Winograd planes V, M account for 393 MB",
                     "kernel": "conv3_1..conv5_3: " + "; ".join(f"{nm}={net.layer_kernel(net.layer_names.index(nm))}" for nm in ROOFLINE_LAYERS)
                               + " (winograd_* = input transform + igemm_kernel<k1x1> batched GEMMs (+ stream-K fix-up) + output transform;"
                                 " others = igemm_kernel<128x128,k3x3> direct)",
