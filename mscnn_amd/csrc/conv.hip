@@ -823,9 +823,15 @@ static void plan_shape(mscnn_conv_plan* p) {
   // A slightly smaller grid that divides the tile count exactly needs no stream-K phase and no fix-up launch at all (the 25
   // plane GEMMs of conv2_2..conv4_3 have 1500 / 3000 / 6000 tiles: G = 500 instead of 512 saves the 18 us fix-up and the
   // slab traffic for 2 % idle workgroup slots).
-  if (!genv && tiles >= 2 * G)
-    for (long g2 = G; g2 >= G - G / 16; --g2)
-      if (tiles % g2 == 0) { G = g2; break; }
+  if (!genv && tiles >= 2 * G) {
+    // the 1x1 GEMM kernel (32 KB LDS, 166 VGPRs) also fits 3 per CU: try that range first (measured G = 750 vs 500 on the
+    // 25-plane GEMMs: conv4_2 259 vs 266 us, conv3_2 332 vs 339, conv2_2 496 vs 510)
+    const long tops[2] = {(k.KH == 1 && k.BN == 128 && k.CK < 64) ? 768 : G, G};
+    bool found = false;
+    for (int c = 0; c < 2 && !found; ++c)
+      for (long g2 = tops[c]; g2 >= tops[c] - tops[c] / 16 && g2 * 2 <= tiles; --g2)
+        if (tiles % g2 == 0) { G = g2; found = true; break; }
+  }
   p->G = (int)G;
   p->full_q = (int)(tiles / G);                               // data-parallel phase
   p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
