@@ -206,6 +206,17 @@ MSCNN_API int mscnn_detections_fwd(const mscnn_detections_desc* desc, const floa
                          const float* props, int R, double* dets_out, int* ids_out, int* count_out_dev,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Image pre-processing in front of net.forward -- MATLAB `run_mscnn_detection.m:64-69`:
+ * imresize(uint8 image, [H W]) (bicubic, uint8 after each 1-D pass), RGB -> BGR, single, subtract the
+ * per-channel mean, hand to the net as its (1,3,H,W) input blob.
+ * img_rgb: device uint8 [org_h][org_w][3] (row-major HWC, as any image decoder delivers it);
+ * out: device float [3][H][W] (planes B, G, R); mean_bgr: host float[3] ({104,117,123} in the reference).
+ * ------------------------------------------------------------------------------------------ */
+MSCNN_API size_t mscnn_preprocess_workspace_bytes(int org_h, int org_w, int H, int W);
+MSCNN_API int mscnn_preprocess_u8_f32(const unsigned char* img_rgb, int org_h, int org_w, float* out, int H, int W,
+                            const float* mean_bgr, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

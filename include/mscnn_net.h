@@ -68,6 +68,11 @@ MSCNN_NET_API int mscnn_net_get_param(mscnn_net* net, int layer, int param, floa
 /* blob.set_data / get_data.  *_device copy device->device on the net's stream (no PCIe). */
 MSCNN_NET_API int mscnn_net_set_blob(mscnn_net* net, const char* name, const float* host, size_t count);
 MSCNN_NET_API int mscnn_net_set_blob_device(mscnn_net* net, const char* name, const float* dev, size_t count);
+/* The MATLAB pre-processing in front of net.forward (run_mscnn_detection.m:64-69), on the device: a decoded uint8 RGB frame
+ * [org_h][org_w][3] (host memory, or device memory when on_device != 0) is resized to the input blob's H x W (imresize
+ * semantics), swapped to BGR, mean-subtracted (mean_bgr == NULL: {104,117,123}) and written into blob `name`. */
+MSCNN_NET_API int mscnn_net_set_image(mscnn_net* net, const char* name, const unsigned char* img_rgb, int on_device,
+                                      int org_h, int org_w, const float* mean_bgr);
 MSCNN_NET_API int mscnn_net_get_blob(mscnn_net* net, const char* name, float* host, size_t capacity, size_t* count);
 MSCNN_NET_API const float* mscnn_net_blob_device_ptr(mscnn_net* net, const char* name);
 

@@ -336,6 +336,23 @@ class BoxOutput:
         return self.rois[:R], self.props[:R], self.aids[:R], nreal
 
 
+def preprocess(img_rgb_u8, out_h, out_w, mean_bgr=(104.0, 117.0, 123.0), out=None):
+    """run_mscnn_detection.m:64-69 on the device: uint8 HWC RGB image (cuda tensor) -> the net's (1, 3, out_h, out_w) input."""
+    oh, ow, ch = img_rgb_u8.shape
+    if ch != 3 or img_rgb_u8.dtype != torch.uint8:
+        raise MscnnError("preprocess: expected a uint8 [H, W, 3] image")
+    if out is None:
+        out = torch.empty((1, 3, out_h, out_w), dtype=torch.float32, device=img_rgb_u8.device)
+    L = lib()
+    L.mscnn_preprocess_workspace_bytes.restype = C.c_size_t
+    wb = L.mscnn_preprocess_workspace_bytes(oh, ow, out_h, out_w)
+    ws = torch.empty(wb, dtype=torch.uint8, device=img_rgb_u8.device)
+    m = (C.c_float * 3)(*mean_bgr)
+    _check(L.mscnn_preprocess_u8_f32(_dev(img_rgb_u8), oh, ow, _dev(out), out_h, out_w, m, _dev(ws), C.c_size_t(wb), _stream()))
+    torch.cuda.current_stream().synchronize()     # ws dies with this frame
+    return out
+
+
 def nms_greedy(boxes_xywh, thr, mode="IOU"):
     n = boxes_xywh.shape[0]
     keep = torch.zeros(max(n, 1), dtype=torch.uint8, device=boxes_xywh.device)

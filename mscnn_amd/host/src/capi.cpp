@@ -17,6 +17,7 @@ struct mscnn_net {
   std::unique_ptr<Net<float> > net;
   int device;
   caffe::DeviceBuffer det_ws, det_out, det_ids, det_cnt;
+  caffe::DeviceBuffer img_in, img_ws;      // set_image: the uint8 frame and the resize scratch
 };
 
 namespace {
@@ -154,6 +155,28 @@ int mscnn_net_set_blob_device(mscnn_net* n, const char* name, const float* dev, 
     auto b = n->net->blob_by_name(name);
     CHECK_EQ((size_t)b->count(), count) << "blob " << name << " has shape " << b->shape_string();
     HIP_CHECK(hipMemcpyAsync(b->mutable_gpu_data(), dev, sizeof(float) * count, hipMemcpyDeviceToDevice, (hipStream_t)Caffe::stream()));
+  });
+}
+int mscnn_net_set_image(mscnn_net* n, const char* name, const unsigned char* img_rgb, int on_device, int org_h, int org_w,
+                        const float* mean_bgr) {
+  return guarded([&] {
+    CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
+    auto b = n->net->blob_by_name(name);
+    CHECK(b->num() == 1 && b->channels() == 3) << "set_image: blob " << name << " has shape " << b->shape_string();
+    hipStream_t st = (hipStream_t)Caffe::stream();
+    const unsigned char* dev_img = img_rgb;
+    if (!on_device) {
+      const size_t bytes = (size_t)org_h * org_w * 3;
+      void* d = n->img_in.Reserve(bytes);
+      HIP_CHECK(hipMemcpyAsync(d, img_rgb, bytes, hipMemcpyHostToDevice, st));
+      dev_img = static_cast<const unsigned char*>(d);
+    }
+    const size_t wb = mscnn_preprocess_workspace_bytes(org_h, org_w, b->height(), b->width());
+    void* ws = n->img_ws.Reserve(wb);
+    static const float kMean[3] = {104.f, 117.f, 123.f};      // run_mscnn_detection.m:38
+    const int rc = mscnn_preprocess_u8_f32(dev_img, org_h, org_w, b->mutable_gpu_data(), b->height(), b->width(),
+                                           mean_bgr ? mean_bgr : kMean, ws, wb, st);
+    CHECK_EQ(rc, 0) << mscnn_last_error();
   });
 }
 int mscnn_net_get_blob(mscnn_net* n, const char* name, float* host, size_t capacity, size_t* count) {

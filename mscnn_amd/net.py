@@ -48,6 +48,7 @@ def lib():
             "mscnn_net_num_inputs": [vp], "mscnn_net_num_outputs": [vp], "mscnn_net_output_name": [vp, ci],
             "mscnn_net_set_param": [vp, ci, ci, vp, C.c_size_t], "mscnn_net_get_param": [vp, ci, ci, vp, C.c_size_t],
             "mscnn_net_set_blob": [vp, cs, vp, C.c_size_t], "mscnn_net_set_blob_device": [vp, cs, vp, C.c_size_t],
+            "mscnn_net_set_image": [vp, cs, vp, ci, ci, ci, vp],
             "mscnn_net_get_blob": [vp, cs, vp, C.c_size_t, vp], "mscnn_net_blob_device_ptr": [vp, cs],
             "mscnn_net_forward": [vp], "mscnn_net_forward_from_to": [vp, ci, ci], "mscnn_net_reshape": [vp],
             "mscnn_net_set_layer_timing": [vp, ci], "mscnn_net_layer_ms": [vp, ci],
@@ -144,6 +145,18 @@ class Net:
             return
         a = np.ascontiguousarray(arr, np.float32)
         _check(lib().mscnn_net_set_blob(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+
+    def set_image(self, name, img_rgb_u8, mean_bgr=None):
+        """uint8 [H, W, 3] RGB frame (numpy array or torch CUDA tensor) -> resized / BGR / mean-subtracted input blob."""
+        m = (C.c_float * 3)(*mean_bgr) if mean_bgr is not None else None
+        if hasattr(img_rgb_u8, "is_cuda"):
+            assert img_rgb_u8.is_cuda and img_rgb_u8.is_contiguous() and str(img_rgb_u8.dtype) == "torch.uint8"
+            h, w, _ = img_rgb_u8.shape
+            _check(lib().mscnn_net_set_image(self._h, name.encode(), C.c_void_p(img_rgb_u8.data_ptr()), 1, h, w, m))
+            return
+        a = np.ascontiguousarray(img_rgb_u8, np.uint8)
+        h, w, _ = a.shape
+        _check(lib().mscnn_net_set_image(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), 0, h, w, m))
 
     def get_blob(self, name):
         a = np.empty(self.blob_shape(name), np.float32)

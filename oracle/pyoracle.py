@@ -245,3 +245,68 @@ def detections(bbox_pred, cls_pred, props, cls_id, bbox_mean=(0, 0, 0, 0), bbox_
 
 def concat_channels(xs):
     return np.concatenate([np.asarray(x, np.float32) for x in xs], axis=1)
+
+
+# ---------------------------------------------------------------------------------------------- pre-processing
+# The step in front of net.forward in the reference's MATLAB driver (examples/kitti_car/run_mscnn_detection.m:64-69):
+#     test_image = imresize(test_image,[imgH imgW]);  single(test_image(:,:,[3 2 1]));  minus mu;  permute [2 1 3]
+# PARITY UNPINNED: MATLAB is not available here; `imresize` is restated from its published algorithm (imresize.m,
+# `contributions`): bicubic kernel (a = -0.5), kernel stretched by 1/scale when shrinking (antialiasing), output pixel
+# centre u = x/scale + 0.5 (1 - 1/scale), P = ceil(kernel_width) + 2 taps starting at floor(u - kernel_width/2), weights
+# normalised to sum 1, symmetric mirroring at the borders, the dimension with the smaller scale factor first, and -- for
+# an integer-class image -- rounding and saturation to uint8 after EACH 1-D pass.
+def _cubic(x):
+    ax = np.abs(x)
+    ax2 = ax * ax
+    ax3 = ax2 * ax
+    return np.where(ax <= 1.0, (1.5 * ax3 - 2.5 * ax2) + 1.0,
+                    np.where(ax <= 2.0, ((-0.5 * ax3 + 2.5 * ax2) - 4.0 * ax) + 2.0, 0.0))
+
+
+def imresize_contributions(in_len, out_len):
+    """weights [out_len, P] (float64), indices [out_len, P] (0-based, mirrored) of MATLAB's 1-D bicubic resize."""
+    scale = np.float64(out_len) / np.float64(in_len)
+    kw = 4.0 / scale if scale < 1.0 else 4.0
+    x = np.arange(1, out_len + 1, dtype=np.float64)
+    u = x / scale + 0.5 * (1.0 - 1.0 / scale)
+    left = np.floor(u - kw / 2.0)
+    P = int(np.ceil(kw)) + 2
+    idx = left[:, None] + np.arange(P, dtype=np.float64)[None, :]          # 1-based, may be outside [1, in_len]
+    d = u[:, None] - idx
+    w = scale * _cubic(scale * d) if scale < 1.0 else _cubic(d)
+    s = np.zeros(out_len, np.float64)
+    for k in range(P):                                                     # fixed summation order (the device does the same)
+        s = s + w[:, k]
+    w = w / s[:, None]
+    period = 2 * in_len
+    m = np.mod(idx.astype(np.int64) - 1, period)                           # aux = [1..n, n..1]
+    idx0 = np.where(m < in_len, m, period - 1 - m)
+    return w, idx0
+
+
+def _resize_u8_along(img, axis, out_len):
+    w, idx = imresize_contributions(img.shape[axis], out_len)
+    a = np.moveaxis(img, axis, 0).astype(np.float64)
+    acc = np.zeros((out_len,) + a.shape[1:], np.float64)
+    for k in range(w.shape[1]):
+        acc = acc + w[:, k].reshape((-1,) + (1,) * (a.ndim - 1)) * a[idx[:, k]]
+    out = np.clip(np.floor(acc + 0.5), 0, 255).astype(np.uint8)            # MATLAB double -> uint8: round, saturate
+    return np.moveaxis(out, 0, axis)
+
+
+def imresize_u8(img, out_h, out_w):
+    """MATLAB imresize(uint8 HxWxC, [out_h out_w]) restated (bicubic, antialiasing when shrinking)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    sh, sw = out_h / img.shape[0], out_w / img.shape[1]
+    order = (0, 1) if sh <= sw else (1, 0)                                 # [~, order] = sort(scale): smaller scale first
+    for ax in order:
+        img = _resize_u8_along(img, ax, out_h if ax == 0 else out_w)
+    return img
+
+
+def preprocess(img_rgb_u8, out_h, out_w, mean_bgr=(104.0, 117.0, 123.0)):
+    """run_mscnn_detection.m:64-69: resize, RGB -> BGR, single, subtract the per-channel mean; returned as the net's
+    input blob (1, 3, out_h, out_w) (the MATLAB permute [2 1 3] is matcaffe's column-major view of the same memory)."""
+    r = imresize_u8(img_rgb_u8, out_h, out_w)
+    bgr = r[:, :, ::-1].astype(np.float32) - np.asarray(mean_bgr, np.float32).reshape(1, 1, 3)
+    return np.ascontiguousarray(bgr.transpose(2, 0, 1)[None])

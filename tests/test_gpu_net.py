@@ -206,3 +206,17 @@ def test_cascade_style_net():
     # and the trunk end to end
     ref = pynet.forward(layers[:names.index("proposals")], ws, {"data": x})
     assert rel_err(n.get_blob("LFCN_1_5x5"), ref["LFCN_1_5x5"]) < 1e-4
+
+
+def test_set_image_preprocessing():
+    """Net-level pre-processing (run_mscnn_detection.m:64-69 on the device): a 375x1242-like uint8 RGB frame -> the input blob,
+    bit-identical to the oracle's restatement, from host memory and from a device tensor."""
+    from oracle import pyoracle as orc
+    n = mnet.Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=192, width=640))
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (125, 414, 3), dtype=np.uint8)
+    ref = orc.preprocess(img, 192, 640)
+    n.set_image("data", img)
+    assert np.array_equal(n.get_blob("data"), ref)
+    n.set_image("data", torch.from_numpy(img[::-1].copy()).cuda(), mean_bgr=(100.0, 110.0, 120.0))
+    assert np.array_equal(n.get_blob("data"), orc.preprocess(img[::-1].copy(), 192, 640, mean_bgr=(100.0, 110.0, 120.0)))

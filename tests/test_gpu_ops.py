@@ -461,3 +461,13 @@ def test_detections_stage(hip, orc, R):
 def test_no_cpu_fallback(hip):
     with pytest.raises(hip.MscnnError):
         hip.relu(torch.zeros(4))
+
+
+# ------------------------------------------------------------------ pre-processing (resize + BGR + mean; bit-exact vs the oracle)
+@pytest.mark.parametrize("org,out", [((375, 1242), (576, 1920)), ((370, 1224), (384, 1280)), ((96, 130), (40, 57)),
+                                     ((50, 200), (120, 210))])
+def test_preprocess_bitexact(hip, orc, org, out):
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (*org, 3), dtype=np.uint8)
+    y = hip.preprocess(torch.from_numpy(img).cuda(), out[0], out[1]).cpu().numpy()
+    assert np.array_equal(y, orc.preprocess(img, out[0], out[1]))

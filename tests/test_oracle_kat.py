@@ -289,3 +289,31 @@ def test_detections_stage(orc):
     far = props.copy(); far[1, 1:5] = [1200, 300, 1300, 380]
     dets, ids = orc.detections(bbox_pred, cls_pred, far, cls_id=2, ratios=(1.0, 1.0), org_hw=(576, 1920))
     assert ids.tolist() == [0, 1, 4]
+
+
+# ---------------------------------------------------------------------------------------------- pre-processing (8f rank 3)
+def test_imresize_contributions_hand_computed(orc):
+    """MATLAB imresize `contributions` for a 2 -> 4 bicubic upsample: u = x/2 + 0.25, taps floor(u - 2) + 0..5, cubic kernel
+    a = -0.5 evaluated by hand (all values are dyadic, exact in binary), symmetric border mirroring aux = [1 2 2 1]."""
+    w, idx = orc.imresize_contributions(2, 4)
+    c175, c075, c025, c125 = -0.0234375, 0.2265625, 0.8671875, -0.0703125
+    assert np.array_equal(w[0], [0.0, c175, c075, c025, c125, 0.0])          # u = 0.75
+    assert np.array_equal(w[1], [0.0, c125, c025, c075, c175, 0.0])          # u = 1.25
+    assert np.array_equal(idx[0], [1, 1, 0, 0, 1, 1])                        # 1-based -2..3 mirrored into {1, 2}
+    assert np.array_equal(idx[3], [0, 0, 1, 1, 0, 0])
+
+
+def test_preprocess_properties(orc):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 124, 3), dtype=np.uint8)
+    assert np.array_equal(orc.imresize_u8(img, 37, 124), img)                # scale 1: every weight row is [.. 0 1 0 ..]
+    flat = np.full((20, 30, 3), 77, np.uint8)
+    assert np.all(orc.imresize_u8(flat, 31, 47) == 77) and np.all(orc.imresize_u8(flat, 9, 11) == 77)   # weights sum to 1
+    up = orc.imresize_u8(img, 57, 191)
+    assert up.shape == (57, 191, 3) and up.dtype == np.uint8
+    down = orc.imresize_u8(img, 12, 40)                                      # antialiased (kernel stretched by 1/scale)
+    assert abs(float(down.mean()) - float(img.mean())) < 2.0
+    x = orc.preprocess(img, 57, 191, mean_bgr=(104.0, 117.0, 123.0))
+    assert x.shape == (1, 3, 57, 191) and x.dtype == np.float32
+    assert np.array_equal(x[0, 0] + 104.0, up[:, :, 2].astype(np.float32))   # plane 0 = blue
+    assert np.array_equal(x[0, 2] + 123.0, up[:, :, 0].astype(np.float32))   # plane 2 = red
