@@ -1,18 +1,22 @@
-// Winograd F(2x2, 3x3) data transforms for gfx950 (the batched GEMM between them is the 1x1 igemm kernel of conv.hip).
+// Winograd data transforms for gfx950 (the batched GEMM between them is the 1x1 igemm kernel of conv.hip).
 //
-// Used for the 3x3 / stride 1 trunk layers whose channel counts make the transforms cheap next to the multiply
-// (conv4_*, loss1_conv1, conv5_*, conv6_1 of the mscnn-7s nets): y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 output tile,
-// i.e. 16 multiplies instead of 36 per tile and channel pair -- 2.25x fewer MFMA FLOPs than the direct form that the
-// reference computes (conv_layer.cu:8-23 im2col + SGEMM).  Result differs from the direct form only by fp32 rounding
-// (different but equally short summation trees); the parity tests hold it to the same 1e-4 bound.
+// Used for the 3x3 / stride 1 layers whose channel counts make the transforms cheap next to the multiply (conv2_2 ... conv6_1
+// and roi_c1 of the mscnn-7s nets): y = A^T [ (G g G^T) . (B^T d B) ] A per m x m output tile.
+//   * F(3x3,3x3) (second half of this file) is the path the plan selects: 25 multiplies per 3x3 tile and channel pair instead
+//     of 81 -- 3.24x fewer MFMA FLOPs than the direct form that the reference computes (conv_layer.cu:8-23 im2col + SGEMM);
+//   * F(2x2,3x3) (first half: 16 multiplies instead of 36, 2.25x) was the first path and stays selectable
+//     (MSCNN_WINOGRAD_PLANE_M=2) for A/B runs and as a second witness in the tests.
+// Results differ from the direct form only by fp32 rounding (different but equally short summation trees); the parity tests
+// hold both to the same 1e-4 bound (measured: DESIGN.md 3.1b).
 //
+// F(2x2,3x3):
 //   B^T = | 1  0 -1  0 |     G = | 1    0    0  |     A^T = | 1  1  1  0 |
 //         | 0  1  1  0 |         | 1/2  1/2  1/2|           | 0  1 -1 -1 |
 //         | 0 -1  1  0 |         | 1/2 -1/2  1/2|
 //         | 0  1  0 -1 |         | 0    0    1  |
 //
-// All three kernels are HBM-bound streaming kernels: one thread per (channel, tile), tiles fastest, so every one of the 16
-// transform planes is read / written as contiguous runs.
+// All transform kernels are HBM-bound streaming kernels: one thread per (channel, tile), tiles fastest, so every transform
+// plane is read / written as contiguous runs.
 #include "winograd.h"
 
 namespace {

@@ -16,7 +16,7 @@ model = sys.argv[1] if len(sys.argv) > 1 else "kitti_car/mscnn-7s-576"
 size = dict(height=192, width=640, max_nms_num=300)
 n = mnet.Net(prototxt_text=zoo.prototxt(model, **size))
 print(f"# {model} at {size['height']}x{size['width']}, synthetic weights; error = max |gpu - oracle| / max(1, |oracle|), bound 1e-4")
-for regime in ("dense", "mid", "sparse"):
+for regime in ("mid",):
     ws = synth.load_into(n, regime)
     n.set_blob("data", synth.frame(size["height"], size["width"]))
     n.forward()
