@@ -43,7 +43,39 @@ def _layers_of(n):
             for i in range(len(n.layer_names))]
 
 
-def cpu_baseline(R_gpu, regime):
+def _full_size_parity(net, x, blobs, kw):
+    """The GPU path against the reference's own CPU layers on the SAME full-size frame and weights (the cpu_baseline run):
+    end-to-end fp32 error of trunk / head / sub-net blobs and matched final detections.  Checker only."""
+    from oracle import pyoracle as orc
+
+    def err(a, b):
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64).reshape(a.shape)
+        return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max())
+
+    net.set_blob("data", x)
+    net.forward()
+    out = {"max_err_vs_reference_cpu": {b: float(f"{err(net.get_blob(b), blobs[b]):.3g}")
+                                        for b in ("conv3_3", "conv4_3", "conv5_3", "conv6_1", "LFCN_1_7x7", "LFCN_3_5x5")},
+           "bound": 1e-4}
+    Rg, Rr = net.blob_shape("proposals")[0], blobs["proposals"].shape[0]
+    dets, ids, _ = net.detect(**kw)
+    dref, _ = orc.detections(blobs["bbox_pred"], blobs["cls_pred"], blobs["proposals_score"].reshape(Rr, 6), **kw)
+    matched = 0.0
+    if len(dets) and len(dref):
+        a = np.stack([dets[:, 0], dets[:, 1], dets[:, 0] + dets[:, 2], dets[:, 1] + dets[:, 3]], 1)
+        b = np.stack([dref[:, 0], dref[:, 1], dref[:, 0] + dref[:, 2], dref[:, 1] + dref[:, 3]], 1)
+        x1 = np.maximum(a[:, None, 0], b[None, :, 0]); y1 = np.maximum(a[:, None, 1], b[None, :, 1])
+        x2 = np.minimum(a[:, None, 2], b[None, :, 2]); y2 = np.minimum(a[:, None, 3], b[None, :, 3])
+        inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+        iou = inter / ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])[:, None] + ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :] - inter)
+        j = iou.argmax(1)
+        matched = float(((iou[np.arange(len(a)), j] >= 0.99) & (np.abs(dets[:, 4] - dref[j, 4]) <= 1e-4)).mean())
+    out.update({"proposals_gpu": int(Rg), "proposals_reference": int(Rr), "detections_gpu": int(len(dets)),
+                "detections_reference": int(len(dref)), "detections_matched_iou99_score1e-4": round(matched, 4)})
+    return out
+
+
+def cpu_baseline(R_gpu, regime, net=None, kw=None):
     """The reference's CPU forward path timed on this box's host cores (rank 0, N=1 only).
 
     kind "reference": oracle/_ref -- the reference's OWN layer sources (im2col + cblas_sgemm through MKL, serial
@@ -62,10 +94,13 @@ def cpu_baseline(R_gpu, regime):
         blobs = pynet.forward(layers, ws, {"data": x}, backend=pyref)
         dt = time.perf_counter() - t0
         R = blobs["proposals"].shape[0]
-        return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "reference",
-                "sample": f"1 full frame (1x3x576x1920, R={R} ROIs) through the reference's own CPU layers "
-                          f"(oracle/_ref: im2col + MKL cblas_sgemm, {cores} threads available), Net::Forward scope, {dt:.2f} s",
-                "seconds_per_image": round(dt, 2)}
+        res = {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "reference",
+               "sample": f"1 full frame (1x3x576x1920, R={R} ROIs) through the reference's own CPU layers "
+                         f"(oracle/_ref: im2col + MKL cblas_sgemm, {cores} threads available), Net::Forward scope, {dt:.2f} s",
+               "seconds_per_image": round(dt, 2)}
+        if net is not None:
+            res["full_size_parity"] = _full_size_parity(net, x, blobs, kw)
+        return res
     pyoracle.lib()
     h, w = H // 2, W // 2
     n = mnet.Net(prototxt_text=zoo.prototxt(MODEL, height=h, width=w, max_nms_num=32), device=-1)
@@ -208,7 +243,7 @@ def main():
                              "parallelism": f"image-parallel x{world}, RCCL all_gather of detections"},
                   "roofline": roofline}
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(max(1, int(round(Rm))), args.regime)
+            result["cpu_baseline"] = cpu_baseline(max(1, int(round(Rm))), args.regime, net=net, kw=kw)
         stage = {}
         for i, nm in enumerate(net.layer_names):
             t = net.layer_types[i]
