@@ -193,8 +193,18 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     MSCNN_CHECK(mscnn_conv2d_pack_weights(plan_, w, packed, S()));
     weights_dirty_ = false;
   }
+  // Transient workspace (stream-K slabs, Winograd V / M planes: up to 0.8 GB for conv2_2): the layers of a net run one after
+  // the other on one stream, so they all share ONE buffer per process (= per GPU) instead of 3 GB of per-layer buffers.
+  // One buffer per device; forwards of different nets on the same device must not overlap in time (they never do: one
+  // process per GPU, one stream).  (Leaked on purpose: a static destructor would call hipFree after the HIP runtime has been
+  // torn down.)
+  static DeviceBuffer* shared_ws[64] = {nullptr};
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  CHECK(dev >= 0 && dev < 64);
+  if (!shared_ws[dev]) shared_ws[dev] = new DeviceBuffer();
   const size_t wbytes = mscnn_conv2d_workspace_bytes(plan_);
-  void* ws = wbytes ? workspace_.Reserve(wbytes) : nullptr;
+  void* ws = wbytes ? shared_ws[dev]->Reserve(wbytes) : nullptr;
   const float* bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
   float* pooled = nullptr;
   if (pooled_top_ && mscnn_conv2d_plan_can_pool(plan_)) {
