@@ -57,6 +57,7 @@ struct Cfg {
   // VEC: 1x1 kernel over planes of exactly 128-pixel rows (the Winograd GEMM operands): the B tile is CK contiguous
   // 512-byte rows, staged with b128 loads / ds_write_b128 and no per-element offset table
   static constexpr int VEC = VEC_;
+  static constexpr bool PREFETCH_NEXT = VEC_ != 0;
   static constexpr int F4_PER_CH = BN_ / 4;                 // float4s per channel row of the B tile (tile = BN contiguous pixels)
   static constexpr int CH_PER_PASS = 256 / F4_PER_CH;       // channels staged per pass of the 256 threads
   static constexpr int BV_PER_T = CK_ * F4_PER_CH / 256;
@@ -236,8 +237,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   const __amdgpu_buffer_rsrc_t bias_rsrc = make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
   const int co_stride = a.Ho * a.Wo;
 
-  for (;;) {
-    int t, k0, k1;
+  // ---- segment state: the segment whose first chunk is in flight / being multiplied --------------------------------------
+  int t = 0, k0 = 0, k1 = 0, mt = 0;
+  TileGeo<C> geo;
+  __amdgpu_buffer_rsrc_t xsrc = wsrc;
+  unsigned g_off[C::B_PER_T];      // byte offsets of this thread's patch elements (channel-chunk term = scalar offset of the load)
+  unsigned bv_voff = 0;            // VEC: float4 number tid + i*256 of the tile = channel tid / F4_PER_CH + CH_PER_PASS * i,
+                                   // pixels 4 (tid % F4_PER_CH) .. +3 of the tile's BN contiguous pixels
+  unsigned a_tile = 0;
+  float4 ra[C::A_PER_T];
+  float rb[C::B_PER_T];
+  float4 rbv[C::VEC ? C::BV_PER_T : 1];
+  const unsigned a_voff = (unsigned)tid * 16u;
+
+  auto next_segment = [&]() -> bool {
     if (full_j < a.full_q) {
       t = wg + full_j * a.G; k0 = 0; k1 = a.KI;
       ++full_j;
@@ -247,16 +260,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       k1 = (int)min((long)a.KI, k0 + (it_end - it));
       it += (k1 - k0);
     } else {
-      break;
+      return false;
     }
-    const int mt = a.nt_major ? t % a.MT : t / a.NT;
+    mt = a.nt_major ? t % a.MT : t / a.NT;
     const int nt = a.nt_major ? t / a.MT : t % a.NT;
-    TileGeo<C> geo;
     geo.decode(a, nt);
-    const __amdgpu_buffer_rsrc_t xsrc = make_rsrc(geo.x_base(a), geo.x_bytes(a));
-
-    // byte offsets of this thread's patch elements (the channel-chunk term is the scalar offset of the load)
-    unsigned g_off[C::B_PER_T];
+    xsrc = make_rsrc(geo.x_base(a), geo.x_bytes(a));
     if constexpr (!C::VEC) {
 #pragma unroll
       for (int i = 0; i < C::B_PER_T; ++i) {
@@ -264,24 +273,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         g_off[i] = o >= 0 ? (unsigned)o * 4u : kOob;
       }
     }
-    // VEC: float4 number tid + i*256 of the tile = channel tid / F4_PER_CH + CH_PER_PASS * i, pixels 4 (tid % F4_PER_CH) .. +3
-    // of the tile's BN contiguous pixels (rows of 128 are contiguous in the plane)
-    const unsigned bv_voff =
-        ((unsigned)(tid / C::F4_PER_CH) * (unsigned)plane + (unsigned)geo.h0 * 128u + (unsigned)(tid % C::F4_PER_CH) * 4u) * 4u;
-
-    f32x16 acc[C::MI][C::NI];
-#pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    float4 ra[C::A_PER_T];
-    float rb[C::B_PER_T];
-    float4 rbv[C::VEC ? C::BV_PER_T : 1];
-    const unsigned a_voff = (unsigned)tid * 16u;
-    const unsigned a_tile = (unsigned)(mt * a.KI) * (C::A_ELEMS * 4u) + (unsigned)geo.img * a.w_img_bytes;
+    bv_voff = ((unsigned)(tid / C::F4_PER_CH) * (unsigned)plane + (unsigned)geo.h0 * 128u + (unsigned)(tid % C::F4_PER_CH) * 4u) * 4u;
+    a_tile = (unsigned)(mt * a.KI) * (C::A_ELEMS * 4u) + (unsigned)geo.img * a.w_img_bytes;
+    return true;
+  };
 
 #define MSCNN_LOAD_CHUNK(kc)                                                                                        \
     {                                                                                                               \
@@ -307,10 +302,37 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       }                                                                                                             \
     }
 
-    MSCNN_LOAD_CHUNK(k0);
-    for (int kc = k0; kc < k1; ++kc) {
+  bool more = false;
+  if constexpr (C::PREFETCH_NEXT) {      // every later segment's first chunk is fetched during the previous segment's last chunk
+    more = next_segment();
+    if (more) MSCNN_LOAD_CHUNK(k0);
+  }
+  for (;;) {
+    if constexpr (C::PREFETCH_NEXT) {
+      if (!more) break;
+    } else {
+      if (!next_segment()) break;
+      MSCNN_LOAD_CHUNK(k0);
+    }
+    f32x16 acc[C::MI][C::NI];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // This segment's identity (the epilogue needs it after the segment state has moved on).  PREFETCH_NEXT kernels (the 1x1
+    // Winograd GEMMs: K = Cin only, so a tile is short and its prologue shows): while the LAST chunk is multiplied, the NEXT
+    // segment's first chunk is already put in flight -- the registers ra / rb are idle then -- so its HBM / L2 latency hides
+    // behind that chunk's MFMAs and the epilogue's stores.  (Costs registers in the epilogue: for the 3x3 kernels it would
+    // take one workgroup of occupancy -- measured slower -- so they fetch it after the epilogue.)
+    const TileGeo<C> geo_e = geo;
+    const int t_e = t, k0_e = k0, k1_e = k1, mt_e = mt;
+    more = false;
+    for (int kc = k0_e; kc < k1_e; ++kc) {
       if (C::PF == 2) __builtin_amdgcn_s_setprio(3);   // staging phase: get through the barriers quickly
-      if (C::PF < 12 || kc == k0) {      // (PF >= 11: timing ablations only, results are wrong by construction)
+      if (C::PF < 12 || C::PF == 14 || kc == k0_e) {      // (PF >= 11: timing ablations only, results are wrong by construction)
       __syncthreads();                 // everyone finished reading the previous chunk
 #pragma unroll
       for (int i = 0; i < C::A_PER_T; ++i)
@@ -325,7 +347,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       }
       __syncthreads();
       }
-      if (kc + 1 < k1 && C::PF < 11) MSCNN_LOAD_CHUNK(kc + 1);   // in flight while this chunk is multiplied
+      if (kc + 1 < k1_e) {
+        if (C::PF < 11 || C::PF == 14) MSCNN_LOAD_CHUNK(kc + 1);   // in flight while this chunk is multiplied
+      } else if constexpr (C::PREFETCH_NEXT) {
+        more = next_segment();                                     // (overwrites t, k0, k1, mt, geo, xsrc, g_off, ...)
+        if (more) MSCNN_LOAD_CHUNK(k0);
+      }
       if (C::PF == 2) __builtin_amdgcn_s_setprio(0);
       if constexpr (C::PF == 0) {
 #pragma unroll
@@ -359,10 +386,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
           _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni) bv[buf][ni] = bRd[ni][cp_ * 2 * C::CH_STRIDE + kh_ * C::ROWS + kw_]; \
         }
         MSCNN_LDS_GROUP(0, 0);
-        if constexpr (C::PF == 13) MSCNN_LDS_GROUP(1, 1);   // ablation: operands loaded once, MFMA-only loop
+        if constexpr (C::PF == 13 || C::PF == 15) MSCNN_LDS_GROUP(1, 1);   // ablation: operands loaded once, MFMA-only loop
         static_for<0, S>([&](auto sc) {
           constexpr int s = decltype(sc)::value;
-          if constexpr (s + 1 < S && C::PF != 13) MSCNN_LDS_GROUP(s + 1, (s + 1) & 1);
+          if constexpr (s + 1 < S && C::PF != 13 && C::PF != 15) MSCNN_LDS_GROUP(s + 1, (s + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);      // pin: next group's ds_reads are issued BEFORE this group's MFMAs
 #pragma unroll
           for (int mi = 0; mi < C::MI; ++mi)
@@ -374,10 +401,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 #undef MSCNN_LDS_GROUP
       }
     }
-#undef MSCNN_LOAD_CHUNK
 
+    {
+    const TileGeo<C>& geo = geo_e;
+    const int t = t_e, k0 = k0_e, k1 = k1_e, mt = mt_e;
+    (void)t;
     const bool full = (k0 == 0 && k1 == a.KI);
-    if (full) {
+    if (C::PF >= 14 && full) {
+      if (acc[0][0][0] == 12345.678f) a.y[tid] = acc[0][0][1];     // ablation: no epilogue (keeps acc live)
+    } else if (full) {
       const __amdgpu_buffer_rsrc_t ysrc = make_rsrc(geo.y_base(a), geo.y_bytes(a));
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi) {
@@ -385,16 +417,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         float bvals[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          bvals[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                   bias_rsrc, (unsigned)co0 * 4u, ((r & 3) + 8 * (r >> 2)) * 4u, 0));
+          bvals[r] = C::VEC ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                  bias_rsrc, (unsigned)co0 * 4u, ((r & 3) + 8 * (r >> 2)) * 4u, 0));
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni) {
           const int o = geo.out_off(a, wn * C::WN + ni * 32 + l31);
           const unsigned voff = o >= 0 ? (unsigned)(co0 * co_stride + o) * 4u : kOob;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float v = acc[mi][ni][r] + bvals[r];
-            if (a.relu) v = v > 0.f ? v : 0.f;
+            float v = C::VEC ? acc[mi][ni][r] : acc[mi][ni][r] + bvals[r];     // (VEC = Winograd GEMM: no bias, no ReLU)
+            if (!C::VEC && a.relu) v = v > 0.f ? v : 0.f;
             const unsigned vo = (co0 + (r & 3) + 8 * (r >> 2) < a.Cout) ? voff : kOob;   // Cout < BM (proposal heads)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, vo,
                                                   (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)co_stride * 4u, 0);
@@ -444,8 +476,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
           for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2)) * C::BN] = acc[mi][ni][r];
         }
     }
+    }
     __syncthreads();   // LDS is re-used by the next segment's first stores
   }
+#undef MSCNN_LOAD_CHUNK
 }
 
 // Sums the partial slabs of every tile that was split across workgroups, in k order (deterministic), + bias + ReLU.
@@ -669,6 +703,9 @@ const KernelEntry kTable[] = {
     {"igemm_128x256_k1x1_ck32_vec", 128, 256, 1, 1, 32, 128, 2, 0, 0, 0, 1, 8, 103, igemm_kernel<Cfg<128, 256, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>,
      igemm_fixup_kernel<Cfg<128, 256, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>},
 #ifdef MSCNN_ABLATIONS
+    {"abl32_mfmaonly", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 123, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 13, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 13, 1>>},
+    {"abl32_noepi", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 124, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 14, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 14, 1>>},
+    {"abl32_mfmaonly_noepi", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 125, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 15, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 15, 1>>},
     {"abl1x1_noload", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 111, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 11, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 11, 1>>},
     {"abl1x1_nostage", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 112, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 12, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 12, 1>>},
     {"abl1x1_mfmaonly", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 113, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 13, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 13, 1>>},
