@@ -18,7 +18,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + 4;
+constexpr int BK = 32, LDK = BK + 4;     // tile shapes: 128 x 128 (2 x 2 waves) or 64 x 256 (1 x 4 waves); each wave 64 x 64
 
 struct GemmArgs {
   const float* x; const float* w; const float* bias; float* y; float* ws;
@@ -31,24 +31,22 @@ __device__ __forceinline__ void wg_range(long total, int G, int g, long& b, long
   e = total * (g + 1) / G;
 }
 
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
+  static_assert(BM * BN == 128 * 128 && BM % 64 == 0 && BN % 64 == 0, "4 waves of 64 x 64");
   __shared__ __attribute__((aligned(16))) float ldsX[BM * LDK];
   __shared__ __attribute__((aligned(16))) float ldsW[BN * LDK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;      // 2 x 2 waves, 64 x 64 each
+  constexpr int WN = BN / 64;                   // waves along N
+  const int wm = wave / WN, wn = wave % WN;     // 64 x 64 per wave
+  constexpr int XV = BM * (BK / 4) / 256, WV = BN * (BK / 4) / 256;     // float4 per thread and operand
 
   long it, it_end;
   wg_range(a.total_iters, a.G, blockIdx.x, it, it_end);
 
-  // staging map: 128 rows x 8 float4 per operand = 1024 float4 -> 4 per thread
-  int s_row[4], s_k4[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int v = tid + i * 256;
-    s_row[i] = v >> 3;
-    s_k4[i] = (v & 7) * 4;
-  }
+  // staging map: rows x 8 float4 per operand; float4 number v = tid + i * 256 is row v / 8, k offset (v % 8) * 4
+  const int s_row0 = tid >> 3, s_k4 = (tid & 7) * 4;      // row of pass i: s_row0 + 32 i
 
   while (it < it_end) {
     const int t = (int)(it / a.KI);
@@ -65,23 +63,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 rx[4], rw[4];
+    float4 rx[XV], rw[WV];
     auto load_chunk = [&](int kc) {
-      const int kb = kc * BK;
+      const int k = kc * BK + s_k4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = kb + s_k4[i];
-        const int m = m0 + s_row[i], n = n0 + s_row[i];
+      for (int i = 0; i < XV; ++i) {
+        const int m = m0 + s_row0 + 32 * i;
         rx[i] = (m < a.M && k < a.K) ? *reinterpret_cast<const float4*>(a.x + (long)m * a.K + k) : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < WV; ++i) {
+        const int n = n0 + s_row0 + 32 * i;
         rw[i] = (n < a.N && k < a.K) ? *reinterpret_cast<const float4*>(a.w + (long)n * a.K + k) : make_float4(0, 0, 0, 0);
       }
     };
     auto store_chunk = [&]() {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<float4*>(&ldsX[s_row[i] * LDK + s_k4[i]]) = rx[i];
-        *reinterpret_cast<float4*>(&ldsW[s_row[i] * LDK + s_k4[i]]) = rw[i];
-      }
+      for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(&ldsX[(s_row0 + 32 * i) * LDK + s_k4]) = rx[i];
+#pragma unroll
+      for (int i = 0; i < WV; ++i) *reinterpret_cast<float4*>(&ldsW[(s_row0 + 32 * i) * LDK + s_k4]) = rw[i];
     };
 
     load_chunk(k0);
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
   }
 }
 
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmArgs a) {
   __shared__ const float* s_slab[64];
   __shared__ int s_n;
@@ -282,6 +283,9 @@ extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const
   GemmArgs a;
   a.x = x; a.w = w; a.bias = bias; a.y = y;
   a.M = M; a.N = N; a.K = K; a.relu = relu;
+  // tile shape: 64-row tiles when they waste fewer padded ROI rows (M = 700: 704 instead of 768 rows, -8 % MFMA work)
+  const bool m64 = cdiv(M, 64) * 64 < cdiv(M, 128) * 128 && N >= 256;
+  const int BM = m64 ? 64 : 128, BN = m64 ? 256 : 128;
   a.MT = cdiv(M, BM); a.NT = cdiv(N, BN); a.KI = cdiv(K, BK);
   a.total_iters = (long)a.MT * a.NT * a.KI;
   long G = 512;
@@ -296,9 +300,11 @@ extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const
     g_ws_bytes = need;
   }
   a.ws = g_ws;
-  gemm_tn_kernel<<<a.G, 256, 0, st>>>(a);
+  if (m64) gemm_tn_kernel<64, 256><<<a.G, 256, 0, st>>>(a);
+  else gemm_tn_kernel<128, 128><<<a.G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
-  gemm_fixup_kernel<<<a.MT * a.NT * 4, 256, 0, st>>>(a);
+  if (m64) gemm_fixup_kernel<64, 256><<<a.MT * a.NT * 4, 256, 0, st>>>(a);
+  else gemm_fixup_kernel<128, 128><<<a.MT * a.NT * 4, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

@@ -266,7 +266,7 @@ def test_conv_identity_asymmetric(hip):
 
 # ------------------------------------------------------------------ inner product
 @pytest.mark.parametrize("M,N,K", [(1, 5, 64), (7, 20, 4096), (3, 128, 256), (130, 192, 1000), (257, 4096, 800), (1, 4096, 12800),
-                                   (3, 10, 9000), (5, 70, 33), (700, 20, 4096)])
+                                   (3, 10, 9000), (5, 70, 33), (700, 20, 4096), (150, 512, 260), (700, 320, 1000)])
 def test_inner_product(hip, orc, M, N, K):
     rng = np.random.default_rng(6)
     x = rng.standard_normal((M, K)).astype(np.float32)
