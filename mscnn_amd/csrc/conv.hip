@@ -52,12 +52,12 @@ struct IgemmArgs {
 //   ROI mode   (RH  > 0): the images are tiny (RH x RW, e.g. the 7x7 ROI-pooled maps of roi_c1) and a tile packs
 //                         IPT whole images: N side = IPT * OH * OW output pixels.  The reference's CAFFE engine runs
 //                         one im2col+GEMM with N = 25 per ROI here (conv_layer.cu:14-21).
-template <int BM_, int BN_, int WGM_, int WGN_, int KH_, int KW_, int CK_, int TW_, int RH_ = 0, int RW_ = 0, int RP_ = 0, int PF_ = 0, int VEC_ = 0>
+template <int BM_, int BN_, int WGM_, int WGN_, int KH_, int KW_, int CK_, int TW_, int RH_ = 0, int RW_ = 0, int RP_ = 0, int PF_ = 0, int VEC_ = 0, int NOPN_ = 0>
 struct Cfg {
   // VEC: 1x1 kernel over planes of exactly 128-pixel rows (the Winograd GEMM operands): the B tile is CK contiguous
   // 512-byte rows, staged with b128 loads / ds_write_b128 and no per-element offset table
   static constexpr int VEC = VEC_;
-  static constexpr bool PREFETCH_NEXT = VEC_ != 0;      // (also tried on the 64x256 conv1_x tiles: 796 vs 775 us, no gain)
+  static constexpr bool PREFETCH_NEXT = VEC_ != 0 && NOPN_ == 0;      // (also tried on the 64x256 conv1_x tiles: 796 vs 775 us, no gain)
   static constexpr int F4_PER_CH = BN_ / 4;                 // float4s per channel row of the B tile (tile = BN contiguous pixels)
   static constexpr int CH_PER_PASS = 256 / F4_PER_CH;       // channels staged per pass of the 256 threads
   static constexpr int BV_PER_T = CK_ * F4_PER_CH / 256;
@@ -698,6 +698,10 @@ const KernelEntry kTable[] = {
     // variants 101 / 102: vectorised staging, planes of exactly 128-pixel rows only (Winograd GEMM)
     {"igemm_128x128_k1x1_ck32_vec", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 101, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>},
+#ifdef MSCNN_ABLATIONS
+    {"igemm_128x128_k1x1_ck32_vec_nopn", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 105, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1, 1>>,
+     igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1, 1>>},
+#endif
     {"igemm_128x128_k1x1_ck64_vec", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 102, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>},
     {"igemm_128x256_k1x1_ck32_vec", 128, 256, 1, 1, 32, 128, 2, 0, 0, 0, 1, 8, 103, igemm_kernel<Cfg<128, 256, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>,
