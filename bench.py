@@ -242,7 +242,7 @@ def main():
                              "regime": args.regime, "mean_rois": round(Rm, 1), "mean_detections": round(float(np.mean(stats["D"])), 1),
                              "parallelism": f"image-parallel x{world}, RCCL all_gather of detections"},
                   "roofline": roofline}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (20 s of host work; other ranks would idle)
             result["cpu_baseline"] = cpu_baseline(max(1, int(round(Rm))), args.regime, net=net, kw=kw)
         stage = {}
         for i, nm in enumerate(net.layer_names):
