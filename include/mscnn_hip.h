@@ -206,6 +206,14 @@ MSCNN_API int mscnn_detections_fwd(const mscnn_detections_desc* desc, const floa
                          const float* props, int R, double* dets_out, int* ids_out, int* count_out_dev,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Final stage of the cascade drivers (examples/kitti_car/run_cascademscnn.m:84-117): `boxes` = the decoded box blob of a
+ * cascade stage [R][5] = [img x1 y1 x2 y2] (DecodeBBox output), `cls_prob` = that stage's in-net probabilities [R][ncls]
+ * (Softmax / Eltwise blob), `props` = its proposal blob [R][5].  Rescale, clip, w = x2 - x1 + 1, drop rows whose proposal
+ * has zero width or height, optional det_thr (> 0), then the same NMS.  desc: ncls, cls_id, ratio_*, org_*, nms_overlap. */
+MSCNN_API int mscnn_detections_cascade_fwd(const mscnn_detections_desc* desc, float det_thr, const float* boxes,
+                                 const float* cls_prob, const float* props, int R, double* dets_out, int* ids_out,
+                                 int* count_out_dev, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Image pre-processing in front of net.forward -- MATLAB `run_mscnn_detection.m:64-69`:
  * imresize(uint8 image, [H W]) (bicubic, uint8 after each 1-D pass), RGB -> BGR, single, subtract the

@@ -38,6 +38,8 @@ struct DetArgs {
   int R, ncls, cls_id;
   float mean[4], stdv[4];
   float proposal_thr, ratio_h, ratio_w, org_h, org_w;
+  int cascade;        // 1: run_cascademscnn.m:84-117 -- bbox_pred = decoded boxes [R][5], cls_pred = in-net probabilities,
+                      //    props = proposal rows [R][5]; proposal_thr = det_thr
 };
 
 enum { DC_N = 0, DC_WORDS = 4 };
@@ -53,6 +55,25 @@ __global__ __launch_bounds__(kSortThreads) void det_transform_sort_kernel(DetArg
   if (tid == 0) s_fill = 0;
   __syncthreads();
   for (int r = tid; r < a.R; r += kSortThreads) {
+    if (a.cascade) {
+      const float* q = a.props + 5 * (size_t)r;
+      const float cw = q[3] - q[1] + 1.f, ch = q[4] - q[2] + 1.f;                      // run_cascademscnn.m:104
+      if (!(cw != 0 && ch != 0)) continue;                                             // :107
+      const float* t = a.bbox_pred + 5 * (size_t)r;
+      float x1 = t[1] / a.ratio_w, x2 = t[3] / a.ratio_w;                              // :88-89
+      float y1 = t[2] / a.ratio_h, y2 = t[4] / a.ratio_h;
+      x1 = fmaxf(0.f, x1); y1 = fmaxf(0.f, y1);                                        // :91
+      x2 = fminf(x2, a.org_w); y2 = fminf(y2, a.org_h);                                // :92
+      const float w = x2 - x1 + 1.f, h = y2 - y1 + 1.f;                                // :93
+      const float prob = a.cls_pred[(size_t)r * a.ncls + (a.cls_id - 1)];              // :113
+      if (a.proposal_thr > 0 && !(prob >= a.proposal_thr)) continue;                   // :115-117 (det_thr)
+      if (!(prob > -INFINITY)) continue;
+      tmp_box[r] = DetBox{(double)x1, (double)y1, (double)w, (double)h};
+      tmp_prob[r] = prob;
+      const int pos = atomicAdd(&s_fill, 1);
+      if (pos < kMaxK) sk[pos] = ((u64)orderable(prob) << 32) | (u64)(0xffffffffu - (unsigned)r);
+      continue;
+    }
     const float* q = a.props + 6 * (size_t)r;
     const float px = q[1], py = q[2], pw = q[3] - q[1], ph = q[4] - q[2], sc = q[5];
     if (!(sc >= a.proposal_thr && pw != 0 && ph != 0)) continue;                       // :82
@@ -198,9 +219,9 @@ extern "C" int mscnn_decodebbox_fwd_f32(const float* bbox, const float* prior, f
 
 extern "C" size_t mscnn_detections_workspace_bytes(int R) { return det_layout(R).total; }
 
-extern "C" int mscnn_detections_fwd(const mscnn_detections_desc* desc, const float* bbox_pred, const float* cls_pred,
-                                    const float* props, int R, double* dets_out, int* ids_out, int* count_out_dev,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
+static int detections_launch(const mscnn_detections_desc* desc, int cascade, float det_thr, const float* bbox_pred,
+                             const float* cls_pred, const float* props, int R, double* dets_out, int* ids_out,
+                             int* count_out_dev, void* workspace, size_t workspace_bytes, void* stream) {
   MSCNN_REQUIRE(desc && count_out_dev && workspace, "detections: null pointer");
   MSCNN_REQUIRE(R >= 0, "detections: R < 0");
   MSCNN_REQUIRE(desc->ncls >= 2 && desc->cls_id >= 1 && desc->cls_id <= desc->ncls, "detections: cls_id %d of %d",
@@ -233,7 +254,8 @@ extern "C" int mscnn_detections_fwd(const mscnn_detections_desc* desc, const flo
   a.bbox_pred = bbox_pred; a.cls_pred = cls_pred; a.props = props;
   a.R = R; a.ncls = desc->ncls; a.cls_id = desc->cls_id;
   for (int k = 0; k < 4; ++k) { a.mean[k] = desc->bbox_mean[k]; a.stdv[k] = desc->bbox_std[k]; }
-  a.proposal_thr = desc->proposal_thr;
+  a.proposal_thr = cascade ? det_thr : desc->proposal_thr;
+  a.cascade = cascade;
   // MATLAB: single op double -> single (the double operand is converted to single first)
   a.ratio_h = (float)desc->ratio_h; a.ratio_w = (float)desc->ratio_w;
   a.org_h = (float)desc->org_h; a.org_w = (float)desc->org_w;
@@ -245,4 +267,18 @@ extern "C" int mscnn_detections_fwd(const mscnn_detections_desc* desc, const flo
                                                                                 count_out_dev);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
+}
+
+extern "C" int mscnn_detections_fwd(const mscnn_detections_desc* desc, const float* bbox_pred, const float* cls_pred,
+                                    const float* props, int R, double* dets_out, int* ids_out, int* count_out_dev,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  return detections_launch(desc, 0, 0.f, bbox_pred, cls_pred, props, R, dets_out, ids_out, count_out_dev, workspace,
+                           workspace_bytes, stream);
+}
+
+extern "C" int mscnn_detections_cascade_fwd(const mscnn_detections_desc* desc, float det_thr, const float* boxes,
+                                            const float* cls_prob, const float* props, int R, double* dets_out, int* ids_out,
+                                            int* count_out_dev, void* workspace, size_t workspace_bytes, void* stream) {
+  return detections_launch(desc, 1, det_thr, boxes, cls_prob, props, R, dets_out, ids_out, count_out_dev, workspace,
+                           workspace_bytes, stream);
 }

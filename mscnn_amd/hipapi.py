@@ -336,6 +336,26 @@ class BoxOutput:
         return self.rois[:R], self.props[:R], self.aids[:R], nreal
 
 
+def detections_cascade(boxes, cls_prob, props, cls_id, det_thr=0.0, ratios=(1.0, 1.0), org_hw=(375, 1242), nms_overlap=0.5):
+    """Final stage of the cascade drivers (run_cascademscnn.m:84-117) for one cascade stage's blobs."""
+    R = props.shape[0]
+    d = DetectionsDesc()
+    d.ncls = cls_prob.shape[1]; d.cls_id = cls_id
+    d.ratio_h, d.ratio_w = ratios
+    d.org_h, d.org_w = org_hw
+    d.nms_overlap = nms_overlap
+    dev = props.device
+    dets = torch.zeros((max(R, 1), 5), dtype=torch.float64, device=dev)
+    ids = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    wb = lib().mscnn_detections_workspace_bytes(R)
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    _check(lib().mscnn_detections_cascade_fwd(C.byref(d), C.c_float(det_thr), _dev(boxes), _dev(cls_prob), _dev(props), R,
+                                              _dev(dets), _dev(ids), _dev(count), _dev(ws), C.c_size_t(wb), _stream()))
+    D = int(count.item())
+    return dets[:D], ids[:D]
+
+
 def preprocess(img_rgb_u8, out_h, out_w, mean_bgr=(104.0, 117.0, 123.0), out=None):
     """run_mscnn_detection.m:64-69 on the device: uint8 HWC RGB image (cuda tensor) -> the net's (1, 3, out_h, out_w) input."""
     oh, ow, ch = img_rgb_u8.shape

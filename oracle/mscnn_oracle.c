@@ -576,7 +576,6 @@ ORC_API int orc_decode_bbox(const float* bbox, const float* prior, float* out, i
 /* single), NMS in double after a STABLE descending sort (ties: lower index first). */
 /* cls_id is 1-based as in the script.  dets_out: rows [x y w h prob], ids_out:     */
 /* index (0-based) into the *input* rows.  Returns D.                               */
-/* ------------------------------------------------------------------ */
 typedef struct { double s; int i; } ds_idx;
 static int cmp_ds_desc_stable(const void* a, const void* b) {
   const ds_idx* p = (const ds_idx*)a; const ds_idx* q = (const ds_idx*)b;
@@ -585,14 +584,47 @@ static int cmp_ds_desc_stable(const void* a, const void* b) {
   return (p->i > q->i) - (p->i < q->i);
 }
 
+/* bbNms.m:112-126 (nmsMax, greedy, 'union') on n rows bb[n][5] = [x y w h score] (double); src[n] = input row of each.
+ * Writes the kept rows in score order, returns their number. */
+static int bbnms_max_union(const double* bb, const int* src, int n, double nms_overlap, double* dets_out, int* ids_out) {
+  ds_idx* ord = (ds_idx*)malloc(sizeof(ds_idx) * (size_t)(n > 0 ? n : 1));
+  unsigned char* kp = (unsigned char*)malloc((size_t)(n > 0 ? n : 1));
+  /* bbNms.m:76 keeps bbs(:,5) > thr with thr = -inf: all rows (NaN excluded). */
+  int m = 0;
+  for (int i = 0; i < n; ++i) if (bb[5 * i + 4] > -INFINITY) { ord[m].s = bb[5 * i + 4]; ord[m].i = i; ++m; }
+  qsort(ord, (size_t)m, sizeof(ds_idx), cmp_ds_desc_stable);             /* bbNms.m:114 */
+  for (int i = 0; i < m; ++i) kp[i] = 1;
+  for (int a = 0; a < m; ++a) {
+    if (!kp[a]) continue;
+    const double* A = bb + 5 * (size_t)ord[a].i;
+    const double as_a = A[2] * A[3], xe_a = A[0] + A[2], ye_a = A[1] + A[3];
+    for (int c = a + 1; c < m; ++c) {
+      if (!kp[c]) continue;
+      const double* B = bb + 5 * (size_t)ord[c].i;
+      const double iw = fmin(xe_a, B[0] + B[2]) - fmax(A[0], B[0]); if (iw <= 0) continue;
+      const double ih = fmin(ye_a, B[1] + B[3]) - fmax(A[1], B[1]); if (ih <= 0) continue;
+      double o = iw * ih; const double u = as_a + B[2] * B[3] - o;
+      o = o / u; if (o > nms_overlap) kp[c] = 0;
+    }
+  }
+  int D = 0;
+  for (int a = 0; a < m; ++a) {
+    if (!kp[a]) continue;
+    memcpy(dets_out + 5 * (size_t)D, bb + 5 * (size_t)ord[a].i, 5 * sizeof(double));
+    if (ids_out) ids_out[D] = src[ord[a].i];
+    ++D;
+  }
+  free(ord); free(kp);
+  return D;
+}
+
+/* ------------------------------------------------------------------ */
 ORC_API int orc_detections(const float* bbox_pred, const float* cls_pred, const float* props,
                            int R, int ncls, int cls_id, const float* bbox_mean, const float* bbox_std,
                            float proposal_thr, double ratio_h, double ratio_w, double org_h, double org_w,
                            double nms_overlap, double* dets_out, int* ids_out) {
   double* bb = (double*)malloc(sizeof(double) * 5 * (size_t)(R > 0 ? R : 1));
-  ds_idx* ord = (ds_idx*)malloc(sizeof(ds_idx) * (size_t)(R > 0 ? R : 1));
   int* src = (int*)malloc(sizeof(int) * (size_t)(R > 0 ? R : 1));
-  unsigned char* kp = (unsigned char*)malloc((size_t)(R > 0 ? R : 1));
   int n = 0;
   for (int r = 0; r < R; ++r) {
     const float* q = props + 6 * (size_t)r;
@@ -620,32 +652,40 @@ ORC_API int orc_detections(const float* bbox_pred, const float* cls_pred, const 
     src[n] = r;
     ++n;
   }
-  /* bbNms.m:76 keeps bbs(:,5) > thr with thr = -inf: all rows (NaN excluded). */
-  int m = 0;
-  for (int i = 0; i < n; ++i) if (bb[5 * i + 4] > -INFINITY) { ord[m].s = bb[5 * i + 4]; ord[m].i = i; ++m; }
-  qsort(ord, (size_t)m, sizeof(ds_idx), cmp_ds_desc_stable);             /* bbNms.m:114 */
-  for (int i = 0; i < m; ++i) kp[i] = 1;
-  for (int a = 0; a < m; ++a) {
-    if (!kp[a]) continue;
-    const double* A = bb + 5 * (size_t)ord[a].i;
-    const double as_a = A[2] * A[3], xe_a = A[0] + A[2], ye_a = A[1] + A[3];
-    for (int c = a + 1; c < m; ++c) {
-      if (!kp[c]) continue;
-      const double* B = bb + 5 * (size_t)ord[c].i;
-      const double iw = fmin(xe_a, B[0] + B[2]) - fmax(A[0], B[0]); if (iw <= 0) continue;
-      const double ih = fmin(ye_a, B[1] + B[3]) - fmax(A[1], B[1]); if (ih <= 0) continue;
-      double o = iw * ih; const double u = as_a + B[2] * B[3] - o;
-      o = o / u; if (o > nms_overlap) kp[c] = 0;
-    }
+  const int D = bbnms_max_union(bb, src, n, nms_overlap, dets_out, ids_out);
+  free(bb); free(src);
+  return D;
+}
+
+/* Final stage of the cascade drivers (examples/kitti_car/run_cascademscnn.m:84-112), PARITY UNPINNED like orc_detections:
+ * boxes come decoded out of the net (DecodeBBox blob rows [img x1 y1 x2 y2]), the class score is the in-net probability
+ * (Softmax / Eltwise blob).  Rescale to the original image, clip, width = x2 - x1 + 1, drop rows whose PROPOSAL has zero
+ * width or height, optional det_thr, then bbNms (maxg, union).  Single-precision arithmetic until double([...]). */
+ORC_API int orc_detections_cascade(const float* boxes, const float* cls_prob, const float* props, int R, int ncls, int cls_id,
+                                   float det_thr, double ratio_h, double ratio_w, double org_h, double org_w,
+                                   double nms_overlap, double* dets_out, int* ids_out) {
+  double* bb = (double*)malloc(sizeof(double) * 5 * (size_t)(R > 0 ? R : 1));
+  int* src = (int*)malloc(sizeof(int) * (size_t)(R > 0 ? R : 1));
+  int n = 0;
+  for (int r = 0; r < R; ++r) {
+    const float* q = props + 5 * (size_t)r;
+    const float pw = q[3] - q[1] + 1.f, ph = q[4] - q[2] + 1.f;             /* :104 */
+    if (!(pw != 0 && ph != 0)) continue;                                    /* :107 */
+    const float* t = boxes + 5 * (size_t)r;
+    float x1 = t[1] / (float)ratio_w, x2 = t[3] / (float)ratio_w;           /* :88-89 */
+    float y1 = t[2] / (float)ratio_h, y2 = t[4] / (float)ratio_h;
+    x1 = fmaxf(0.f, x1); y1 = fmaxf(0.f, y1);                               /* :91 */
+    x2 = fminf(x2, (float)org_w); y2 = fminf(y2, (float)org_h);             /* :92 */
+    const float w = x2 - x1 + 1.f, h = y2 - y1 + 1.f;                       /* :93 */
+    const float prob = cls_prob[(size_t)r * ncls + (cls_id - 1)];           /* :113 */
+    if (det_thr > 0 && !(prob >= det_thr)) continue;                        /* :115-117 */
+    double* d = bb + 5 * (size_t)n;
+    d[0] = x1; d[1] = y1; d[2] = w; d[3] = h; d[4] = prob;
+    src[n] = r;
+    ++n;
   }
-  int D = 0;
-  for (int a = 0; a < m; ++a) {
-    if (!kp[a]) continue;
-    memcpy(dets_out + 5 * (size_t)D, bb + 5 * (size_t)ord[a].i, 5 * sizeof(double));
-    if (ids_out) ids_out[D] = src[ord[a].i];
-    ++D;
-  }
-  free(bb); free(ord); free(src); free(kp);
+  const int D = bbnms_max_union(bb, src, n, nms_overlap, dets_out, ids_out);
+  free(bb); free(src);
   return D;
 }
 

@@ -243,6 +243,17 @@ def detections(bbox_pred, cls_pred, props, cls_id, bbox_mean=(0, 0, 0, 0), bbox_
     return dets[:D].copy(), ids[:D].copy()
 
 
+def detections_cascade(boxes, cls_prob, props, cls_id, det_thr=0.0, ratios=(1.0, 1.0), org_hw=(375, 1242), nms_overlap=0.5):
+    """Final stage of the cascade drivers (run_cascademscnn.m:84-117). Returns (dets[D,5] float64 [x y w h prob], ids[D])."""
+    boxes, bp = _f(boxes); cls_prob, cp = _f(cls_prob); props, pp = _f(props)
+    R = props.shape[0]; ncls = cls_prob.shape[1]
+    dets = np.zeros((max(R, 1), 5), np.float64); ids = np.zeros(max(R, 1), np.int32)
+    D = lib().orc_detections_cascade(bp, cp, pp, R, ncls, cls_id, C.c_float(det_thr), C.c_double(ratios[0]), C.c_double(ratios[1]),
+                                     C.c_double(org_hw[0]), C.c_double(org_hw[1]), C.c_double(nms_overlap),
+                                     dets.ctypes.data_as(C.POINTER(C.c_double)), ids.ctypes.data_as(i32p))
+    return dets[:D].copy(), ids[:D].copy()
+
+
 def concat_channels(xs):
     return np.concatenate([np.asarray(x, np.float32) for x in xs], axis=1)
 

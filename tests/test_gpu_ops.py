@@ -457,6 +457,22 @@ def test_detections_stage(hip, orc, R):
     close(dets.cpu().numpy(), dref)
 
 
+@pytest.mark.parametrize("R,det_thr", [(1, 0.0), (41, 0.0), (1500, 0.0), (1500, 0.3)])
+def test_detections_cascade_stage(hip, orc, R, det_thr):
+    rng = np.random.default_rng(100 + R)
+    b = _clustered_boxes(rng, R)
+    boxes = np.concatenate([np.zeros((R, 1), np.float32), b[:, :2] - 30, b[:, :2] + b[:, 2:] + 25], 1).astype(np.float32)
+    props = np.concatenate([np.zeros((R, 1), np.float32), b[:, :2], b[:, :2] + b[:, 2:]], 1).astype(np.float32)
+    props[3::31, 3] = props[3::31, 1] - 1                         # degenerate proposal (width 0 in the +1 convention)
+    prob = rng.uniform(0, 1, (R, 3)).astype(np.float32)
+    prob[3::7] = prob[2::7][: len(prob[3::7])]                    # exact ties -> stable order
+    kw = dict(cls_id=2, det_thr=det_thr, ratios=(576 / 375, 1920 / 1242), org_hw=(375, 1242))
+    dets, ids = hip.detections_cascade(dev(boxes), dev(prob), dev(props), **kw)
+    dref, iref = orc.detections_cascade(boxes, prob, props, **kw)
+    assert np.array_equal(ids.cpu().numpy(), iref)
+    assert np.array_equal(dets.cpu().numpy(), dref)              # no transcendental in this stage: bit-exact
+
+
 # ------------------------------------------------------------------ loud failure without a GPU tensor
 def test_no_cpu_fallback(hip):
     with pytest.raises(hip.MscnnError):

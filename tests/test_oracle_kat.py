@@ -317,3 +317,21 @@ def test_preprocess_properties(orc):
     assert x.shape == (1, 3, 57, 191) and x.dtype == np.float32
     assert np.array_equal(x[0, 0] + 104.0, up[:, :, 2].astype(np.float32))   # plane 0 = blue
     assert np.array_equal(x[0, 2] + 123.0, up[:, :, 0].astype(np.float32))   # plane 2 = red
+
+
+def test_detections_cascade_stage(orc):
+    """run_cascademscnn.m:84-117 by hand: rescale by the ratios, clip to the original image, w = x2 - x1 + 1, rows whose
+    PROPOSAL is degenerate dropped, det_thr, NMS (union > 0.5)."""
+    boxes = np.array([[0, 100, 100, 199, 179], [0, 104, 100, 203, 179], [0, -20, -5, 50, 40], [0, 1900, 560, 2000, 600],
+                      [0, 300, 300, 340, 330]], np.float32)
+    props = boxes.copy()
+    props[4, 3] = props[4, 1] - 1                        # proposal width x2 - x1 + 1 == 0 -> row dropped
+    prob = np.zeros((5, 3), np.float32)
+    prob[:, 1] = [0.9, 0.8, 0.7, 0.6, 0.99]
+    dets, ids = orc.detections_cascade(boxes, prob, props, cls_id=2, ratios=(2.0, 2.0), org_hw=(288, 960))
+    assert ids.tolist() == [0, 2, 3]                     # row 1 suppressed by row 0, row 4 dropped
+    assert dets[0].tolist() == [50.0, 50.0, 50.5, 40.5, np.float32(0.9)]
+    assert dets[1].tolist() == [0.0, 0.0, 26.0, 21.0, np.float32(0.7)]          # clipped at 0: w = 25 - 0 + 1
+    assert dets[2].tolist() == [950.0, 280.0, 11.0, 9.0, np.float32(0.6)]       # clipped at org_w / org_h
+    d2, i2 = orc.detections_cascade(boxes, prob, props, cls_id=2, det_thr=0.65, ratios=(2.0, 2.0), org_hw=(288, 960))
+    assert i2.tolist() == [0, 2]
