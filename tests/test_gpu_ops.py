@@ -186,6 +186,36 @@ def test_conv_winograd_f3x3(hip, orc, case, monkeypatch):
     close(plan.forward(dev(x2), dev(b)).cpu().numpy(), np.concatenate([ref, ref[:7]], 0))
 
 
+@pytest.mark.parametrize("shape", [(1, 512, 72, 240, 512, 1), (1, 128, 288, 960, 128, 1), (700, 1024, 7, 7, 512, 0)])
+def test_winograd_full_size_matches_direct(hip, shape, monkeypatch):
+    """BASELINE.json sizes (conv4_2, conv2_2, roi_c1 at R = 700), too large for the CPU oracle in a unit test: the Winograd
+    F(3x3,3x3) path against the direct implicit-GEMM path (itself oracle-checked at small sizes) on the same device data,
+    1e-4; plus linearity of the Winograd path, y(2a + b) = 2 y(a) + y(b), which needs no second implementation at all."""
+    N, Cin, H, W, Cout, pad = shape
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.relu(torch.randn((N, Cin, H, W), device="cuda", generator=g))
+    w = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MSCNN_WINOGRAD", mode)
+        plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad))
+        assert plan.kernel.startswith("winograd_f3x3") == (mode == "1")
+        plan.pack(w)
+        outs[mode] = plan.forward(x).clone()
+        if mode == "1":
+            x2 = torch.relu(torch.randn((N, Cin, H, W), device="cuda", generator=g))
+            lin = plan.forward(2 * x + x2).clone()
+            y2 = plan.forward(x2).clone()
+            err = ((lin - (2 * outs["1"] + y2)).abs() / torch.clamp((2 * outs["1"] + y2).abs(), min=1.0)).max().item()
+            assert err < 3e-4, err          # three independent roundings, at up to 3x the input scale
+            print(f"linearity err {err:.2e}")
+        torch.cuda.synchronize()
+    d, r = outs["1"].double(), outs["0"].double()
+    err = ((d - r).abs() / torch.clamp(r.abs(), min=1.0)).max().item()
+    print(f"winograd vs direct err {err:.2e}, |y|max {r.abs().max().item():.1f}")
+    assert err < 1e-4, err
+
+
 POOL_CASES = [   # N, Cin, H, W, Cout, winograd (0: direct igemm, 2: F(2x2,3x3), 3: F(3x3,3x3))
     (1, 40, 12, 24, 130, 3),      # F(3x3,3x3): 4 x 8 tiles -> 2 x 4 groups of 6x6 outputs
     (2, 24, 18, 36, 32, 3),       # F(3x3,3x3), batch 2
