@@ -38,6 +38,24 @@ def test_oracle_roipool_decode_layers(orc):
     assert np.array_equal(orc.deconv2d(G["conv_x"], orc.bilinear_filler((16, 1, 4, 4)), None, (1, 1), (2, 2), 16), G["deconv_y"])
 
 
+GB = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_layers_b.npz"))
+ALIGN_CASES = {"a": (7, 7, 0.125, 0.0), "b": (7, 7, 0.125, 0.25), "c": (4, 6, 0.25, 0.5)}
+
+
+def test_oracle_cascade_layers(orc):
+    """ROIAlign, Eltwise, AVE pooling, Softmax of the cascade / WiderFace deploys against the reference's own outputs
+    (tests/golden/make_golden_b.py)."""
+    for tag, (ph, pw, sc, pad) in ALIGN_CASES.items():
+        assert np.array_equal(orc.roialign(GB["roialign_feat"], GB["roialign_rois"], ph, pw, sc, pad), GB[f"roialign_{tag}"])
+    xs = [GB["elt_a"], GB["elt_b"], GB["elt_c"]]
+    assert np.array_equal(orc.eltwise(xs, "SUM"), GB["elt_sum"])
+    close(orc.eltwise(xs[:2], "SUM", [0.5, 0.5]), GB["elt_avg"], 1e-6)     # reference: MKL saxpy (fma) -> 1 ulp
+    assert np.array_equal(orc.eltwise(xs, "PROD"), GB["elt_prod"])
+    assert np.array_equal(orc.eltwise(xs, "MAX"), GB["elt_max"])
+    close(orc.pool2d(GB["ave_x"], (2, 2), (0, 0), (1, 1), "AVE"), GB["ave_y"], 1e-6)
+    close(orc.softmax(GB["softmax_x"]), GB["softmax_y"], 1e-6)
+
+
 # ---------------------------------------------------------------- GPU: HIP path vs reference outputs
 @pytest.fixture(scope="module")
 def hip():
@@ -77,3 +95,17 @@ def test_hip_roipool_decode_layers(hip):
     close(hip.inner_product(dev(G["ip_x"]), dev(G["ip_w"]), dev(G["conv_b"][:10])).cpu().numpy(), G["ip_y"])
     w = np.tile(np.outer([0.25, 0.75, 0.75, 0.25], [0.25, 0.75, 0.75, 0.25]).astype(np.float32), (16, 1, 1, 1))
     close(hip.deconv_depthwise(dev(G["conv_x"]), dev(w), None, (1, 1), (2, 2)).cpu().numpy(), G["deconv_y"], 1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_cascade_layers(hip):
+    for tag, (ph, pw, sc, pad) in ALIGN_CASES.items():
+        y = hip.roialign(dev(GB["roialign_feat"]), dev(GB["roialign_rois"]), ph, pw, sc, pad)
+        assert np.array_equal(y.cpu().numpy(), GB[f"roialign_{tag}"])
+    xs = [dev(GB["elt_a"]), dev(GB["elt_b"]), dev(GB["elt_c"])]
+    assert np.array_equal(hip.eltwise(xs, "SUM").cpu().numpy(), GB["elt_sum"])
+    close(hip.eltwise(xs[:2], "SUM", [0.5, 0.5]).cpu().numpy(), GB["elt_avg"], 1e-6)
+    assert np.array_equal(hip.eltwise(xs, "PROD").cpu().numpy(), GB["elt_prod"])
+    assert np.array_equal(hip.eltwise(xs, "MAX").cpu().numpy(), GB["elt_max"])
+    close(hip.pool2d(dev(GB["ave_x"]), (2, 2), (0, 0), (1, 1), "AVE").cpu().numpy(), GB["ave_y"], 1e-6)
+    close(hip.softmax(dev(GB["softmax_x"])).cpu().numpy(), GB["softmax_y"], 1e-6)
