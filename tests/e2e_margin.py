@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""End-to-end error of trunk / head blobs against the oracle's OWN run (errors accumulate through the layers), for A/B runs of
+the convolution paths on a GPU box -- not collected by pytest:
+
+    python tests/e2e_margin.py                                  # default: Winograd F(3x3,3x3)
+    MSCNN_WINOGRAD_PLANE_M=2 python tests/e2e_margin.py         # F(2x2,3x3)
+    MSCNN_WINOGRAD=0 python tests/e2e_margin.py                 # direct implicit GEMM only
+"""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import numpy as np
