@@ -16,8 +16,12 @@ using caffe::Net;
 struct mscnn_net {
   std::unique_ptr<Net<float> > net;
   int device;
-  caffe::DeviceBuffer det_ws, det_out, det_ids, det_cnt;
+  caffe::DeviceBuffer det_ws;
   caffe::DeviceBuffer img_in, img_ws;      // set_image: the uint8 frame and the resize scratch
+  caffe::DeviceBuffer det_pack;            // detect: [count | dets | ids] in one allocation -> ONE D2H copy, one sync
+  void* det_host = nullptr;                // pinned staging for that copy
+  size_t det_host_bytes = 0;
+  ~mscnn_net() { if (det_host) (void)hipHostFree(det_host); }
 };
 
 namespace {
@@ -226,19 +230,29 @@ int mscnn_net_detect(mscnn_net* n, const mscnn_detect_params* p, double* dets_ho
     d.ratio_h = p->ratio_h; d.ratio_w = p->ratio_w; d.org_h = p->org_h; d.org_w = p->org_w; d.nms_overlap = p->nms_overlap;
     const size_t wb = mscnn_detections_workspace_bytes(R);
     void* ws = n->det_ws.Reserve(wb);
-    double* dets = static_cast<double*>(n->det_out.Reserve(sizeof(double) * 5 * (size_t)(R > 0 ? R : 1)));
-    int* ids = static_cast<int*>(n->det_ids.Reserve(sizeof(int) * (size_t)(R > 0 ? R : 1)));
-    int* cnt = static_cast<int*>(n->det_cnt.Reserve(sizeof(int)));
+    // device layout: [int count, pad to 16 B][R x 5 doubles][R ints]
+    const size_t rows = (size_t)(R > 0 ? R : 1);
+    const size_t off_d = 16, off_i = off_d + sizeof(double) * 5 * rows, total = off_i + sizeof(int) * rows;
+    char* pack = static_cast<char*>(n->det_pack.Reserve(total));
+    int* cnt = reinterpret_cast<int*>(pack);
+    double* dets = reinterpret_cast<double*>(pack + off_d);
+    int* ids = reinterpret_cast<int*>(pack + off_i);
     hipStream_t st = (hipStream_t)Caffe::stream();
     MSCNN_CHECK(mscnn_detections_fwd(&d, bbox->gpu_data(), cls->gpu_data(), props->gpu_data(), R, dets, ids, cnt, ws, wb, st));
-    int D = 0;
-    HIP_CHECK(hipMemcpyAsync(&D, cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (n->det_host_bytes < total) {
+      if (n->det_host) HIP_CHECK(hipHostFree(n->det_host));
+      n->det_host = nullptr; n->det_host_bytes = 0;
+      HIP_CHECK(hipHostMalloc(&n->det_host, total, hipHostMallocDefault));
+      n->det_host_bytes = total;
+    }
+    HIP_CHECK(hipMemcpyAsync(n->det_host, pack, total, hipMemcpyDeviceToHost, st));      // <= 44 R + 16 bytes
     HIP_CHECK(hipStreamSynchronize(st));
+    const char* hp = static_cast<const char*>(n->det_host);
+    const int D = *reinterpret_cast<const int*>(hp);
     CHECK_LE(D, cap) << "detections buffer too small";
     if (D > 0) {
-      HIP_CHECK(hipMemcpyAsync(dets_host, dets, sizeof(double) * 5 * D, hipMemcpyDeviceToHost, st));
-      if (ids_host) HIP_CHECK(hipMemcpyAsync(ids_host, ids, sizeof(int) * D, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
+      std::memcpy(dets_host, hp + off_d, sizeof(double) * 5 * D);
+      if (ids_host) std::memcpy(ids_host, hp + off_i, sizeof(int) * D);
     }
     *num_dets = D;
     if (num_rois) *num_rois = R;
