@@ -238,7 +238,7 @@ static int detections_launch(const mscnn_detections_desc* desc, int cascade, flo
   hipStream_t st = as_stream(stream);
   char* ws = static_cast<char*>(workspace);
   int* cnt = reinterpret_cast<int*>(ws + L.cnt);
-  MSCNN_HIP_TRY(hipMemsetAsync(cnt, 0, DC_WORDS * sizeof(int), st));
+  // (cnt needs no clearing: det_transform_sort_kernel writes cnt[DC_N] unconditionally before anything reads it)
   if (R == 0) {
     MSCNN_HIP_TRY(hipMemsetAsync(count_out_dev, 0, sizeof(int), st));
     return MSCNN_OK;
