@@ -55,11 +55,24 @@ MSCNN_API const char* mscnn_version(void);
  * ------------------------------------------------------------------------------------------ */
 typedef struct mscnn_conv_plan mscnn_conv_plan;   /* opaque */
 
+typedef enum {
+  MSCNN_CONV_ALGO_AUTO = 0,     /* Winograd F(3x3,3x3) where the arithmetic-intensity heuristic says it pays, direct otherwise */
+  MSCNN_CONV_ALGO_DIRECT = 1,   /* never Winograd: the k-ordered implicit-GEMM sum (per-layer numerical fall-back) */
+  MSCNN_CONV_ALGO_WINO_F2 = 2,  /* F(2x2,3x3) on whole planes wherever it is legal (small ROI maps: F(3x3,3x3)) */
+  MSCNN_CONV_ALGO_WINO_F3 = 3   /* F(3x3,3x3) wherever it is legal */
+} mscnn_conv_algo;
+
 typedef struct {
   int N, Cin, H, W;          /* bottom shape */
   int Cout, Kh, Kw;
   int pad_h, pad_w, stride_h, stride_w, group;
   int relu;                  /* 1: apply max(x,0) in the epilogue (negative_slope 0) */
+  int algo;                  /* mscnn_conv_algo; shapes an algorithm does not cover fall back to the direct kernels */
+  /* Tuning knobs for A/B measurements (tools/bench_layers.py); 0 = the measured default.  None changes results beyond
+   * fp32 rounding.  tune_variant: igemm tile variant (value + 1, so that 0 keeps the default); tune_grid: workgroups of the
+   * persistent igemm / head kernels; tune_flags: bit 0 = no XCD-aware workgroup map, bit 1 = proposal heads on the 32-row
+   * igemm tile instead of the M = 4 head kernel, bit 2 = no phase-staggered first tile. */
+  int tune_variant, tune_grid, tune_flags;
 } mscnn_conv_desc;
 
 MSCNN_API int mscnn_conv2d_plan_create(const mscnn_conv_desc* desc, mscnn_conv_plan** plan_out);
@@ -69,8 +82,16 @@ MSCNN_API size_t mscnn_conv2d_packed_weight_bytes(const mscnn_conv_plan* plan);
 MSCNN_API size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* plan);
 /* "igemm_mfma_f32" | "direct_f32": which kernel family the plan selected. */
 MSCNN_API const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* plan);
-/* Algorithmic FLOPs (2*MACs) of one forward call, for roofline accounting. */
+/* Algorithmic FLOPs (2*MACs of the direct convolution the reference computes) of one forward call. */
 MSCNN_API double mscnn_conv2d_plan_flops(const mscnn_conv_plan* plan);
+/* FLOPs the MFMA pipe really executes for the real (unpadded) problem: equal to the algorithmic count for the direct
+ * kernels, 2 * planes * Cout * Cin * tiles for the Winograd forms (25/81 resp. 16/36 of it on exactly tiled planes). */
+MSCNN_API double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* plan);
+/* Roofline accounting: with profiling on, every forward brackets the plan's stages with HIP events on the call's stream;
+ * mscnn_conv2d_plan_stage_ms waits for the last forward and returns {input transform, MFMA GEMM kernel(s) incl. the
+ * stream-K fix-up, output transform} in milliseconds (direct / head kernels: {0, total, 0}). */
+MSCNN_API int mscnn_conv2d_plan_set_profiling(mscnn_conv_plan* plan, int on);
+MSCNN_API int mscnn_conv2d_plan_stage_ms(const mscnn_conv_plan* plan, float ms_out[3]);
 /* Re-shape a plan for a new batch size N (ROI count changes per image, layer.hpp:451-456). */
 MSCNN_API int mscnn_conv2d_plan_set_batch(mscnn_conv_plan* plan, int N);
 /* Identifies the packed-weight layout the plan currently expects (0: none, the kernel reads the Caffe layout).
@@ -113,6 +134,16 @@ MSCNN_API int mscnn_concat_channels_f32(const float* x, float* y, int N, int C, 
 MSCNN_API int mscnn_deconv_depthwise_fwd_f32(const float* x, const float* w, const float* bias, float* y,
                                    int N, int C, int H, int W, int Kh, int Kw, int pad_h, int pad_w,
                                    int stride_h, int stride_w, void* stream);
+
+/* Deconvolution, general case (any group / stride / pad; w[Cin][Cout/group][Kh][Kw], base_conv_layer.cpp:135-140 with
+ * reverse_dimensions()); routes the depthwise case to the kernel above. */
+MSCNN_API int mscnn_deconv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
+                                     int Cout, int Kh, int Kw, int pad_h, int pad_w, int stride_h, int stride_w, int group,
+                                     void* stream);
+
+/* out_dev[0] = max_i |a[i] - ref[i]| / max(floor, |ref[i]|) (+inf if any NaN): the parity metric of the test-suite on the
+ * device; used by the host runtime's per-layer numerical calibration (Winograd against the direct sum). */
+MSCNN_API int mscnn_max_rel_diff_f32(const float* a, const float* ref, size_t count, float floor, float* out_dev, void* stream);
 
 /* Softmax over axis 1 of x[outer][C][inner] -- SoftmaxLayer::Forward_gpu (softmax_layer.cu:83-120). */
 MSCNN_API int mscnn_softmax_fwd_f32(const float* x, float* y, int outer, int C, int inner, void* stream);

@@ -32,6 +32,10 @@ MSCNN_NET_API const char* mscnn_net_last_error(void);
  * device < 0 builds the graph without touching a device (shape / naming inspection only; forward then fails). */
 MSCNN_NET_API int mscnn_net_create_from_file(const char* prototxt_path, int device, mscnn_net** out);
 MSCNN_NET_API int mscnn_net_create_from_string(const char* prototxt_text, int device, mscnn_net** out);
+/* flags: MSCNN_NET_NO_FUSION builds the net without the Net-level operator fusion (every layer runs its own kernel, as in the
+ * reference; results are bit-identical, roi_pool_org / roi_pool_ctx style intermediate blobs are written eagerly). */
+#define MSCNN_NET_NO_FUSION 1
+MSCNN_NET_API int mscnn_net_create_from_string_ex(const char* prototxt_text, int device, unsigned flags, mscnn_net** out);
 MSCNN_NET_API void mscnn_net_destroy(mscnn_net* net);
 /* net.copy_from(caffemodel) -- Net::CopyTrainedLayersFrom, net.cpp:750-803 (binary NetParameter). */
 MSCNN_NET_API int mscnn_net_load_caffemodel(mscnn_net* net, const char* path);
@@ -54,6 +58,21 @@ MSCNN_NET_API const char* mscnn_net_layer_param_text(const mscnn_net* net, int l
 MSCNN_NET_API int mscnn_net_layer_fused_away(const mscnn_net* net, int layer);              /* 1: ReLU folded into its producer */
 MSCNN_NET_API const char* mscnn_net_layer_kernel(const mscnn_net* net, int layer);          /* conv kernel family, "" otherwise */
 MSCNN_NET_API double mscnn_net_layer_flops(const mscnn_net* net, int layer);                /* of the last forward */
+/* Roofline accounting of Convolution layers: FLOPs the MFMA pipe executes (Winograd forms: fewer than the algorithmic
+ * count above) and, with conv profiling on, the HIP-event time of the last forward split into {input transform, MFMA GEMM
+ * kernels, output transform} (direct kernels: {0, total, 0}); non-convolution layers report zeros. */
+MSCNN_NET_API double mscnn_net_layer_executed_flops(const mscnn_net* net, int layer);
+MSCNN_NET_API int mscnn_net_set_conv_profiling(mscnn_net* net, int on);
+MSCNN_NET_API int mscnn_net_layer_stage_ms(const mscnn_net* net, int layer, float ms_out[3]);
+/* Convolution algorithm of one layer (layer < 0: all): mscnn_conv_algo of include/mscnn_hip.h (0 auto, 1 direct,
+ * 2 / 3 Winograd F(2x2,3x3) / F(3x3,3x3) wherever legal); tuning knobs = mscnn_conv_desc::tune_* (A/B runs). */
+MSCNN_NET_API int mscnn_net_set_conv_algo(mscnn_net* net, int layer, int algo);
+MSCNN_NET_API int mscnn_net_set_conv_tuning(mscnn_net* net, int layer, int variant, int grid, int flags);
+/* Numerical calibration (call after a forward on representative input): every Winograd convolution is re-computed with the
+ * direct k-ordered kernel on the same bottom; layers whose max |dy| / max(1, |y|) exceeds tol run the direct kernel from
+ * then on.  *num_switched = how many; mscnn_net_layer_calibration_err gives each layer's measured value. */
+MSCNN_NET_API int mscnn_net_calibrate_numerics(mscnn_net* net, double tol, int* num_switched);
+MSCNN_NET_API double mscnn_net_layer_calibration_err(const mscnn_net* net, int layer);
 MSCNN_NET_API int mscnn_net_num_blobs(const mscnn_net* net);
 MSCNN_NET_API const char* mscnn_net_blob_name(const mscnn_net* net, int blob);
 MSCNN_NET_API int mscnn_net_blob_shape(const mscnn_net* net, const char* name, int* dims8, int* ndim);

@@ -1,4 +1,5 @@
 #include "common.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace mscnn {
@@ -9,7 +10,13 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+#ifdef MSCNN_TUNING_ENV
+int tune_env(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e && *e ? std::atoi(e) : dflt;
+}
+#endif
 }  // namespace mscnn
 
 extern "C" const char* mscnn_last_error(void) { return mscnn::g_err; }
-extern "C" const char* mscnn_version(void) { return "mscnn_hip 0.1 gfx950"; }
+extern "C" const char* mscnn_version(void) { return "mscnn_hip 0.2 gfx950"; }

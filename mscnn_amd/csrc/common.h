@@ -34,4 +34,12 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Tuning knobs come from the descriptors (mscnn_conv_desc::tune_*).  Only a debug build (make EXTRA=-DMSCNN_TUNING_ENV)
+// lets an environment variable override them for quick A/B runs; the product library never reads the environment.
+#ifdef MSCNN_TUNING_ENV
+int tune_env(const char* name, int dflt);
+#else
+inline int tune_env(const char*, int dflt) { return dflt; }
+#endif
+
 }  // namespace mscnn

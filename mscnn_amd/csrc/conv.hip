@@ -26,7 +26,6 @@
 #include "common.h"
 #include "headconv.h"
 #include "winograd.h"
-#include <cstdlib>
 #include <new>
 #include <type_traits>
 
@@ -45,7 +44,9 @@ struct IgemmArgs {
   unsigned w_img_bytes;  // per-image weight stride in bytes (0: one weight set; Winograd GEMM: one U matrix per "image")
   int full_q;          // whole tiles per workgroup in the data-parallel phase (tile t = g + j * G, j < full_q)
   long total_iters;    // iterations (tile, chunk) of the stream-K phase: the remaining tiles [full_q * G, MT * NT)
+  int stagger;         // > 1: workgroups co-resident on a CU start their first tile at different chunks (see igemm_kernel)
 };
+constexpr int kSlabsPerWg = 3;   // stream-K tail partial, stream-K head partial, staggered first tile
 
 // Tile configuration.  Two geometries share one kernel:
 //   plane mode (RH == 0): the N side of a tile is a TH x TW patch of one image's output plane (trunk, heads);
@@ -61,6 +62,9 @@ struct Cfg {
   static constexpr int F4_PER_CH = BN_ / 4;                 // float4s per channel row of the B tile (tile = BN contiguous pixels)
   static constexpr int CH_PER_PASS = 256 / F4_PER_CH;       // channels staged per pass of the 256 threads
   static constexpr int BV_PER_T = CK_ * F4_PER_CH / 256;
+  // phase-staggered first tile (see igemm_kernel).  Compiled in only where it costs no occupancy: the 128x128 3x3 kernels
+  // sit at 167 VGPRs = 3 waves / SIMD and the extra segment state would push them to 181 = 2 waves.
+  static constexpr bool STAGGER = RH_ == 0 && (VEC_ != 0 || (BM_ == 64 && BN_ == 256));
   static constexpr int PF = PF_;   // 1: LDS operand reads software-pipelined one MFMA group ahead
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, KH = KH_, KW = KW_, CK = CK_, TW = TW_;
   static constexpr bool ROI = RH_ > 0;
@@ -222,6 +226,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   wg_range(a.total_iters, a.G, wg, it, it_end);
   int full_j = 0;
   const int rem_tile0 = a.full_q * a.G;
+  // Phase stagger.  Every workgroup does identical work, so the 2-3 workgroups that share a CU (dispatch order: blocks b,
+  // b + 256, b + 512) would run in lockstep: all in their K loops together, then all in the epilogue / next prologue together
+  // with the matrix pipe idle (ablation: epilogue 8 % + prologue 13 % of the 25-plane GEMMs).  Workgroups of "slot" s > 0
+  // therefore start their FIRST tile at chunk KI * s / slots (partial -> own slab), and finish chunks [0, KI * s / slots) of
+  // that tile as their LAST segment, adding their own slab back (same thread, same addresses: program order suffices).
+  // The sum is still a fixed function of (shape, grid): deterministic, within fp32 rounding of the unsplit chain.
+  int stag_ks = 0, stag_state = 0;       // state 0: first part pending, 1: running the other segments, 2: done
+  if (C::STAGGER && a.stagger > 1 && a.full_q > 0) {
+    const int slot = (int)(blockIdx.x / 256) % a.stagger;
+    stag_ks = a.KI * slot / a.stagger;
+  }
 
   // per-lane LDS read bases (floats)
   const float* aRd = ldsA + khalf * C::BM + wm * C::WM + l31;
@@ -239,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 
   // ---- segment state: the segment whose first chunk is in flight / being multiplied --------------------------------------
   int t = 0, k0 = 0, k1 = 0, mt = 0;
+  int seg_kind = 0;                // 0: ordinary, 1: staggered first part (-> own slab), 2: staggered last part (+ own slab)
   TileGeo<C> geo;
   __amdgpu_buffer_rsrc_t xsrc = wsrc;
   unsigned g_off[C::B_PER_T];      // byte offsets of this thread's patch elements (channel-chunk term = scalar offset of the load)
@@ -251,14 +267,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   const unsigned a_voff = (unsigned)tid * 16u;
 
   auto next_segment = [&]() -> bool {
-    if (full_j < a.full_q) {
-      t = wg + full_j * a.G; k0 = 0; k1 = a.KI;
+    if (C::STAGGER && stag_ks > 0 && stag_state == 0) {
+      t = wg; k0 = stag_ks; k1 = a.KI; seg_kind = 1;
+      stag_state = 1; full_j = 1;
+    } else if (full_j < a.full_q) {
+      t = wg + full_j * a.G; k0 = 0; k1 = a.KI; seg_kind = 0;
       ++full_j;
     } else if (it < it_end) {
+      seg_kind = 0;
       t = rem_tile0 + (int)(it / a.KI);
       k0 = (int)(it % a.KI);
       k1 = (int)min((long)a.KI, k0 + (it_end - it));
       it += (k1 - k0);
+    } else if (C::STAGGER && stag_ks > 0 && stag_state == 1) {
+      t = wg; k0 = 0; k1 = stag_ks; seg_kind = 2;
+      stag_state = 2;
     } else {
       return false;
     }
@@ -315,12 +338,27 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       MSCNN_LOAD_CHUNK(k0);
     }
     f32x16 acc[C::MI][C::NI];
+    float* own_slab = a.ws + ((long)wg * kSlabsPerWg + 2) * (C::BM * C::BN);
+    if (C::STAGGER && seg_kind == 2) {          // staggered last part: the accumulators start from the first part parked in this workgroup's slab
+      const __amdgpu_buffer_rsrc_t ssrc = make_rsrc(own_slab, (unsigned)(C::BM * C::BN) * 4u);
 #pragma unroll
-    for (int mi = 0; mi < C::MI; ++mi)
+      for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < C::NI; ++ni)
+        for (int ni = 0; ni < C::NI; ++ni) {
+          const unsigned vo = (unsigned)((wm * C::WM + mi * 32 + 4 * khalf) * C::BN + wn * C::WN + ni * 32 + l31) * 4u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+          for (int r = 0; r < 16; ++r)
+            acc[mi][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           ssrc, vo, (unsigned)(((r & 3) + 8 * (r >> 2)) * C::BN) * 4u, 0));
+        }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    }
 
     // This segment's identity (the epilogue needs it after the segment state has moved on).  PREFETCH_NEXT kernels (the 1x1
     // Winograd GEMMs: K = Cin only, so a tile is short and its prologue shows): while the LAST chunk is multiplied, the NEXT
@@ -328,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     // behind that chunk's MFMAs and the epilogue's stores.  (Costs registers in the epilogue: for the 3x3 kernels it would
     // take one workgroup of occupancy -- measured slower -- so they fetch it after the epilogue.)
     const TileGeo<C> geo_e = geo;
-    const int t_e = t, k0_e = k0, k1_e = k1, mt_e = mt;
+    const int t_e = t, k0_e = k0, k1_e = k1, mt_e = mt, kind_e = seg_kind;
     more = false;
     for (int kc = k0_e; kc < k1_e; ++kc) {
       if (C::PF == 2) __builtin_amdgcn_s_setprio(3);   // staging phase: get through the barriers quickly
@@ -406,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     const TileGeo<C>& geo = geo_e;
     const int t = t_e, k0 = k0_e, k1 = k1_e, mt = mt_e;
     (void)t;
-    const bool full = (k0 == 0 && k1 == a.KI);
+    const bool full = (k0 == 0 && k1 == a.KI) || (C::STAGGER && kind_e == 2);
     if (C::PF >= 14 && full) {
       if (acc[0][0][0] == 12345.678f) a.y[tid] = acc[0][0][1];     // ablation: no epilogue (keeps acc live)
     } else if (full) {
@@ -465,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         }
       }
     } else {
-      float* slab = a.ws + ((long)wg * 2 + (k0 > 0 ? 0 : 1)) * (C::BM * C::BN);
+      float* slab = (C::STAGGER && kind_e == 1) ? own_slab : a.ws + ((long)wg * kSlabsPerWg + (k0 > 0 ? 0 : 1)) * (C::BM * C::BN);
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
@@ -487,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 // contributing slabs is resolved once per workgroup (the 64-bit range arithmetic is kept out of the element loop).
 template <class C>
 __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
-  __shared__ const float* s_slab[256];   // a tile has at most KI <= 256 contributors
+  __shared__ const float* s_slab[256];   // a tile has at most KI contributors; the plan refuses KI > 256 (plan_shape)
   __shared__ int s_n;
   const int tr = blockIdx.x / C::FIX_SPLIT, part = blockIdx.x % C::FIX_SPLIT;   // tr: index among the stream-K tiles
   const int t = a.full_q * a.G + tr;
@@ -506,7 +544,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
       for (int g = gf; g <= gl && n < 256; ++g) {
         wg_range(a.total_iters, a.G, g, b, e);
         if (e <= b) continue;   // empty range: this workgroup contributed nothing
-        s_slab[n++] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * (C::BM * C::BN);
+        s_slab[n++] = a.ws + ((long)g * kSlabsPerWg + (b > its ? 0 : 1)) * (C::BM * C::BN);
       }
     }
     s_n = n;
@@ -566,7 +604,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_pool_kernel(IgemmArgs a) {
       for (int g = gf; g <= gl && n < 256; ++g) {
         wg_range(a.total_iters, a.G, g, b, e);
         if (e <= b) continue;
-        s_slab[n++] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * (C::BM * C::BN);
+        s_slab[n++] = a.ws + ((long)g * kSlabsPerWg + (b > its ? 0 : 1)) * (C::BM * C::BN);
       }
     }
     s_n = n;
@@ -742,7 +780,15 @@ struct mscnn_conv_plan {
   mscnn_conv_plan* wino = nullptr;
   int wino_m = 2;        // output tile edge: 2 = F(2x2,3x3) (16 planes), 3 = F(3x3,3x3) (25 planes; small ROI maps)
   int tiles_h = 0, tiles_w = 0, T_pad = 0;
-  ~mscnn_conv_plan() { delete wino; }
+  int stagger = 0;       // igemm: co-resident workgroup slots whose first tile is phase-shifted (0 / 1: off)
+  // roofline accounting (mscnn_conv2d_plan_set_profiling): events around {input transform | GEMM | output transform}
+  bool profiling = false;
+  mutable hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  mutable bool ev_valid = false;
+  ~mscnn_conv_plan() {
+    delete wino;
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+  }
 };
 
 using namespace mscnn;
@@ -753,13 +799,14 @@ static void plan_shape(mscnn_conv_plan* p);
 // of the transforms (V and M are 4x / 2.78x the input / output and are written and read once each): GEMM FLOPs per transform
 // byte grow with Cin * Cout / (Cin + Cout).  F(2x2,3x3) numbers:  Measured on MI355X: conv2_2 (64) 706 vs 640 us direct, conv3_1 (85) 329 vs 332, conv3_2 (128) 503 vs 614, conv4_1 (171) 250 vs 346,
 // conv4_2 (256) 407 vs 617 -> threshold 100.
-// MSCNN_WINOGRAD=0 disables the path, =2 forces it wherever it is legal (tests).
+// desc.algo: DIRECT disables the path, WINO_F2 / WINO_F3 force that form wherever it is legal (tests, A/B runs, and the
+// per-layer numerical fall-back of the host runtime: Net::CalibrateNumerics).
 static bool wino_plan(mscnn_conv_plan* p) {
   const mscnn_conv_desc& d = p->d;
-  const char* menv = std::getenv("MSCNN_WINOGRAD");      // read per plan: the tests switch it
-  const int mode = menv ? std::atoi(menv) : 1;
-  if (mode == 0 || d.Kh != 3 || d.Kw != 3 || d.stride_h != 1 || d.stride_w != 1 || d.group != 1) return false;
+  const int algo = tune_env("MSCNN_CONV_ALGO", d.algo);
+  if (algo == MSCNN_CONV_ALGO_DIRECT || d.Kh != 3 || d.Kw != 3 || d.stride_h != 1 || d.stride_w != 1 || d.group != 1) return false;
   if (p->Ho < 2 || p->Wo < 2) return false;
+  const bool force = algo == MSCNN_CONV_ALGO_WINO_F2 || algo == MSCNN_CONV_ALGO_WINO_F3;
   const double intensity = (double)d.Cin * d.Cout / (d.Cin + d.Cout);
   // small maps (the ROI-pooled 7x7 / 7x5 / 8x4 inputs of roi_c1): F(3x3,3x3) -- a 5x5 output is 2x2 tiles x 25 multiplies
   // instead of 225 (measured 1293 -> see DESIGN.md); larger planes: F(2x2,3x3)
@@ -767,11 +814,10 @@ static bool wino_plan(mscnn_conv_plan* p) {
   // whole planes: F(3x3,3x3) as well (3.24x fewer multiplies, planes 2.78x the tensor instead of 4x; measured conv3_2 380 vs
   // 481 us with F(2x2,3x3), conv4_2 304 vs 389, conv5_1 107 vs 125, and the same end-to-end error, 3e-5).
   // Threshold for F(3x3,3x3): conv2_2 (intensity 64) 523 vs 642 us direct, conv2_1 (43) 375 vs 383 (tie -> direct), conv1_2
-  // (32) 1175 vs 762.  MSCNN_WINOGRAD_PLANE_M=2 selects F(2x2,3x3) for A/B runs and tests.
-  const char* m3env = std::getenv("MSCNN_WINOGRAD_PLANE_M");
-  const int m = (roi_map || !(m3env && std::atoi(m3env) == 2)) ? 3 : 2, planes = m == 3 ? 25 : 16;
-  if (mode != 2 && (intensity < (m == 3 ? 60.0 : 100.0) || (!roi_map && d.H * d.W < 256))) return false;
-  if (roi_map && (mode == 3 || d.N < 8)) return false;          // MSCNN_WINOGRAD=3: F(2x2,3x3) layers only
+  // (32) 1175 vs 762.  WINO_F2 selects F(2x2,3x3) on planes for A/B runs and tests.
+  const int m = (roi_map || algo != MSCNN_CONV_ALGO_WINO_F2) ? 3 : 2, planes = m == 3 ? 25 : 16;
+  if (!force && (intensity < (m == 3 ? 60.0 : 100.0) || (!roi_map && d.H * d.W < 256))) return false;
+  if (roi_map && d.N < 8) return false;
   const int th = cdiv(p->Ho, m), tw = cdiv(p->Wo, m);
   const long T = (long)d.N * th * tw;
   const long T_pad = (T + 127) / 128 * 128;
@@ -780,6 +826,7 @@ static bool wino_plan(mscnn_conv_plan* p) {
   if (!g) return false;
   g->d = d;
   g->d.N = planes; g->d.H = (int)(T_pad / 128); g->d.W = 128; g->d.Kh = g->d.Kw = 1; g->d.pad_h = g->d.pad_w = 0; g->d.relu = 0;
+  g->d.algo = MSCNN_CONV_ALGO_DIRECT;
   plan_shape(g);
   if (g->entry < 0 || g->wino || g->head.entry >= 0) { delete g; return false; }
   p->wino_m = m;
@@ -798,6 +845,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->packed_bytes = 0;
   p->ws_bytes = 0;
   p->head.entry = -1;
+  p->stagger = 0;
   if (head_plan(d, p->Ho, p->Wo, &p->head)) {
     p->packed_bytes = p->head.packed_bytes;
     p->ws_bytes = p->head.ws_bytes;
@@ -811,9 +859,11 @@ static void plan_shape(mscnn_conv_plan* p) {
   const double win_x = (double)d.Cin * d.H * d.W * 4.0, win_y = (double)d.Cout * p->Ho * p->Wo * 4.0;
   // choose the table entry with the least padded work; an ROI-mode entry wins whenever it matches the image shape
   double best = 1e300;
-  const char* venv = std::getenv("MSCNN_IGEMM_VARIANT");     // tuning knob: 0 baseline, 1 pipelined LDS reads, 2 128x256 tiles
+  // tune_variant (value + 1): 0 baseline, 1 pipelined LDS reads, 2 128x256 tiles; 1x1 kernels: 0 generic, 101.. vectorised
+  const int tv = tune_env("MSCNN_TUNE_VARIANT", d.tune_variant);
+  const bool venv = tv > 0 && d.Kh == 3 && d.Kw == 3;
   // default: pipelined LDS reads for the 128-row tiles (+1..3 % measured on conv2_2..conv4_3), baseline for Cout = 64
-  const int want = venv ? std::atoi(venv) : (d.Cout >= 128 ? 1 : 0);
+  const int want = venv ? tv - 1 : (d.Cout >= 128 ? 1 : 0);
   for (int i = 0; i < kTableN; ++i) {
     const KernelEntry& k = kTable[i];
     if (k.KH != d.Kh || k.KW != d.Kw) continue;
@@ -824,10 +874,9 @@ static void plan_shape(mscnn_conv_plan* p) {
     }
     if (k.KH == 1 && k.KW == 1) {
       const bool rows128 = d.W == 128 && d.pad_h == 0 && d.pad_w == 0;        // Winograd GEMM operand planes
-      const char* e1 = std::getenv("MSCNN_GEMM1X1_VARIANT");                  // tuning knob: 0 generic, 101 / 102 vectorised
       // measured on the F(3x3,3x3) GEMMs of mscnn-7s-576 (25 planes; conv3_2 / conv4_2 / conv5_1, us per layer, G = 512):
       // 128x128 CK 32 (101): 362 / 292 / 100;  128x128 CK 64 (102): 377 / 307 / 107;  128x256 CK 32 (103): 381 / 324 / 105
-      const int want1 = !rows128 ? 0 : (e1 ? std::atoi(e1) : 101);
+      const int want1 = !rows128 ? 0 : (tv > 0 ? tv - 1 : 101);
       if (k.variant != want1) continue;
     }
     double cost;
@@ -855,10 +904,11 @@ static void plan_shape(mscnn_conv_plan* p) {
     p->NT = d.N * p->NTH * p->NTW;
   }
   p->KI = cdiv(d.Cin, k.CK);
+  if (p->KI > 256) { p->entry = -1; return; }   // the fix-up kernels list at most 256 contributing slabs per tile: use the direct kernel
   const long tiles = (long)p->MT * p->NT;
   // grid: G workgroups (default 2 per CU; 3 for the 128x128 tiles whose 43 KB of LDS and 168 VGPRs allow it)
-  const char* genv = std::getenv("MSCNN_SK_WGS");            // tuning knob
-  long G = genv ? std::atol(genv) : ((k.BM == 128 && k.BN == 128 && k.KH == 3) ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
+  const int genv = tune_env("MSCNN_TUNE_GRID", d.tune_grid);   // tuning knob
+  long G = genv > 0 ? genv : ((k.BM == 128 && k.BN == 128 && k.KH == 3) ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
   if (tiles * p->KI / 4 < G) G = tiles * p->KI / 4;         // never less than ~4 chunks per workgroup
   if (G < 1) G = 1;
   // A slightly smaller grid that divides the tile count exactly needs no stream-K phase and no fix-up launch at all (the 25
@@ -877,7 +927,13 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->full_q = (int)(tiles / G);                               // data-parallel phase
   p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
   p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * sizeof(float);
-  p->ws_bytes = (size_t)p->G * 2 * k.BM * k.BN * sizeof(float);
+  p->ws_bytes = (size_t)p->G * kSlabsPerWg * k.BM * k.BN * sizeof(float);
+  // phase stagger (igemm_kernel): one slot per workgroup that shares a CU; only worth it when a workgroup has several
+  // whole tiles of several chunks each
+  const int flags = tune_env("MSCNN_TUNE_FLAGS", d.tune_flags);
+  const int slots = (int)((G + 255) / 256);
+  const bool can_stagger = k.RH == 0 && (k.variant >= 101 || (k.BM == 64 && k.BN == 256));      // == Cfg::STAGGER
+  p->stagger = (can_stagger && !(flags & 4) && slots > 1 && p->full_q >= 2 && p->KI >= 2 * slots) ? slots : 0;
 }
 
 extern "C" int mscnn_conv2d_plan_create(const mscnn_conv_desc* desc, mscnn_conv_plan** plan_out) {
@@ -918,6 +974,30 @@ extern "C" double mscnn_conv2d_plan_flops(const mscnn_conv_plan* p) {
   const mscnn_conv_desc& d = p->d;
   return 2.0 * d.N * d.Cout * p->Ho * p->Wo * (double)(d.Cin / d.group) * d.Kh * d.Kw;
 }
+extern "C" double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* p) {
+  if (!p) return 0;
+  if (!p->wino) return mscnn_conv2d_plan_flops(p);
+  const mscnn_conv_desc& d = p->d;
+  const double planes = p->wino_m == 3 ? 25.0 : 16.0;
+  return 2.0 * planes * d.Cout * d.Cin * ((double)d.N * p->tiles_h * p->tiles_w);
+}
+extern "C" int mscnn_conv2d_plan_set_profiling(mscnn_conv_plan* p, int on) {
+  MSCNN_REQUIRE(p, "conv plan: null");
+  p->profiling = on != 0;
+  p->ev_valid = false;
+  if (p->profiling)
+    for (hipEvent_t& e : p->ev)
+      if (!e) MSCNN_HIP_TRY(hipEventCreate(&e));
+  return MSCNN_OK;
+}
+extern "C" int mscnn_conv2d_plan_stage_ms(const mscnn_conv_plan* p, float ms_out[3]) {
+  MSCNN_REQUIRE(p && ms_out, "conv plan: null");
+  ms_out[0] = ms_out[1] = ms_out[2] = 0.f;
+  MSCNN_REQUIRE(p->profiling && p->ev_valid, "conv plan: no profiled forward yet (mscnn_conv2d_plan_set_profiling)");
+  MSCNN_HIP_TRY(hipEventSynchronize(p->ev[3]));
+  for (int i = 0; i < 3; ++i) MSCNN_HIP_TRY(hipEventElapsedTime(&ms_out[i], p->ev[i], p->ev[i + 1]));
+  return MSCNN_OK;
+}
 extern "C" int mscnn_conv2d_plan_set_batch(mscnn_conv_plan* p, int N) {
   MSCNN_REQUIRE(p && N >= 0, "conv plan: bad batch");
   p->d.N = N;
@@ -956,7 +1036,7 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
   const KernelEntry& k = kTable[p->entry];
   const long rem_tiles = (long)p->MT * p->NT - (long)p->full_q * p->G;
   const bool split = rem_tiles > 0;
-  if (split) {
+  if (split || p->stagger > 1) {
     if (!workspace || workspace_bytes < p->ws_bytes) {
       set_error("conv: workspace %zu < %zu", workspace_bytes, p->ws_bytes);
       return MSCNN_ERR_WORKSPACE;
@@ -968,12 +1048,13 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
   a.MT = p->MT; a.NTH = p->NTH; a.NTW = p->NTW; a.NT = p->NT; a.KI = p->KI; a.G = p->G; a.relu = d.relu;
   a.total_iters = p->total_iters; a.full_q = p->full_q;
   a.w_img_bytes = w_img_bytes; a.nt_major = nt_major;
+  a.stagger = p->stagger;
   a.yp = y_pool; a.Hp = (p->Ho + 1) / 2; a.Wp = (p->Wo + 1) / 2;
   if (y_pool && !k.fix_pool_fn) {
     set_error("conv: kernel %s has no fused pooling epilogue", k.name);
     return MSCNN_ERR_BAD_ARG;
   }
-  { static const bool noxcd = [] { const char* e = std::getenv("MSCNN_SK_NOXCD"); return e && *e == '1'; }(); a.xcd_map = noxcd ? 0 : 1; }
+  a.xcd_map = (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 1) ? 0 : 1;
   k.main_fn<<<p->G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   if (split) {
@@ -989,6 +1070,9 @@ extern "C" int mscnn_conv2d_plan_can_pool(const mscnn_conv_plan* p) {
   return p->entry >= 0 && kTable[p->entry].fix_pool_fn != nullptr;
 }
 
+static int conv_forward_single(const mscnn_conv_plan* p, const float* x, const float* w, const float* packed, const float* bias,
+                               float* y, float* y_pool, void* workspace, size_t workspace_bytes, hipStream_t st);
+
 extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, const float* w, const float* packed,
                                     const float* bias, float* y, void* workspace, size_t workspace_bytes, void* stream) {
   return mscnn_conv2d_fwd_pool_f32(p, x, w, packed, bias, y, nullptr, workspace, workspace_bytes, stream);
@@ -1003,11 +1087,16 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
   if (d.N == 0) return MSCNN_OK;
   MSCNN_REQUIRE(x && y, "conv: null pointer");
   hipStream_t st = as_stream(stream);
-  if (p->head.entry >= 0) {
-    MSCNN_REQUIRE(packed, "conv: head kernel needs packed weights (mscnn_conv2d_pack_weights)");
-    return head_forward(d, p->head, p->Ho, p->Wo, x, packed, bias, y, workspace, workspace_bytes, st);
+#define MSCNN_STAGE_EVENT(i) do { if (p->profiling) MSCNN_HIP_TRY(hipEventRecord(p->ev[i], st)); } while (0)
+  if (!p->wino) {        // one-stage kernels: {0, total, 0}
+    MSCNN_STAGE_EVENT(0); MSCNN_STAGE_EVENT(1);
+    const int rc = conv_forward_single(p, x, w, packed, bias, y, y_pool, workspace, workspace_bytes, st);
+    if (rc != MSCNN_OK) return rc;
+    MSCNN_STAGE_EVENT(2); MSCNN_STAGE_EVENT(3);
+    p->ev_valid = p->profiling;
+    return MSCNN_OK;
   }
-  if (p->wino) {
+  {
     MSCNN_REQUIRE(packed, "conv: Winograd path needs packed weights (mscnn_conv2d_pack_weights)");
     if (!workspace || workspace_bytes < p->ws_bytes) {
       set_error("conv(winograd): workspace %zu < %zu", workspace_bytes, p->ws_bytes);
@@ -1018,11 +1107,29 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
     float* V = static_cast<float*>(workspace);
     float* M = V + planes * d.Cin * p->T_pad;
     float* gws = M + planes * d.Cout * p->T_pad;
+    MSCNN_STAGE_EVENT(0);
     int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st);
     if (rc != MSCNN_OK) return rc;
+    MSCNN_STAGE_EVENT(1);
     rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
     if (rc != MSCNN_OK) return rc;
-    return wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st);
+    MSCNN_STAGE_EVENT(2);
+    rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st);
+    if (rc != MSCNN_OK) return rc;
+    MSCNN_STAGE_EVENT(3);
+    p->ev_valid = p->profiling;
+    return MSCNN_OK;
+  }
+#undef MSCNN_STAGE_EVENT
+}
+
+// Head / direct / igemm forward (everything except the three-stage Winograd path).
+static int conv_forward_single(const mscnn_conv_plan* p, const float* x, const float* w, const float* packed, const float* bias,
+                               float* y, float* y_pool, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const mscnn_conv_desc& d = p->d;
+  if (p->head.entry >= 0) {
+    MSCNN_REQUIRE(packed, "conv: head kernel needs packed weights (mscnn_conv2d_pack_weights)");
+    return head_forward(d, p->head, p->Ho, p->Wo, x, packed, bias, y, workspace, workspace_bytes, st);
   }
   if (p->entry < 0) {
     MSCNN_REQUIRE(w, "conv: direct kernel needs the Caffe-layout weights");

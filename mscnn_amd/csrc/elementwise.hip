@@ -189,9 +189,82 @@ __global__ __launch_bounds__(kThreads) void eltwise_kernel(EltArgs a, float* __r
   }
 }
 
+// ---- generic transposed convolution (any group / stride / pad), one output element per thread: gathers the taps
+// (kh, kw) whose input position is integral, sums the group's input channels per tap (deconv_layer.cpp:8-40 computes
+// col = W^T x per image and scatters it with col2im; same sum, different order -> 1e-4 class like every conv).
+__global__ __launch_bounds__(kThreads) void deconv_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, float* __restrict__ y, int N,
+                                                                  int Cin, int H, int W, int Cout, int Ho, int Wo, int Kh, int Kw,
+                                                                  int ph, int pw, int sh, int sw, int group) {
+  const long total = (long)N * Cout * Ho * Wo;
+  const int cig = Cin / group, cog = Cout / group;
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+    const int ow = (int)(i % Wo);
+    long r = i / Wo;
+    const int oh = (int)(r % Ho); r /= Ho;
+    const int co = (int)(r % Cout);
+    const int n = (int)(r / Cout);
+    const int g = co / cog, col = co % cog;
+    float acc = 0.f;
+    for (int kh = 0; kh < Kh; ++kh) {
+      const int th = oh + ph - kh;
+      if (th < 0 || th % sh != 0 || th / sh >= H) continue;
+      for (int kw = 0; kw < Kw; ++kw) {
+        const int tw = ow + pw - kw;
+        if (tw < 0 || tw % sw != 0 || tw / sw >= W) continue;
+        const float* xp = x + (((long)n * Cin + g * cig) * H + th / sh) * W + tw / sw;
+        const float* wp = w + (((long)(g * cig) * cog + col) * Kh + kh) * Kw + kw;      // w[Cin][Cout/g][Kh][Kw]
+        for (int c = 0; c < cig; ++c) acc += xp[(long)c * H * W] * wp[(long)c * cog * Kh * Kw];
+      }
+    }
+    if (bias) acc += bias[co];
+    y[i] = acc;
+  }
+}
+
+// ---- max_i |a_i - ref_i| / max(floor, |ref_i|): the parity metric of the tests, on the device (Net::CalibrateNumerics).
+// Non-negative floats order like their bit patterns, so the reduction is an integer atomicMax; NaN anywhere -> +inf.
+__global__ __launch_bounds__(kThreads) void max_rel_diff_kernel(const float* __restrict__ a, const float* __restrict__ ref, long n,
+                                                                float floor_, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    const float r = ref[i], d = fabsf(a[i] - r) / fmaxf(floor_, fabsf(r));
+    m = (d != d) ? __builtin_inff() : fmaxf(m, d);
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 }  // namespace
 
 using namespace mscnn;
+
+extern "C" int mscnn_max_rel_diff_f32(const float* a, const float* ref, size_t count, float floor_, float* out_dev, void* stream) {
+  MSCNN_REQUIRE(out_dev && (count == 0 || (a && ref)) && floor_ > 0.f, "max_rel_diff: bad argument");
+  MSCNN_HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float), as_stream(stream)));
+  if (count == 0) return MSCNN_OK;
+  max_rel_diff_kernel<<<grid_for((long)count), kThreads, 0, as_stream(stream)>>>(a, ref, (long)count, floor_,
+                                                                                 reinterpret_cast<unsigned*>(out_dev));
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+extern "C" int mscnn_deconv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
+                                      int Cout, int Kh, int Kw, int pad_h, int pad_w, int stride_h, int stride_w, int group,
+                                      void* stream) {
+  MSCNN_REQUIRE(x && w && y, "deconv: null pointer");
+  MSCNN_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && Kh > 0 && Kw > 0 && stride_h > 0 && stride_w > 0 && group > 0,
+                "deconv: bad shape");
+  MSCNN_REQUIRE(Cin % group == 0 && Cout % group == 0, "deconv: channels not divisible by group");
+  if (group == Cin && Cout == Cin)      // depthwise (the bilinear 2x up-sampling of the "-2x" nets): its own kernel
+    return mscnn_deconv_depthwise_fwd_f32(x, w, bias, y, N, Cin, H, W, Kh, Kw, pad_h, pad_w, stride_h, stride_w, stream);
+  const int Ho = stride_h * (H - 1) + Kh - 2 * pad_h, Wo = stride_w * (W - 1) + Kw - 2 * pad_w;
+  MSCNN_REQUIRE(Ho > 0 && Wo > 0, "deconv: empty output");
+  deconv_generic_kernel<<<grid_for((long)N * Cout * Ho * Wo), kThreads, 0, as_stream(stream)>>>(
+      x, w, bias, y, N, Cin, H, W, Cout, Ho, Wo, Kh, Kw, pad_h, pad_w, stride_h, stride_w, group);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
 
 extern "C" int mscnn_eltwise_fwd_f32(const float* const* bottoms_host, int num_bottoms, const float* coeffs_host, float* y,
                                      size_t count, int op, void* stream) {

@@ -323,7 +323,7 @@ constexpr int kHeadsN = sizeof(kHeads) / sizeof(kHeads[0]);
 namespace mscnn {
 
 bool head_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp) {
-  static const bool off = [] { const char* e = std::getenv("MSCNN_HEAD_IGEMM"); return e && *e == '1'; }();   // A/B switch
+  const bool off = (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 2) != 0;   // A/B switch: heads on the 32-row igemm tile
   hp->entry = -1;
   if (off || d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0 || d.Cout > 12 || d.Cin > 1024) return false;
   if ((double)d.Cin * d.H * d.W * 4.0 >= 2.0e9 || (double)d.Cout * Ho * Wo * 4.0 >= 2.0e9) return false;
@@ -337,8 +337,8 @@ bool head_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp) {
   hp->KI = cdiv(d.Cin, k.CK);       // <= 256 contributors per tile (fix-up slab list)
   const long tiles = (long)d.N * hp->NTH * hp->NTW;
   hp->total_iters = tiles * hp->KI;
-  const char* genv = std::getenv("MSCNN_HEAD_WGS");          // tuning knob
-  long G = genv ? std::atol(genv) : 512;
+  const int genv = tune_env("MSCNN_TUNE_GRID", d.tune_grid);   // tuning knob
+  long G = genv > 0 ? genv : 512;
   if (hp->total_iters / 2 < G) G = hp->total_iters / 2;      // at least ~2 chunks per workgroup
   if (G < 1) G = 1;
   hp->G = (int)G;

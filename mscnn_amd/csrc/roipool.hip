@@ -293,8 +293,8 @@ extern "C" int mscnn_roipool_fwd_f32(const float* feat, const float* rois, float
   if (chan_per_block > C) chan_per_block = C;
   if (C % 128 == 0) chan_per_block = 16;            // C/16 channel groups: a multiple of 8
   dim3 grid(cdiv(C, chan_per_block), R);
-  static const bool per_bin = getenv("MSCNN_ROIPOOL_PERBIN") != nullptr;      // A/B switch for profiling
-  static const int cpb = getenv("MSCNN_ROIPOOL_CPB") ? atoi(getenv("MSCNN_ROIPOOL_CPB")) : 0;   // tuning knob
+  const bool per_bin = tune_env("MSCNN_ROIPOOL_PERBIN", 0) != 0;      // A/B switches: debug builds only (MSCNN_TUNING_ENV)
+  const int cpb = tune_env("MSCNN_ROIPOOL_CPB", 0);
   if (cpb > 0) { chan_per_block = cpb; grid.x = cdiv(C, cpb); }
   if (!per_bin && pooled_h <= kMaxP && pooled_w <= kMaxP && (size_t)C * H * W < (1u << 30))
     roipool_rows_kernel<<<grid, kThreads, 512 * pooled_h * sizeof(float), as_stream(stream)>>>(

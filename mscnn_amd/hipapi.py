@@ -20,7 +20,11 @@ class MscnnError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("N", "Cin", "H", "W", "Cout", "Kh", "Kw", "pad_h", "pad_w",
-                                       "stride_h", "stride_w", "group", "relu")]
+                                       "stride_h", "stride_w", "group", "relu", "algo", "tune_variant", "tune_grid", "tune_flags")]
+
+
+# mscnn_conv_algo
+ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_F2, ALGO_WINO_F3 = 0, 1, 2, 3
 
 
 MAX_HEADS = 16
@@ -57,8 +61,11 @@ def lib():
         L.mscnn_version.restype = C.c_char_p
         L.mscnn_conv2d_plan_kernel.restype = C.c_char_p
         L.mscnn_conv2d_plan_kernel.argtypes = [C.c_void_p]
-        L.mscnn_conv2d_plan_flops.restype = C.c_double
-        L.mscnn_conv2d_plan_flops.argtypes = [C.c_void_p]
+        for f in ("mscnn_conv2d_plan_flops", "mscnn_conv2d_plan_executed_flops"):
+            getattr(L, f).restype = C.c_double
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.mscnn_conv2d_plan_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.mscnn_conv2d_plan_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         for f in ("mscnn_conv2d_packed_weight_bytes", "mscnn_conv2d_workspace_bytes"):
             getattr(L, f).restype = C.c_size_t
             getattr(L, f).argtypes = [C.c_void_p]
@@ -120,8 +127,10 @@ def _stream():
 class ConvPlan:
     """Owns a mscnn_conv_plan plus its packed weights and stream-K workspace (device memory)."""
 
-    def __init__(self, N, Cin, H, W, Cout, Kh, Kw, pad=(0, 0), stride=(1, 1), group=1, relu=False, device="cuda"):
-        self.desc = ConvDesc(N, Cin, H, W, Cout, Kh, Kw, pad[0], pad[1], stride[0], stride[1], group, int(relu))
+    def __init__(self, N, Cin, H, W, Cout, Kh, Kw, pad=(0, 0), stride=(1, 1), group=1, relu=False, device="cuda",
+                 algo=ALGO_AUTO, tune_variant=0, tune_grid=0, tune_flags=0):
+        self.desc = ConvDesc(N, Cin, H, W, Cout, Kh, Kw, pad[0], pad[1], stride[0], stride[1], group, int(relu),
+                             algo, tune_variant, tune_grid, tune_flags)
         self._p = C.c_void_p()
         _check(lib().mscnn_conv2d_plan_create(C.byref(self.desc), C.byref(self._p)))
         self.device = device
@@ -145,6 +154,19 @@ class ConvPlan:
     @property
     def flops(self):
         return lib().mscnn_conv2d_plan_flops(self._p)
+
+    @property
+    def executed_flops(self):
+        return lib().mscnn_conv2d_plan_executed_flops(self._p)
+
+    def set_profiling(self, on=True):
+        _check(lib().mscnn_conv2d_plan_set_profiling(self._p, int(on)))
+
+    def stage_ms(self):
+        """(input transform, MFMA GEMM kernels, output transform) of the last forward, HIP events on its stream."""
+        out = (C.c_float * 3)()
+        _check(lib().mscnn_conv2d_plan_stage_ms(self._p, out))
+        return tuple(out)
 
     def out_shape(self):
         d = self.desc
@@ -186,10 +208,10 @@ class ConvPlan:
             pass
 
 
-def conv2d(x, w, bias=None, pad=(0, 0), stride=(1, 1), group=1, relu=False):
+def conv2d(x, w, bias=None, pad=(0, 0), stride=(1, 1), group=1, relu=False, algo=ALGO_AUTO):
     N, Cin, H, W = x.shape
     Cout, _, Kh, Kw = w.shape
-    plan = ConvPlan(N, Cin, H, W, Cout, Kh, Kw, pad, stride, group, relu, device=x.device)
+    plan = ConvPlan(N, Cin, H, W, Cout, Kh, Kw, pad, stride, group, relu, device=x.device, algo=algo)
     plan.pack(w)
     y = plan.forward(x, bias)
     torch.cuda.current_stream().synchronize()   # plan buffers die with the plan

@@ -61,7 +61,10 @@ class SplitLayer : public Layer<Dtype> {
 template <typename Dtype>
 class ConvolutionLayer : public Layer<Dtype> {
  public:
-  explicit ConvolutionLayer(const LayerParameter& param) : Layer<Dtype>(param), plan_(nullptr), relu_(false), weights_dirty_(true), planned_n_(-1) {}
+  explicit ConvolutionLayer(const LayerParameter& param)
+      : Layer<Dtype>(param), plan_(nullptr), relu_(false), weights_dirty_(true), planned_n_(-1), algo_(0), profiling_(false) {
+    tune_[0] = tune_[1] = tune_[2] = 0;
+  }
   virtual ~ConvolutionLayer();
   virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
@@ -73,6 +76,20 @@ class ConvolutionLayer : public Layer<Dtype> {
   virtual bool FusePool2x2(Blob<Dtype>* pooled_top);
   virtual double ForwardFlops() const;
   const char* kernel_name() const;
+  // --- extensions of this build (no reference counterpart) ---
+  // Algorithm of this layer (mscnn_conv_algo in include/mscnn_hip.h: 0 auto, 1 direct, 2 / 3 Winograd F(2x2) / F(3x3));
+  // Net::CalibrateNumerics sets 1 on layers whose Winograd result strays from the direct sum on representative data.
+  void set_algo(int algo);
+  int algo() const { return algo_; }
+  void set_tuning(int variant, int grid, int flags);      // A/B measurement knobs (mscnn_conv_desc::tune_*)
+  // FLOPs the MFMA pipe executes (Winograd forms: fewer than ForwardFlops) and per-stage HIP-event times of the last
+  // Forward {input transform, MFMA GEMM, output transform} -- roofline accounting (bench.py).
+  double ExecutedFlops() const;
+  void set_profiling(bool on);
+  bool StageMs(float ms[3]) const;
+  // max |y - y_direct| / max(1, |y_direct|) of the current algorithm against the direct kernel on the given bottom
+  // (device scratch only; the layer's tops are not touched).  0 when the layer already runs a direct kernel.
+  double ErrorAgainstDirect(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
  protected:
   MSCNN_NO_CPU_PATH("Convolution")
   virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
@@ -84,9 +101,11 @@ class ConvolutionLayer : public Layer<Dtype> {
   int planned_n_, planned_h_, planned_w_;
   Blob<Dtype>* pooled_top_ = nullptr;     // fused Pooling layer's top (FusePool2x2)
   DeviceBuffer packed_, workspace_;
+  int algo_, tune_[3];
+  bool profiling_;
 };
 
-// include/caffe/layers/deconv_layer.hpp -- depthwise (group == channels) transposed conv only
+// include/caffe/layers/deconv_layer.hpp -- transposed conv; the depthwise case of the "-2x" nets has its own kernel
 template <typename Dtype>
 class DeconvolutionLayer : public Layer<Dtype> {
  public:

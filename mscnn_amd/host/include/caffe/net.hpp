@@ -23,8 +23,11 @@ void InsertSplits(const vector<LayerParameter>& in, vector<LayerParameter>* out)
 template <typename Dtype>
 class Net {
  public:
+  // fusion: Net-level operator fusion (ReLU / MAX 2x2 pooling into the producing convolution, ROIPooling -> Concat).  On by
+  // default; the process-wide default can be turned off with MSCNN_NO_FUSE=1 (results are bit-identical either way).
   explicit Net(const NetParameter& param, Phase phase = TEST);
   explicit Net(const string& param_file, Phase phase);
+  Net(const NetParameter& param, Phase phase, bool fusion);
   virtual ~Net() {}
 
   const vector<Blob<Dtype>*>& Forward(Dtype* loss = NULL);
@@ -60,6 +63,16 @@ class Net {
   // Per-layer HIP-event timing of the last Forward when enabled (the `caffe time` loop, tools/caffe.cpp:380-400).
   void set_layer_timing(bool on) { timing_ = on; }
   const vector<float>& layer_ms() const { return layer_ms_; }
+  // Tops whose producer was redirected into a fused Concat's top (roi_pool_org / roi_pool_ctx) are materialised lazily:
+  // blob_by_name() copies the channel window back into the blob's own storage when the producer has run since the last
+  // copy.  Code that reaches into blobs() directly must call this first.
+  void MaterializeBlob(int blob_id) const;
+  // Numerical calibration on representative data: call after a Forward.  Every Convolution layer that runs a Winograd
+  // form is re-computed with the direct k-ordered kernel on the same bottom; where max |dy| / max(1, |y|) exceeds `tol`
+  // the layer is switched to the direct kernel for good (ConvolutionLayer::set_algo).  Returns the layers switched;
+  // errors (per layer index, 0 for layers not checked) are left in calibration_err().
+  vector<int> CalibrateNumerics(double tol);
+  const vector<double>& calibration_err() const { return calib_err_; }
 
  protected:
   void Init(const NetParameter& param);
@@ -82,6 +95,12 @@ class Net {
   vector<bool> fused_away_;
   bool fusion_, timing_;
   vector<float> layer_ms_;
+  // fused layer i -> the layers that now produce its top(s) (ReLU / Pooling: one convolution; Concat: the ROIPooling layers)
+  vector<vector<int> > fused_producers_;
+  struct Redirect { int target_blob, c_total, c_offset; };
+  std::map<int, Redirect> redirect_;               // blob id -> where its data really lives
+  mutable std::map<int, bool> redirect_dirty_;     // producer ran since the last MaterializeBlob
+  vector<double> calib_err_;
   DISABLE_COPY_AND_ASSIGN(Net);
 };
 

@@ -43,14 +43,15 @@ void fill_shape(const Blob<float>& b, int* dims8, int* ndim) {
   for (int i = 0; i < 8; ++i) dims8[i] = i < b.num_axes() ? b.shape(i) : 1;
 }
 
-int create(caffe::NetParameter param, int device, mscnn_net** out) {
+int create(caffe::NetParameter param, int device, mscnn_net** out, unsigned flags = 0, bool use_default_fusion = true) {
   return guarded([&] {
     CHECK(out != nullptr);
     if (device >= 0) Caffe::SetDevice(device);   // device < 0: graph construction only (no HIP device touched)
     Caffe::set_mode(Caffe::GPU);
     std::unique_ptr<mscnn_net> h(new mscnn_net());
     h->device = device;
-    h->net.reset(new Net<float>(param, caffe::TEST));
+    if (use_default_fusion) h->net.reset(new Net<float>(param, caffe::TEST));
+    else h->net.reset(new Net<float>(param, caffe::TEST, !(flags & MSCNN_NET_NO_FUSION)));
     *out = h.release();
   });
 }
@@ -70,6 +71,12 @@ int mscnn_net_create_from_string(const char* text, int device, mscnn_net** out) 
   caffe::NetParameter p;
   int rc = guarded([&] { p = caffe::NetParameterFromString(text); });
   return rc ? rc : create(p, device, out);
+}
+
+int mscnn_net_create_from_string_ex(const char* text, int device, unsigned flags, mscnn_net** out) {
+  caffe::NetParameter p;
+  int rc = guarded([&] { p = caffe::NetParameterFromString(text); });
+  return rc ? rc : create(p, device, out, flags, false);
 }
 
 void mscnn_net_destroy(mscnn_net* net) { delete net; }
@@ -115,6 +122,46 @@ const char* mscnn_net_layer_kernel(const mscnn_net* n, int l) {
   return c ? c->kernel_name() : "";
 }
 double mscnn_net_layer_flops(const mscnn_net* n, int l) { return n->net->layers()[l]->ForwardFlops(); }
+static caffe::ConvolutionLayer<float>* conv_of(const mscnn_net* n, int l) {
+  return dynamic_cast<caffe::ConvolutionLayer<float>*>(n->net->layers()[l].get());
+}
+double mscnn_net_layer_executed_flops(const mscnn_net* n, int l) {
+  auto* c = conv_of(n, l);
+  return c ? c->ExecutedFlops() : n->net->layers()[l]->ForwardFlops();
+}
+int mscnn_net_set_conv_profiling(mscnn_net* n, int on) {
+  return guarded([&] {
+    for (size_t l = 0; l < n->net->layers().size(); ++l)
+      if (auto* c = conv_of(n, (int)l)) c->set_profiling(on != 0);
+  });
+}
+int mscnn_net_layer_stage_ms(const mscnn_net* n, int l, float ms_out[3]) {
+  ms_out[0] = ms_out[1] = ms_out[2] = 0.f;
+  auto* c = conv_of(n, l);
+  return (c && c->StageMs(ms_out)) ? 0 : 1;
+}
+int mscnn_net_set_conv_algo(mscnn_net* n, int layer, int algo) {
+  return guarded([&] {
+    CHECK_LT(layer, (int)n->net->layers().size());
+    for (int l = (layer < 0 ? 0 : layer); l < (layer < 0 ? (int)n->net->layers().size() : layer + 1); ++l)
+      if (auto* c = conv_of(n, l)) c->set_algo(algo);
+      else CHECK_LT(layer, 0) << "layer " << n->net->layer_names()[l] << " is not a Convolution";
+  });
+}
+int mscnn_net_set_conv_tuning(mscnn_net* n, int layer, int variant, int grid, int flags) {
+  return guarded([&] {
+    CHECK_LT(layer, (int)n->net->layers().size());
+    for (int l = (layer < 0 ? 0 : layer); l < (layer < 0 ? (int)n->net->layers().size() : layer + 1); ++l)
+      if (auto* c = conv_of(n, l)) c->set_tuning(variant, grid, flags);
+  });
+}
+int mscnn_net_calibrate_numerics(mscnn_net* n, double tol, int* num_switched) {
+  return guarded([&] {
+    const std::vector<int> sw = n->net->CalibrateNumerics(tol);
+    if (num_switched) *num_switched = (int)sw.size();
+  });
+}
+double mscnn_net_layer_calibration_err(const mscnn_net* n, int l) { return n->net->calibration_err()[l]; }
 int mscnn_net_num_blobs(const mscnn_net* n) { return (int)n->net->blobs().size(); }
 const char* mscnn_net_blob_name(const mscnn_net* n, int b) { return n->net->blob_names()[b].c_str(); }
 int mscnn_net_blob_shape(const mscnn_net* n, const char* name, int* dims8, int* ndim) {

@@ -155,9 +155,65 @@ void ConvolutionLayer<Dtype>::Plan(int n, int h, int w) {
   mscnn_conv_desc d;
   d.N = n; d.Cin = channels_; d.H = h; d.W = w; d.Cout = num_output_; d.Kh = kernel_h_; d.Kw = kernel_w_;
   d.pad_h = pad_h_; d.pad_w = pad_w_; d.stride_h = stride_h_; d.stride_w = stride_w_; d.group = group_; d.relu = relu_ ? 1 : 0;
+  d.algo = algo_; d.tune_variant = tune_[0]; d.tune_grid = tune_[1]; d.tune_flags = tune_[2];
   MSCNN_CHECK(mscnn_conv2d_plan_create(&d, &plan_));
+  if (profiling_) MSCNN_CHECK(mscnn_conv2d_plan_set_profiling(plan_, 1));
   planned_n_ = n; planned_h_ = h; planned_w_ = w;
   weights_dirty_ = true;
+}
+
+template <typename Dtype>
+void ConvolutionLayer<Dtype>::set_algo(int algo) {
+  CHECK(algo >= 0 && algo <= 3) << "unknown mscnn_conv_algo " << algo;
+  if (algo == algo_) return;
+  algo_ = algo;
+  if (plan_) { mscnn_conv2d_plan_destroy(plan_); plan_ = nullptr; }
+}
+template <typename Dtype>
+void ConvolutionLayer<Dtype>::set_tuning(int variant, int grid, int flags) {
+  tune_[0] = variant; tune_[1] = grid; tune_[2] = flags;
+  if (plan_) { mscnn_conv2d_plan_destroy(plan_); plan_ = nullptr; }
+}
+template <typename Dtype>
+double ConvolutionLayer<Dtype>::ExecutedFlops() const { return plan_ ? mscnn_conv2d_plan_executed_flops(plan_) : 0; }
+template <typename Dtype>
+void ConvolutionLayer<Dtype>::set_profiling(bool on) {
+  profiling_ = on;
+  if (plan_) MSCNN_CHECK(mscnn_conv2d_plan_set_profiling(plan_, on ? 1 : 0));
+}
+template <typename Dtype>
+bool ConvolutionLayer<Dtype>::StageMs(float ms[3]) const {
+  ms[0] = ms[1] = ms[2] = 0.f;
+  return plan_ && profiling_ && mscnn_conv2d_plan_stage_ms(plan_, ms) == 0;
+}
+
+template <typename Dtype>
+double ConvolutionLayer<Dtype>::ErrorAgainstDirect(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  Plan(bottom[0]->num(), bottom[0]->height(), bottom[0]->width());
+  const std::string kname = mscnn_conv2d_plan_kernel(plan_);
+  if (kname.compare(0, 8, "winograd") != 0 || bottom[0]->count() == 0) return 0.0;
+  // a second, direct plan of the same layer with its own packed weights and workspace; everything is released on return
+  mscnn_conv_desc d;
+  d.N = bottom[0]->num(); d.Cin = channels_; d.H = bottom[0]->height(); d.W = bottom[0]->width(); d.Cout = num_output_;
+  d.Kh = kernel_h_; d.Kw = kernel_w_; d.pad_h = pad_h_; d.pad_w = pad_w_; d.stride_h = stride_h_; d.stride_w = stride_w_;
+  d.group = group_; d.relu = relu_ ? 1 : 0; d.algo = MSCNN_CONV_ALGO_DIRECT; d.tune_variant = d.tune_grid = d.tune_flags = 0;
+  mscnn_conv_plan* dp = nullptr;
+  MSCNN_CHECK(mscnn_conv2d_plan_create(&d, &dp));
+  DeviceBuffer packed, ws, y, err;
+  const size_t pb = mscnn_conv2d_packed_weight_bytes(dp), wb = mscnn_conv2d_workspace_bytes(dp);
+  float* pk = pb ? static_cast<float*>(packed.Reserve(pb)) : nullptr;
+  const float* w = this->blobs_[0]->gpu_data();
+  MSCNN_CHECK(mscnn_conv2d_pack_weights(dp, w, pk, S()));
+  float* yd = static_cast<float*>(y.Reserve(sizeof(float) * top[0]->count()));
+  float* ed = static_cast<float*>(err.Reserve(sizeof(float)));
+  MSCNN_CHECK(mscnn_conv2d_fwd_f32(dp, bottom[0]->gpu_data(), w, pk, bias_term_ ? this->blobs_[1]->gpu_data() : nullptr, yd,
+                                   wb ? ws.Reserve(wb) : nullptr, wb, S()));
+  MSCNN_CHECK(mscnn_max_rel_diff_f32(top[0]->gpu_data(), yd, (size_t)top[0]->count(), 1.0f, ed, S()));
+  float e = 0.f;
+  HIP_CHECK(hipMemcpyAsync(&e, ed, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)S()));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)S()));
+  mscnn_conv2d_plan_destroy(dp);
+  return e;
 }
 
 template <typename Dtype>
@@ -207,12 +263,11 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
   void* ws = wbytes ? shared_ws[dev]->Reserve(wbytes) : nullptr;
   const float* bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
   float* pooled = nullptr;
-  if (pooled_top_ && mscnn_conv2d_plan_can_pool(plan_)) {
-    CHECK_EQ(pooled_top_->num(), top[0]->num());
-    CHECK_EQ(pooled_top_->channels(), top[0]->channels());
-    CHECK_EQ(pooled_top_->height(), (top[0]->height() + 1) / 2);
-    CHECK_EQ(pooled_top_->width(), (top[0]->width() + 1) / 2);
-    pooled = pooled_top_->mutable_gpu_data();
+  if (pooled_top_) {
+    // the fused-away Pooling layer's Reshape would run AFTER this Forward (layer.hpp:451-456): shape its top here, so that a
+    // bottom reshaped between two Forward calls (legal without Net::Reshape) propagates as in the reference
+    pooled_top_->Reshape(top[0]->num(), top[0]->channels(), (top[0]->height() + 1) / 2, (top[0]->width() + 1) / 2);
+    if (mscnn_conv2d_plan_can_pool(plan_)) pooled = pooled_top_->mutable_gpu_data();
   }
   MSCNN_CHECK(mscnn_conv2d_fwd_pool_f32(plan_, bottom[0]->gpu_data(), w, packed, bias, top[0]->mutable_gpu_data(), pooled, ws,
                                         wbytes, S()));
@@ -237,8 +292,9 @@ void DeconvolutionLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, c
   channels_ = bottom[0]->channels();
   num_output_ = p.num_output();
   group_ = p.group();
-  CHECK(group_ == channels_ && num_output_ == channels_)
-      << "Deconvolution: only the depthwise case (group == channels == num_output) of the '-2x' deploy nets is built";
+  CHECK_GT(num_output_, 0);
+  CHECK_EQ(channels_ % group_, 0);
+  CHECK_EQ(num_output_ % group_, 0) << "Number of output should be multiples of group.";
   bias_term_ = p.bias_term();
   if (this->blobs_.size() == 0) {
     this->blobs_.resize(bias_term_ ? 2 : 1);
@@ -260,10 +316,10 @@ void DeconvolutionLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, cons
 }
 template <typename Dtype>
 void DeconvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
-  MSCNN_CHECK(mscnn_deconv_depthwise_fwd_f32(bottom[0]->gpu_data(), this->blobs_[0]->gpu_data(),
-                                             bias_term_ ? this->blobs_[1]->gpu_data() : nullptr, top[0]->mutable_gpu_data(),
-                                             bottom[0]->num(), channels_, bottom[0]->height(), bottom[0]->width(), kernel_h_,
-                                             kernel_w_, pad_h_, pad_w_, stride_h_, stride_w_, S()));
+  MSCNN_CHECK(mscnn_deconv2d_fwd_f32(bottom[0]->gpu_data(), this->blobs_[0]->gpu_data(),
+                                     bias_term_ ? this->blobs_[1]->gpu_data() : nullptr, top[0]->mutable_gpu_data(),
+                                     bottom[0]->num(), channels_, bottom[0]->height(), bottom[0]->width(), num_output_, kernel_h_,
+                                     kernel_w_, pad_h_, pad_w_, stride_h_, stride_w_, group_, S()));
 }
 
 // ------------------------------------------------------------------------------------------------ Pooling

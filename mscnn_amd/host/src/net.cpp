@@ -103,11 +103,18 @@ void InsertSplits(const vector<LayerParameter>& in, vector<LayerParameter>* out)
   }
 }
 
-template <typename Dtype>
-Net<Dtype>::Net(const NetParameter& param, Phase phase) : phase_(phase), fusion_(true), timing_(false) { Init(param); }
+static bool DefaultFusion() {
+  const char* nofuse = std::getenv("MSCNN_NO_FUSE");      // host-runtime option (not a kernel switch): results are identical
+  return !(nofuse && *nofuse && *nofuse != '0');
+}
 
 template <typename Dtype>
-Net<Dtype>::Net(const string& param_file, Phase phase) : phase_(phase), fusion_(true), timing_(false) {
+Net<Dtype>::Net(const NetParameter& param, Phase phase) : phase_(phase), fusion_(DefaultFusion()), timing_(false) { Init(param); }
+template <typename Dtype>
+Net<Dtype>::Net(const NetParameter& param, Phase phase, bool fusion) : phase_(phase), fusion_(fusion), timing_(false) { Init(param); }
+
+template <typename Dtype>
+Net<Dtype>::Net(const string& param_file, Phase phase) : phase_(phase), fusion_(DefaultFusion()), timing_(false) {
   NetParameter param;
   ReadNetParamsFromTextFileOrDie(param_file, &param);
   Init(param);
@@ -117,8 +124,6 @@ static bool StateMeetsRule(Phase phase, const NetStateRule& rule) { return !rule
 
 template <typename Dtype>
 void Net<Dtype>::Init(const NetParameter& in_param) {
-  const char* nofuse = std::getenv("MSCNN_NO_FUSE");
-  if (nofuse && *nofuse && *nofuse != '0') fusion_ = false;
   name_ = in_param.name();
   vector<LayerParameter> upgraded, filtered, layers;
   UpgradeNetInput(in_param, &upgraded);
@@ -193,6 +198,8 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
   for (size_t i = 0; i < blob_names_.size(); ++i) blob_names_index_[blob_names_[i]] = (int)i;
   for (size_t i = 0; i < layer_names_.size(); ++i) layer_names_index_[layer_names_[i]] = (int)i;
   fused_away_.assign(layers_.size(), false);
+  fused_producers_.assign(layers_.size(), vector<int>());
+  calib_err_.assign(layers_.size(), 0.0);
   layer_ms_.assign(layers_.size(), 0.f);
   if (fusion_) ApplyFusion();
   LOG(INFO) << "Network initialization done.";
@@ -209,7 +216,7 @@ void Net<Dtype>::ApplyFusion() {
     if (top_vecs_[i].size() != 1 || bottom_vecs_[i + 1].size() != 1) continue;
     if (bottom_vecs_[i + 1][0] != top_vecs_[i][0] || top_vecs_[i + 1][0] != top_vecs_[i][0]) continue;   // in-place only
     const Dtype slope = layers_[i + 1]->layer_param().relu_param().negative_slope();
-    if (layers_[i]->FuseReLU(slope)) fused_away_[i + 1] = true;
+    if (layers_[i]->FuseReLU(slope)) { fused_away_[i + 1] = true; fused_producers_[i + 1].push_back((int)i); }
   }
   // Convolution (+ fused ReLU) -> [Split ->] Pooling(MAX 2x2 / 2): the convolution's epilogue also writes the pooled blob
   // (pool1..pool6 of the VGG trunk); the Pooling layer becomes a no-op.  The convolution's own top is still written.
@@ -234,7 +241,7 @@ void Net<Dtype>::ApplyFusion() {
     for (size_t k = prod + 1; k < i && clean; ++k)
       for (Blob<Dtype>* t : top_vecs_[k]) if (t == top_vecs_[prod][0] && !fused_away_[k]) clean = false;
     if (!clean) continue;
-    if (layers_[prod]->FusePool2x2(top_vecs_[i][0])) fused_away_[i] = true;
+    if (layers_[prod]->FusePool2x2(top_vecs_[i][0])) { fused_away_[i] = true; fused_producers_[i].push_back(prod); }
   }
   // Channel Concat whose bottoms all come straight from ROIPooling layers (roi_pool_org + roi_pool_ctx -> roi_pool): the
   // producers write their channel window of the concatenated blob and the copy layer disappears (concat_layer.cu:28-46
@@ -260,10 +267,49 @@ void Net<Dtype>::ApplyFusion() {
     int off = 0;
     for (size_t b = 0; b < producers.size(); ++b) {
       CHECK(layers_[producers[b]]->SetOutputWindow(top_vecs_[i][0], c_total, off));
+      Redirect rd;
+      rd.target_blob = top_id_vecs_[i][0]; rd.c_total = c_total; rd.c_offset = off;
+      redirect_[bottom_id_vecs_[i][b]] = rd;
+      redirect_dirty_[bottom_id_vecs_[i][b]] = false;
       off += bottom_vecs_[i][b]->channels();
     }
     fused_away_[i] = true;
+    fused_producers_[i] = producers;
   }
+}
+
+template <typename Dtype>
+void Net<Dtype>::MaterializeBlob(int blob_id) const {
+  typename std::map<int, Redirect>::const_iterator it = redirect_.find(blob_id);
+  if (it == redirect_.end() || !redirect_dirty_[blob_id]) return;
+  const Redirect& rd = it->second;
+  const Blob<Dtype>* src = blobs_[rd.target_blob].get();
+  Blob<Dtype>* dst = blobs_[blob_id].get();
+  const int R = src->num(), inner = src->count(2), c = dst->channels();
+  dst->Reshape(R, c, src->height(), src->width());
+  if (R > 0)       // one strided D2D copy: R rows of c * inner floats out of rows of c_total * inner floats
+    HIP_CHECK(hipMemcpy2DAsync(dst->mutable_gpu_data(), sizeof(Dtype) * c * inner, src->gpu_data() + (size_t)rd.c_offset * inner,
+                               sizeof(Dtype) * rd.c_total * inner, sizeof(Dtype) * c * inner, R, hipMemcpyDeviceToDevice,
+                               (hipStream_t)Caffe::stream()));
+  redirect_dirty_[blob_id] = false;
+}
+
+template <typename Dtype>
+vector<int> Net<Dtype>::CalibrateNumerics(double tol) {
+  vector<int> switched;
+  for (size_t i = 0; i < layers_.size(); ++i) {
+    calib_err_[i] = 0.0;
+    ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
+    if (!c || c->algo() == 1) continue;
+    calib_err_[i] = c->ErrorAgainstDirect(bottom_vecs_[i], top_vecs_[i]);
+    if (!(calib_err_[i] <= tol)) {      // (NaN counts as a failure)
+      LOG(WARNING) << "layer " << layer_names_[i] << ": Winograd result off the direct sum by " << calib_err_[i] << " > " << tol
+                   << " on the calibration input: using the direct kernel";
+      c->set_algo(1);
+      switched.push_back((int)i);
+    }
+  }
+  return switched;
 }
 
 template <typename Dtype>
@@ -273,9 +319,23 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing_) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
   for (int i = start; i <= end; ++i) {
-    if (fused_away_[i]) { layer_ms_[i] = 0.f; continue; }
+    bool run = !fused_away_[i];
+    if (fused_away_[i]) {
+      // A fused-away layer's work is done by its producer(s).  When a partial range starts after one of them (the reference
+      // would recompute this layer from its bottoms, net.cpp:544-555), run the layer itself -- the un-fused kernels are
+      // bit-identical.  Its bottoms may be tops that were redirected into a Concat: bring them up to date first.
+      for (size_t k = 0; k < fused_producers_[i].size(); ++k)
+        if (fused_producers_[i][k] < start) run = true;
+      if (run)
+        for (size_t b = 0; b < bottom_id_vecs_[i].size(); ++b) MaterializeBlob(bottom_id_vecs_[i][b]);
+      else
+        layers_[i]->Reshape(bottom_vecs_[i], top_vecs_[i]);      // shapes follow the bottoms exactly as Layer::Forward would
+    }
+    if (!run) { layer_ms_[i] = 0.f; continue; }
     if (timing_) HIP_CHECK(hipEventRecord(e0, (hipStream_t)Caffe::stream()));
     layers_[i]->Forward(bottom_vecs_[i], top_vecs_[i]);
+    for (size_t t = 0; t < top_id_vecs_[i].size(); ++t)
+      if (redirect_.count(top_id_vecs_[i][t])) redirect_dirty_[top_id_vecs_[i][t]] = true;
     if (timing_) {
       HIP_CHECK(hipEventRecord(e1, (hipStream_t)Caffe::stream()));
       HIP_CHECK(hipEventSynchronize(e1));
@@ -309,8 +369,11 @@ bool Net<Dtype>::has_blob(const string& blob_name) const { return blob_names_ind
 template <typename Dtype>
 const shared_ptr<Blob<Dtype> > Net<Dtype>::blob_by_name(const string& blob_name) const {
   shared_ptr<Blob<Dtype> > blob_ptr;
-  if (has_blob(blob_name)) blob_ptr = blobs_[blob_names_index_.find(blob_name)->second];
-  else LOG(WARNING) << "Unknown blob name " << blob_name;
+  if (has_blob(blob_name)) {
+    const int id = blob_names_index_.find(blob_name)->second;
+    MaterializeBlob(id);        // no-op unless the blob's producer writes into a fused Concat's top
+    blob_ptr = blobs_[id];
+  } else LOG(WARNING) << "Unknown blob name " << blob_name;
   return blob_ptr;
 }
 
@@ -329,28 +392,52 @@ const shared_ptr<Layer<Dtype> > Net<Dtype>::layer_by_name(const string& layer_na
 // caffe.proto: NetParameter{ layer = 100 } ; LayerParameter{ name = 1, blobs = 7 } ;
 // BlobProto{ num=1 channels=2 height=3 width=4 data=5 (packed float) shape=7 } ; BlobShape{ dim=1 (packed int64) }
 namespace {
+// Every advance is bounds-checked: a truncated or corrupt file is a CHECK failure, never a read past the buffer.
 struct Reader {
   const unsigned char* p; const unsigned char* end;
   bool ok() const { return p < end; }
+  size_t left() const { return (size_t)(end - p); }
+  void need(size_t n) const { CHECK_LE(n, left()) << "truncated caffemodel"; }
   unsigned long long varint() {
     unsigned long long v = 0; int shift = 0;
-    while (p < end) { const unsigned char b = *p++; v |= (unsigned long long)(b & 0x7f) << shift; if (!(b & 0x80)) break; shift += 7; }
+    for (;;) {
+      need(1);
+      const unsigned char b = *p++;
+      CHECK_LT(shift, 64) << "malformed varint in caffemodel";
+      v |= (unsigned long long)(b & 0x7f) << shift;
+      if (!(b & 0x80)) break;
+      shift += 7;
+    }
     return v;
   }
-  Reader sub() { const size_t n = (size_t)varint(); CHECK_LE(n, (size_t)(end - p)) << "truncated caffemodel"; Reader r{p, p + n}; p += n; return r; }
+  Reader sub() { const size_t n = (size_t)varint(); need(n); Reader r{p, p + n}; p += n; return r; }
   void skip(int wire) {
     if (wire == 0) varint();
-    else if (wire == 1) p += 8;
-    else if (wire == 2) { const size_t n = (size_t)varint(); p += n; }
-    else if (wire == 5) p += 4;
+    else if (wire == 1) { need(8); p += 8; }
+    else if (wire == 2) { const size_t n = (size_t)varint(); need(n); p += n; }
+    else if (wire == 5) { need(4); p += 4; }
     else LOG(FATAL) << "unsupported wire type " << wire << " in caffemodel";
   }
 };
 struct ParsedBlob { vector<int> shape; vector<float> data; int legacy[4] = {0, 0, 0, 0}; bool has_legacy = false; };
+
+// Blob::FromProto's shape rule (blob.cpp:448-470): explicit `shape`, else the legacy 4-D num/channels/height/width;
+// Blob::ShapeEquals (blob.cpp:417-437) lets a legacy 4-D source match a lower-rank target whose leading dims are 1.
+bool ShapeMatches(const ParsedBlob& pb, const vector<int>& target) {
+  if (!pb.shape.empty()) return pb.shape == target;
+  if (!pb.has_legacy) return target.empty();    // neither given: an empty BlobShape only equals a 0-axis blob
+  if (target.size() > 4) return false;
+  vector<int> t4(4, 1);
+  for (size_t i = 0; i < target.size(); ++i) t4[4 - target.size() + i] = target[i];
+  return t4[0] == pb.legacy[0] && t4[1] == pb.legacy[1] && t4[2] == pb.legacy[2] && t4[3] == pb.legacy[3];
+}
 }  // namespace
 
 template <typename Dtype>
 void Net<Dtype>::CopyTrainedLayersFrom(const string& trained_filename) {
+  if (trained_filename.size() >= 3 && trained_filename.compare(trained_filename.size() - 3, 3, ".h5") == 0)
+    LOG(FATAL) << "HDF5 weight files (net.cpp:805-848) are not read by this build: convert " << trained_filename
+               << " to a binary .caffemodel";
   string bytes;
   CHECK(ReadFileToString(trained_filename, &bytes)) << "cannot read " << trained_filename;
   Reader net{(const unsigned char*)bytes.data(), (const unsigned char*)bytes.data() + bytes.size()};
@@ -365,7 +452,7 @@ void Net<Dtype>::CopyTrainedLayersFrom(const string& trained_filename) {
     while (lr.ok()) {
       const unsigned long long k = lr.varint();
       const int f = (int)(k >> 3), w = (int)(k & 7);
-      if (f == 1 && w == 2) { Reader s = lr.sub(); lname.assign((const char*)s.p, (size_t)(s.end - s.p)); }
+      if (f == 1 && w == 2) { Reader s = lr.sub(); lname.assign((const char*)s.p, s.left()); }
       else if (f == 7 && w == 2) {
         Reader br = lr.sub();
         ParsedBlob pb;
@@ -373,9 +460,19 @@ void Net<Dtype>::CopyTrainedLayersFrom(const string& trained_filename) {
           const unsigned long long bk = br.varint();
           const int bf = (int)(bk >> 3), bw = (int)(bk & 7);
           if (bf >= 1 && bf <= 4 && bw == 0) { pb.legacy[bf - 1] = (int)br.varint(); pb.has_legacy = true; }
-          else if (bf == 5 && bw == 2) { Reader d = br.sub(); const size_t n = (size_t)(d.end - d.p) / 4; const size_t o = pb.data.size(); pb.data.resize(o + n); memcpy(pb.data.data() + o, d.p, n * 4); }
-          else if (bf == 5 && bw == 5) { float v; memcpy(&v, br.p, 4); br.p += 4; pb.data.push_back(v); }
-          else if (bf == 7 && bw == 2) {
+          else if (bf == 5 && bw == 2) {                       // data: packed float
+            Reader d = br.sub();
+            CHECK_EQ(d.left() % 4, 0u) << "packed float field of odd length in caffemodel";
+            const size_t n = d.left() / 4, o = pb.data.size();
+            pb.data.resize(o + n);
+            if (n) memcpy(pb.data.data() + o, d.p, n * 4);
+          } else if (bf == 5 && bw == 5) { br.need(4); float v; memcpy(&v, br.p, 4); br.p += 4; pb.data.push_back(v); }
+          else if (bf == 8 && (bw == 2 || bw == 1)) {          // double_data (blob.cpp:472-476): narrowed to the net's float
+            Reader d = bw == 2 ? br.sub() : Reader{br.p, br.p};
+            if (bw == 1) { br.need(8); d = Reader{br.p, br.p + 8}; br.p += 8; }
+            CHECK_EQ(d.left() % 8, 0u) << "packed double field of odd length in caffemodel";
+            for (; d.ok(); d.p += 8) { double v; memcpy(&v, d.p, 8); pb.data.push_back((float)v); }
+          } else if (bf == 7 && bw == 2) {
             Reader sr = br.sub();
             while (sr.ok()) {
               const unsigned long long sk = sr.varint();
@@ -394,8 +491,10 @@ void Net<Dtype>::CopyTrainedLayersFrom(const string& trained_filename) {
     if (pblobs.empty()) continue;
     CHECK_EQ(target.size(), pblobs.size()) << "Incompatible number of blobs for layer " << lname;
     for (size_t j = 0; j < target.size(); ++j) {
-      CHECK_EQ((size_t)target[j]->count(), pblobs[j].data.size())
-          << "Cannot copy param " << j << " weights from layer '" << lname << "'; shape mismatch (target " << target[j]->shape_string() << ")";
+      // net.cpp:771-780: shape mismatch is fatal, with both shapes in the message
+      CHECK(ShapeMatches(pblobs[j], target[j]->shape()) && (size_t)target[j]->count() == pblobs[j].data.size())
+          << "Cannot copy param " << j << " weights from layer '" << lname << "'; shape mismatch (target " << target[j]->shape_string()
+          << ", source holds " << pblobs[j].data.size() << " values)";
       memcpy(target[j]->mutable_cpu_data(), pblobs[j].data.data(), sizeof(float) * pblobs[j].data.size());   // blob.cpp:448-482
     }
     layer->OnWeightsChanged();

@@ -33,12 +33,18 @@ def lib():
                   "mscnn_net_layer_top", "mscnn_net_layer_kernel", "mscnn_net_layer_param_text", "mscnn_net_blob_name", "mscnn_net_output_name"):
             getattr(L, f).restype = C.c_char_p
         L.mscnn_net_layer_flops.restype = C.c_double
+        L.mscnn_net_layer_executed_flops.restype = C.c_double
+        L.mscnn_net_layer_calibration_err.restype = C.c_double
         L.mscnn_net_layer_ms.restype = C.c_float
         L.mscnn_net_blob_device_ptr.restype = C.c_void_p
         L.mscnn_net_destroy.restype = None
         vp, ci, cs = C.c_void_p, C.c_int, C.c_char_p
         sig = {
             "mscnn_net_create_from_file": [cs, ci, vp], "mscnn_net_create_from_string": [cs, ci, vp], "mscnn_net_destroy": [vp],
+            "mscnn_net_create_from_string_ex": [cs, ci, C.c_uint, vp],
+            "mscnn_net_layer_executed_flops": [vp, ci], "mscnn_net_set_conv_profiling": [vp, ci], "mscnn_net_layer_stage_ms": [vp, ci, vp],
+            "mscnn_net_set_conv_algo": [vp, ci, ci], "mscnn_net_set_conv_tuning": [vp, ci, ci, ci, ci],
+            "mscnn_net_calibrate_numerics": [vp, C.c_double, vp], "mscnn_net_layer_calibration_err": [vp, ci],
             "mscnn_net_load_caffemodel": [vp, cs], "mscnn_net_set_stream": [vp], "mscnn_net_num_layers": [vp],
             "mscnn_net_layer_name": [vp, ci], "mscnn_net_layer_type": [vp, ci], "mscnn_net_layer_index": [vp, cs],
             "mscnn_net_layer_num_bottoms": [vp, ci], "mscnn_net_layer_num_tops": [vp, ci], "mscnn_net_layer_bottom": [vp, ci, ci],
@@ -68,9 +74,14 @@ def _check(rc):
 class Net:
     """caffe.Net(prototxt, 'test') on one MI355X."""
 
-    def __init__(self, prototxt_path=None, prototxt_text=None, device=0):
+    def __init__(self, prototxt_path=None, prototxt_text=None, device=0, fusion=None):
+        """fusion: None = the process default (on unless MSCNN_NO_FUSE=1), True / False = explicit."""
         self._h = C.c_void_p()
-        if prototxt_text is not None:
+        if prototxt_text is None and fusion is not None:
+            prototxt_text = open(prototxt_path).read()
+        if prototxt_text is not None and fusion is not None:
+            _check(lib().mscnn_net_create_from_string_ex(prototxt_text.encode(), device, 0 if fusion else 1, C.byref(self._h)))
+        elif prototxt_text is not None:
             _check(lib().mscnn_net_create_from_string(prototxt_text.encode(), device, C.byref(self._h)))
         else:
             _check(lib().mscnn_net_create_from_file(str(prototxt_path).encode(), device, C.byref(self._h)))
@@ -120,6 +131,38 @@ class Net:
 
     def layer_flops(self, i):
         return lib().mscnn_net_layer_flops(self._h, i)
+
+    def layer_executed_flops(self, i):
+        return lib().mscnn_net_layer_executed_flops(self._h, i)
+
+    def set_conv_profiling(self, on):
+        _check(lib().mscnn_net_set_conv_profiling(self._h, int(on)))
+
+    def layer_stage_ms(self, i):
+        """(input transform, MFMA GEMM kernels, output transform) ms of layer i's last forward; zeros for non-conv layers."""
+        out = (C.c_float * 3)()
+        lib().mscnn_net_layer_stage_ms(self._h, i, out)
+        return tuple(out)
+
+    def set_conv_algo(self, layer, algo):
+        i = layer if isinstance(layer, int) else self.layer_names.index(layer)
+        _check(lib().mscnn_net_set_conv_algo(self._h, i, algo))
+
+    def set_conv_tuning(self, layer, variant=0, grid=0, flags=0):
+        i = layer if isinstance(layer, int) else self.layer_names.index(layer)
+        _check(lib().mscnn_net_set_conv_tuning(self._h, i, variant, grid, flags))
+
+    def calibrate_numerics(self, tol=5e-5):
+        """After a forward on representative input: Winograd layers that stray more than tol from the direct kernel fall
+        back to it.  Returns ({layer name: measured error}, [names switched])."""
+        n = C.c_int()
+        before = [self.layer_kernel(i) for i in range(len(self.layer_names))]
+        _check(lib().mscnn_net_calibrate_numerics(self._h, tol, C.byref(n)))
+        errs = {self.layer_names[i]: lib().mscnn_net_layer_calibration_err(self._h, i)
+                for i in range(len(self.layer_names)) if before[i].startswith("winograd")}
+        switched = [nm for nm, e in errs.items() if not e <= tol]
+        assert len(switched) == n.value
+        return errs, switched
 
     # ---- weights ----
     def set_param(self, layer, p, arr):

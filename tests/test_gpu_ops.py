@@ -134,18 +134,17 @@ WINO_CASES = [   # N, Cin, H, W, Cout, pad
 @pytest.mark.parametrize("case", WINO_CASES)
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("m", [2, 3])
-def test_conv_winograd(hip, orc, case, relu, m, monkeypatch):
+def test_conv_winograd(hip, orc, case, relu, m):
     """Winograd paths on whole planes -- F(2x2,3x3) (16 planes) and F(3x3,3x3) (25 planes, the default): input transform ->
     batched 1x1 igemm GEMMs -> output transform, against the oracle's direct convolution: same 1e-4 bound as every other fp32
     layer."""
     N, Cin, H, W, Cout, pad = case
-    monkeypatch.setenv("MSCNN_WINOGRAD", "2")
-    monkeypatch.setenv("MSCNN_WINOGRAD_PLANE_M", str(m))
+    algo = hip.ALGO_WINO_F2 if m == 2 else hip.ALGO_WINO_F3
     rng = np.random.default_rng(4242)
     x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
-    plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), relu=relu)
+    plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), relu=relu, algo=algo)
     assert plan.kernel == f"winograd_f{m}x{m}_3x3"
     plan.pack(dev(w))
     y = plan.forward(dev(x), dev(b)).cpu().numpy()
@@ -153,8 +152,7 @@ def test_conv_winograd(hip, orc, case, relu, m, monkeypatch):
     if relu:
         ref = orc.relu(ref)
     close(y, ref)
-    monkeypatch.setenv("MSCNN_WINOGRAD", "0")
-    assert not hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad)).kernel.startswith("winograd")
+    assert not hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), algo=hip.ALGO_DIRECT).kernel.startswith("winograd")
 
 
 WINO33_CASES = [   # R, Cin, H, W, Cout, pad  (ROI-pooled maps -> roi_c1)
@@ -166,16 +164,15 @@ WINO33_CASES = [   # R, Cin, H, W, Cout, pad  (ROI-pooled maps -> roi_c1)
 
 
 @pytest.mark.parametrize("case", WINO33_CASES)
-def test_conv_winograd_f3x3(hip, orc, case, monkeypatch):
+def test_conv_winograd_f3x3(hip, orc, case):
     """Winograd F(3x3,3x3) on the small ROI maps against the oracle's direct convolution, 1e-4 bound, inputs post-ReLU
     like the ROI-pooled features."""
     R, Cin, H, W, Cout, pad = case
-    monkeypatch.setenv("MSCNN_WINOGRAD", "2")
     rng = np.random.default_rng(99)
     x = np.maximum(rng.standard_normal((R, Cin, H, W)), 0).astype(np.float32) * 2.0
     w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
-    plan = hip.ConvPlan(R, Cin, H, W, Cout, 3, 3, (pad, pad), relu=True)
+    plan = hip.ConvPlan(R, Cin, H, W, Cout, 3, 3, (pad, pad), relu=True, algo=hip.ALGO_WINO_F3)
     assert plan.kernel == "winograd_f3x3_3x3" and not plan.can_pool
     plan.pack(dev(w))
     y = plan.forward(dev(x), dev(b)).cpu().numpy()
@@ -187,7 +184,7 @@ def test_conv_winograd_f3x3(hip, orc, case, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(1, 512, 72, 240, 512, 1), (1, 128, 288, 960, 128, 1), (700, 1024, 7, 7, 512, 0)])
-def test_winograd_full_size_matches_direct(hip, shape, monkeypatch):
+def test_winograd_full_size_matches_direct(hip, shape):
     """BASELINE.json sizes (conv4_2, conv2_2, roi_c1 at R = 700), too large for the CPU oracle in a unit test: the Winograd
     F(3x3,3x3) path against the direct implicit-GEMM path (itself oracle-checked at small sizes) on the same device data,
     1e-4; plus linearity of the Winograd path, y(2a + b) = 2 y(a) + y(b), which needs no second implementation at all."""
@@ -197,8 +194,7 @@ def test_winograd_full_size_matches_direct(hip, shape, monkeypatch):
     w = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) * (2.0 / (Cin * 9)) ** 0.5
     outs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("MSCNN_WINOGRAD", mode)
-        plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad))
+        plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), algo=hip.ALGO_DIRECT if mode == "0" else hip.ALGO_AUTO)
         assert plan.kernel.startswith("winograd_f3x3") == (mode == "1")
         plan.pack(w)
         outs[mode] = plan.forward(x).clone()
@@ -229,17 +225,16 @@ POOL_CASES = [   # N, Cin, H, W, Cout, winograd (0: direct igemm, 2: F(2x2,3x3),
 
 
 @pytest.mark.parametrize("case", POOL_CASES)
-def test_conv_fused_pool(hip, orc, case, monkeypatch):
+def test_conv_fused_pool(hip, orc, case):
     """Conv + ReLU with the following MAX 2x2/2 PoolingLayer fused into the epilogue: y unchanged, pooled output
     bit-identical to the stand-alone pooling kernel on y, and equal to the oracle's pooling of y."""
     N, Cin, H, W, Cout, wino = case
-    monkeypatch.setenv("MSCNN_WINOGRAD", "2" if wino else "0")
-    monkeypatch.setenv("MSCNN_WINOGRAD_PLANE_M", "2" if wino == 2 else "3")
+    algo = {0: hip.ALGO_DIRECT, 2: hip.ALGO_WINO_F2, 3: hip.ALGO_WINO_F3}[wino]
     rng = np.random.default_rng(77)
     x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
-    plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True)
+    plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True, algo=algo)
     assert plan.can_pool and plan.kernel == {0: plan.kernel, 2: "winograd_f2x2_3x3", 3: "winograd_f3x3_3x3"}[wino]
     assert plan.kernel.startswith("winograd") == (wino != 0)
     plan.pack(dev(w))
@@ -252,8 +247,6 @@ def test_conv_fused_pool(hip, orc, case, monkeypatch):
     assert np.array_equal(yp.cpu().numpy(), orc.pool2d(y0.cpu().numpy(), (2, 2), (0, 0), (2, 2), "MAX"))
     close(y0.cpu().numpy(), orc.relu(orc.conv2d(x, w, b, (1, 1))))
     assert not hip.ConvPlan(1, 512, 72, 240, 9, 5, 5, (2, 2)).can_pool       # proposal-head kernel: no pooling epilogue
-    monkeypatch.delenv("MSCNN_WINOGRAD_PLANE_M")
-    monkeypatch.setenv("MSCNN_WINOGRAD", "1")
     p3 = hip.ConvPlan(1, 512, 72, 240, 512, 3, 3, (1, 1))
     assert p3.kernel == "winograd_f3x3_3x3" and p3.can_pool                    # 24 x 80 tiles: even -> fused pooling
     assert not hip.ConvPlan(1, 512, 75, 240, 512, 3, 3, (1, 1)).can_pool       # 25 tile rows: the caller pools separately
@@ -270,11 +263,7 @@ def test_conv_no_bias_and_kernel_selection(hip, orc):
     assert hip.ConvPlan(1, 3, 8, 16, 32, 3, 3, (1, 1)).kernel.startswith("igemm_")          # Cin 3 is zero-padded
     assert hip.ConvPlan(1, 8, 8, 16, 32, 3, 3, (1, 1), stride=(2, 2)).kernel == "direct_f32"
     assert hip.ConvPlan(50, 1024, 7, 7, 512, 3, 3).kernel == "winograd_f3x3_3x3"             # roi_c1: F(3x3,3x3)
-    os.environ["MSCNN_WINOGRAD"] = "0"
-    try:
-        assert "roi7x7p0" in hip.ConvPlan(50, 1024, 7, 7, 512, 3, 3).kernel                # direct ROI-mode igemm
-    finally:
-        del os.environ["MSCNN_WINOGRAD"]
+    assert "roi7x7p0" in hip.ConvPlan(50, 1024, 7, 7, 512, 3, 3, algo=hip.ALGO_DIRECT).kernel   # direct ROI-mode igemm
     assert hip.ConvPlan(1, 512, 72, 240, 9, 7, 7, (3, 3)).kernel == "head4x4_k7x7_m3x4"     # proposal heads: M = 4 MFMA
     assert hip.ConvPlan(1, 512, 72, 240, 6, 5, 3, (2, 1)).kernel == "head4x4_k5x3_m2x4"
     assert plan.flops == 2.0 * 32 * 8 * 16 * 8 * 9

@@ -146,7 +146,8 @@ def _blobproto(arr, legacy=False):
     a = np.ascontiguousarray(arr, np.float32)
     body = b""
     if legacy:                    # num/channels/height/width = fields 1..4 (varint)
-        dims = list(a.shape) + [1] * (4 - a.ndim) if a.ndim <= 4 else list(a.shape)
+        # legacy blobs index from the END of the shape: a bias is 1 x 1 x 1 x N (blob.cpp:392-406)
+        dims = [1] * (4 - a.ndim) + list(a.shape) if a.ndim <= 4 else list(a.shape)
         for f, d in enumerate(dims[:4], start=1):
             body += _varint((f << 3) | 0) + _varint(d)
     else:                         # shape = 7 { dim = 1 packed }
