@@ -1,0 +1,62 @@
+/*
+ * mscnn_dist.h -- C ABI of libmscnn_dist.so: the ONE exchange step of multi-GPU MS-CNN inference.
+ *
+ * Images are independent (the only per-image coupling in the reference is BoxOutput's `for i < num` loop,
+ * box_output_layer.cpp:107): image k runs on GPU k mod G with its own net replica -- one host thread (or process) per
+ * GPU, mirroring the reference's thread-local Caffe singleton (src/caffe/common.cpp:13-20) -- and nothing but the final
+ * detections ever crosses xGMI.  This library gathers the DEVICE-RESIDENT detection pack that
+ * mscnn_net_detect_device() (include/mscnn_net.h) leaves behind: one fixed-size ncclAllGather per step straight out of /
+ * into HBM, then one D2H copy of the gathered packs.  No fp32 narrowing, no host bounce before the collective; a rank
+ * whose detections do not fit the agreed capacity is an ERROR, never a silent truncation.
+ *
+ * RCCL (librccl.so.1) is resolved at run time with dlopen, so the library loads on machines without it and does not
+ * collide with an RCCL another component (e.g. PyTorch) already mapped.
+ *
+ * All functions return 0 on success; mscnn_dist_last_error() has the text otherwise.
+ */
+#ifndef MSCNN_DIST_H_
+#define MSCNN_DIST_H_
+
+#include <stddef.h>
+
+#if defined(__GNUC__)
+#define MSCNN_DIST_API __attribute__((visibility("default")))
+#else
+#define MSCNN_DIST_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mscnn_dist mscnn_dist;
+#define MSCNN_DIST_ID_BYTES 128          /* sizeof(ncclUniqueId) */
+
+MSCNN_DIST_API const char* mscnn_dist_last_error(void);
+
+/* Rank 0 creates the rendezvous id and hands the 128 bytes to every other rank by any out-of-band channel (the launcher's
+ * store, a file, a socket); every rank then calls mscnn_dist_init with the same id. */
+MSCNN_DIST_API int mscnn_dist_unique_id(unsigned char id_out[MSCNN_DIST_ID_BYTES]);
+
+/* One communicator per GPU.  `device` must be the HIP device of the calling thread's net replica; pack_bytes is the fixed
+ * per-rank message size (mscnn_net_detect_pack_bytes(cap)).  Collective: returns when all `world` ranks have called it. */
+MSCNN_DIST_API int mscnn_dist_init(const unsigned char id[MSCNN_DIST_ID_BYTES], int rank, int world, int device,
+                                   size_t pack_bytes, mscnn_dist** out);
+MSCNN_DIST_API void mscnn_dist_destroy(mscnn_dist* d);
+MSCNN_DIST_API int mscnn_dist_rank(const mscnn_dist* d);
+MSCNN_DIST_API int mscnn_dist_world(const mscnn_dist* d);
+
+/* The exchange: ncclAllGather of send_dev[pack_bytes] (device memory, e.g. the pack of mscnn_net_detect_device) on
+ * `stream` into the communicator's device buffer, one asynchronous D2H copy of all `world` packs into the
+ * communicator's pinned host buffer, then a wait on the stream.  *gathered_host = world * pack_bytes bytes, rank-major,
+ * valid until the next call. */
+MSCNN_DIST_API int mscnn_dist_all_gather(mscnn_dist* d, const void* send_dev, void* stream, const void** gathered_host);
+/* Same without the D2H copy / wait: *gathered_dev = the device buffer (the caller orders later work on `stream`). */
+MSCNN_DIST_API int mscnn_dist_all_gather_device(mscnn_dist* d, const void* send_dev, void* stream, const void** gathered_dev);
+/* Barrier over the communicator (a 4-byte ncclAllReduce + stream wait): brackets the timed region of the benchmark. */
+MSCNN_DIST_API int mscnn_dist_barrier(mscnn_dist* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

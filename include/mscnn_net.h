@@ -119,6 +119,17 @@ typedef struct {
 MSCNN_NET_API int mscnn_net_detect(mscnn_net* net, const mscnn_detect_params* p, double* dets_host, int* ids_host,
                                    int cap, int* num_dets, int* num_rois);
 
+
+/* Multi-GPU form of the same stage (include/mscnn_dist.h gathers its result over RCCL): the detections stay in HBM, in a
+ * fixed-size pack  [int32 count, int32 num_rois, int32 cap, int32 0][cap x 5 doubles x y w h prob][cap x int32 roi row]
+ * of mscnn_net_detect_pack_bytes(cap) bytes (a multiple of 16).  cap must be >= the net's ROI count (BoxOutput's
+ * max_nms_num bounds it); more ROIs than cap is an error, never a truncation.  Asynchronous on the net's stream;
+ * *pack_dev stays valid until the next detect call on this net.  mscnn_net_unpack_detections reads one pack on the host. */
+MSCNN_NET_API size_t mscnn_net_detect_pack_bytes(int cap);
+MSCNN_NET_API int mscnn_net_detect_device(mscnn_net* net, const mscnn_detect_params* p, int cap, const void** pack_dev);
+MSCNN_NET_API int mscnn_net_unpack_detections(const void* pack_host, int cap, double* dets_host, int* ids_host, int* num_dets,
+                                              int* num_rois);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,12 +1,52 @@
 """Image-parallel inference across the GPUs of one node.
 
 The path shards by independent units: image k goes to rank k mod world, every rank owns a full net replica (weights are
-0.31 GB) and there is NO activation or weight traffic between GPUs.  The only exchange is one all_gather per step of a
-fixed-size padded detection buffer ([max_det + 1, 6] fp32 per rank: row 0 = count, rows 1.. = x y w h prob roi_id),
-latency-bound by construction.  Backend "nccl" (= RCCL over xGMI on ROCm) on GPUs, "gloo" in the CPU tests."""
+0.31 GB) and there is NO activation or weight traffic between GPUs.  The only exchange is one all_gather per step of the
+fixed-size DEVICE-RESIDENT detection pack the final stage leaves in HBM (mscnn_net_detect_device: [count, R, cap, 0 |
+cap x 5 float64 | cap x int32], 16 + 44 cap bytes): lossless (float64 as computed), no host bounce before the collective,
+and a rank whose ROI count exceeds the agreed capacity raises instead of truncating.
+
+  RcclGather   -- the product path: libmscnn_dist.so (include/mscnn_dist.h) calls ncclAllGather directly (RCCL over xGMI);
+                  the 128-byte ncclUniqueId travels over the launcher's torch.distributed store.
+  TorchGather  -- the same exchange through torch.distributed.all_gather_into_tensor on a uint8 tensor: "nccl" (= RCCL) on
+                  GPUs as a second route to the same bytes, "gloo" in the CPU tests of the sharding / pack logic.
+"""
+import ctypes as C
+import os
+
 import numpy as np
-import torch
-import torch.distributed as dist
+
+from . import net as mnet
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DIST_LIB_PATH = os.path.join(_HERE, "libmscnn_dist.so")
+_dlib = None
+
+
+class DistError(RuntimeError):
+    pass
+
+
+def dist_lib():
+    global _dlib
+    if _dlib is None:
+        if not os.path.exists(DIST_LIB_PATH):
+            raise DistError(f"{DIST_LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(DIST_LIB_PATH)
+        L.mscnn_dist_last_error.restype = C.c_char_p
+        L.mscnn_dist_unique_id.argtypes = [C.c_void_p]
+        L.mscnn_dist_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+        L.mscnn_dist_destroy.argtypes = [C.c_void_p]
+        L.mscnn_dist_destroy.restype = None
+        L.mscnn_dist_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mscnn_dist_barrier.argtypes = [C.c_void_p, C.c_void_p]
+        _dlib = L
+    return _dlib
+
+
+def _dcheck(rc):
+    if rc != 0:
+        raise DistError(dist_lib().mscnn_dist_last_error().decode())
 
 
 def shard(num_images, rank, world):
@@ -14,39 +54,67 @@ def shard(num_images, rank, world):
     return list(range(rank, num_images, world))
 
 
-def pack_detections(dets, ids, max_det):
-    """dets [D,5] float64 + ids [D] -> fixed-size float32 buffer [max_det + 1, 6]; detections are score-sorted, the tail is cut."""
-    d = min(len(dets), max_det)
-    buf = np.zeros((max_det + 1, 6), np.float32)
-    buf[0, 0] = d
-    buf[0, 1] = len(dets)            # how many there were before truncation
-    if d:
-        buf[1:d + 1, :5] = dets[:d]
-        buf[1:d + 1, 5] = ids[:d]
-    return buf
+def split_packs(gathered, world, cap):
+    """world concatenated packs (bytes-like) -> [(dets float64 [D,5], ids int32 [D], R)] per rank."""
+    pb = mnet.detect_pack_bytes(cap)
+    buf = np.frombuffer(gathered, np.uint8) if not isinstance(gathered, np.ndarray) else gathered.reshape(-1)
+    assert buf.size == world * pb, (buf.size, world, pb)
+    return [mnet.unpack_detections(buf[r * pb:(r + 1) * pb], cap) for r in range(world)]
 
 
-def unpack_detections(buf):
-    d = int(buf[0, 0])
-    return buf[1:d + 1, :5].astype(np.float64), buf[1:d + 1, 5].astype(np.int32)
+class RcclGather:
+    """ncclAllGather of the device pack through libmscnn_dist.so.  `exchange_id(b)`: callable that returns rank 0's bytes on
+    every rank (e.g. a torch.distributed broadcast_object_list or a TCPStore get/set)."""
+
+    def __init__(self, rank, world, device, cap, exchange_id):
+        L = dist_lib()
+        self.cap, self.world, self.rank = cap, world, rank
+        self.pack_bytes = mnet.detect_pack_bytes(cap)
+        idb = (C.c_ubyte * 128)()
+        if rank == 0:
+            _dcheck(L.mscnn_dist_unique_id(idb))
+        raw = exchange_id(bytes(idb))
+        idb = (C.c_ubyte * 128).from_buffer_copy(raw)
+        self._h = C.c_void_p()
+        _dcheck(L.mscnn_dist_init(idb, rank, world, device, self.pack_bytes, C.byref(self._h)))
+
+    def __call__(self, pack_dev_ptr, stream=None):
+        """pack_dev_ptr: device address from Net.detect_device(cap, ...).  Returns the per-rank list of (dets, ids, R)."""
+        out = C.c_void_p()
+        _dcheck(dist_lib().mscnn_dist_all_gather(self._h, C.c_void_p(pack_dev_ptr), C.c_void_p(stream or 0), C.byref(out)))
+        host = (C.c_ubyte * (self.world * self.pack_bytes)).from_address(out.value)
+        return split_packs(np.frombuffer(host, np.uint8), self.world, self.cap)
+
+    def barrier(self, stream=None):
+        _dcheck(dist_lib().mscnn_dist_barrier(self._h, C.c_void_p(stream or 0)))
+
+    def close(self):
+        if self._h:
+            dist_lib().mscnn_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-class DetectionGather:
-    """One all_gather per step; buffers are allocated once (no per-step allocation on the hot path)."""
+class TorchGather:
+    """The same fixed-size byte exchange through torch.distributed (backend "nccl" = RCCL on GPUs, "gloo" on CPU)."""
 
-    def __init__(self, max_det, device, group=None):
+    def __init__(self, cap, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.cap, self.group = cap, group
         self.world = dist.get_world_size(group)
-        self.group = group
-        self.max_det = max_det
-        self.send = torch.zeros((max_det + 1, 6), dtype=torch.float32, device=device)
-        self.recv = torch.zeros((self.world * (max_det + 1), 6), dtype=torch.float32, device=device)   # concatenated along dim 0
+        self.pack_bytes = mnet.detect_pack_bytes(cap)
+        self.device = device
+        self.recv = torch.zeros(self.world * self.pack_bytes, dtype=torch.uint8, device=device)
 
-    def __call__(self, dets, ids):
-        self.send.copy_(torch.from_numpy(pack_detections(dets, ids, self.max_det)))
-        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        return self.recv
-
-    def result(self):
-        """Host copy of the last gather: list of (dets, ids) per rank."""
-        host = self.recv.cpu().numpy().reshape(self.world, self.max_det + 1, 6)
-        return [unpack_detections(host[r]) for r in range(self.world)]
+    def __call__(self, pack):
+        """pack: uint8 tensor of pack_bytes on self.device (a view of the device pack, or a host pack in the CPU tests)."""
+        assert pack.dtype == self.torch.uint8 and pack.numel() == self.pack_bytes
+        self.dist.all_gather_into_tensor(self.recv, pack, group=self.group)
+        return split_packs(self.recv.cpu().numpy(), self.world, self.cap)

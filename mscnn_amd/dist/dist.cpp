@@ -1,0 +1,163 @@
+// libmscnn_dist.so: detections all-gather over RCCL / xGMI (include/mscnn_dist.h).  Host-only C++; RCCL is resolved with
+// dlopen so that nothing here interposes on (or depends on) an RCCL another component of the process has mapped.
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "../../include/mscnn_dist.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.handle) break;
+    }
+    if (!r.handle) return;
+#define LOAD(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym))
+    LOAD(GetUniqueId, "ncclGetUniqueId");
+    LOAD(CommInitRank, "ncclCommInitRank");
+    LOAD(CommDestroy, "ncclCommDestroy");
+    LOAD(AllGather, "ncclAllGather");
+    LOAD(AllReduce, "ncclAllReduce");
+    LOAD(GetErrorString, "ncclGetErrorString");
+#undef LOAD
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString) {
+      dlclose(r.handle);
+      r.handle = nullptr;
+    }
+  });
+  return r.handle ? &r : nullptr;
+}
+
+#define DIST_REQUIRE(cond, ...) do { if (!(cond)) { set_error(__VA_ARGS__); return 1; } } while (0)
+#define DIST_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); return 2; } } while (0)
+#define DIST_NCCL(expr) do { ncclResult_t e__ = (expr); if (e__ != ncclSuccess) { set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, R->GetErrorString(e__)); return 3; } } while (0)
+
+}  // namespace
+
+struct mscnn_dist {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  size_t pack_bytes = 0;
+  void* recv_dev = nullptr;       // world * pack_bytes
+  void* recv_host = nullptr;      // pinned, same size
+  int* flag_dev = nullptr;        // barrier payload
+};
+
+extern "C" {
+
+const char* mscnn_dist_last_error(void) { return g_err; }
+
+int mscnn_dist_unique_id(unsigned char id_out[MSCNN_DIST_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == MSCNN_DIST_ID_BYTES, "ncclUniqueId size");
+  Rccl* R = rccl();
+  DIST_REQUIRE(R, "librccl.so.1 not found (dlopen): multi-GPU gather unavailable");
+  DIST_REQUIRE(id_out, "null id");
+  ncclUniqueId id;
+  DIST_NCCL(R->GetUniqueId(&id));
+  std::memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+int mscnn_dist_init(const unsigned char idb[MSCNN_DIST_ID_BYTES], int rank, int world, int device, size_t pack_bytes,
+                    mscnn_dist** out) {
+  Rccl* R = rccl();
+  DIST_REQUIRE(R, "librccl.so.1 not found (dlopen): multi-GPU gather unavailable");
+  DIST_REQUIRE(idb && out && world >= 1 && rank >= 0 && rank < world && pack_bytes > 0 && pack_bytes % 16 == 0,
+               "dist init: bad argument (rank %d of %d, pack %zu bytes)", rank, world, pack_bytes);
+  DIST_HIP(hipSetDevice(device));
+  mscnn_dist* d = new (std::nothrow) mscnn_dist();
+  DIST_REQUIRE(d, "out of memory");
+  d->rank = rank; d->world = world; d->device = device; d->pack_bytes = pack_bytes;
+  ncclUniqueId id;
+  std::memcpy(&id, idb, sizeof(id));
+  ncclResult_t rc = R->CommInitRank(&d->comm, world, id, rank);
+  if (rc != ncclSuccess) {
+    set_error("ncclCommInitRank(rank %d of %d, device %d) -> %s", rank, world, device, R->GetErrorString(rc));
+    delete d;
+    return 3;
+  }
+  hipError_t e = hipMalloc(&d->recv_dev, pack_bytes * world);
+  if (e == hipSuccess) e = hipHostMalloc(&d->recv_host, pack_bytes * world, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->flag_dev), 2 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(d->flag_dev, 0, 2 * sizeof(int));
+  if (e != hipSuccess) {
+    set_error("dist init: buffers: %s", hipGetErrorString(e));
+    mscnn_dist_destroy(d);
+    return 2;
+  }
+  *out = d;
+  return 0;
+}
+
+void mscnn_dist_destroy(mscnn_dist* d) {
+  if (!d) return;
+  Rccl* R = rccl();
+  (void)hipSetDevice(d->device);
+  if (d->comm && R) (void)R->CommDestroy(d->comm);
+  if (d->recv_dev) (void)hipFree(d->recv_dev);
+  if (d->recv_host) (void)hipHostFree(d->recv_host);
+  if (d->flag_dev) (void)hipFree(d->flag_dev);
+  delete d;
+}
+
+int mscnn_dist_rank(const mscnn_dist* d) { return d ? d->rank : -1; }
+int mscnn_dist_world(const mscnn_dist* d) { return d ? d->world : 0; }
+
+int mscnn_dist_all_gather_device(mscnn_dist* d, const void* send_dev, void* stream, const void** gathered_dev) {
+  Rccl* R = rccl();
+  DIST_REQUIRE(R && d && send_dev, "dist all_gather: bad argument");
+  DIST_NCCL(R->AllGather(send_dev, d->recv_dev, d->pack_bytes, ncclChar, d->comm, reinterpret_cast<hipStream_t>(stream)));
+  if (gathered_dev) *gathered_dev = d->recv_dev;
+  return 0;
+}
+
+int mscnn_dist_all_gather(mscnn_dist* d, const void* send_dev, void* stream, const void** gathered_host) {
+  const int rc = mscnn_dist_all_gather_device(d, send_dev, stream, nullptr);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DIST_HIP(hipMemcpyAsync(d->recv_host, d->recv_dev, d->pack_bytes * d->world, hipMemcpyDeviceToHost, st));
+  DIST_HIP(hipStreamSynchronize(st));
+  if (gathered_host) *gathered_host = d->recv_host;
+  return 0;
+}
+
+int mscnn_dist_barrier(mscnn_dist* d, void* stream) {
+  Rccl* R = rccl();
+  DIST_REQUIRE(R && d, "dist barrier: bad argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DIST_NCCL(R->AllReduce(d->flag_dev, d->flag_dev + 1, 1, ncclInt, ncclSum, d->comm, st));
+  DIST_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // extern "C"

@@ -21,7 +21,16 @@ struct mscnn_net {
   caffe::DeviceBuffer det_pack;            // detect: [count | dets | ids] in one allocation -> ONE D2H copy, one sync
   void* det_host = nullptr;                // pinned staging for that copy
   size_t det_host_bytes = 0;
-  ~mscnn_net() { if (det_host) (void)hipHostFree(det_host); }
+  static constexpr int kHdrSlots = 4;
+  int* det_hdr = nullptr;                  // pinned ring of 16-byte pack headers {0, R, cap, 0}
+  hipEvent_t det_hdr_ev[kHdrSlots] = {nullptr, nullptr, nullptr, nullptr};
+  bool det_hdr_used[kHdrSlots] = {false, false, false, false};
+  unsigned det_hdr_next = 0;
+  ~mscnn_net() {
+    if (det_host) (void)hipHostFree(det_host);
+    if (det_hdr) (void)hipHostFree(det_hdr);
+    for (hipEvent_t e : det_hdr_ev) if (e) (void)hipEventDestroy(e);
+  }
 };
 
 namespace {
@@ -256,52 +265,102 @@ int mscnn_net_reshape(mscnn_net* n) { return guarded([&] { n->net->Reshape(); })
 int mscnn_net_set_layer_timing(mscnn_net* n, int on) { n->net->set_layer_timing(on != 0); return 0; }
 float mscnn_net_layer_ms(const mscnn_net* n, int l) { return n->net->layer_ms()[l]; }
 
+size_t mscnn_net_detect_pack_bytes(int cap) {
+  const size_t rows = (size_t)(cap > 0 ? cap : 1);
+  return (16 + rows * (5 * sizeof(double) + sizeof(int)) + 15) / 16 * 16;
+}
+
+// Final stage into the fixed-capacity device pack [count, R, cap, 0 | cap x 5 doubles | cap ints]; no host transfer.
+static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap, int* R_out) {
+  CHECK(p != nullptr);
+  CHECK(n->net->has_blob("bbox_pred") && n->net->has_blob("cls_pred") && n->net->has_blob("proposals_score"))
+      << "net has no bbox_pred / cls_pred / proposals_score outputs";
+  auto bbox = n->net->blob_by_name("bbox_pred");
+  auto cls = n->net->blob_by_name("cls_pred");
+  auto props = n->net->blob_by_name("proposals_score");
+  const int R = props->num();
+  CHECK_EQ(bbox->num(), R);
+  CHECK_EQ(cls->num(), R);
+  CHECK_LE(R, cap) << "detection pack capacity " << cap << " < " << R << " ROIs (size it by BoxOutput's max_nms_num)";
+  mscnn_detections_desc d;
+  d.ncls = R > 0 ? cls->count() / R : 1;
+  if (R > 0) CHECK_EQ(bbox->count() / R, 4 * d.ncls);
+  d.cls_id = p->cls_id;
+  for (int k = 0; k < 4; ++k) { d.bbox_mean[k] = p->bbox_mean[k]; d.bbox_std[k] = p->bbox_std[k]; }
+  d.proposal_thr = p->proposal_thr;
+  d.ratio_h = p->ratio_h; d.ratio_w = p->ratio_w; d.org_h = p->org_h; d.org_w = p->org_w; d.nms_overlap = p->nms_overlap;
+  const size_t wb = mscnn_detections_workspace_bytes(R);
+  void* ws = n->det_ws.Reserve(wb);
+  const size_t rows = (size_t)(cap > 0 ? cap : 1), total = mscnn_net_detect_pack_bytes(cap);
+  char* pack = static_cast<char*>(n->det_pack.Reserve(total));
+  int* hdr = reinterpret_cast<int*>(pack);
+  double* dets = reinterpret_cast<double*>(pack + 16);
+  int* ids = reinterpret_cast<int*>(pack + 16 + sizeof(double) * 5 * rows);
+  hipStream_t st = (hipStream_t)Caffe::stream();
+  // header {0, R, cap, 0} from a small ring of pinned slots; a slot is reused only after its previous copy has completed
+  // (event wait: a no-op in practice, every caller synchronises the stream once per image)
+  if (n->det_hdr == nullptr) {
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&n->det_hdr), 16 * mscnn_net::kHdrSlots, hipHostMallocDefault));
+    for (int i = 0; i < mscnn_net::kHdrSlots; ++i) HIP_CHECK(hipEventCreateWithFlags(&n->det_hdr_ev[i], hipEventDisableTiming));
+  }
+  const int slot = n->det_hdr_next++ % mscnn_net::kHdrSlots;
+  if (n->det_hdr_used[slot]) HIP_CHECK(hipEventSynchronize(n->det_hdr_ev[slot]));
+  int* head = n->det_hdr + 4 * slot;
+  head[0] = 0; head[1] = R; head[2] = cap; head[3] = 0;
+  HIP_CHECK(hipMemcpyAsync(hdr, head, 16, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipEventRecord(n->det_hdr_ev[slot], st));
+  n->det_hdr_used[slot] = true;
+  MSCNN_CHECK(mscnn_detections_fwd(&d, bbox->gpu_data(), cls->gpu_data(), props->gpu_data(), R, dets, ids, hdr, ws, wb, st));
+  if (R_out) *R_out = R;
+}
+
+int mscnn_net_detect_device(mscnn_net* n, const mscnn_detect_params* p, int cap, const void** pack_dev) {
+  return guarded([&] {
+    CHECK(pack_dev != nullptr);
+    detect_into_pack(n, p, cap, nullptr);
+    *pack_dev = n->det_pack.get();
+  });
+}
+
+int mscnn_net_unpack_detections(const void* pack_host, int cap, double* dets_host, int* ids_host, int* num_dets, int* num_rois) {
+  return guarded([&] {
+    CHECK(pack_host && num_dets);
+    const char* hp = static_cast<const char*>(pack_host);
+    const int* hdr = reinterpret_cast<const int*>(hp);
+    const int D = hdr[0], R = hdr[1];
+    CHECK_EQ(hdr[2], cap) << "detection pack was written for another capacity";
+    CHECK(D >= 0 && D <= R && R <= cap) << "corrupt detection pack: " << D << " detections, " << R << " ROIs, capacity " << cap;
+    const size_t rows = (size_t)(cap > 0 ? cap : 1);
+    if (D > 0 && dets_host) std::memcpy(dets_host, hp + 16, sizeof(double) * 5 * D);
+    if (D > 0 && ids_host) std::memcpy(ids_host, hp + 16 + sizeof(double) * 5 * rows, sizeof(int) * D);
+    *num_dets = D;
+    if (num_rois) *num_rois = R;
+  });
+}
+
 int mscnn_net_detect(mscnn_net* n, const mscnn_detect_params* p, double* dets_host, int* ids_host, int cap, int* num_dets,
                      int* num_rois) {
   return guarded([&] {
     CHECK(p && dets_host && num_dets);
-    CHECK(n->net->has_blob("bbox_pred") && n->net->has_blob("cls_pred") && n->net->has_blob("proposals_score"))
-        << "net has no bbox_pred / cls_pred / proposals_score outputs";
-    auto bbox = n->net->blob_by_name("bbox_pred");
-    auto cls = n->net->blob_by_name("cls_pred");
-    auto props = n->net->blob_by_name("proposals_score");
-    const int R = props->num();
-    CHECK_EQ(bbox->num(), R);
-    CHECK_EQ(cls->num(), R);
-    mscnn_detections_desc d;
-    d.ncls = cls->count() / R;
-    CHECK_EQ(bbox->count() / R, 4 * d.ncls);
-    d.cls_id = p->cls_id;
-    for (int k = 0; k < 4; ++k) { d.bbox_mean[k] = p->bbox_mean[k]; d.bbox_std[k] = p->bbox_std[k]; }
-    d.proposal_thr = p->proposal_thr;
-    d.ratio_h = p->ratio_h; d.ratio_w = p->ratio_w; d.org_h = p->org_h; d.org_w = p->org_w; d.nms_overlap = p->nms_overlap;
-    const size_t wb = mscnn_detections_workspace_bytes(R);
-    void* ws = n->det_ws.Reserve(wb);
-    // device layout: [int count, pad to 16 B][R x 5 doubles][R ints]
-    const size_t rows = (size_t)(R > 0 ? R : 1);
-    const size_t off_d = 16, off_i = off_d + sizeof(double) * 5 * rows, total = off_i + sizeof(int) * rows;
-    char* pack = static_cast<char*>(n->det_pack.Reserve(total));
-    int* cnt = reinterpret_cast<int*>(pack);
-    double* dets = reinterpret_cast<double*>(pack + off_d);
-    int* ids = reinterpret_cast<int*>(pack + off_i);
-    hipStream_t st = (hipStream_t)Caffe::stream();
-    MSCNN_CHECK(mscnn_detections_fwd(&d, bbox->gpu_data(), cls->gpu_data(), props->gpu_data(), R, dets, ids, cnt, ws, wb, st));
+    // single-GPU form: the pack is sized by this image's ROI count, so the one D2H copy moves 16 + 44 R bytes
+    int R = 0;
+    const int rows = n->net->has_blob("proposals_score") ? n->net->blob_by_name("proposals_score")->num() : 0;
+    detect_into_pack(n, p, rows, &R);
+    const size_t total = mscnn_net_detect_pack_bytes(rows);
     if (n->det_host_bytes < total) {
       if (n->det_host) HIP_CHECK(hipHostFree(n->det_host));
       n->det_host = nullptr; n->det_host_bytes = 0;
       HIP_CHECK(hipHostMalloc(&n->det_host, total, hipHostMallocDefault));
       n->det_host_bytes = total;
     }
-    HIP_CHECK(hipMemcpyAsync(n->det_host, pack, total, hipMemcpyDeviceToHost, st));      // <= 44 R + 16 bytes
+    hipStream_t st = (hipStream_t)Caffe::stream();
+    HIP_CHECK(hipMemcpyAsync(n->det_host, n->det_pack.get(), total, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    const char* hp = static_cast<const char*>(n->det_host);
-    const int D = *reinterpret_cast<const int*>(hp);
+    const int D = *reinterpret_cast<const int*>(n->det_host);
     CHECK_LE(D, cap) << "detections buffer too small";
-    if (D > 0) {
-      std::memcpy(dets_host, hp + off_d, sizeof(double) * 5 * D);
-      if (ids_host) std::memcpy(ids_host, hp + off_i, sizeof(int) * D);
-    }
-    *num_dets = D;
+    int Rr = 0, Dd = 0;
+    CHECK_EQ(mscnn_net_unpack_detections(n->det_host, rows, dets_host, ids_host, &Dd, &Rr), 0) << mscnn_net_last_error();
+    *num_dets = Dd;
     if (num_rois) *num_rois = R;
   });
 }

@@ -552,6 +552,14 @@ void BoxOutputLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const
   output_proposal_with_score_ = (top.size() == 2);
   cap_ = 0;
   last_rows_ = 1;
+  // Limit of this build, reported at set-up rather than at the first Forward: the sorted top-K and its NMS bit matrix live
+  // in LDS-sized buffers of 4032 boxes.  max_nms_num: 0 (caffe.proto default = no cap) or > 4032 is accepted only while the
+  // heads have no more anchors than that; every deploy file of the reference sets 2000.
+  mscnn_boxoutput_desc d;
+  FillBoxOutputDesc(this->layer_param_, bottom, fg_thr_, iou_thr_, nms_type_, &d);
+  CHECK_GT(mscnn_boxoutput_workspace_bytes(&d), 0u)
+      << "BoxOutput layer '" << this->layer_param_.name() << "': " << mscnn_last_error()
+      << " -- set box_output_param.max_nms_num to a value in [1, 4032] (the reference's deploy nets use 2000)";
 }
 template <typename Dtype>
 void BoxOutputLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
@@ -561,38 +569,47 @@ void BoxOutputLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const ve
   top[0]->Reshape(1, 5, 1, 1);
   if (output_proposal_with_score_) top[1]->Reshape(1, 6, 1, 1);
 }
+// The layer's parameters + bottom shapes as the C ABI's descriptor (box_output_layer.cpp:80-103).
 template <typename Dtype>
-void BoxOutputLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
-  const BoxOutputParameter p = this->layer_param_.box_output_param();
+static void FillBoxOutputDesc(const LayerParameter& lp, const vector<Blob<Dtype>*>& bottom, float fg_thr, float iou_thr,
+                              const string& nms_type, mscnn_boxoutput_desc* dp) {
+  mscnn_boxoutput_desc& d = *dp;
+  const BoxOutputParameter p = lp.box_output_param();
   const int n = (int)bottom.size();
   CHECK_EQ(n, p.field_h_size());        // :80-82
   CHECK_EQ(n, p.field_w_size());
   CHECK_EQ(n, p.downsample_rate_size());
-  mscnn_boxoutput_desc d;
   std::memset(&d, 0, sizeof(d));
   CHECK_LE(n, MSCNN_BOXOUT_MAX_HEADS);
   d.num_heads = n;
   d.num = bottom[0]->num();
   d.channels = bottom[0]->channels();
-  const float* heads[MSCNN_BOXOUT_MAX_HEADS];
   for (int j = 0; j < n; ++j) {
     CHECK_EQ(bottom[j]->num(), d.num);
     CHECK_EQ(bottom[j]->channels(), d.channels);
     d.head_h[j] = bottom[j]->height(); d.head_w[j] = bottom[j]->width();
     d.field_w[j] = (float)p.field_w(j); d.field_h[j] = (float)p.field_h(j); d.downsample_rate[j] = (float)p.downsample_rate(j);
-    heads[j] = bottom[j]->gpu_data();
   }
-  d.fg_thr = fg_thr_; d.iou_thr = iou_thr_;
-  d.nms_mode = nms_type_ == "IOMU" ? 1 : nms_type_ == "IOFU" ? 2 : 0;   // BoxIOU: anything else is IOU (math_functions.cpp:26-32)
+  d.fg_thr = fg_thr; d.iou_thr = iou_thr;
+  d.nms_mode = nms_type == "IOMU" ? 1 : nms_type == "IOFU" ? 2 : 0;   // BoxIOU: anything else is IOU (math_functions.cpp:26-32)
   d.field_whr = p.field_whr(); d.field_xyr = p.field_xyr();
   d.max_nms_num = (int)p.max_nms_num(); d.max_post_nms_num = (int)p.max_post_nms_num();
   d.min_size = p.min_size();
-  const BBoxRegParameter br = this->layer_param_.bbox_reg_param();
+  const BBoxRegParameter br = lp.bbox_reg_param();
   if (br.bbox_mean_size() > 0 && br.bbox_std_size() > 0) {   // :92-103
     CHECK_EQ(br.bbox_mean_size(), 4); CHECK_EQ(br.bbox_std_size(), 4);
     d.do_bbox_norm = 1;
     for (int k = 0; k < 4; ++k) { d.bbox_mean[k] = br.bbox_mean(k); d.bbox_std[k] = br.bbox_std(k); }
   }
+}
+
+template <typename Dtype>
+void BoxOutputLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  const int n = (int)bottom.size();
+  mscnn_boxoutput_desc d;
+  FillBoxOutputDesc(this->layer_param_, bottom, fg_thr_, iou_thr_, nms_type_, &d);
+  const float* heads[MSCNN_BOXOUT_MAX_HEADS];
+  for (int j = 0; j < n; ++j) heads[j] = bottom[j]->gpu_data();
   const size_t wbytes = mscnn_boxoutput_workspace_bytes(&d);
   CHECK_GT(wbytes, 0u) << mscnn_last_error();
   void* ws = workspace_.Reserve(wbytes);

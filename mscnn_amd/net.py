@@ -38,6 +38,7 @@ def lib():
         L.mscnn_net_layer_ms.restype = C.c_float
         L.mscnn_net_blob_device_ptr.restype = C.c_void_p
         L.mscnn_net_destroy.restype = None
+        L.mscnn_net_detect_pack_bytes.restype = C.c_size_t
         vp, ci, cs = C.c_void_p, C.c_int, C.c_char_p
         sig = {
             "mscnn_net_create_from_file": [cs, ci, vp], "mscnn_net_create_from_string": [cs, ci, vp], "mscnn_net_destroy": [vp],
@@ -59,6 +60,8 @@ def lib():
             "mscnn_net_forward": [vp], "mscnn_net_forward_from_to": [vp, ci, ci], "mscnn_net_reshape": [vp],
             "mscnn_net_set_layer_timing": [vp, ci], "mscnn_net_layer_ms": [vp, ci],
             "mscnn_net_detect": [vp, vp, vp, vp, ci, vp, vp],
+            "mscnn_net_detect_pack_bytes": [ci], "mscnn_net_detect_device": [vp, vp, ci, vp],
+            "mscnn_net_unpack_detections": [vp, ci, vp, vp, vp, vp],
         }
         for name, args in sig.items():
             getattr(L, name).argtypes = args
@@ -222,6 +225,27 @@ class Net:
     def layer_ms(self):
         return [lib().mscnn_net_layer_ms(self._h, i) for i in range(len(self.layer_names))]
 
+    @staticmethod
+    def _params(cls_id, ratios, org_hw, bbox_mean, bbox_std, proposal_thr, nms_overlap):
+        p = DetectParams()
+        p.cls_id = cls_id
+        for k in range(4):
+            p.bbox_mean[k] = bbox_mean[k]; p.bbox_std[k] = bbox_std[k]
+        p.proposal_thr = proposal_thr
+        p.ratio_h, p.ratio_w = ratios
+        p.org_h, p.org_w = org_hw
+        p.nms_overlap = nms_overlap
+        return p
+
+    def detect_device(self, cap, cls_id, ratios, org_hw, bbox_mean=(0, 0, 0, 0), bbox_std=(0.1, 0.1, 0.2, 0.2),
+                      proposal_thr=-10.0, nms_overlap=0.5):
+        """Final stage into the fixed-capacity DEVICE pack (multi-GPU gather input, include/mscnn_dist.h); asynchronous.
+        Returns the device address of the pack (detect_pack_bytes(cap) bytes)."""
+        p = self._params(cls_id, ratios, org_hw, bbox_mean, bbox_std, proposal_thr, nms_overlap)
+        ptr = C.c_void_p()
+        _check(lib().mscnn_net_detect_device(self._h, C.byref(p), cap, C.byref(ptr)))
+        return ptr.value
+
     def detect(self, cls_id, ratios, org_hw, bbox_mean=(0, 0, 0, 0), bbox_std=(0.1, 0.1, 0.2, 0.2), proposal_thr=-10.0,
                nms_overlap=0.5, cap=4096):
         """Final detection stage on the device; returns (dets[D,5] float64 [x y w h prob], roi ids[D], R)."""
@@ -238,3 +262,19 @@ class Net:
         _check(lib().mscnn_net_detect(self._h, C.byref(p), dets.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), cap,
                                       C.byref(D), C.byref(R)))
         return dets[:D.value].copy(), ids[:D.value].copy(), R.value
+
+
+def detect_pack_bytes(cap):
+    return lib().mscnn_net_detect_pack_bytes(cap)
+
+
+def unpack_detections(pack_host, cap):
+    """One host copy of a detection pack (bytes / ctypes buffer / numpy uint8) -> (dets[D,5] float64, ids[D] int32, R)."""
+    buf = np.frombuffer(pack_host, np.uint8) if not isinstance(pack_host, np.ndarray) else pack_host
+    assert buf.nbytes >= detect_pack_bytes(cap)
+    buf = np.ascontiguousarray(buf)
+    dets = np.zeros((max(cap, 1), 5), np.float64); ids = np.zeros(max(cap, 1), np.int32)
+    D = C.c_int(); R = C.c_int()
+    _check(lib().mscnn_net_unpack_detections(buf.ctypes.data_as(C.c_void_p), cap, dets.ctypes.data_as(C.c_void_p),
+                                             ids.ctypes.data_as(C.c_void_p), C.byref(D), C.byref(R)))
+    return dets[:D.value].copy(), ids[:D.value].copy(), R.value

@@ -51,23 +51,26 @@ def _conv_geom(p):
     return kh, kw, ph, pw, sh, sw, int(_num(p, "group", 1))
 
 
-def forward(layers, weights, inputs, stop_after=None, backend=None):
+def forward(layers, weights, inputs, stop_after=None, backend=None, timings=None):
     """layers: list of (name, type, bottoms, tops, param_text).  weights: {layer: [w, b]}.  inputs: {blob: array}.
     Returns {blob name: array} (in-place layers overwrite their blob, like the net) plus '__anchor_ids__'.
-    backend: oracle.pyoracle (default, the C restatement) or oracle.pyref (the reference's own sources, oracle/_ref)."""
+    backend: oracle.pyoracle (default, the C restatement) or oracle.pyref (the reference's own sources, oracle/_ref).
+    timings: optional list that receives (layer name, type, seconds) per layer (the `caffe time` loop, tools/caffe.cpp:380-400)."""
     global orc
     _saved = orc
     if backend is not None:
         orc = backend
     try:
-        return _forward(layers, weights, inputs, stop_after)
+        return _forward(layers, weights, inputs, stop_after, timings)
     finally:
         orc = _saved
 
 
-def _forward(layers, weights, inputs, stop_after):
+def _forward(layers, weights, inputs, stop_after, timings=None):
+    import time
     blobs = dict(inputs)
     for name, typ, bottoms, tops, ptext in layers:
+        _t0 = time.perf_counter()
         P = parse_param_text(ptext)
         x = [blobs[b] for b in bottoms]
         if typ == "Input":
@@ -134,6 +137,8 @@ def _forward(layers, weights, inputs, stop_after):
             blobs[tops[0]] = orc.decode_bbox(x[0].reshape(x[0].shape[0], -1), x[1].reshape(-1, 5), mean, std).reshape(-1, 5, 1, 1)
         else:
             raise NotImplementedError(typ)
+        if timings is not None:
+            timings.append((name, typ, time.perf_counter() - _t0))
         if stop_after == name:
             break
     return blobs

@@ -34,6 +34,16 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """BLAS threads of the reference's cblas_sgemm (MKL through libmkl_rt); everything else in the reference's CPU path is
+    single-threaded anyway.  n = 1 gives the 1-core baseline row; returns the previous maximum."""
+    lib()
+    mkl = C.CDLL("libmkl_rt.so.1")
+    prev = mkl.MKL_Get_Max_Threads()
+    mkl.MKL_Set_Num_Threads(int(n))
+    return prev
+
+
 def _ck(rc):
     if rc < 0:
         raise RuntimeError("reference layer failed: " + lib().ref_last_error().decode())

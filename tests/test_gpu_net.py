@@ -36,55 +36,72 @@ CONFIGS = [
     ("caltech/mscnn-7s-480", dict(height=240, width=320, max_nms_num=150), "mid", 2),
 ]
 
+# BASELINE.json sizes: the deploy files' own input sizes and top-K (2000), every configuration the north star names, against
+# oracle/_ref = the reference's own CPU layer sources (im2col + MKL sgemm; 20-60 s of host time per frame on the GPU box)
+FULL_SIZE = [
+    ("kitti_car/mscnn-7s-576", {}, "mid", 2, (375, 1242)),
+    ("kitti_car/mscnn-7s-576", {}, "dense", 2, (375, 1242)),            # every anchor passes fg_thr: 2000-box sort + NMS worst case
+    ("kitti_car/mscnn-8s-768-trainval", {}, "mid", 2, (375, 1242)),     # 1x3x768x2560, 8 heads, 81,600 anchors
+    ("kitti_ped_cyc/mscnn-7s-576-2x", {}, "mid", 2, (375, 1242)),       # deconv 2x, 7x5 ROI pooling, fc6 2048
+    ("caltech/mscnn-7s-480", {}, "mid", 2, (480, 640)),
+]
 
-@pytest.mark.parametrize("model,size,regime,cls_id", CONFIGS)
-def test_net_layerwise_and_end_to_end(model, size, regime, cls_id):
-    if not torch.cuda.is_available():
-        pytest.fail("needs a MI355X")
+
+def check_net(model, size, regime, cls_id, org_hw=(375, 1242), backend=None):
     from oracle import pynet, pyoracle as orc
     n = mnet.Net(prototxt_text=zoo.prototxt(model, **size))
     ws = synth.load_into(n, regime)
-    x = synth.frame(size["height"], size["width"])
+    H, W = n.blob_shape("data")[2:]
+    x = synth.frame(H, W, org_hw=org_hw)
     n.set_blob("data", x)
     n.forward()
     layers = layer_list(n)
+    report = {}
 
     # (1) end-to-end oracle run (its own intermediate values)
-    ref = pynet.forward(layers, ws, {"data": x})
+    ref = pynet.forward(layers, ws, {"data": x}, backend=backend)
     # trunk + heads: fp32 within 1e-4 relative
-    for b in ("conv1_2", "conv3_3", "conv4_3", "conv5_3", "conv6_1", "pool6"):
-        assert rel_err(n.get_blob(b), ref[b]) < 1e-4, b
+    for b in ("conv1_2", "conv2_2", "conv3_3", "conv4_3", "conv5_3", "conv6_1", "pool6"):
+        report[b] = rel_err(n.get_blob(b), ref[b])
+        assert report[b] < 1e-4, (b, report[b])
     head_tops = [t for (nm, ty, bo, to, _) in layers if nm.startswith("LFCN_") for t in to]
     for b in head_tops:
-        assert rel_err(n.get_blob(b), ref[b]) < 1e-4, b
+        report[b] = rel_err(n.get_blob(b), ref[b])
+        assert report[b] < 1e-4, (b, report[b])
 
     # (2) per-layer, identical inputs: BoxOutput selection must be index-exact given the device's own head blobs
     heads_dev = [n.get_blob(b) for b in layers[[l[0] for l in layers].index("proposals")][2]]
     bo = [l for l in layers if l[1] == "BoxOutput"][0]
-    r2 = pynet.forward([bo], ws, dict(zip(bo[2], heads_dev)))
+    r2 = pynet.forward([bo], ws, dict(zip(bo[2], heads_dev)), backend=backend)
     rois_dev = n.get_blob("proposals")
     R = rois_dev.shape[0]
     assert R == r2["proposals"].shape[0]
     assert np.array_equal(rois_dev, r2["proposals"])                      # bit-identical boxes and order
     assert np.array_equal(n.get_blob("proposals_score"), r2["proposals_score"])
-    # ROI pooling on the device's conv4_3 + ROIs: bit-exact.  The two ROIPooling layers write straight into the Concat top
-    # (the Concat layer is fused away), so the check is made on the concatenated blob.
+    # ROI pooling on the device's feature map + ROIs: bit-exact.  The two ROIPooling layers write straight into the Concat
+    # top (the Concat layer is fused away); their own tops are materialised lazily when somebody asks for them.
     assert n.fused_away(n.layer_names.index("roi_pool"))
     parts = []
     for l in layers:
         if l[1] == "ROIPooling":
-            parts.append(pynet.forward([l], ws, {l[2][0]: n.get_blob(l[2][0]), l[2][1]: rois_dev})[l[3][0]])
+            parts.append(pynet.forward([l], ws, {l[2][0]: n.get_blob(l[2][0]), l[2][1]: rois_dev}, backend=backend)[l[3][0]])
+            assert np.array_equal(n.get_blob(l[3][0]), parts[-1]), l[0]      # roi_pool_org / roi_pool_ctx read back correctly
     assert np.array_equal(n.get_blob("roi_pool"), np.concatenate(parts, axis=1))
+    if "conv4_3_2x" in n.blob_names:                                       # "-2x" nets: the bilinear Deconvolution
+        l = [l for l in layers if l[1] == "Deconvolution"][0]
+        d = pynet.forward([l], ws, {l[2][0]: n.get_blob(l[2][0])}, backend=backend)[l[3][0]]
+        report["conv4_3_2x"] = rel_err(n.get_blob("conv4_3_2x"), d)
+        assert report["conv4_3_2x"] < 1e-6
     # detection sub-net with identical inputs
     sub = layers[[l[0] for l in layers].index("roi_pool") + 1:]        # roi_c1 ... bbox_pred, incl. the auto-inserted Split
     feeds = {"roi_pool": n.get_blob("roi_pool")}
-    r3 = pynet.forward(sub, ws, feeds)
+    r3 = pynet.forward(sub, ws, feeds, backend=backend)
     for b in ("roi_c1", "fc6", "cls_pred", "bbox_pred"):
-        assert rel_err(n.get_blob(b), r3[b]) < 1e-4, b
+        report["sub:" + b] = rel_err(n.get_blob(b), r3[b])
+        assert report["sub:" + b] < 1e-4, (b, report["sub:" + b])
 
     # (3) final detection stage on the device outputs: selection exact, values 1e-4
-    H, W = size["height"], size["width"]
-    kw = dict(cls_id=cls_id, ratios=(H / 375.0, W / 1242.0), org_hw=(375, 1242))
+    kw = dict(cls_id=cls_id, ratios=(H / float(org_hw[0]), W / float(org_hw[1])), org_hw=org_hw)
     dets, ids, Rd = n.detect(**kw)
     assert Rd == R
     dref, iref = orc.detections(n.get_blob("bbox_pred"), n.get_blob("cls_pred"), n.get_blob("proposals_score").reshape(R, 6), **kw)
@@ -95,6 +112,7 @@ def test_net_layerwise_and_end_to_end(model, size, regime, cls_id):
     # fg_thr / top-K / IoU boundaries may legitimately flip because MFMA and CPU summation orders differ
     Rr = ref["proposals"].shape[0]
     de, ie = orc.detections(ref["bbox_pred"], ref["cls_pred"], ref["proposals_score"].reshape(Rr, 6), **kw)
+    matched = None
     if len(de) and len(dets):
         a = np.stack([dets[:, 0], dets[:, 1], dets[:, 0] + dets[:, 2], dets[:, 1] + dets[:, 3]], 1)
         b = np.stack([de[:, 0], de[:, 1], de[:, 0] + de[:, 2], de[:, 1] + de[:, 3]], 1)
@@ -103,24 +121,100 @@ def test_net_layerwise_and_end_to_end(model, size, regime, cls_id):
         matched = (m[np.arange(len(a)), j] >= 0.99) & (np.abs(dets[:, 4] - de[j, 4]) <= 1e-4)
         assert matched.mean() >= 0.98, f"only {matched.mean():.3f} of {len(a)} detections matched"
     assert abs(len(de) - len(dets)) <= max(2, 0.02 * len(de))
+    report.update(R=R, R_ref=Rr, dets=len(dets), dets_ref=len(de), matched=None if matched is None else float(matched.mean()))
+    return report
 
 
-def test_unfused_equals_fused(monkeypatch):
+@pytest.mark.parametrize("model,size,regime,cls_id", CONFIGS)
+def test_net_layerwise_and_end_to_end(model, size, regime, cls_id):
+    if not torch.cuda.is_available():
+        pytest.fail("needs a MI355X")
+    check_net(model, size, regime, cls_id)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("model,size,regime,cls_id,org_hw", FULL_SIZE)
+def test_full_size_parity_vs_reference(model, size, regime, cls_id, org_hw):
+    """Every north-star configuration at ITS OWN input size and top-K against the reference's own CPU layers: the same
+    assertions as the reduced-size test (per-layer 1e-4, BoxOutput / ROIPooling bit-exact on identical inputs, final-stage
+    selection exact, >= 98 % matched detections end to end)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a MI355X")
+    from oracle import pyref
+    if not pyref.available():
+        pytest.fail("oracle/_ref/libmscnn_ref.so did not travel to this box (it is built by __graft_entry__.build() where "
+                    "/root/reference exists and must not be listed in .gpurunignore)")
+    rep = check_net(model, size, regime, cls_id, org_hw, backend=pyref)
+    worst = max(v for k, v in rep.items() if isinstance(v, float) and k != "matched")
+    print(f"\nFULLSIZE {model} {regime}: R {rep['R']}/{rep['R_ref']} dets {rep['dets']}/{rep['dets_ref']} matched {rep['matched']} "
+          f"worst per-blob err {worst:.2e} " + " ".join(f"{k}={v:.1e}" for k, v in rep.items() if isinstance(v, float) and k != "matched"))
+
+
+def test_unfused_equals_fused():
     """Conv+ReLU fusion must be bit-identical to the separate layers (Layer API parity for stand-alone use)."""
     txt = zoo.prototxt("kitti_car/mscnn-7s-576", height=96, width=160)
     x = synth.frame(96, 160)
     outs = []
     for nofuse in ("0", "1"):
-        monkeypatch.setenv("MSCNN_NO_FUSE", nofuse)
-        n = mnet.Net(prototxt_text=txt)
+        n = mnet.Net(prototxt_text=txt, fusion=(nofuse == "0"))
         synth.load_into(n, "mid")
         n.set_blob("data", x)
         n.forward()
         assert n.fused_away(n.layer_names.index("relu1_1")) == (nofuse == "0")
         assert n.fused_away(n.layer_names.index("roi_pool")) == (nofuse == "0")
-        outs.append({b: n.get_blob(b) for b in ("conv4_3", "conv6_1", "proposals_score", "roi_pool", "fc6", "bbox_pred")})
+        outs.append({b: n.get_blob(b) for b in ("conv4_3", "conv6_1", "pool5", "proposals_score", "roi_pool_org", "roi_pool_ctx",
+                                                 "roi_pool", "fc6", "bbox_pred")})
     for b in outs[0]:
         assert np.array_equal(outs[0][b], outs[1][b]), b
+
+
+def test_partial_forward_over_fused_layers():
+    """Net::ForwardFromTo with a range that starts after a fused layer's producer (net.cpp:544-555): the fused-away layer
+    must recompute its top from its bottom, as the reference does, and a bottom reshaped between two Forward calls must
+    propagate without Net::Reshape (layer.hpp:451-456)."""
+    n = mnet.Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=96, width=160, max_nms_num=100))
+    synth.load_into(n, "dense")
+    n.set_blob("data", synth.frame(96, 160))
+    n.forward()
+    want = {b: n.get_blob(b) for b in ("pool1", "pool4", "roi_pool", "fc6", "cls_pred")}
+    names = n.layer_names
+    # (a) clobber a fused Pooling layer's top, run the net from that layer on: it must be rebuilt from conv1_2
+    i = names.index("pool1")
+    assert n.fused_away(i)
+    n.set_blob("pool1", np.full(n.blob_shape("pool1"), 7.0, np.float32))
+    n.forward(i, i)
+    assert np.array_equal(n.get_blob("pool1"), want["pool1"])
+    # (b) from a fused in-place ReLU on: idempotent on the already rectified blob
+    n.forward(names.index("relu4_3"), len(names) - 1)
+    for b in ("roi_pool", "fc6", "cls_pred"):
+        assert np.array_equal(n.get_blob(b), want[b]), b
+    # (c) from the fused Concat on: its bottoms live inside the Concat top and are materialised first
+    n.set_blob("roi_pool", np.zeros(n.blob_shape("roi_pool"), np.float32))
+    n.forward(names.index("roi_pool_ctx"), names.index("roi_pool_ctx"))       # re-run one producer: writes its window
+    n.forward(names.index("roi_pool_org"), names.index("roi_pool_org"))
+    n.forward(names.index("roi_pool"), len(names) - 1)
+    for b in ("roi_pool", "fc6", "cls_pred"):
+        assert np.array_equal(n.get_blob(b), want[b]), b
+
+
+def test_numerical_calibration_falls_back_per_layer():
+    """Net::CalibrateNumerics: Winograd layers are compared with the direct kernel on the current input; with an impossible
+    tolerance every one of them must fall back (and the net must still agree with itself), with the default one none does."""
+    n = mnet.Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=192, width=384, max_nms_num=100))
+    synth.load_into(n, "mid")
+    n.set_blob("data", synth.frame(192, 384))
+    n.forward()
+    before = {b: n.get_blob(b) for b in ("conv4_3", "conv5_3", "fc6")}
+    wino = [nm for i, nm in enumerate(n.layer_names) if n.layer_kernel(i).startswith("winograd")]
+    assert "conv4_2" in wino and "roi_c1" in wino
+    errs, switched = n.calibrate_numerics(5e-5)
+    assert sorted(errs) == sorted(wino) and switched == [] and 0 < max(errs.values()) < 5e-5, errs
+    errs, switched = n.calibrate_numerics(1e-9)
+    assert sorted(switched) == sorted(wino)
+    n.forward()
+    assert not any(n.layer_kernel(i).startswith("winograd") for i in range(len(n.layer_names)))
+    for b, v in before.items():
+        assert rel_err(n.get_blob(b), v) < 1e-4, b
 
 
 def test_dynamic_roi_count_across_forwards():

@@ -1,37 +1,74 @@
 #!/usr/bin/env python3
-"""Per-layer timing of the mscnn-7s-576 trunk convolutions at full size (1x3x576x1920) with HIP events.
-Usage: python tools/bench_layers.py [--iters 20] [--only conv4_2]"""
+"""Per-layer timing of the mscnn-7s-576 convolutions at full size (1x3x576x1920, roi_c1 at R = 700) with HIP events, with the
+Winograd stage split {input transform, MFMA GEMM, output transform} and executed-FLOP rates.  A/B mode runs every variant of a
+tuning knob on the same box, interleaved.
+
+  python tools/bench_layers.py [--iters 20] [--only conv4_2]
+  python tools/bench_layers.py --ab flags=0,4            # phase stagger on / off (mscnn_conv_desc::tune_flags bit 2)
+  python tools/bench_layers.py --ab algo=0,1 --only conv3 # Winograd heuristic vs direct
+  python tools/bench_layers.py --ab grid=0,500,750 --only conv4_2
+"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mscnn_amd import hipapi as hip
 
-LAYERS = [  # name, Cin, H, W, Cout, k, pad
-    ("conv1_2", 64, 576, 1920, 64, 3, 1), ("conv2_1", 64, 288, 960, 128, 3, 1), ("conv2_2", 128, 288, 960, 128, 3, 1),
-    ("conv3_1", 128, 144, 480, 256, 3, 1), ("conv3_2", 256, 144, 480, 256, 3, 1),
-    ("conv4_1", 256, 72, 240, 512, 3, 1), ("conv4_2", 512, 72, 240, 512, 3, 1), ("conv4_3", 512, 72, 240, 512, 3, 1),
-    ("conv5_1", 512, 36, 120, 512, 3, 1), ("conv6_1", 512, 18, 60, 512, 3, 1),
-    ("LFCN_1_5x5", 512, 72, 240, 9, 5, 2), ("LFCN_1_7x7", 512, 72, 240, 9, 7, 3),
-    ("LFCN_2_7x7", 512, 36, 120, 9, 7, 3),
+LAYERS = [  # name, N, Cin, H, W, Cout, k, pad
+    ("conv1_1", 1, 3, 576, 1920, 64, 3, 1), ("conv1_2", 1, 64, 576, 1920, 64, 3, 1),
+    ("conv2_1", 1, 64, 288, 960, 128, 3, 1), ("conv2_2", 1, 128, 288, 960, 128, 3, 1),
+    ("conv3_1", 1, 128, 144, 480, 256, 3, 1), ("conv3_2", 1, 256, 144, 480, 256, 3, 1),
+    ("conv4_1", 1, 256, 72, 240, 512, 3, 1), ("conv4_2", 1, 512, 72, 240, 512, 3, 1),
+    ("conv5_1", 1, 512, 36, 120, 512, 3, 1), ("conv6_1", 1, 512, 18, 60, 512, 3, 1),
+    ("LFCN_1_5x5", 1, 512, 72, 240, 9, 5, 2), ("LFCN_1_7x7", 1, 512, 72, 240, 9, 7, 3),
+    ("LFCN_2_7x7", 1, 512, 36, 120, 9, 7, 3), ("roi_c1", 700, 1024, 7, 7, 512, 3, 0),
 ]
-ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=20); ap.add_argument("--only", default=""); ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS probe)")
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--only", default="")
+ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS probe)")
+ap.add_argument("--ab", default="", help="knob=v1,v2,...  with knob in {algo, variant, grid, flags}")
 a = ap.parse_args()
+knob, vals = None, [0]
+if a.ab:
+    knob, v = a.ab.split("=")
+    vals = [int(t) for t in v.split(",")]
 torch.manual_seed(0)
-tot_f = tot_t = 0.0
-for name, Cin, H, W, Cout, k, pad in LAYERS:
-    if a.only and a.only not in name: continue
-    x = torch.randn(1, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
+for name, N, Cin, H, W, Cout, k, pad in LAYERS:
+    if a.only and a.only not in name:
+        continue
+    x = torch.relu(torch.randn(N, Cin, H, W, device="cuda")); w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
     b = torch.randn(Cout, device="cuda")
-    if a.zero: x.zero_(); w.zero_()
-    plan = hip.ConvPlan(1, Cin, H, W, Cout, k, k, (pad, pad), relu=True); plan.pack(w)
-    y = plan.forward(x, b)
-    for _ in range(3): plan.forward(x, b, out=y)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(a.iters): plan.forward(x, b, out=y)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / a.iters
-    tf = plan.flops / ms / 1e9
-    tot_f += plan.flops; tot_t += ms
-    print(f"{name:12s} {plan.kernel:28s} {ms*1e3:9.1f} us  {tf:7.1f} TFLOP/s  {100*tf/157.3:5.1f}% of fp32 MFMA peak")
-print(f"total {tot_t:.3f} ms  {tot_f/tot_t/1e9:.1f} TFLOP/s")
+    if a.zero:
+        x.zero_(); w.zero_()
+    plans = []
+    for v in vals:
+        kw = dict(algo=0, tune_variant=0, tune_grid=0, tune_flags=0)
+        if knob:
+            kw[{"algo": "algo", "variant": "tune_variant", "grid": "tune_grid", "flags": "tune_flags"}[knob]] = v
+        p = hip.ConvPlan(N, Cin, H, W, Cout, k, k, (pad, pad), relu=True, **kw)
+        p.pack(w)
+        p.set_profiling(True)
+        plans.append(p)
+    y = plans[0].forward(x, b)
+    ms = [0.0] * len(plans); st = [[0.0, 0.0, 0.0] for _ in plans]
+    for p in plans:
+        for _ in range(3):
+            p.forward(x, b, out=y)
+    rounds = 4
+    for r in range(rounds):              # interleave the variants: clock / thermal drift hits all of them alike
+        for i, p in enumerate(plans):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(max(1, a.iters // rounds)):
+                p.forward(x, b, out=y)
+            e1.record(); torch.cuda.synchronize()
+            ms[i] += e0.elapsed_time(e1) / max(1, a.iters // rounds) / rounds
+            s = p.stage_ms()
+            for j in range(3):
+                st[i][j] += s[j] / rounds
+    for i, p in enumerate(plans):
+        tf = p.executed_flops / ms[i] / 1e9
+        tag = f"{knob}={vals[i]}" if knob else ""
+        stage = f"  [in {st[i][0]*1e3:6.1f} | gemm {st[i][1]*1e3:6.1f} ({p.executed_flops / max(st[i][1], 1e-9) / 1e9:5.1f} TF) | out {st[i][2]*1e3:6.1f}]" if p.kernel.startswith("wino") else ""
+        print(f"{name:12s} {tag:10s} {p.kernel:30s} {ms[i]*1e3:9.1f} us  {tf:6.1f} TF executed = {100*tf/157.3:5.1f}% of fp32 MFMA peak"
+              f"  ({p.flops / ms[i] / 1e9:6.1f} TF algorithmic){stage}", flush=True)
