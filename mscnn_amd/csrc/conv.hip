@@ -44,9 +44,9 @@ struct IgemmArgs {
   unsigned w_img_bytes;  // per-image weight stride in bytes (0: one weight set; Winograd GEMM: one U matrix per "image")
   int full_q;          // whole tiles per workgroup in the data-parallel phase (tile t = g + j * G, j < full_q)
   long total_iters;    // iterations (tile, chunk) of the stream-K phase: the remaining tiles [full_q * G, MT * NT)
-  int stagger;         // > 1: workgroups co-resident on a CU start their first tile at different chunks (see igemm_kernel)
+  int row0;            // plane mode: first tile row of this launch (a launch may cover a slab [row0, row0 + NTH) of the plane)
 };
-constexpr int kSlabsPerWg = 3;   // stream-K tail partial, stream-K head partial, staggered first tile
+constexpr int kSlabsPerWg = 2;   // stream-K tail partial, stream-K head partial
 
 // Tile configuration.  Two geometries share one kernel:
 //   plane mode (RH == 0): the N side of a tile is a TH x TW patch of one image's output plane (trunk, heads);
@@ -62,9 +62,6 @@ struct Cfg {
   static constexpr int F4_PER_CH = BN_ / 4;                 // float4s per channel row of the B tile (tile = BN contiguous pixels)
   static constexpr int CH_PER_PASS = 256 / F4_PER_CH;       // channels staged per pass of the 256 threads
   static constexpr int BV_PER_T = CK_ * F4_PER_CH / 256;
-  // phase-staggered first tile (see igemm_kernel).  Compiled in only where it costs no occupancy: the 128x128 3x3 kernels
-  // sit at 167 VGPRs = 3 waves / SIMD and the extra segment state would push them to 181 = 2 waves.
-  static constexpr bool STAGGER = RH_ == 0 && (VEC_ != 0 || (BM_ == 64 && BN_ == 256));
   static constexpr int PF = PF_;   // 1: LDS operand reads software-pipelined one MFMA group ahead
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, KH = KH_, KW = KW_, CK = CK_, TW = TW_;
   static constexpr bool ROI = RH_ > 0;
@@ -144,7 +141,7 @@ struct TileGeo {
       r0 = nt * C::IPT; h0 = w0 = img = 0;
     } else {
       const int tw = nt % a.NTW, th = (nt / a.NTW) % a.NTH;
-      img = nt / (a.NTW * a.NTH); h0 = th * C::TH; w0 = tw * C::TW; r0 = 0;
+      img = nt / (a.NTW * a.NTH); h0 = (th + a.row0) * C::TH; w0 = tw * C::TW; r0 = 0;
     }
   }
   // x / y buffer windows the 32-bit offsets are relative to
@@ -226,17 +223,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   wg_range(a.total_iters, a.G, wg, it, it_end);
   int full_j = 0;
   const int rem_tile0 = a.full_q * a.G;
-  // Phase stagger.  Every workgroup does identical work, so the 2-3 workgroups that share a CU (dispatch order: blocks b,
-  // b + 256, b + 512) would run in lockstep: all in their K loops together, then all in the epilogue / next prologue together
-  // with the matrix pipe idle (ablation: epilogue 8 % + prologue 13 % of the 25-plane GEMMs).  Workgroups of "slot" s > 0
-  // therefore start their FIRST tile at chunk KI * s / slots (partial -> own slab), and finish chunks [0, KI * s / slots) of
-  // that tile as their LAST segment, adding their own slab back (same thread, same addresses: program order suffices).
-  // The sum is still a fixed function of (shape, grid): deterministic, within fp32 rounding of the unsplit chain.
-  int stag_ks = 0, stag_state = 0;       // state 0: first part pending, 1: running the other segments, 2: done
-  if (C::STAGGER && a.stagger > 1 && a.full_q > 0) {
-    const int slot = (int)(blockIdx.x / 256) % a.stagger;
-    stag_ks = a.KI * slot / a.stagger;
-  }
 
   // per-lane LDS read bases (floats)
   const float* aRd = ldsA + khalf * C::BM + wm * C::WM + l31;
@@ -254,7 +240,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 
   // ---- segment state: the segment whose first chunk is in flight / being multiplied --------------------------------------
   int t = 0, k0 = 0, k1 = 0, mt = 0;
-  int seg_kind = 0;                // 0: ordinary, 1: staggered first part (-> own slab), 2: staggered last part (+ own slab)
   TileGeo<C> geo;
   __amdgpu_buffer_rsrc_t xsrc = wsrc;
   unsigned g_off[C::B_PER_T];      // byte offsets of this thread's patch elements (channel-chunk term = scalar offset of the load)
@@ -267,21 +252,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   const unsigned a_voff = (unsigned)tid * 16u;
 
   auto next_segment = [&]() -> bool {
-    if (C::STAGGER && stag_ks > 0 && stag_state == 0) {
-      t = wg; k0 = stag_ks; k1 = a.KI; seg_kind = 1;
-      stag_state = 1; full_j = 1;
-    } else if (full_j < a.full_q) {
-      t = wg + full_j * a.G; k0 = 0; k1 = a.KI; seg_kind = 0;
+    if (full_j < a.full_q) {
+      t = wg + full_j * a.G; k0 = 0; k1 = a.KI;
       ++full_j;
     } else if (it < it_end) {
-      seg_kind = 0;
       t = rem_tile0 + (int)(it / a.KI);
       k0 = (int)(it % a.KI);
       k1 = (int)min((long)a.KI, k0 + (it_end - it));
       it += (k1 - k0);
-    } else if (C::STAGGER && stag_ks > 0 && stag_state == 1) {
-      t = wg; k0 = 0; k1 = stag_ks; seg_kind = 2;
-      stag_state = 2;
     } else {
       return false;
     }
@@ -338,27 +316,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       MSCNN_LOAD_CHUNK(k0);
     }
     f32x16 acc[C::MI][C::NI];
-    float* own_slab = a.ws + ((long)wg * kSlabsPerWg + 2) * (C::BM * C::BN);
-    if (C::STAGGER && seg_kind == 2) {          // staggered last part: the accumulators start from the first part parked in this workgroup's slab
-      const __amdgpu_buffer_rsrc_t ssrc = make_rsrc(own_slab, (unsigned)(C::BM * C::BN) * 4u);
 #pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi)
+    for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni) {
-          const unsigned vo = (unsigned)((wm * C::WM + mi * 32 + 4 * khalf) * C::BN + wn * C::WN + ni * 32 + l31) * 4u;
+      for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            acc[mi][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                           ssrc, vo, (unsigned)(((r & 3) + 8 * (r >> 2)) * C::BN) * 4u, 0));
-        }
-    } else {
-#pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    }
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     // This segment's identity (the epilogue needs it after the segment state has moved on).  PREFETCH_NEXT kernels (the 1x1
     // Winograd GEMMs: K = Cin only, so a tile is short and its prologue shows): while the LAST chunk is multiplied, the NEXT
@@ -366,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     // behind that chunk's MFMAs and the epilogue's stores.  (Costs registers in the epilogue: for the 3x3 kernels it would
     // take one workgroup of occupancy -- measured slower -- so they fetch it after the epilogue.)
     const TileGeo<C> geo_e = geo;
-    const int t_e = t, k0_e = k0, k1_e = k1, mt_e = mt, kind_e = seg_kind;
+    const int t_e = t, k0_e = k0, k1_e = k1, mt_e = mt;
     more = false;
     for (int kc = k0_e; kc < k1_e; ++kc) {
       if (C::PF == 2) __builtin_amdgcn_s_setprio(3);   // staging phase: get through the barriers quickly
@@ -444,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     const TileGeo<C>& geo = geo_e;
     const int t = t_e, k0 = k0_e, k1 = k1_e, mt = mt_e;
     (void)t;
-    const bool full = (k0 == 0 && k1 == a.KI) || (C::STAGGER && kind_e == 2);
+    const bool full = (k0 == 0 && k1 == a.KI);
     if (C::PF >= 14 && full) {
       if (acc[0][0][0] == 12345.678f) a.y[tid] = acc[0][0][1];     // ablation: no epilogue (keeps acc live)
     } else if (full) {
@@ -503,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         }
       }
     } else {
-      float* slab = (C::STAGGER && kind_e == 1) ? own_slab : a.ws + ((long)wg * kSlabsPerWg + (k0 > 0 ? 0 : 1)) * (C::BM * C::BN);
+      float* slab = a.ws + ((long)wg * kSlabsPerWg + (k0 > 0 ? 0 : 1)) * (C::BM * C::BN);
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
@@ -780,7 +743,13 @@ struct mscnn_conv_plan {
   mscnn_conv_plan* wino = nullptr;
   int wino_m = 2;        // output tile edge: 2 = F(2x2,3x3) (16 planes), 3 = F(3x3,3x3) (25 planes; small ROI maps)
   int tiles_h = 0, tiles_w = 0, T_pad = 0;
-  int stagger = 0;       // igemm: co-resident workgroup slots whose first tile is phase-shifted (0 / 1: off)
+  // Slab pipeline of the Winograd path: the tile range is cut into `slabs` pieces; while the MFMA GEMM of slab i runs on the
+  // caller's stream, a second stream (owned by the plan) runs the HBM-bound input transform of slab i + 1 and the output
+  // transform of slab i - 1.
+  int slabs = 1;
+  static constexpr int kMaxSlabs = 4;
+  mutable hipStream_t aux = nullptr;
+  mutable hipEvent_t ev_start = nullptr, ev_done = nullptr, ev_it[kMaxSlabs] = {}, ev_gemm[kMaxSlabs] = {};
   // roofline accounting (mscnn_conv2d_plan_set_profiling): events around {input transform | GEMM | output transform}
   bool profiling = false;
   mutable hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -788,12 +757,42 @@ struct mscnn_conv_plan {
   ~mscnn_conv_plan() {
     delete wino;
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_it) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_gemm) if (e) (void)hipEventDestroy(e);
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    if (ev_done) (void)hipEventDestroy(ev_done);
+    if (aux) (void)hipStreamDestroy(aux);
   }
 };
 
 using namespace mscnn;
 
 static void plan_shape(mscnn_conv_plan* p);
+
+// Persistent-grid schedule of `tiles` output tiles of KI chunks each: G workgroups, full_q whole tiles per workgroup, the
+// remainder cut stream-K style into G equal (tile, chunk) ranges.
+static void igemm_schedule(const KernelEntry& k, const mscnn_conv_desc& d, long tiles, int KI, int* G_out, int* full_q, long* total_iters) {
+  // grid: G workgroups (default 2 per CU; 3 for the 128x128 tiles whose 43 KB of LDS and 168 VGPRs allow it)
+  const int genv = tune_env("MSCNN_TUNE_GRID", d.tune_grid);   // tuning knob
+  long G = genv > 0 ? genv : ((k.BM == 128 && k.BN == 128 && k.KH == 3) ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
+  if (tiles * KI / 4 < G) G = tiles * KI / 4;               // never less than ~4 chunks per workgroup
+  if (G < 1) G = 1;
+  // A slightly smaller grid that divides the tile count exactly needs no stream-K phase and no fix-up launch at all (the 25
+  // plane GEMMs of conv2_2..conv4_3 have 1500 / 3000 / 6000 tiles: G = 500 instead of 512 saves the 18 us fix-up and the
+  // slab traffic for 2 % idle workgroup slots).
+  if (!genv && tiles >= 2 * G) {
+    // the 1x1 GEMM kernel (32 KB LDS, 166 VGPRs) also fits 3 per CU: try that range first (measured G = 750 vs 500 on the
+    // 25-plane GEMMs: conv4_2 259 vs 266 us, conv3_2 332 vs 339, conv2_2 496 vs 510)
+    const long tops[2] = {(k.KH == 1 && k.BN == 128 && k.CK < 64) ? 768 : G, G};
+    bool found = false;
+    for (int c = 0; c < 2 && !found; ++c)
+      for (long g2 = tops[c]; g2 >= tops[c] - tops[c] / 16 && g2 * 2 <= tiles; --g2)
+        if (tiles % g2 == 0) { G = g2; found = true; break; }
+  }
+  *G_out = (int)G;
+  *full_q = (int)(tiles / G);                               // data-parallel phase
+  *total_iters = (tiles - (long)*full_q * G) * KI;          // stream-K phase over the remainder tiles
+}
 
 // Winograd is chosen where the cut in multiplies (2.25x for F(2x2,3x3), 3.24x for F(3x3,3x3)) outweighs the extra HBM traffic
 // of the transforms (V and M are 4x / 2.78x the input / output and are written and read once each): GEMM FLOPs per transform
@@ -834,6 +833,17 @@ static bool wino_plan(mscnn_conv_plan* p) {
   p->tiles_h = th; p->tiles_w = tw; p->T_pad = (int)T_pad;
   p->packed_bytes = (size_t)planes * g->packed_bytes;
   p->ws_bytes = (size_t)planes * ((size_t)d.Cin + d.Cout) * T_pad * sizeof(float) + g->ws_bytes;
+  // slab pipeline (F(3x3,3x3) only): slabs of whole 128-tile GEMM rows with >= ~1000 GEMM tiles each, so that every slab still
+  // fills the chip; ROI maps additionally need slab boundaries on the input transform's 8-ROI blocks.  tune_flags bit 2: off.
+  p->slabs = 1;
+  if (m == 3 && !(tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 4)) {
+    const long rows = T_pad / 128, gemm_tiles = (long)planes * g->MT * rows;
+    long S = gemm_tiles / 1000;
+    if (S > mscnn_conv_plan::kMaxSlabs) S = mscnn_conv_plan::kMaxSlabs;
+    if (S > rows) S = rows;
+    if (roi_map && (128 % (th * tw) != 0 || (128 / (th * tw)) % 8 != 0)) S = 1;
+    p->slabs = S < 1 ? 1 : (int)S;
+  }
   return true;
 }
 
@@ -845,7 +855,6 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->packed_bytes = 0;
   p->ws_bytes = 0;
   p->head.entry = -1;
-  p->stagger = 0;
   if (head_plan(d, p->Ho, p->Wo, &p->head)) {
     p->packed_bytes = p->head.packed_bytes;
     p->ws_bytes = p->head.ws_bytes;
@@ -906,34 +915,10 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->KI = cdiv(d.Cin, k.CK);
   if (p->KI > 256) { p->entry = -1; return; }   // the fix-up kernels list at most 256 contributing slabs per tile: use the direct kernel
   const long tiles = (long)p->MT * p->NT;
-  // grid: G workgroups (default 2 per CU; 3 for the 128x128 tiles whose 43 KB of LDS and 168 VGPRs allow it)
-  const int genv = tune_env("MSCNN_TUNE_GRID", d.tune_grid);   // tuning knob
-  long G = genv > 0 ? genv : ((k.BM == 128 && k.BN == 128 && k.KH == 3) ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
-  if (tiles * p->KI / 4 < G) G = tiles * p->KI / 4;         // never less than ~4 chunks per workgroup
-  if (G < 1) G = 1;
-  // A slightly smaller grid that divides the tile count exactly needs no stream-K phase and no fix-up launch at all (the 25
-  // plane GEMMs of conv2_2..conv4_3 have 1500 / 3000 / 6000 tiles: G = 500 instead of 512 saves the 18 us fix-up and the
-  // slab traffic for 2 % idle workgroup slots).
-  if (!genv && tiles >= 2 * G) {
-    // the 1x1 GEMM kernel (32 KB LDS, 166 VGPRs) also fits 3 per CU: try that range first (measured G = 750 vs 500 on the
-    // 25-plane GEMMs: conv4_2 259 vs 266 us, conv3_2 332 vs 339, conv2_2 496 vs 510)
-    const long tops[2] = {(k.KH == 1 && k.BN == 128 && k.CK < 64) ? 768 : G, G};
-    bool found = false;
-    for (int c = 0; c < 2 && !found; ++c)
-      for (long g2 = tops[c]; g2 >= tops[c] - tops[c] / 16 && g2 * 2 <= tiles; --g2)
-        if (tiles % g2 == 0) { G = g2; found = true; break; }
-  }
-  p->G = (int)G;
-  p->full_q = (int)(tiles / G);                               // data-parallel phase
-  p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
+  igemm_schedule(k, d, tiles, p->KI, &p->G, &p->full_q, &p->total_iters);
   p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * sizeof(float);
-  p->ws_bytes = (size_t)p->G * kSlabsPerWg * k.BM * k.BN * sizeof(float);
-  // phase stagger (igemm_kernel): one slot per workgroup that shares a CU; only worth it when a workgroup has several
-  // whole tiles of several chunks each
-  const int flags = tune_env("MSCNN_TUNE_FLAGS", d.tune_flags);
-  const int slots = (int)((G + 255) / 256);
-  const bool can_stagger = k.RH == 0 && (k.variant >= 101 || (k.BM == 64 && k.BN == 256));      // == Cfg::STAGGER
-  p->stagger = (can_stagger && !(flags & 4) && slots > 1 && p->full_q >= 2 && p->KI >= 2 * slots) ? slots : 0;
+  // (slab launches of the Winograd GEMM re-run the schedule on fewer tiles: never more than 768 workgroups)
+  p->ws_bytes = (size_t)(p->G > 768 ? p->G : 768) * kSlabsPerWg * k.BM * k.BN * sizeof(float);
 }
 
 extern "C" int mscnn_conv2d_plan_create(const mscnn_conv_desc* desc, mscnn_conv_plan** plan_out) {
@@ -1029,14 +1014,21 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
 }
 
 // igemm launch (main kernel + fix-up).  w_img_bytes / nt_major: see IgemmArgs (non-zero only for the Winograd GEMM).
+// row0 / rows (plane mode, rows > 0): only tile rows [row0, row0 + rows) of every image -- a slab of the Winograd GEMM.
 static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* packed, const float* bias, float* y,
                         float* y_pool, void* workspace, size_t workspace_bytes, hipStream_t st, unsigned w_img_bytes,
-                        int nt_major) {
+                        int nt_major, int row0 = 0, int rows = 0) {
   const mscnn_conv_desc& d = p->d;
   const KernelEntry& k = kTable[p->entry];
-  const long rem_tiles = (long)p->MT * p->NT - (long)p->full_q * p->G;
+  int G = p->G, full_q = p->full_q, NTH = p->NTH, NT = p->NT;
+  long total_iters = p->total_iters;
+  if (rows > 0 && rows != p->NTH) {
+    NTH = rows; NT = d.N * NTH * p->NTW;
+    igemm_schedule(k, d, (long)p->MT * NT, p->KI, &G, &full_q, &total_iters);
+  }
+  const long rem_tiles = (long)p->MT * NT - (long)full_q * G;
   const bool split = rem_tiles > 0;
-  if (split || p->stagger > 1) {
+  if (split) {
     if (!workspace || workspace_bytes < p->ws_bytes) {
       set_error("conv: workspace %zu < %zu", workspace_bytes, p->ws_bytes);
       return MSCNN_ERR_WORKSPACE;
@@ -1045,17 +1037,16 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
   IgemmArgs a;
   a.x = x; a.wp = packed; a.bias = bias; a.y = y; a.ws = static_cast<float*>(workspace);
   a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.Ho = p->Ho; a.Wo = p->Wo; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
-  a.MT = p->MT; a.NTH = p->NTH; a.NTW = p->NTW; a.NT = p->NT; a.KI = p->KI; a.G = p->G; a.relu = d.relu;
-  a.total_iters = p->total_iters; a.full_q = p->full_q;
+  a.MT = p->MT; a.NTH = NTH; a.NTW = p->NTW; a.NT = NT; a.KI = p->KI; a.G = G; a.relu = d.relu;
+  a.total_iters = total_iters; a.full_q = full_q; a.row0 = row0;
   a.w_img_bytes = w_img_bytes; a.nt_major = nt_major;
-  a.stagger = p->stagger;
   a.yp = y_pool; a.Hp = (p->Ho + 1) / 2; a.Wp = (p->Wo + 1) / 2;
   if (y_pool && !k.fix_pool_fn) {
     set_error("conv: kernel %s has no fused pooling epilogue", k.name);
     return MSCNN_ERR_BAD_ARG;
   }
   a.xcd_map = (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 1) ? 0 : 1;
-  k.main_fn<<<p->G, 256, 0, st>>>(a);
+  k.main_fn<<<G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   if (split) {
     (y_pool ? k.fix_pool_fn : k.fix_fn)<<<(int)rem_tiles * k.fix_split, 256, 0, st>>>(a);
@@ -1107,17 +1098,68 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
     float* V = static_cast<float*>(workspace);
     float* M = V + planes * d.Cin * p->T_pad;
     float* gws = M + planes * d.Cout * p->T_pad;
-    MSCNN_STAGE_EVENT(0);
-    int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st);
+    const int T = d.N * p->tiles_h * p->tiles_w, tile_rows = d.N * p->tiles_h;
+    const int S = p->profiling ? 1 : p->slabs;      // stage timing wants the three stages back to back
+    if (S <= 1) {
+      MSCNN_STAGE_EVENT(0);
+      int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, 0, p->T_pad, st);
+      if (rc != MSCNN_OK) return rc;
+      MSCNN_STAGE_EVENT(1);
+      rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
+      if (rc != MSCNN_OK) return rc;
+      MSCNN_STAGE_EVENT(2);
+      rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, 0, tile_rows, st);
+      if (rc != MSCNN_OK) return rc;
+      MSCNN_STAGE_EVENT(3);
+      p->ev_valid = p->profiling;
+      return MSCNN_OK;
+    }
+    // ---- slab pipeline: caller's stream = the MFMA GEMMs, plan's second stream = the HBM-bound transforms ------------------
+    //   aux : IT(0) IT(1) | wait GEMM(0) | OT(0) IT(2) | wait GEMM(1) | OT(1) IT(3) | ... | wait GEMM(S-1) | OT(S-1)
+    //   main: wait IT(0) | GEMM(0) | wait IT(1) | GEMM(1) | ...                                  | wait OT(S-1)
+    if (!p->aux) {
+      MSCNN_HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+      MSCNN_HIP_TRY(hipEventCreateWithFlags(&p->ev_start, hipEventDisableTiming));
+      MSCNN_HIP_TRY(hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming));
+      for (int i = 0; i < mscnn_conv_plan::kMaxSlabs; ++i) {
+        MSCNN_HIP_TRY(hipEventCreateWithFlags(&p->ev_it[i], hipEventDisableTiming));
+        MSCNN_HIP_TRY(hipEventCreateWithFlags(&p->ev_gemm[i], hipEventDisableTiming));
+      }
+    }
+    const int rows = p->T_pad / 128;
+    auto row_of = [&](int i) { return (int)((long)rows * i / S); };      // slab i = GEMM rows [row_of(i), row_of(i + 1))
+    auto it_slab = [&](int i) -> int {
+      const int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad,
+                                          128 * row_of(i), 128 * row_of(i + 1), p->aux);
+      if (rc != MSCNN_OK) return rc;
+      MSCNN_HIP_TRY(hipEventRecord(p->ev_it[i], p->aux));
+      return MSCNN_OK;
+    };
+    MSCNN_HIP_TRY(hipEventRecord(p->ev_start, st));               // x (and the workspace's previous user) are ready
+    MSCNN_HIP_TRY(hipStreamWaitEvent(p->aux, p->ev_start, 0));
+    int rc = it_slab(0);
     if (rc != MSCNN_OK) return rc;
-    MSCNN_STAGE_EVENT(1);
-    rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
-    if (rc != MSCNN_OK) return rc;
-    MSCNN_STAGE_EVENT(2);
-    rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st);
-    if (rc != MSCNN_OK) return rc;
-    MSCNN_STAGE_EVENT(3);
-    p->ev_valid = p->profiling;
+    int done_rows = 0;                                            // tile rows already output-transformed
+    for (int i = 0; i < S; ++i) {
+      if (i + 1 < S && (rc = it_slab(i + 1)) != MSCNN_OK) return rc;
+      MSCNN_HIP_TRY(hipStreamWaitEvent(st, p->ev_it[i], 0));
+      rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1, row_of(i),
+                        row_of(i + 1) - row_of(i));
+      if (rc != MSCNN_OK) return rc;
+      MSCNN_HIP_TRY(hipEventRecord(p->ev_gemm[i], st));
+      // tile rows that are complete once GEMM(i) has finished (all of them after the last slab)
+      long have = (long)128 * row_of(i + 1);
+      if (have > T) have = T;
+      int upto = i + 1 == S ? tile_rows : (int)(have / p->tiles_w);
+      if (y_pool && i + 1 < S) upto &= ~1;
+      MSCNN_HIP_TRY(hipStreamWaitEvent(p->aux, p->ev_gemm[i], 0));
+      rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu,
+                                 done_rows, upto, p->aux);
+      if (rc != MSCNN_OK) return rc;
+      if (upto > done_rows) done_rows = upto;
+    }
+    MSCNN_HIP_TRY(hipEventRecord(p->ev_done, p->aux));
+    MSCNN_HIP_TRY(hipStreamWaitEvent(st, p->ev_done, 0));
     return MSCNN_OK;
   }
 #undef MSCNN_STAGE_EVENT

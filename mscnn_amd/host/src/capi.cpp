@@ -21,15 +21,8 @@ struct mscnn_net {
   caffe::DeviceBuffer det_pack;            // detect: [count | dets | ids] in one allocation -> ONE D2H copy, one sync
   void* det_host = nullptr;                // pinned staging for that copy
   size_t det_host_bytes = 0;
-  static constexpr int kHdrSlots = 4;
-  int* det_hdr = nullptr;                  // pinned ring of 16-byte pack headers {0, R, cap, 0}
-  hipEvent_t det_hdr_ev[kHdrSlots] = {nullptr, nullptr, nullptr, nullptr};
-  bool det_hdr_used[kHdrSlots] = {false, false, false, false};
-  unsigned det_hdr_next = 0;
   ~mscnn_net() {
     if (det_host) (void)hipHostFree(det_host);
-    if (det_hdr) (void)hipHostFree(det_hdr);
-    for (hipEvent_t e : det_hdr_ev) if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -271,7 +264,7 @@ size_t mscnn_net_detect_pack_bytes(int cap) {
 }
 
 // Final stage into the fixed-capacity device pack [count, R, cap, 0 | cap x 5 doubles | cap ints]; no host transfer.
-static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap, int* R_out) {
+static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap, int* R_out, bool with_header) {
   CHECK(p != nullptr);
   CHECK(n->net->has_blob("bbox_pred") && n->net->has_blob("cls_pred") && n->net->has_blob("proposals_score"))
       << "net has no bbox_pred / cls_pred / proposals_score outputs";
@@ -297,19 +290,12 @@ static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap
   double* dets = reinterpret_cast<double*>(pack + 16);
   int* ids = reinterpret_cast<int*>(pack + 16 + sizeof(double) * 5 * rows);
   hipStream_t st = (hipStream_t)Caffe::stream();
-  // header {0, R, cap, 0} from a small ring of pinned slots; a slot is reused only after its previous copy has completed
-  // (event wait: a no-op in practice, every caller synchronises the stream once per image)
-  if (n->det_hdr == nullptr) {
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&n->det_hdr), 16 * mscnn_net::kHdrSlots, hipHostMallocDefault));
-    for (int i = 0; i < mscnn_net::kHdrSlots; ++i) HIP_CHECK(hipEventCreateWithFlags(&n->det_hdr_ev[i], hipEventDisableTiming));
+  // header {count (written by the kernels), R, cap, 0}: only the multi-GPU pack needs R / cap on the device -- two 4-byte fills
+  if (with_header) {
+    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hdr + 1), R, 1, st));
+    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hdr + 2), cap, 1, st));
+    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hdr + 3), 0, 1, st));
   }
-  const int slot = n->det_hdr_next++ % mscnn_net::kHdrSlots;
-  if (n->det_hdr_used[slot]) HIP_CHECK(hipEventSynchronize(n->det_hdr_ev[slot]));
-  int* head = n->det_hdr + 4 * slot;
-  head[0] = 0; head[1] = R; head[2] = cap; head[3] = 0;
-  HIP_CHECK(hipMemcpyAsync(hdr, head, 16, hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipEventRecord(n->det_hdr_ev[slot], st));
-  n->det_hdr_used[slot] = true;
   MSCNN_CHECK(mscnn_detections_fwd(&d, bbox->gpu_data(), cls->gpu_data(), props->gpu_data(), R, dets, ids, hdr, ws, wb, st));
   if (R_out) *R_out = R;
 }
@@ -317,7 +303,7 @@ static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap
 int mscnn_net_detect_device(mscnn_net* n, const mscnn_detect_params* p, int cap, const void** pack_dev) {
   return guarded([&] {
     CHECK(pack_dev != nullptr);
-    detect_into_pack(n, p, cap, nullptr);
+    detect_into_pack(n, p, cap, nullptr, true);
     *pack_dev = n->det_pack.get();
   });
 }
@@ -345,7 +331,7 @@ int mscnn_net_detect(mscnn_net* n, const mscnn_detect_params* p, double* dets_ho
     // single-GPU form: the pack is sized by this image's ROI count, so the one D2H copy moves 16 + 44 R bytes
     int R = 0;
     const int rows = n->net->has_blob("proposals_score") ? n->net->blob_by_name("proposals_score")->num() : 0;
-    detect_into_pack(n, p, rows, &R);
+    detect_into_pack(n, p, rows, &R, false);
     const size_t total = mscnn_net_detect_pack_bytes(rows);
     if (n->det_host_bytes < total) {
       if (n->det_host) HIP_CHECK(hipHostFree(n->det_host));
@@ -356,10 +342,15 @@ int mscnn_net_detect(mscnn_net* n, const mscnn_detect_params* p, double* dets_ho
     hipStream_t st = (hipStream_t)Caffe::stream();
     HIP_CHECK(hipMemcpyAsync(n->det_host, n->det_pack.get(), total, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    const int D = *reinterpret_cast<const int*>(n->det_host);
-    CHECK_LE(D, cap) << "detections buffer too small";
-    int Rr = 0, Dd = 0;
-    CHECK_EQ(mscnn_net_unpack_detections(n->det_host, rows, dets_host, ids_host, &Dd, &Rr), 0) << mscnn_net_last_error();
+    const char* hp = static_cast<const char*>(n->det_host);
+    const int Dd = *reinterpret_cast<const int*>(hp);
+    CHECK_LE(Dd, cap) << "detections buffer too small";
+    CHECK_LE(Dd, rows);
+    const size_t prow = (size_t)(rows > 0 ? rows : 1);
+    if (Dd > 0) {
+      std::memcpy(dets_host, hp + 16, sizeof(double) * 5 * Dd);
+      if (ids_host) std::memcpy(ids_host, hp + 16 + sizeof(double) * 5 * prow, sizeof(int) * Dd);
+    }
     *num_dets = Dd;
     if (num_rois) *num_rois = R;
   });

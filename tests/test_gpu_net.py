@@ -39,8 +39,9 @@ CONFIGS = [
 # BASELINE.json sizes: the deploy files' own input sizes and top-K (2000), every configuration the north star names, against
 # oracle/_ref = the reference's own CPU layer sources (im2col + MKL sgemm; 20-60 s of host time per frame on the GPU box)
 FULL_SIZE = [
-    ("kitti_car/mscnn-7s-576", {}, "mid", 2, (375, 1242)),
-    ("kitti_car/mscnn-7s-576", {}, "dense", 2, (375, 1242)),            # every anchor passes fg_thr: 2000-box sort + NMS worst case
+    ("kitti_car/mscnn-7s-576", {}, "mid", 2, (375, 1242)),              # > 2000 anchors pass fg_thr: full top-K sort + NMS (the
+                                                                        # "dense" weights select the same 2000, scores shifted)
+    ("kitti_car/mscnn-7s-576", {}, "sparse", 2, (375, 1242)),           # fewer candidates than the top-K
     ("kitti_car/mscnn-8s-768-trainval", {}, "mid", 2, (375, 1242)),     # 1x3x768x2560, 8 heads, 81,600 anchors
     ("kitti_ped_cyc/mscnn-7s-576-2x", {}, "mid", 2, (375, 1242)),       # deconv 2x, 7x5 ROI pooling, fc6 2048
     ("caltech/mscnn-7s-480", {}, "mid", 2, (480, 640)),
