@@ -44,7 +44,6 @@ struct IgemmArgs {
   unsigned w_img_bytes;  // per-image weight stride in bytes (0: one weight set; Winograd GEMM: one U matrix per "image")
   int full_q;          // whole tiles per workgroup in the data-parallel phase (tile t = g + j * G, j < full_q)
   long total_iters;    // iterations (tile, chunk) of the stream-K phase: the remaining tiles [full_q * G, MT * NT)
-  int row0;            // plane mode: first tile row of this launch (a launch may cover a slab [row0, row0 + NTH) of the plane)
 };
 constexpr int kSlabsPerWg = 2;   // stream-K tail partial, stream-K head partial
 
@@ -141,7 +140,7 @@ struct TileGeo {
       r0 = nt * C::IPT; h0 = w0 = img = 0;
     } else {
       const int tw = nt % a.NTW, th = (nt / a.NTW) % a.NTH;
-      img = nt / (a.NTW * a.NTH); h0 = (th + a.row0) * C::TH; w0 = tw * C::TW; r0 = 0;
+      img = nt / (a.NTW * a.NTH); h0 = th * C::TH; w0 = tw * C::TW; r0 = 0;
     }
   }
   // x / y buffer windows the 32-bit offsets are relative to
@@ -743,13 +742,6 @@ struct mscnn_conv_plan {
   mscnn_conv_plan* wino = nullptr;
   int wino_m = 2;        // output tile edge: 2 = F(2x2,3x3) (16 planes), 3 = F(3x3,3x3) (25 planes; small ROI maps)
   int tiles_h = 0, tiles_w = 0, T_pad = 0;
-  // Slab pipeline of the Winograd path: the tile range is cut into `slabs` pieces; while the MFMA GEMM of slab i runs on the
-  // caller's stream, a second stream (owned by the plan) runs the HBM-bound input transform of slab i + 1 and the output
-  // transform of slab i - 1.
-  int slabs = 1;
-  static constexpr int kMaxSlabs = 4;
-  mutable hipStream_t aux = nullptr;
-  mutable hipEvent_t ev_start = nullptr, ev_done = nullptr, ev_it[kMaxSlabs] = {}, ev_gemm[kMaxSlabs] = {};
   // roofline accounting (mscnn_conv2d_plan_set_profiling): events around {input transform | GEMM | output transform}
   bool profiling = false;
   mutable hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -757,42 +749,12 @@ struct mscnn_conv_plan {
   ~mscnn_conv_plan() {
     delete wino;
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ev_it) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ev_gemm) if (e) (void)hipEventDestroy(e);
-    if (ev_start) (void)hipEventDestroy(ev_start);
-    if (ev_done) (void)hipEventDestroy(ev_done);
-    if (aux) (void)hipStreamDestroy(aux);
   }
 };
 
 using namespace mscnn;
 
 static void plan_shape(mscnn_conv_plan* p);
-
-// Persistent-grid schedule of `tiles` output tiles of KI chunks each: G workgroups, full_q whole tiles per workgroup, the
-// remainder cut stream-K style into G equal (tile, chunk) ranges.
-static void igemm_schedule(const KernelEntry& k, const mscnn_conv_desc& d, long tiles, int KI, int* G_out, int* full_q, long* total_iters) {
-  // grid: G workgroups (default 2 per CU; 3 for the 128x128 tiles whose 43 KB of LDS and 168 VGPRs allow it)
-  const int genv = tune_env("MSCNN_TUNE_GRID", d.tune_grid);   // tuning knob
-  long G = genv > 0 ? genv : ((k.BM == 128 && k.BN == 128 && k.KH == 3) ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
-  if (tiles * KI / 4 < G) G = tiles * KI / 4;               // never less than ~4 chunks per workgroup
-  if (G < 1) G = 1;
-  // A slightly smaller grid that divides the tile count exactly needs no stream-K phase and no fix-up launch at all (the 25
-  // plane GEMMs of conv2_2..conv4_3 have 1500 / 3000 / 6000 tiles: G = 500 instead of 512 saves the 18 us fix-up and the
-  // slab traffic for 2 % idle workgroup slots).
-  if (!genv && tiles >= 2 * G) {
-    // the 1x1 GEMM kernel (32 KB LDS, 166 VGPRs) also fits 3 per CU: try that range first (measured G = 750 vs 500 on the
-    // 25-plane GEMMs: conv4_2 259 vs 266 us, conv3_2 332 vs 339, conv2_2 496 vs 510)
-    const long tops[2] = {(k.KH == 1 && k.BN == 128 && k.CK < 64) ? 768 : G, G};
-    bool found = false;
-    for (int c = 0; c < 2 && !found; ++c)
-      for (long g2 = tops[c]; g2 >= tops[c] - tops[c] / 16 && g2 * 2 <= tiles; --g2)
-        if (tiles % g2 == 0) { G = g2; found = true; break; }
-  }
-  *G_out = (int)G;
-  *full_q = (int)(tiles / G);                               // data-parallel phase
-  *total_iters = (tiles - (long)*full_q * G) * KI;          // stream-K phase over the remainder tiles
-}
 
 // Winograd is chosen where the cut in multiplies (2.25x for F(2x2,3x3), 3.24x for F(3x3,3x3)) outweighs the extra HBM traffic
 // of the transforms (V and M are 4x / 2.78x the input / output and are written and read once each): GEMM FLOPs per transform
@@ -833,17 +795,6 @@ static bool wino_plan(mscnn_conv_plan* p) {
   p->tiles_h = th; p->tiles_w = tw; p->T_pad = (int)T_pad;
   p->packed_bytes = (size_t)planes * g->packed_bytes;
   p->ws_bytes = (size_t)planes * ((size_t)d.Cin + d.Cout) * T_pad * sizeof(float) + g->ws_bytes;
-  // slab pipeline (F(3x3,3x3) only): slabs of whole 128-tile GEMM rows with >= ~1000 GEMM tiles each, so that every slab still
-  // fills the chip; ROI maps additionally need slab boundaries on the input transform's 8-ROI blocks.  tune_flags bit 2: off.
-  p->slabs = 1;
-  if (m == 3 && !(tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 4)) {
-    const long rows = T_pad / 128, gemm_tiles = (long)planes * g->MT * rows;
-    long S = gemm_tiles / 1000;
-    if (S > mscnn_conv_plan::kMaxSlabs) S = mscnn_conv_plan::kMaxSlabs;
-    if (S > rows) S = rows;
-    if (roi_map && (128 % (th * tw) != 0 || (128 / (th * tw)) % 8 != 0)) S = 1;
-    p->slabs = S < 1 ? 1 : (int)S;
-  }
   return true;
 }
 
@@ -915,10 +866,28 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->KI = cdiv(d.Cin, k.CK);
   if (p->KI > 256) { p->entry = -1; return; }   // the fix-up kernels list at most 256 contributing slabs per tile: use the direct kernel
   const long tiles = (long)p->MT * p->NT;
-  igemm_schedule(k, d, tiles, p->KI, &p->G, &p->full_q, &p->total_iters);
+  // grid: G workgroups (default 2 per CU; 3 for the 128x128 tiles whose 43 KB of LDS and 168 VGPRs allow it)
+  const int genv = tune_env("MSCNN_TUNE_GRID", d.tune_grid);   // tuning knob
+  long G = genv > 0 ? genv : ((k.BM == 128 && k.BN == 128 && k.KH == 3) ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
+  if (tiles * p->KI / 4 < G) G = tiles * p->KI / 4;         // never less than ~4 chunks per workgroup
+  if (G < 1) G = 1;
+  // A slightly smaller grid that divides the tile count exactly needs no stream-K phase and no fix-up launch at all (the 25
+  // plane GEMMs of conv2_2..conv4_3 have 1500 / 3000 / 6000 tiles: G = 500 instead of 512 saves the 18 us fix-up and the
+  // slab traffic for 2 % idle workgroup slots).
+  if (!genv && tiles >= 2 * G) {
+    // the 1x1 GEMM kernel (32 KB LDS, 166 VGPRs) also fits 3 per CU: try that range first (measured G = 750 vs 500 on the
+    // 25-plane GEMMs: conv4_2 259 vs 266 us, conv3_2 332 vs 339, conv2_2 496 vs 510)
+    const long tops[2] = {(k.KH == 1 && k.BN == 128 && k.CK < 64) ? 768 : G, G};
+    bool found = false;
+    for (int c = 0; c < 2 && !found; ++c)
+      for (long g2 = tops[c]; g2 >= tops[c] - tops[c] / 16 && g2 * 2 <= tiles; --g2)
+        if (tiles % g2 == 0) { G = g2; found = true; break; }
+  }
+  p->G = (int)G;
+  p->full_q = (int)(tiles / G);                               // data-parallel phase
+  p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
   p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * sizeof(float);
-  // (slab launches of the Winograd GEMM re-run the schedule on fewer tiles: never more than 768 workgroups)
-  p->ws_bytes = (size_t)(p->G > 768 ? p->G : 768) * kSlabsPerWg * k.BM * k.BN * sizeof(float);
+  p->ws_bytes = (size_t)p->G * kSlabsPerWg * k.BM * k.BN * sizeof(float);
 }
 
 extern "C" int mscnn_conv2d_plan_create(const mscnn_conv_desc* desc, mscnn_conv_plan** plan_out) {
@@ -1014,19 +983,12 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
 }
 
 // igemm launch (main kernel + fix-up).  w_img_bytes / nt_major: see IgemmArgs (non-zero only for the Winograd GEMM).
-// row0 / rows (plane mode, rows > 0): only tile rows [row0, row0 + rows) of every image -- a slab of the Winograd GEMM.
 static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* packed, const float* bias, float* y,
                         float* y_pool, void* workspace, size_t workspace_bytes, hipStream_t st, unsigned w_img_bytes,
-                        int nt_major, int row0 = 0, int rows = 0) {
+                        int nt_major) {
   const mscnn_conv_desc& d = p->d;
   const KernelEntry& k = kTable[p->entry];
-  int G = p->G, full_q = p->full_q, NTH = p->NTH, NT = p->NT;
-  long total_iters = p->total_iters;
-  if (rows > 0 && rows != p->NTH) {
-    NTH = rows; NT = d.N * NTH * p->NTW;
-    igemm_schedule(k, d, (long)p->MT * NT, p->KI, &G, &full_q, &total_iters);
-  }
-  const long rem_tiles = (long)p->MT * NT - (long)full_q * G;
+  const long rem_tiles = (long)p->MT * p->NT - (long)p->full_q * p->G;
   const bool split = rem_tiles > 0;
   if (split) {
     if (!workspace || workspace_bytes < p->ws_bytes) {
@@ -1037,8 +999,8 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
   IgemmArgs a;
   a.x = x; a.wp = packed; a.bias = bias; a.y = y; a.ws = static_cast<float*>(workspace);
   a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.Ho = p->Ho; a.Wo = p->Wo; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
-  a.MT = p->MT; a.NTH = NTH; a.NTW = p->NTW; a.NT = NT; a.KI = p->KI; a.G = G; a.relu = d.relu;
-  a.total_iters = total_iters; a.full_q = full_q; a.row0 = row0;
+  a.MT = p->MT; a.NTH = p->NTH; a.NTW = p->NTW; a.NT = p->NT; a.KI = p->KI; a.G = p->G; a.relu = d.relu;
+  a.total_iters = p->total_iters; a.full_q = p->full_q;
   a.w_img_bytes = w_img_bytes; a.nt_major = nt_major;
   a.yp = y_pool; a.Hp = (p->Ho + 1) / 2; a.Wp = (p->Wo + 1) / 2;
   if (y_pool && !k.fix_pool_fn) {
@@ -1046,7 +1008,7 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
     return MSCNN_ERR_BAD_ARG;
   }
   a.xcd_map = (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 1) ? 0 : 1;
-  k.main_fn<<<G, 256, 0, st>>>(a);
+  k.main_fn<<<p->G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   if (split) {
     (y_pool ? k.fix_pool_fn : k.fix_fn)<<<(int)rem_tiles * k.fix_split, 256, 0, st>>>(a);
@@ -1098,68 +1060,17 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
     float* V = static_cast<float*>(workspace);
     float* M = V + planes * d.Cin * p->T_pad;
     float* gws = M + planes * d.Cout * p->T_pad;
-    const int T = d.N * p->tiles_h * p->tiles_w, tile_rows = d.N * p->tiles_h;
-    const int S = p->profiling ? 1 : p->slabs;      // stage timing wants the three stages back to back
-    if (S <= 1) {
-      MSCNN_STAGE_EVENT(0);
-      int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, 0, p->T_pad, st);
-      if (rc != MSCNN_OK) return rc;
-      MSCNN_STAGE_EVENT(1);
-      rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
-      if (rc != MSCNN_OK) return rc;
-      MSCNN_STAGE_EVENT(2);
-      rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, 0, tile_rows, st);
-      if (rc != MSCNN_OK) return rc;
-      MSCNN_STAGE_EVENT(3);
-      p->ev_valid = p->profiling;
-      return MSCNN_OK;
-    }
-    // ---- slab pipeline: caller's stream = the MFMA GEMMs, plan's second stream = the HBM-bound transforms ------------------
-    //   aux : IT(0) IT(1) | wait GEMM(0) | OT(0) IT(2) | wait GEMM(1) | OT(1) IT(3) | ... | wait GEMM(S-1) | OT(S-1)
-    //   main: wait IT(0) | GEMM(0) | wait IT(1) | GEMM(1) | ...                                  | wait OT(S-1)
-    if (!p->aux) {
-      MSCNN_HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
-      MSCNN_HIP_TRY(hipEventCreateWithFlags(&p->ev_start, hipEventDisableTiming));
-      MSCNN_HIP_TRY(hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming));
-      for (int i = 0; i < mscnn_conv_plan::kMaxSlabs; ++i) {
-        MSCNN_HIP_TRY(hipEventCreateWithFlags(&p->ev_it[i], hipEventDisableTiming));
-        MSCNN_HIP_TRY(hipEventCreateWithFlags(&p->ev_gemm[i], hipEventDisableTiming));
-      }
-    }
-    const int rows = p->T_pad / 128;
-    auto row_of = [&](int i) { return (int)((long)rows * i / S); };      // slab i = GEMM rows [row_of(i), row_of(i + 1))
-    auto it_slab = [&](int i) -> int {
-      const int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad,
-                                          128 * row_of(i), 128 * row_of(i + 1), p->aux);
-      if (rc != MSCNN_OK) return rc;
-      MSCNN_HIP_TRY(hipEventRecord(p->ev_it[i], p->aux));
-      return MSCNN_OK;
-    };
-    MSCNN_HIP_TRY(hipEventRecord(p->ev_start, st));               // x (and the workspace's previous user) are ready
-    MSCNN_HIP_TRY(hipStreamWaitEvent(p->aux, p->ev_start, 0));
-    int rc = it_slab(0);
+    MSCNN_STAGE_EVENT(0);
+    int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st);
     if (rc != MSCNN_OK) return rc;
-    int done_rows = 0;                                            // tile rows already output-transformed
-    for (int i = 0; i < S; ++i) {
-      if (i + 1 < S && (rc = it_slab(i + 1)) != MSCNN_OK) return rc;
-      MSCNN_HIP_TRY(hipStreamWaitEvent(st, p->ev_it[i], 0));
-      rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1, row_of(i),
-                        row_of(i + 1) - row_of(i));
-      if (rc != MSCNN_OK) return rc;
-      MSCNN_HIP_TRY(hipEventRecord(p->ev_gemm[i], st));
-      // tile rows that are complete once GEMM(i) has finished (all of them after the last slab)
-      long have = (long)128 * row_of(i + 1);
-      if (have > T) have = T;
-      int upto = i + 1 == S ? tile_rows : (int)(have / p->tiles_w);
-      if (y_pool && i + 1 < S) upto &= ~1;
-      MSCNN_HIP_TRY(hipStreamWaitEvent(p->aux, p->ev_gemm[i], 0));
-      rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu,
-                                 done_rows, upto, p->aux);
-      if (rc != MSCNN_OK) return rc;
-      if (upto > done_rows) done_rows = upto;
-    }
-    MSCNN_HIP_TRY(hipEventRecord(p->ev_done, p->aux));
-    MSCNN_HIP_TRY(hipStreamWaitEvent(st, p->ev_done, 0));
+    MSCNN_STAGE_EVENT(1);
+    rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
+    if (rc != MSCNN_OK) return rc;
+    MSCNN_STAGE_EVENT(2);
+    rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st);
+    if (rc != MSCNN_OK) return rc;
+    MSCNN_STAGE_EVENT(3);
+    p->ev_valid = p->profiling;
     return MSCNN_OK;
   }
 #undef MSCNN_STAGE_EVENT

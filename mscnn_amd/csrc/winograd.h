@@ -11,15 +11,12 @@ int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, i
 
 // V[xinu][ci][t] = (B^T d B)[xi][nu],  d = the 4x4 input patch of output tile t = (n, ty, tx) (zero outside the image);
 // t < T real tiles, row stride T_pad (columns T..T_pad are written as zeros).
-// Only tiles [t_begin, t_end) of [0, T_pad) are produced (slab pipeline of the conv plan: multiples of 128, on 8-ROI block
-// boundaries for ROI maps; t_end == T_pad for the slab that also owns the zero padding).
 int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
-                         int tiles_w, int T_pad, int t_begin, int t_end, hipStream_t st);
+                         int tiles_w, int T_pad, hipStream_t st);
 
 // y[n][co][2ty + i][2tx + j] = (A^T m A)[i][j] + bias[co], optional ReLU;  m[xi][nu] = M[xinu][co][t].
 // y_pool != nullptr: also write max over the tile's (in-plane) outputs to y_pool[n][co][ty][tx] (fused 2x2/2 max pooling).
-// Only the global tile rows [row_begin, row_end) of the N * tiles_h rows of tiles (even bounds with y_pool).
 int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
-                          int tiles_h, int tiles_w, int T_pad, int relu, int row_begin, int row_end, hipStream_t st);
+                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st);
 
 }  // namespace mscnn

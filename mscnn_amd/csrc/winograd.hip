@@ -216,11 +216,10 @@ __global__ __launch_bounds__(256) void wino33_weight_kernel(const float* __restr
 constexpr int kW33Rois = 8, kW33Ch = 16, kW33MaxHW = 64;
 
 __global__ __launch_bounds__(256) void wino33_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int Cin, int H,
-                                                           int W, int pad_h, int pad_w, int tiles_h, int tiles_w, int T, int T_pad,
-                                                           int blk_begin, int pad_writer) {
+                                                           int W, int pad_h, int pad_w, int tiles_h, int tiles_w, int T, int T_pad) {
   __shared__ __attribute__((aligned(16))) float sm[kW33Rois * kW33Ch * kW33MaxHW];
   const int tid = threadIdx.x;
-  const int r0 = (blk_begin + blockIdx.x) * kW33Rois, c0 = blockIdx.y * kW33Ch;
+  const int r0 = blockIdx.x * kW33Rois, c0 = blockIdx.y * kW33Ch;
   const int HW = H * W, tpr = tiles_h * tiles_w;
   const int nch = min(kW33Ch, Cin - c0);
   const int run = nch * HW;                              // contiguous floats per ROI
@@ -277,8 +276,8 @@ __global__ __launch_bounds__(256) void wino33_input_kernel(const float* __restri
       for (int j = 0; j < 5; ++j) dst[(i * 5 + j) * plane_stride] = o[j];
     }
   }
-  // columns T .. T_pad of every plane (GEMM padding) must be zero: the last ROI block of the launch that owns them writes them
-  if (pad_writer && blockIdx.x == gridDim.x - 1) {
+  // columns T .. T_pad of every plane (GEMM padding) must be zero: the last ROI block writes them
+  if (blockIdx.x == gridDim.x - 1) {
     for (int i = tid; i < nch * (T_pad - T); i += 256) {
       const int c = i / (T_pad - T), t = T + i % (T_pad - T);
 #pragma unroll 1
@@ -290,10 +289,10 @@ __global__ __launch_bounds__(256) void wino33_input_kernel(const float* __restri
 // F(3x3,3x3) input transform for whole image planes (one thread per (channel, tile), tiles fastest), as wino_input_kernel.
 __global__ __launch_bounds__(256) void wino33_input_plane_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int Cin,
                                                                  int H, int W, int pad_h, int pad_w, int tiles_h, int tiles_w,
-                                                                 int T, int T_pad, int t_begin, int t_end) {
-  const int t = t_begin + blockIdx.x * 256 + threadIdx.x;
+                                                                 int T, int T_pad) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
   const int ci = blockIdx.y;
-  if (t >= t_end) return;
+  if (t >= T_pad) return;
   const long plane_stride = (long)Cin * T_pad;
   float* dst = V + (long)ci * T_pad + t;
   float d[5][5];
@@ -337,10 +336,10 @@ __global__ __launch_bounds__(256) void wino33_input_plane_kernel(const float* __
 
 __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                             float* __restrict__ y, int N, int Cout, int Ho, int Wo, int tiles_h,
-                                                            int tiles_w, int T, int T_pad, int relu, int t_begin, int t_end) {
-  const int t = t_begin + blockIdx.x * 256 + threadIdx.x;
+                                                            int tiles_w, int T, int T_pad, int relu) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
   const int co = blockIdx.y;
-  if (t >= t_end) return;
+  if (t >= T) return;
   const long plane_stride = (long)Cout * T_pad;
   const float* src = M + (long)co * T_pad + t;
   float r[3][5];   // A^T m
@@ -387,12 +386,12 @@ __device__ __forceinline__ void at5(const float m[5], float o[3]) {
 
 __global__ __launch_bounds__(256) void wino33_output_pool_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                                  float* __restrict__ y, float* __restrict__ yp, int N, int Cout,
-                                                                 int Ho, int Wo, int tiles_h, int tiles_w, int T_pad, int relu,
-                                                                 int s_begin, int s_end) {
+                                                                 int Ho, int Wo, int tiles_h, int tiles_w, int T_pad, int relu) {
   const int sw = tiles_w / 2, sh = tiles_h / 2;
-  const int sidx = s_begin + blockIdx.x * 256 + threadIdx.x;
+  const int S = N * sh * sw;
+  const int sidx = blockIdx.x * 256 + threadIdx.x;
   const int co = blockIdx.y;
-  if (sidx >= s_end) return;
+  if (sidx >= S) return;
   const int sx = sidx % sw, sy = (sidx / sw) % sh, n = sidx / (sw * sh);
   const long plane_stride = (long)Cout * T_pad;
   const float b = bias ? bias[co] : 0.f;
@@ -474,47 +473,30 @@ int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, i
 }
 
 int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
-                         int tiles_w, int T_pad, int t_begin, int t_end, hipStream_t st) {
+                         int tiles_w, int T_pad, hipStream_t st) {
   const int T = N * tiles_h * tiles_w;
-  if (t_end <= t_begin) return MSCNN_OK;
+  dim3 grid(cdiv(T_pad, 256), Cin);
   if (m == 3 && H * W <= kW33MaxHW) {
-    // ROI maps: a launch covers whole 8-ROI blocks; the launch that reaches T_pad also zero-fills the padding columns
-    const int tpr = tiles_h * tiles_w, per_blk = kW33Rois * tpr;
-    MSCNN_REQUIRE(t_begin % per_blk == 0 && (t_end % per_blk == 0 || t_end == T_pad), "winograd: ROI slab not on an 8-ROI block");
-    const int blk0 = t_begin / per_blk, blk1 = t_end == T_pad ? cdiv(N, kW33Rois) : t_end / per_blk;
-    MSCNN_REQUIRE(blk1 > blk0, "winograd: empty ROI slab");        // (T_pad - T < 128: no slab is padding only)
-    dim3 g3(blk1 - blk0, cdiv(Cin, kW33Ch));
-    wino33_input_kernel<<<g3, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad, blk0, t_end == T_pad ? 1 : 0);
+    dim3 g3(cdiv(N, kW33Rois), cdiv(Cin, kW33Ch));
+    wino33_input_kernel<<<g3, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
   } else if (m == 3) {
-    dim3 grid(cdiv(t_end - t_begin, 256), Cin);
-    wino33_input_plane_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad, t_begin, t_end);
-  } else {
-    MSCNN_REQUIRE(t_begin == 0 && t_end == T_pad, "winograd F(2x2,3x3): whole planes only");
-    dim3 grid(cdiv(T_pad, 256), Cin);
-    wino_input_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
-  }
+    wino33_input_plane_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
+  } else wino_input_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }
 
-// Output transform of the global tile rows [row_begin, row_end) of the N * tiles_h rows of tiles (even bounds when pooling).
 int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
-                          int tiles_h, int tiles_w, int T_pad, int relu, int row_begin, int row_end, hipStream_t st) {
+                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st) {
   const int T = N * tiles_h * tiles_w;
-  if (row_end <= row_begin) return MSCNN_OK;
+  dim3 grid(cdiv(T, 256), Cout);
   if (m == 3 && y_pool) {
     MSCNN_REQUIRE(tiles_h % 2 == 0 && tiles_w % 2 == 0, "winograd F(3x3,3x3): fused pooling needs even tile counts");
-    MSCNN_REQUIRE(row_begin % 2 == 0 && row_end % 2 == 0, "winograd F(3x3,3x3): pooled slabs need even tile-row bounds");
-    const int sw = tiles_w / 2, s_begin = (row_begin / 2) * sw, s_end = (row_end / 2) * sw;
-    dim3 gp(cdiv(s_end - s_begin, 256), Cout);
-    wino33_output_pool_kernel<<<gp, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T_pad, relu, s_begin, s_end);
+    dim3 gp(cdiv((long)N * (tiles_h / 2) * (tiles_w / 2), 256), Cout);
+    wino33_output_pool_kernel<<<gp, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T_pad, relu);
   } else if (m == 3) {
-    const int t_begin = row_begin * tiles_w, t_end = row_end * tiles_w;
-    dim3 grid(cdiv(t_end - t_begin, 256), Cout);
-    wino33_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu, t_begin, t_end);
+    wino33_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu);
   } else {
-    MSCNN_REQUIRE(row_begin == 0 && row_end == N * tiles_h, "winograd F(2x2,3x3): whole planes only");
-    dim3 grid(cdiv(T, 256), Cout);
     wino_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu);
   }
   MSCNN_POST_LAUNCH();

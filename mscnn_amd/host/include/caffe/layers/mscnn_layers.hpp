@@ -90,9 +90,6 @@ class ConvolutionLayer : public Layer<Dtype> {
   // max |y - y_direct| / max(1, |y_direct|) of the current algorithm against the direct kernel on the given bottom
   // (device scratch only; the layer's tops are not touched).  0 when the layer already runs a direct kernel.
   double ErrorAgainstDirect(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
-  // Which of the per-device transient workspaces this layer uses: 0 = the trunk's (layers that run one after the other on
-  // the net's stream), 1 = the side branch's (layers Net launches on its second stream, concurrently with lane 0).
-  void set_workspace_lane(int lane) { ws_lane_ = lane; }
  protected:
   MSCNN_NO_CPU_PATH("Convolution")
   virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
@@ -106,7 +103,6 @@ class ConvolutionLayer : public Layer<Dtype> {
   DeviceBuffer packed_, workspace_;
   int algo_, tune_[3];
   bool profiling_;
-  int ws_lane_ = 0;
 };
 
 // include/caffe/layers/deconv_layer.hpp -- transposed conv; the depthwise case of the "-2x" nets has its own kernel

@@ -28,7 +28,7 @@ class Net {
   explicit Net(const NetParameter& param, Phase phase = TEST);
   explicit Net(const string& param_file, Phase phase);
   Net(const NetParameter& param, Phase phase, bool fusion);
-  virtual ~Net();
+  virtual ~Net() {}
 
   const vector<Blob<Dtype>*>& Forward(Dtype* loss = NULL);
   const vector<Blob<Dtype>*>& ForwardPrefilled(Dtype* loss = NULL) { return Forward(loss); }
@@ -101,14 +101,6 @@ class Net {
   std::map<int, Redirect> redirect_;               // blob id -> where its data really lives
   mutable std::map<int, bool> redirect_dirty_;     // producer ran since the last MaterializeBlob
   vector<double> calib_err_;
-  // Branch-parallel execution: a Convolution whose tops feed nothing but BoxOutput (the proposal heads LFCN_*: small-M,
-  // latency-bound kernels) is launched on a second HIP stream, so that it overlaps the trunk layers that follow it in the
-  // layer list (conv5_x / conv6_1, which do not fill the chip either); BoxOutput joins.  Off while per-layer timing is on.
-  vector<bool> side_branch_;
-  void* side_stream_;
-  void* ev_fork_;
-  vector<void*> ev_join_;
-  void SetUpSideBranches();
   DISABLE_COPY_AND_ASSIGN(Net);
 };
 

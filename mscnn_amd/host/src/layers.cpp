@@ -254,14 +254,13 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
   // One buffer per device; forwards of different nets on the same device must not overlap in time (they never do: one
   // process per GPU, one stream).  (Leaked on purpose: a static destructor would call hipFree after the HIP runtime has been
   // torn down.)
-  static DeviceBuffer* shared_ws[64][2] = {{nullptr, nullptr}};
+  static DeviceBuffer* shared_ws[64] = {nullptr};
   int dev = 0;
   HIP_CHECK(hipGetDevice(&dev));
   CHECK(dev >= 0 && dev < 64);
-  const int lane = ws_lane_ ? 1 : 0;        // lane 1: layers Net runs on its side stream, concurrently with lane 0
-  if (!shared_ws[dev][lane]) shared_ws[dev][lane] = new DeviceBuffer();
+  if (!shared_ws[dev]) shared_ws[dev] = new DeviceBuffer();
   const size_t wbytes = mscnn_conv2d_workspace_bytes(plan_);
-  void* ws = wbytes ? shared_ws[dev][lane]->Reserve(wbytes) : nullptr;
+  void* ws = wbytes ? shared_ws[dev]->Reserve(wbytes) : nullptr;
   const float* bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
   float* pooled = nullptr;
   if (pooled_top_) {

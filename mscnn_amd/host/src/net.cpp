@@ -202,36 +202,7 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
   calib_err_.assign(layers_.size(), 0.0);
   layer_ms_.assign(layers_.size(), 0.f);
   if (fusion_) ApplyFusion();
-  side_stream_ = nullptr; ev_fork_ = nullptr;
-  side_branch_.assign(layers_.size(), false);
-  ev_join_.assign(layers_.size(), nullptr);
-  if (fusion_) SetUpSideBranches();
   LOG(INFO) << "Network initialization done.";
-}
-
-template <typename Dtype>
-Net<Dtype>::~Net() {
-  for (void* e : ev_join_) if (e) (void)hipEventDestroy((hipEvent_t)e);
-  if (ev_fork_) (void)hipEventDestroy((hipEvent_t)ev_fork_);
-  if (side_stream_) (void)hipStreamDestroy((hipStream_t)side_stream_);
-}
-
-template <typename Dtype>
-void Net<Dtype>::SetUpSideBranches() {
-  for (size_t i = 0; i < layers_.size(); ++i) {
-    if (string(layers_[i]->type()) != "Convolution" || fused_away_[i] || top_vecs_[i].size() != 1) continue;
-    if (bottom_vecs_[i].size() == 1 && bottom_vecs_[i][0] == top_vecs_[i][0]) continue;
-    int consumers = 0;
-    bool only_boxoutput = true;
-    for (size_t l = 0; l < layers_.size(); ++l)
-      for (Blob<Dtype>* b : bottom_vecs_[l])
-        if (b == top_vecs_[i][0]) { ++consumers; if (string(layers_[l]->type()) != "BoxOutput") only_boxoutput = false; }
-    ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
-    if (consumers > 0 && only_boxoutput && c) {
-      side_branch_[i] = true;
-      c->set_workspace_lane(1);          // its transient workspace must not alias the trunk layers' it now overlaps with
-    }
-  }
 }
 
 // Conv / InnerProduct followed by an in-place ReLU on its top (every trunk conv of the deploy nets): the ReLU is
@@ -347,8 +318,6 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   CHECK_LT(end, (int)layers_.size());
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing_) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
-  void* const main_stream = Caffe::stream();
-  vector<int> pending;                  // side-branch layers launched and not yet joined
   for (int i = start; i <= end; ++i) {
     bool run = !fused_away_[i];
     if (fused_away_[i]) {
@@ -363,33 +332,6 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
         layers_[i]->Reshape(bottom_vecs_[i], top_vecs_[i]);      // shapes follow the bottoms exactly as Layer::Forward would
     }
     if (!run) { layer_ms_[i] = 0.f; continue; }
-    // join: a layer that reads a side-branch top waits for it
-    if (!pending.empty()) {
-      bool needs = false;
-      for (int sl : pending)
-        for (Blob<Dtype>* b : bottom_vecs_[i]) if (b == top_vecs_[sl][0]) needs = true;
-      if (needs) {
-        for (int sl : pending) HIP_CHECK(hipStreamWaitEvent((hipStream_t)main_stream, (hipEvent_t)ev_join_[sl], 0));
-        pending.clear();
-      }
-    }
-    if (side_branch_[i] && !timing_) {
-      if (!side_stream_) {
-        hipStream_t ss; hipEvent_t ev;
-        HIP_CHECK(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking)); side_stream_ = ss;
-        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); ev_fork_ = ev;
-      }
-      if (!ev_join_[i]) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); ev_join_[i] = ev; }
-      HIP_CHECK(hipEventRecord((hipEvent_t)ev_fork_, (hipStream_t)main_stream));           // its bottom has been enqueued
-      HIP_CHECK(hipStreamWaitEvent((hipStream_t)side_stream_, (hipEvent_t)ev_fork_, 0));
-      Caffe::set_stream(side_stream_);
-      try { layers_[i]->Forward(bottom_vecs_[i], top_vecs_[i]); } catch (...) { Caffe::set_stream(main_stream); throw; }
-      HIP_CHECK(hipEventRecord((hipEvent_t)ev_join_[i], (hipStream_t)side_stream_));
-      Caffe::set_stream(main_stream);
-      pending.push_back(i);
-      layer_ms_[i] = 0.f;
-      continue;
-    }
     if (timing_) HIP_CHECK(hipEventRecord(e0, (hipStream_t)Caffe::stream()));
     layers_[i]->Forward(bottom_vecs_[i], top_vecs_[i]);
     for (size_t t = 0; t < top_id_vecs_[i].size(); ++t)
@@ -400,7 +342,6 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
       HIP_CHECK(hipEventElapsedTime(&layer_ms_[i], e0, e1));
     }
   }
-  for (int sl : pending) HIP_CHECK(hipStreamWaitEvent((hipStream_t)main_stream, (hipEvent_t)ev_join_[sl], 0));
   if (timing_) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
   return 0;
 }

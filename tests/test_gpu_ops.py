@@ -212,49 +212,6 @@ def test_winograd_full_size_matches_direct(hip, shape):
     assert err < 1e-4, err
 
 
-SLAB_CASES = [   # N, Cin, H, W, Cout, pad, pooled
-    (1, 256, 144, 480, 256, 1, True),      # conv3_3: 3 slabs, fused 2x2 pooling (even tile-row slab bounds)
-    (1, 128, 288, 960, 128, 1, True),      # conv2_2: 4 slabs
-    (1, 256, 144, 480, 256, 1, False),
-    (700, 1024, 7, 7, 512, 0, False),      # roi_c1: 2 slabs on 8-ROI block boundaries, padding columns in the last one
-    (2, 128, 90, 250, 128, 1, False),      # batch 2, ragged tiles: slab bounds inside an image's tile rows
-]
-
-
-@pytest.mark.parametrize("case", SLAB_CASES)
-def test_winograd_slab_pipeline_equals_whole_plane(hip, case):
-    """The slab pipeline (input / output transforms of neighbouring slabs on the plan's second stream while the MFMA GEMM of a
-    slab runs on the caller's) must give what the three whole-plane launches give: same transforms, same k order inside a
-    GEMM tile; only tiles the per-slab stream-K schedule splits differently may differ by fp32 rounding."""
-    N, Cin, H, W, Cout, pad, pooled = case
-    g = torch.Generator(device="cuda").manual_seed(5)
-    x = torch.relu(torch.randn((N, Cin, H, W), device="cuda", generator=g))
-    w = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) * (2.0 / (Cin * 9)) ** 0.5
-    b = torch.randn(Cout, device="cuda", generator=g)
-    outs = []
-    for flags in (4, 0):
-        plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), relu=True, tune_flags=flags)
-        assert plan.kernel == "winograd_f3x3_3x3"
-        plan.pack(w)
-        Ho, Wo = plan.out_shape()[2:]
-        yp = torch.full((N, Cout, (Ho + 1) // 2, (Wo + 1) // 2), float("nan"), device="cuda") if pooled else None
-        for rep in range(2):                      # twice: the second call reuses the plan's stream and events
-            y = torch.full(plan.out_shape(), float("nan"), device="cuda")
-            plan.forward(x, b, out=y, pool_out=yp)
-        torch.cuda.synchronize()
-        outs.append((y, yp))
-        del plan
-    (y0, p0), (y1, p1) = outs
-    assert not torch.isnan(y1).any()
-    err = ((y1 - y0).abs() / torch.clamp(y0.abs(), min=1.0)).max().item()
-    same = (y1 == y0).float().mean().item()
-    print(f"slab pipeline vs whole plane: max err {err:.2e}, bit-identical {100 * same:.2f} %")
-    assert err < 1e-5 and same > 0.9
-    if pooled:
-        assert not torch.isnan(p1).any()
-        assert torch.equal(p1, hip.pool2d(y1, (2, 2), (0, 0), (2, 2)))
-
-
 # ---- Winograd robustness over input / filter statistics --------------------------------------------------------------------
 def _stat_inputs(kind, rng, shape):
     """Activation statistics beyond the unit-scale He-normal data of the other tests."""
