@@ -120,6 +120,14 @@ MSCNN_NET_API int mscnn_net_detect(mscnn_net* net, const mscnn_detect_params* p,
                                    int cap, int* num_dets, int* num_rois);
 
 
+/* Final stage of the cascade drivers (examples/kitti_car/run_cascademscnn.m:84-127) for ONE cascade output nn: the decoded boxes
+ * of stage nn (`bbox_blob`, e.g. "output_bbox_3rd"), its in-net probabilities (`prob_blob`, "cls_prob_3rd" / "cls_prob_3rd_avg")
+ * and the proposals it refined (`proposal_blob`, "proposals_3rd"), all read from the net on the device: rescale, clip, drop
+ * zero-size proposals, optional det_thr (> 0), bbNms.  Same outputs as mscnn_net_detect; p->bbox_mean/std, proposal_thr unused. */
+MSCNN_NET_API int mscnn_net_detect_cascade(mscnn_net* net, const mscnn_detect_params* p, float det_thr, const char* bbox_blob,
+                                           const char* prob_blob, const char* proposal_blob, double* dets_host, int* ids_host,
+                                           int cap, int* num_dets, int* num_rois);
+
 /* Multi-GPU form of the same stage (include/mscnn_dist.h gathers its result over RCCL): the detections stay in HBM, in a
  * fixed-size pack  [int32 count, int32 num_rois, int32 cap, int32 0][cap x 5 doubles x y w h prob][cap x int32 roi row]
  * of mscnn_net_detect_pack_bytes(cap) bytes (a multiple of 16).  cap must be >= the net's ROI count (BoxOutput's

@@ -356,4 +356,49 @@ int mscnn_net_detect(mscnn_net* n, const mscnn_detect_params* p, double* dets_ho
   });
 }
 
+int mscnn_net_detect_cascade(mscnn_net* n, const mscnn_detect_params* p, float det_thr, const char* bbox_blob, const char* prob_blob,
+                             const char* proposal_blob, double* dets_host, int* ids_host, int cap, int* num_dets, int* num_rois) {
+  return guarded([&] {
+    CHECK(p && dets_host && num_dets && bbox_blob && prob_blob && proposal_blob);
+    for (const char* b : {bbox_blob, prob_blob, proposal_blob}) CHECK(n->net->has_blob(b)) << "Unknown blob name " << b;
+    auto boxes = n->net->blob_by_name(bbox_blob);
+    auto prob = n->net->blob_by_name(prob_blob);
+    auto props = n->net->blob_by_name(proposal_blob);
+    const int R = boxes->num();
+    CHECK_EQ(prob->num(), R);
+    CHECK_EQ(props->num(), R);
+    CHECK_EQ(boxes->count(), 5 * R) << bbox_blob << " is not an [R, 5] box blob";
+    mscnn_detections_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.ncls = R > 0 ? prob->count() / R : 1;
+    d.cls_id = p->cls_id;
+    d.ratio_h = p->ratio_h; d.ratio_w = p->ratio_w; d.org_h = p->org_h; d.org_w = p->org_w; d.nms_overlap = p->nms_overlap;
+    const size_t wb = mscnn_detections_workspace_bytes(R);
+    void* ws = n->det_ws.Reserve(wb);
+    const size_t rows = (size_t)(R > 0 ? R : 1), total = mscnn_net_detect_pack_bytes((int)rows);
+    char* pack = static_cast<char*>(n->det_pack.Reserve(total));
+    hipStream_t st = (hipStream_t)Caffe::stream();
+    MSCNN_CHECK(mscnn_detections_cascade_fwd(&d, det_thr, boxes->gpu_data(), prob->gpu_data(), props->gpu_data(), R,
+                                             reinterpret_cast<double*>(pack + 16), reinterpret_cast<int*>(pack + 16 + sizeof(double) * 5 * rows),
+                                             reinterpret_cast<int*>(pack), ws, wb, st));
+    if (n->det_host_bytes < total) {
+      if (n->det_host) HIP_CHECK(hipHostFree(n->det_host));
+      n->det_host = nullptr; n->det_host_bytes = 0;
+      HIP_CHECK(hipHostMalloc(&n->det_host, total, hipHostMallocDefault));
+      n->det_host_bytes = total;
+    }
+    HIP_CHECK(hipMemcpyAsync(n->det_host, pack, total, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const char* hp = static_cast<const char*>(n->det_host);
+    const int D = *reinterpret_cast<const int*>(hp);
+    CHECK_LE(D, cap) << "detections buffer too small";
+    if (D > 0) {
+      std::memcpy(dets_host, hp + 16, sizeof(double) * 5 * D);
+      if (ids_host) std::memcpy(ids_host, hp + 16 + sizeof(double) * 5 * rows, sizeof(int) * D);
+    }
+    *num_dets = D;
+    if (num_rois) *num_rois = R;
+  });
+}
+
 }  // extern "C"

@@ -60,6 +60,7 @@ def lib():
             "mscnn_net_forward": [vp], "mscnn_net_forward_from_to": [vp, ci, ci], "mscnn_net_reshape": [vp],
             "mscnn_net_set_layer_timing": [vp, ci], "mscnn_net_layer_ms": [vp, ci],
             "mscnn_net_detect": [vp, vp, vp, vp, ci, vp, vp],
+            "mscnn_net_detect_cascade": [vp, vp, C.c_float, cs, cs, cs, vp, vp, ci, vp, vp],
             "mscnn_net_detect_pack_bytes": [ci], "mscnn_net_detect_device": [vp, vp, ci, vp],
             "mscnn_net_unpack_detections": [vp, ci, vp, vp, vp, vp],
         }
@@ -245,6 +246,15 @@ class Net:
         ptr = C.c_void_p()
         _check(lib().mscnn_net_detect_device(self._h, C.byref(p), cap, C.byref(ptr)))
         return ptr.value
+
+    def detect_cascade(self, bbox_blob, prob_blob, proposal_blob, cls_id, ratios, org_hw, det_thr=0.0, nms_overlap=0.5, cap=4096):
+        """Final stage of the cascade drivers (run_cascademscnn.m:84-127) for one cascade output; returns (dets, ids, R)."""
+        p = self._params(cls_id, ratios, org_hw, (0, 0, 0, 0), (1, 1, 1, 1), 0.0, nms_overlap)
+        dets = np.zeros((cap, 5), np.float64); ids = np.zeros(cap, np.int32)
+        D = C.c_int(); R = C.c_int()
+        _check(lib().mscnn_net_detect_cascade(self._h, C.byref(p), det_thr, bbox_blob.encode(), prob_blob.encode(), proposal_blob.encode(),
+                                              dets.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), cap, C.byref(D), C.byref(R)))
+        return dets[:D.value].copy(), ids[:D.value].copy(), R.value
 
     def detect(self, cls_id, ratios, org_hw, bbox_mean=(0, 0, 0, 0), bbox_std=(0.1, 0.1, 0.2, 0.2), proposal_thr=-10.0,
                nms_overlap=0.5, cap=4096):

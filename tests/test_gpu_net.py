@@ -303,6 +303,69 @@ def test_cascade_style_net():
     assert rel_err(n.get_blob("LFCN_1_5x5"), ref["LFCN_1_5x5"]) < 1e-4
 
 
+CASCADES = [   # model, reduced input, cls_id, original image size
+    ("kitti_car/cascade-mscnn-7s-576-2x", dict(height=192, width=448, max_nms_num=150), 2, (375, 1242)),
+    ("citypersons/mscnn-8s-1344-2x", dict(height=256, width=384, max_nms_num=150), 2, (1024, 2048)),
+    ("citypersons/cascade-mscnn-8s-1344-2x", dict(height=256, width=384, max_nms_num=150), 2, (1024, 2048)),
+    ("widerface/cascade-mscnn-12s-align", dict(height=160, width=192, max_nms_num=150), 2, (600, 720)),
+]
+
+
+@pytest.mark.parametrize("model,size,cls_id,org_hw", CASCADES)
+def test_cascade_deploys_whole_net(model, size, cls_id, org_hw):
+    """The reference's cascade / CityPersons / WiderFace deploy nets (the generated prototxts are checked against the shipped
+    files in tests/test_prototxt.py) forwarded on the GPU: trunk + heads end to end within 1e-4 of the oracle, then EVERY layer
+    from BoxOutput on with the device's own bottoms (DecodeBBox chains, stage-wise re-pooling, ROIAlign + AVE pooling, the
+    third-stage ensemble, Softmax, Eltwise) bit-exact for selection / sampling layers and 1e-4 for GEMM layers, and the cascade
+    drivers' final stage (run_cascademscnn.m:84-127) on each cascade output against its oracle."""
+    from oracle import pynet, pyoracle as orc
+    n = mnet.Net(prototxt_text=zoo.prototxt(model, **size))
+    ws = synth.load_into(n, "mid")
+    H, W = n.blob_shape("data")[2:]
+    x = synth.frame(H, W)
+    n.set_blob("data", x)
+    n.forward()
+    layers = layer_list(n)
+    names = [l[0] for l in layers]
+    ip = names.index("proposals")
+    ref = pynet.forward(layers[:ip], ws, {"data": x})
+    for l in layers[:ip]:
+        if l[0].startswith("LFCN_") or l[0] in ("conv4_3", "conv5_3", "pool6"):
+            assert rel_err(n.get_blob(l[3][0]), ref[l[3][0]]) < 1e-4, l[0]
+    R = n.blob_shape("proposals")[0]
+    assert R > 8, R
+    relu_inplace = {l[2][0] for l in layers if l[1] == "ReLU" and l[2] == l[3]}
+    for l in layers[ip:]:
+        if l[1] in ("Split", "ReLU", "Dropout"):
+            continue
+        feeds = {b: n.get_blob(b) for b in l[2]}
+        out = pynet.forward([l], ws, feeds)
+        for t in l[3]:
+            a, b = n.get_blob(t), out[t].reshape(n.blob_shape(t))
+            if t in relu_inplace:
+                b = np.maximum(b, 0)        # the device blob has already been through its (fused) in-place ReLU
+            if l[1] in ("BoxOutput", "ROIAlign", "ROIPooling", "DecodeBBox", "Eltwise", "Concat"):
+                assert np.array_equal(a, b), (l[0], t)
+            elif l[1] == "Pooling" and "AVE" in l[4]:
+                assert rel_err(a, b) < 1e-6, (l[0], t)
+            else:
+                assert rel_err(a, b) < 1e-4, (l[0], t)
+    # the cascade drivers' final stage on every cascade output of this net
+    kw = dict(cls_id=cls_id, ratios=(H / float(org_hw[0]), W / float(org_hw[1])), org_hw=org_hw)
+    outs = [("output_bbox_1st", "cls_prob_1st", "proposals"), ("output_bbox_2nd", "cls_prob_2nd", "proposals_2nd"),
+            ("output_bbox_3rd", "cls_prob_3rd_avg" if "cls_prob_3rd_avg" in n.blob_names else "cls_prob_3rd", "proposals_3rd")]
+    seen = 0
+    for bb, pb, qb in outs:
+        if bb not in n.blob_names:
+            continue
+        dets, ids, Rd = n.detect_cascade(bb, pb, qb, det_thr=0.0, **kw)
+        Rr = n.blob_shape(bb)[0]
+        dref, iref = orc.detections_cascade(n.get_blob(bb).reshape(Rr, 5), n.get_blob(pb).reshape(Rr, -1), n.get_blob(qb).reshape(Rr, 5), **kw)
+        assert Rd == Rr and np.array_equal(ids, iref) and np.array_equal(dets, dref), bb
+        seen += 1
+    assert seen == (3 if "proposals_3rd" in n.blob_names else 1)
+
+
 def test_set_image_preprocessing():
     """Net-level pre-processing (run_mscnn_detection.m:64-69 on the device): a 375x1242-like uint8 RGB frame -> the input blob,
     bit-identical to the oracle's restatement, from host memory and from a device tensor."""

@@ -100,6 +100,24 @@ def test_other_configs_shapes():
     assert n.blob_shape("roi_c1") == (1, 512, 8, 4) and n.blob_shape("bbox_pred") == (1, 8)
 
 
+def _semantic_params(n, i):
+    """The layer's parameter message with everything that does not change a TEST-phase forward removed (fillers, lr / decay
+    multipliers, propagate_down, phase) and numbers normalised (0.25 == 0.250, "IOU" == IOU)."""
+    from oracle import pynet
+
+    def norm(v):
+        if isinstance(v, dict):
+            return {k: [norm(x) for x in vs] for k, vs in sorted(v.items()) if k not in ("weight_filler", "bias_filler")}
+        try:
+            return float(v)
+        except ValueError:
+            return v.strip('"')
+    d = pynet.parse_param_text(n.layer_param_text(i))
+    for k in ("name", "type", "bottom", "top", "param", "propagate_down", "phase"):
+        d.pop(k, None)
+    return norm(d)
+
+
 @needs_ref
 @pytest.mark.parametrize("model", sorted(zoo.MODELS))
 def test_generated_net_equals_reference_file(model):
@@ -109,6 +127,8 @@ def test_generated_net_equals_reference_file(model):
     assert gen.blob_names == ref.blob_names and gen.outputs == ref.outputs
     for b in gen.blob_names:
         assert gen.blob_shape(b) == ref.blob_shape(b)
+    for i, name in enumerate(gen.layer_names):          # every numeric parameter: fields, strides, thresholds, stds, coeffs ...
+        assert _semantic_params(gen, i) == _semantic_params(ref, i), name
 
 
 @needs_ref
