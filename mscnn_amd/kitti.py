@@ -45,3 +45,25 @@ def write_kitti_labels(save_dir, image_index, dets_by_type, score_scale=1000.0):
                 # type truncated occluded alpha x1 y1 x2 y2 h w l x y z ry score   (devkit readme; -1 / -10 / -1000 = unknown)
                 f.write("%s -1 -1 -10 %.2f %.2f %.2f %.2f -1 -1 -1 -1000 -1000 -1000 -10 %.4f\n"
                         % (typ, x1, y1, x2, y2, d[4] * score_scale))
+
+
+EVAL_BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kitti_eval")
+
+
+def evaluate(gt_dir, result_dir, list_file):
+    """Runs the evaluator (mscnn_amd/host/tools/kitti_eval.cpp, the devkit's examples/kitti_result/eval/evaluate_object.cpp
+    restated) on <result_dir>/data/*.txt.  Returns {class: {"precision": [[41] x easy/moderate/hard], "ap11": [3]}}."""
+    import subprocess
+    if not os.path.exists(EVAL_BIN):
+        raise RuntimeError(f"{EVAL_BIN} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    r = subprocess.run([EVAL_BIN, gt_dir, result_dir, list_file], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("kitti_eval failed: " + r.stderr.strip())
+    out = {}
+    for cls in ("car", "pedestrian", "cyclist"):
+        path = os.path.join(result_dir, f"stats_{cls}_detection.txt")
+        if not os.path.exists(path):
+            continue
+        prec = [[float(v) for v in line.split()] for line in open(path) if line.strip()]
+        out[cls] = {"precision": prec, "ap11": [100.0 * sum(p[0:41:4]) / 11.0 for p in prec]}
+    return out

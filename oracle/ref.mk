@@ -10,7 +10,12 @@ REF_OBJS := $(addprefix _ref/obj/,$(subst /,_,$(REF_SRCS:.cpp=.o)))
 MKL_DIR  ?= /opt/conda/lib
 REF_CXXFLAGS := -O2 -ffp-contract=off -fPIC -std=c++11 -DCPU_ONLY -Ishim -I$(REF)/include -w
 
-ref: _ref/libmscnn_ref.so
+ref: _ref/libmscnn_ref.so _ref/kitti_eval_ref
+
+# the devkit evaluator the reference ships (one self-contained file): the pin of mscnn_amd/host/tools/kitti_eval.cpp
+_ref/kitti_eval_ref: $(REF)/examples/kitti_result/eval/evaluate_object.cpp
+	@mkdir -p _ref
+	$(CXX) -O2 -w -o $@ $<
 
 SHIM_HDRS := $(shell find shim -name '*.h' -o -name '*.hpp')
 

@@ -212,3 +212,42 @@ def test_caffemodel_reader(tmp_path):
     bad.write_bytes(_caffemodel([("conv1_1", "Convolution", [np.zeros((3, 3), np.float32), np.zeros(64, np.float32)])]))
     with pytest.raises(mnet.NetError, match="shape mismatch"):
         n.load_caffemodel(bad)
+
+
+def test_caffemodel_written_by_protobuf_python(tmp_path):
+    """The reader against an encoder this repository did not write: the protobuf runtime serialises a NetParameter declared
+    with caffe.proto's field numbers (tests/caffemodel_pb.py): BlobShape-style, legacy 4-D and double_data blobs, an
+    unpacked repeated float (loss_weight) and enum / string fields to skip."""
+    import numpy as np
+    from tests import caffemodel_pb
+    n = Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=64, width=128))
+    rng = np.random.default_rng(3)
+    want, layers = {}, []
+    for name, mode in (("conv1_1", "shape"), ("conv3_2", "legacy"), ("LFCN_1_7x7", "double"), ("fc6", "legacy"), ("cls_pred", "shape")):
+        shapes = n.param_shapes(n.layer_names.index(name))
+        arrs = [rng.standard_normal(sh).astype(np.float32) for sh in shapes]
+        want[name] = arrs
+        layers.append((name, "Convolution", [(a, mode) for a in arrs]))
+    layers.append(("not_in_this_net", "ReLU", []))
+    path = tmp_path / "pb.caffemodel"
+    data = caffemodel_pb.serialize(layers)
+    path.write_bytes(data)
+    back = caffemodel_pb.classes()["NetParameter"](); back.ParseFromString(data)          # the fixture itself round-trips
+    assert [l.name for l in back.layer][:2] == ["conv1_1", "conv3_2"] and len(back.layer[1].blobs[1].data) == 256
+    n.load_caffemodel(path)
+    for name, arrs in want.items():
+        for p_, a in enumerate(arrs):
+            assert np.array_equal(n.get_param(name, p_), a), (name, p_)        # float -> double -> float is exact
+    # truncated file: a CHECK failure, never a read past the buffer
+    cut = tmp_path / "cut.caffemodel"
+    cut.write_bytes(data[:len(data) // 2])
+    with pytest.raises(mnet.NetError, match="truncated caffemodel"):
+        n.load_caffemodel(cut)
+    # wrong shape with the right element count (3x3x64x3 instead of 64x3x3x3): the reference's ShapeEquals refuses it
+    w = want["conv1_1"][0]
+    bad = tmp_path / "bad.caffemodel"
+    bad.write_bytes(caffemodel_pb.serialize([("conv1_1", "Convolution", [(w.reshape(3, 3, 64, 3), "shape"), (want["conv1_1"][1], "shape")])]))
+    with pytest.raises(mnet.NetError, match="shape mismatch"):
+        n.load_caffemodel(bad)
+    with pytest.raises(mnet.NetError, match="HDF5"):
+        n.load_caffemodel(tmp_path / "weights.caffemodel.h5")
