@@ -1,0 +1,54 @@
+"""The multi-GPU exchange on real hardware, at the one world size a single-GPU box allows: libmscnn_dist.so's ncclAllGather
+(RCCL, world = 1) of the device-resident detection pack must hand back exactly what the single-GPU path
+(mscnn_net_detect) returns -- same float64 bytes, same ROI rows; and the C++ host driver (one thread + replica per GPU)
+must run end to end.  World sizes > 1: tests/test_dist_cpu.py (pack / shard logic over gloo) and the driver's scaling run."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from mscnn_amd import dist as mdist, net as mnet, synth, zoo   # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_gather_world1_is_bit_identical_to_single_gpu_detect():
+    if not torch.cuda.is_available():
+        pytest.fail("needs a MI355X")
+    n = mnet.Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=192, width=640, max_nms_num=300))
+    synth.load_into(n, "mid")
+    kw = dict(cls_id=2, ratios=(192 / 375.0, 640 / 1242.0), org_hw=(375, 1242))
+    cap = 300
+    gather = mdist.RcclGather(0, 1, 0, cap, exchange_id=lambda b: b)
+    assert gather.pack_bytes == mnet.detect_pack_bytes(cap) == (16 + 44 * cap + 15) // 16 * 16
+    for seed in (1, 2, 3):
+        n.set_blob("data", synth.frame(192, 640, seed=seed))
+        n.forward()
+        dets, ids, R = n.detect(**kw)
+        (gd, gi, gR), = gather(n.detect_device(cap, **kw))
+        assert gR == R and len(gd) == len(dets) > 0
+        assert gd.tobytes() == dets.tobytes() and np.array_equal(gi, ids)
+    gather.barrier()
+    # capacity below the ROI count is an error, not a truncation
+    with pytest.raises(mnet.NetError, match="capacity"):
+        n.detect_device(R - 1, **kw)
+    gather.close()
+
+
+def test_cpp_multi_gpu_host_driver(tmp_path):
+    """mscnn_amd/detect_multi_gpu (host/tools/detect_multi_gpu.cpp): threads + net replicas + RCCL gather through the C ABIs."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a MI355X")
+    exe = os.path.join(ROOT, "mscnn_amd/detect_multi_gpu")
+    assert os.path.exists(exe), "detect_multi_gpu not built"
+    proto = tmp_path / "deploy.prototxt"
+    proto.write_text(zoo.prototxt("kitti_car/mscnn-7s-576", height=192, width=640, max_nms_num=300))
+    r = subprocess.run([exe, str(proto), "--gpus", "1", "--images", "3", "--cap", "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("image")]
+    assert len(lines) == 3 and "3 images on 1 GPU(s)" in r.stdout
+    assert all(int(l.split("->")[1].split()[0]) > 0 for l in lines), r.stdout      # every frame yields detections
