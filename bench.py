@@ -113,31 +113,43 @@ def cpu_baseline(model, regime, R_gpu, net=None, kw=None, layer_table=None):
         layers = _layers_of(n)
         ws = synth.weights(n.layer_names, n.layer_types, [n.param_shapes(i) for i in range(len(n.layer_names))], regime)
         x = synth.frame(H, W, seed=1701, org_hw=MODELS[model]["org_hw"])
-        timings = []
-        t0 = time.perf_counter()
-        blobs = pynet.forward(layers, ws, {"data": x}, backend=pyref, timings=timings)
-        dt = time.perf_counter() - t0
-        R = blobs["proposals"].shape[0]
-        res = {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "reference", "cpu": _cpu_model(),
-               "sample": f"1 full frame (1x3x{H}x{W}, R={R} ROIs) through the reference's own CPU layers "
-                         f"(oracle/_ref: im2col + MKL cblas_sgemm, {cores} threads available), Net::Forward scope, {dt:.2f} s",
-               "seconds_per_image": round(dt, 2)}
-        if layer_table is not None:
-            layer_table.extend(timings)
-        # 1-thread row on a bounded sample: conv1_1 .. pool2 (4 convolutions, 207.7 GFLOP of the 7s-576 frame)
+        # BLAS thread count: the reference's CPU path is single-threaded outside cblas_sgemm (im2col, ReLU, pooling, BoxOutput,
+        # ROI pooling), and MKL with every hardware thread on these skinny GEMMs is SLOWER than a few threads -- time the layers
+        # up to pool2 (4 convolutions, a bounded sample) at several thread counts and run the full frame with the best one.
         cut = [l[0] for l in layers].index("pool2") + 1
-        t_all = sum(t for (nm, ty, t) in timings[:cut])
+        sample = {}
         prev = pyref.set_threads(1)
         try:
+            for nt in sorted({1, 8, 32, min(cores, 128), cores}):
+                if nt > cores:
+                    continue
+                pyref.set_threads(nt)
+                t0 = time.perf_counter()
+                pynet.forward(layers[:cut], ws, {"data": x}, backend=pyref)
+                sample[nt] = time.perf_counter() - t0
+            best = min(sample, key=sample.get)
+            pyref.set_threads(best)
+            timings = []
             t0 = time.perf_counter()
-            pynet.forward(layers[:cut], ws, {"data": x}, backend=pyref)
-            t1 = time.perf_counter() - t0
+            blobs = pynet.forward(layers, ws, {"data": x}, backend=pyref, timings=timings)
+            dt = time.perf_counter() - t0
         finally:
             pyref.set_threads(prev)
-        est = dt * t1 / max(t_all, 1e-9)
+        R = blobs["proposals"].shape[0]
+        res = {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": best, "kind": "reference", "cpu": _cpu_model(),
+               "host_threads_available": cores,
+               "sample": f"1 full frame (1x3x{H}x{W}, R={R} ROIs) through the reference's own CPU layers (oracle/_ref: im2col + MKL "
+                         f"cblas_sgemm on {best} BLAS threads = the fastest of {sorted(sample)} on conv1_1..pool2 of this frame; everything "
+                         f"else in that path is serial), Net::Forward scope, {dt:.2f} s",
+               "seconds_per_image": round(dt, 2),
+               "blas_threads_sample_s": {str(k): round(v, 2) for k, v in sorted(sample.items())}}
+        if layer_table is not None:
+            layer_table.extend(timings)
+        t_all = sum(t for (nm, ty, t) in timings[:cut])
+        est = dt * sample[1] / max(t_all, 1e-9)
         res["one_core"] = {"value": round(1.0 / est, 5), "unit": "images/sec", "cores": 1,
-                           "sample": f"conv1_1..pool2 of the same frame with MKL_NUM_THREADS=1: {t1:.2f} s against {t_all:.2f} s on "
-                                     f"{cores} threads; whole frame estimated as {dt:.2f} s x that ratio = {est:.1f} s",
+                           "sample": f"conv1_1..pool2 of the same frame with 1 BLAS thread: {sample[1]:.2f} s against {t_all:.2f} s on {best}; "
+                                     f"whole frame estimated as {dt:.2f} s x that ratio = {est:.1f} s",
                            "seconds_per_image_est": round(est, 1)}
         if net is not None:
             res["full_size_parity"] = _full_size_parity(net, x, blobs, kw)
