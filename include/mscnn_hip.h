@@ -59,7 +59,12 @@ typedef enum {
   MSCNN_CONV_ALGO_AUTO = 0,     /* Winograd F(3x3,3x3) where the arithmetic-intensity heuristic says it pays, direct otherwise */
   MSCNN_CONV_ALGO_DIRECT = 1,   /* never Winograd: the k-ordered implicit-GEMM sum (per-layer numerical fall-back) */
   MSCNN_CONV_ALGO_WINO_F2 = 2,  /* F(2x2,3x3) on whole planes wherever it is legal (small ROI maps: F(3x3,3x3)) */
-  MSCNN_CONV_ALGO_WINO_F3 = 3   /* F(3x3,3x3) wherever it is legal */
+  MSCNN_CONV_ALGO_WINO_F3 = 3,  /* F(3x3,3x3) wherever it is legal */
+  /* Reduced-precision mode (no reference counterpart): operands rounded to fp16 on their way into LDS, v_mfma_f32_32x32x16_f16
+   * with fp32 accumulators, direct 3x3 implicit GEMM (no Winograd).  Blobs stay fp32.  Shapes without an fp16 kernel (stride,
+   * groups, heads) run their fp32 kernel.  Tolerance policy: DESIGN.md (per-layer 5e-3 of the layer's scale; detections IoU >=
+   * 0.95 and |dscore| <= 5e-3 against the fp32 path). */
+  MSCNN_CONV_ALGO_F16 = 4
 } mscnn_conv_algo;
 
 typedef struct {
@@ -84,6 +89,8 @@ MSCNN_API size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* plan);
 MSCNN_API const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* plan);
 /* Algorithmic FLOPs (2*MACs of the direct convolution the reference computes) of one forward call. */
 MSCNN_API double mscnn_conv2d_plan_flops(const mscnn_conv_plan* plan);
+/* "f32" | "f16": the arithmetic type of the plan's MFMA operands (accumulation is fp32 in both). */
+MSCNN_API const char* mscnn_conv2d_plan_dtype(const mscnn_conv_plan* plan);
 /* FLOPs the MFMA pipe really executes for the real (unpadded) problem: equal to the algorithmic count for the direct
  * kernels, 2 * planes * Cout * Cin * tiles for the Winograd forms (25/81 resp. 16/36 of it on exactly tiled planes). */
 MSCNN_API double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* plan);
@@ -124,6 +131,14 @@ MSCNN_API int mscnn_pool2d_fwd_f32(const float* x, float* y, int N, int C, int H
  * y[M,N] = x[M,K] * w[N,K]^T + bias[N]  (transpose_ = false), optional fused ReLU. */
 MSCNN_API int mscnn_inner_product_fwd_f32(const float* x, const float* w, const float* bias, float* y,
                                 int M, int N, int K, int relu, void* stream);
+
+/* fp16-operand InnerProduct (the counterpart of MSCNN_CONV_ALGO_F16; no reference counterpart): w16 = the weights converted
+ * once to fp16 [N][K] (mscnn_inner_product_pack_f16, N * K * 2 bytes), x rounded to fp16 on its way into LDS, fp32 accumulate.
+ * Needs N >= 64 and K % 8 == 0 (mscnn_inner_product_f16_supported); smaller layers stay on the fp32 entry point. */
+MSCNN_API int mscnn_inner_product_f16_supported(int N, int K);
+MSCNN_API int mscnn_inner_product_pack_f16(const float* w, void* w16, int N, int K, void* stream);
+MSCNN_API int mscnn_inner_product_fwd_f16(const float* x, const void* w16, const float* bias, float* y, int M, int N, int K, int relu,
+                                          void* stream);
 
 /* Concat along channels -- ConcatLayer::Forward_gpu (concat_layer.cu:9-46).
  * Copies x[N, C, inner] into y[N, C_total, inner] at channel offset c_offset. */

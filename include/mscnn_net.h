@@ -68,6 +68,11 @@ MSCNN_NET_API int mscnn_net_layer_stage_ms(const mscnn_net* net, int layer, floa
  * 2 / 3 Winograd F(2x2,3x3) / F(3x3,3x3) wherever legal); tuning knobs = mscnn_conv_desc::tune_* (A/B runs). */
 MSCNN_NET_API int mscnn_net_set_conv_algo(mscnn_net* net, int layer, int algo);
 MSCNN_NET_API int mscnn_net_set_conv_tuning(mscnn_net* net, int layer, int variant, int grid, int flags);
+/* Arithmetic of the MFMA layers of the whole net: "f32" (default: the path that matches the reference within 1e-4) or "f16"
+ * (fp16 operands, fp32 accumulate, no reference counterpart -- BASELINE config 5): 3x3 stride-1 convolutions and InnerProduct
+ * layers with N >= 64 switch, everything else keeps its fp32 kernel.  mscnn_net_layer_dtype: what layer i really runs. */
+MSCNN_NET_API int mscnn_net_set_precision(mscnn_net* net, const char* dtype);
+MSCNN_NET_API const char* mscnn_net_layer_dtype(const mscnn_net* net, int layer);
 /* Numerical calibration (call after a forward on representative input): every Winograd convolution is re-computed with the
  * direct k-ordered kernel on the same bottom; layers whose max |dy| / max(1, |y|) exceeds tol run the direct kernel from
  * then on.  *num_switched = how many; mscnn_net_layer_calibration_err gives each layer's measured value. */

@@ -32,6 +32,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct IgemmArgs {
   const float* x; const float* wp; const float* bias; float* y; float* ws;
@@ -52,8 +53,13 @@ constexpr int kSlabsPerWg = 2;   // stream-K tail partial, stream-K head partial
 //   ROI mode   (RH  > 0): the images are tiny (RH x RW, e.g. the 7x7 ROI-pooled maps of roi_c1) and a tile packs
 //                         IPT whole images: N side = IPT * OH * OW output pixels.  The reference's CAFFE engine runs
 //                         one im2col+GEMM with N = 25 per ROI here (conv_layer.cu:14-21).
-template <int BM_, int BN_, int WGM_, int WGN_, int KH_, int KW_, int CK_, int TW_, int RH_ = 0, int RW_ = 0, int RP_ = 0, int PF_ = 0, int VEC_ = 0, int NOPN_ = 0>
+template <int BM_, int BN_, int WGM_, int WGN_, int KH_, int KW_, int CK_, int TW_, int RH_ = 0, int RW_ = 0, int RP_ = 0, int PF_ = 0, int VEC_ = 0, int NOPN_ = 0, int F16_ = 0>
 struct Cfg {
+  // F16: operands rounded to fp16 while they are staged into LDS, v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate), fp32
+  // accumulators; blobs stay fp32 in HBM.  A k-step is 16 input channels of one tap: a lane holds 8 consecutive channels, so
+  // both LDS tiles are channel-innermost 16-byte units: A [tap][kg][BM][8], B [kg][patch pixel][8]  (kg = 8-channel group).
+  static constexpr bool F16 = F16_ != 0;
+  static constexpr int KG = CK_ / 8;
   // VEC: 1x1 kernel over planes of exactly 128-pixel rows (the Winograd GEMM operands): the B tile is CK contiguous
   // 512-byte rows, staged with b128 loads / ds_write_b128 and no per-element offset table
   static constexpr int VEC = VEC_;
@@ -76,10 +82,13 @@ struct Cfg {
   static constexpr int CH_STRIDE = ROI ? IPT * IPH * IPW : PH * PW;     // LDS floats per channel
   static constexpr int TAPS = KH * KW;
   static constexpr int A_ELEMS = TAPS * CK * BM;
-  static constexpr int A_VEC4 = A_ELEMS / 4;
+  static constexpr int A_VEC4 = (F16_ ? A_ELEMS / 2 : A_ELEMS) / 4;      // float4s of one chunk's packed weight slab
   static constexpr int A_PER_T = (A_VEC4 + 255) / 256;
   static constexpr int B_ELEMS = CK * CH_STRIDE;
-  static constexpr int B_PER_T = (B_ELEMS + 255) / 256;
+  static constexpr int B_PER_T = F16_ ? 1 : (B_ELEMS + 255) / 256;
+  static constexpr int B_UNITS = (CK_ / 8) * CH_STRIDE;                  // F16: 16-byte units (8 channels of one patch pixel)
+  static constexpr int BU_PER_T = F16_ ? (B_UNITS + 255) / 256 : 1;
+  static constexpr int A_LDS_FLOATS = F16_ ? A_ELEMS / 2 : A_ELEMS, B_LDS_FLOATS = F16_ ? B_ELEMS / 2 : B_ELEMS;
   static constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
   static constexpr int FIX_SPLIT = (BM * BN) / 4096;                    // fix-up workgroups per tile
   // fused 2x2 max pooling in the epilogue: a 32-pixel MFMA block is two 16-pixel rows (TW 16) or one row whose partner
@@ -87,6 +96,7 @@ struct Cfg {
   static constexpr bool CAN_POOL = !ROI && (BN / TW) % 2 == 0 && (TW_ == 16 || (TW_ == 32 && (BN / WGN / 32) % 2 == 0));
   static_assert(!VEC_ || (KH_ == 1 && KW_ == 1 && TW_ == 128 && (BN_ == 128 || BN_ == 256) && RH_ == 0 && CK_ % 8 == 0),
                 "VEC: 1x1, tiles of one or two whole 128-pixel rows");
+  static_assert(!F16_ || (CK_ % 16 == 0 && VEC_ == 0), "F16: k-steps of 16 channels");
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(WM % 32 == 0 && WN % 32 == 0 && BN % TW == 0 && CK % 2 == 0 && A_ELEMS % 4 == 0, "tile shape");
   static_assert((BM * BN) % 4096 == 0, "fix-up split");
@@ -118,6 +128,25 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     const int mt = (int)r;
     const int co = mt * BM + m, ci = kc * CK + ck;
     wp[i] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * taps + tap] : 0.f;
+  }
+}
+
+// F16 kernels: w[Cout][Cin][KH][KW] (fp32) -> halves wp[mt][kc][tap][kg][BM][8]: the 16-byte unit (tap, kg, m) holds input
+// channels kc * CK + kg * 8 .. + 7 of output channel mt * BM + m -- exactly one lane's MFMA A operand.  Round to nearest even.
+__global__ __launch_bounds__(256) void pack_weights_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cout,
+                                                               int Cin, int taps, int BM, int CK, int MT, int KI) {
+  const long total = (long)MT * KI * taps * CK * BM;
+  const int KG = CK / 8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long r = i;
+    const int e = (int)(r % 8); r /= 8;
+    const int m = (int)(r % BM); r /= BM;
+    const int kg = (int)(r % KG); r /= KG;
+    const int tap = (int)(r % taps); r /= taps;
+    const int kc = (int)(r % KI); r /= KI;
+    const int mt = (int)r;
+    const int co = mt * BM + m, ci = kc * CK + kg * 8 + e;
+    wp[i] = (_Float16)((co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * taps + tap] : 0.f);
   }
 }
 
@@ -202,8 +231,8 @@ constexpr float kNegMax = -3.402823466e+38f;
 
 template <class C>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float ldsA[C::A_ELEMS];
-  __shared__ __attribute__((aligned(16))) float ldsB[C::B_ELEMS];
+  __shared__ __attribute__((aligned(16))) float ldsA[C::A_LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float ldsB[C::B_LDS_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -233,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   const int plane = a.H * a.W;
   const bool ragged_c = (a.Cin % C::CK) != 0;    // last chunk has fewer than CK real channels (conv1_1: Cin = 3)
   const __amdgpu_buffer_rsrc_t wsrc =
-      make_rsrc(a.wp, (unsigned)((long)a.MT * a.KI * C::A_ELEMS * 4) + (a.w_img_bytes ? (unsigned)(a.N - 1) * a.w_img_bytes : 0u));
+      make_rsrc(a.wp, (unsigned)((long)a.MT * a.KI * C::A_LDS_FLOATS * 4) + (a.w_img_bytes ? (unsigned)(a.N - 1) * a.w_img_bytes : 0u));
   const __amdgpu_buffer_rsrc_t bias_rsrc = make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
   const int co_stride = a.Ho * a.Wo;
 
@@ -247,6 +276,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   unsigned a_tile = 0;
   float4 ra[C::A_PER_T];
   float rb[C::B_PER_T];
+  float rh[C::BU_PER_T][8];        // F16: the 8 channels of this thread's units (fp32 until they are stored into LDS)
+  unsigned u_off[C::BU_PER_T];     // F16: byte offset of unit i's pixel in channel (8 kg) of the chunk, or kOob
   float4 rbv[C::VEC ? C::BV_PER_T : 1];
   const unsigned a_voff = (unsigned)tid * 16u;
 
@@ -266,7 +297,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     const int nt = a.nt_major ? t / a.MT : t % a.NT;
     geo.decode(a, nt);
     xsrc = make_rsrc(geo.x_base(a), geo.x_bytes(a));
-    if constexpr (!C::VEC) {
+    if constexpr (C::F16) {
+#pragma unroll
+      for (int i = 0; i < C::BU_PER_T; ++i) {
+        const int u = tid + i * 256;
+        // staging element (kg * 8, pixel): in_off's index is channel * CH_STRIDE + pixel
+        const int o = u < C::B_UNITS ? geo.in_off(a, (u / C::CH_STRIDE) * 8 * C::CH_STRIDE + u % C::CH_STRIDE) : -1;
+        u_off[i] = o >= 0 ? (unsigned)o * 4u : kOob;
+      }
+    } else if constexpr (!C::VEC) {
 #pragma unroll
       for (int i = 0; i < C::B_PER_T; ++i) {
         const int o = geo.in_off(a, tid + i * 256);
@@ -274,20 +313,28 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
       }
     }
     bv_voff = ((unsigned)(tid / C::F4_PER_CH) * (unsigned)plane + (unsigned)geo.h0 * 128u + (unsigned)(tid % C::F4_PER_CH) * 4u) * 4u;
-    a_tile = (unsigned)(mt * a.KI) * (C::A_ELEMS * 4u) + (unsigned)geo.img * a.w_img_bytes;
+    a_tile = (unsigned)(mt * a.KI) * (C::A_LDS_FLOATS * 4u) + (unsigned)geo.img * a.w_img_bytes;
     return true;
   };
 
 #define MSCNN_LOAD_CHUNK(kc)                                                                                        \
     {                                                                                                               \
-      const unsigned a_soff = a_tile + (unsigned)(kc) * (C::A_ELEMS * 4u);                                          \
+      const unsigned a_soff = a_tile + (unsigned)(kc) * (C::A_LDS_FLOATS * 4u);                                     \
       _Pragma("unroll") for (int i = 0; i < C::A_PER_T; ++i) {                                                      \
         const unsigned vo = (C::A_VEC4 % 256 == 0 || tid + i * 256 < C::A_VEC4) ? a_voff : kOob;                    \
         ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, vo, a_soff + i * 4096u, 0)); \
       }                                                                                                             \
       const unsigned b_soff = (unsigned)(kc) * (unsigned)(C::CK * 4) * (unsigned)plane;                             \
       const int c_left = a.Cin - (kc) * C::CK;                                                                      \
-      if constexpr (C::VEC) {                                                                                       \
+      if constexpr (C::F16) {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < C::BU_PER_T; ++i)                                                     \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                           \
+            unsigned vo = u_off[i];                                                                                 \
+            if (ragged_c && ((tid + i * 256) / C::CH_STRIDE) * 8 + j >= c_left) vo = kOob;                          \
+            rh[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                              \
+                                               xsrc, vo, b_soff + (unsigned)j * (unsigned)plane * 4u, 0));           \
+          }                                                                                                         \
+      } else if constexpr (C::VEC) {                                                                                \
         _Pragma("unroll") for (int i = 0; i < C::BV_PER_T; ++i) {                                                   \
           const unsigned vo = (ragged_c && tid / C::F4_PER_CH + C::CH_PER_PASS * i >= c_left) ? kOob : bv_voff;     \
           rbv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(                                \
@@ -337,7 +384,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
       for (int i = 0; i < C::A_PER_T; ++i)
         if (C::A_VEC4 % 256 == 0 || tid + i * 256 < C::A_VEC4) aWr[i * 256] = ra[i];
-      if constexpr (C::VEC) {
+      if constexpr (C::F16) {
+#pragma unroll
+        for (int i = 0; i < C::BU_PER_T; ++i) {
+          f16x8 h;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h[j] = (_Float16)rh[i][j];            // round to nearest even
+          if (C::B_UNITS % 256 == 0 || tid + i * 256 < C::B_UNITS) reinterpret_cast<f16x8*>(ldsB)[tid + i * 256] = h;
+        }
+      } else if constexpr (C::VEC) {
 #pragma unroll
         for (int i = 0; i < C::BV_PER_T; ++i) reinterpret_cast<float4*>(ldsB)[tid + i * 256] = rbv[i];
       } else {
@@ -354,7 +409,31 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         if (more) MSCNN_LOAD_CHUNK(k0);
       }
       if (C::PF == 2) __builtin_amdgcn_s_setprio(0);
-      if constexpr (C::PF == 0) {
+      if constexpr (C::F16) {
+        // unit (16 B) indices: A [tap][kg][BM], B [kg][CH_STRIDE]; this lane's k-group inside a 16-channel step = khalf
+        const f16x8* a16 = reinterpret_cast<const f16x8*>(ldsA) + khalf * C::BM + wm * C::WM + l31;
+        const f16x8* b16 = reinterpret_cast<const f16x8*>(ldsB) + khalf * C::CH_STRIDE;
+        int poff[C::NI];
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni) poff[ni] = lane_patch_off<C>(wn * C::WN + ni * 32 + l31);
+#pragma unroll
+        for (int kh = 0; kh < C::KH; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < C::KW; ++kw)
+#pragma unroll
+            for (int ks = 0; ks < C::CK / 16; ++ks) {
+              f16x8 av[C::MI], bv[C::NI];
+#pragma unroll
+              for (int mi = 0; mi < C::MI; ++mi) av[mi] = a16[((kh * C::KW + kw) * C::KG + 2 * ks) * C::BM + mi * 32];
+#pragma unroll
+              for (int ni = 0; ni < C::NI; ++ni) bv[ni] = b16[2 * ks * C::CH_STRIDE + poff[ni] + kh * C::ROWS + kw];
+#pragma unroll
+              for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < C::NI; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+            }
+      } else if constexpr (C::PF == 0) {
 #pragma unroll
         for (int kh = 0; kh < C::KH; ++kh)
 #pragma unroll
@@ -715,6 +794,21 @@ const KernelEntry kTable[] = {
     {"abl1x1_mfmaonly", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 113, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 13, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 13, 1>>},
 #endif
     ENTRY(128, 256, 2, 2, 3, 3, 8, 32),     // variant 2 (selected with MSCNN_IGEMM_VARIANT=2): 64x128 wave tiles
+    // fp16-operand variants (variant 200, mscnn_conv_desc::algo == MSCNN_CONV_ALGO_F16): trunk 3x3 planes and the ROI maps of roi_c1
+#define ENTRY16(BM, BN, WGM, WGN, TW)                                                                                        \
+  {"igemm16_" #BM "x" #BN "_k3x3_tw" #TW, BM, BN, 3, 3, 16, TW, BN / TW, 0, 0, 0, 1, (BM * BN) / 4096, 200,                    \
+   igemm_kernel<Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 0, 0, 0, 1>>, igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 0, 0, 0, 1>>, \
+   Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 0, 0, 0, 1>::CAN_POOL ? igemm_fixup_pool_kernel<Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 0, 0, 0, 1>> : nullptr}
+#define ROI_ENTRY16(RH, RW, RP)                                                                                              \
+  {"igemm16_128x128_k3x3_roi" #RH "x" #RW "p" #RP, 128, 128, 3, 3, 16, 0, 0, RH, RW, RP,                                       \
+   Cfg<128, 128, 2, 2, 3, 3, 16, 32, RH, RW, RP, 0, 0, 0, 1>::IPT, 4, 200, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 16, 32, RH, RW, RP, 0, 0, 0, 1>>, \
+   igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 16, 32, RH, RW, RP, 0, 0, 0, 1>>}
+    ENTRY16(128, 128, 2, 2, 16),
+    ENTRY16(128, 128, 2, 2, 32),
+    ENTRY16(64, 256, 1, 4, 32),
+    ROI_ENTRY16(7, 7, 0),
+    ROI_ENTRY16(7, 5, 0),
+    ROI_ENTRY16(8, 4, 1),
     // proposal heads (Cout = 4 + classes <= 32): kitti_car 5x5 / 7x7, ped-cyc + caltech 3x5 / 5x7
     ENTRY(32, 128, 1, 4, 5, 5, 8, 16),
     ENTRY(32, 128, 1, 4, 7, 7, 8, 16),
@@ -814,7 +908,8 @@ static void plan_shape(mscnn_conv_plan* p) {
   delete p->wino;
   p->wino = nullptr;
   if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0 || d.Cin > 2048) return;   // KI <= 256
-  if (wino_plan(p)) return;
+  const bool want16 = tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_F16 && d.Kh == 3 && d.Kw == 3;
+  if (!want16 && wino_plan(p)) return;
   // 32-bit buffer offsets: every tensor window the kernel addresses must stay below 2 GiB
   const double win_x = (double)d.Cin * d.H * d.W * 4.0, win_y = (double)d.Cout * p->Ho * p->Wo * 4.0;
   // choose the table entry with the least padded work; an ROI-mode entry wins whenever it matches the image shape
@@ -827,8 +922,9 @@ static void plan_shape(mscnn_conv_plan* p) {
   for (int i = 0; i < kTableN; ++i) {
     const KernelEntry& k = kTable[i];
     if (k.KH != d.Kh || k.KW != d.Kw) continue;
+    if ((k.variant == 200) != want16) continue;
     const bool is256 = (k.BM == 128 && k.BN == 256);
-    if (k.KH == 3 && k.KW == 3 && k.RH == 0) {
+    if (k.KH == 3 && k.KW == 3 && k.RH == 0 && k.variant != 200) {
       if (is256 && k.variant == 0) continue;                  // (kept for reference; superseded by variant 3)
       if (k.variant != ((d.Cin <= 4 && d.Cout <= 64 && !venv) ? 50 : want)) continue;
     }
@@ -886,7 +982,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->G = (int)G;
   p->full_q = (int)(tiles / G);                               // data-parallel phase
   p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
-  p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * sizeof(float);
+  p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * (k.variant == 200 ? sizeof(_Float16) : sizeof(float));
   p->ws_bytes = (size_t)p->G * kSlabsPerWg * k.BM * k.BN * sizeof(float);
 }
 
@@ -919,7 +1015,7 @@ extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_p
   unsigned long long kind, e, mt, ki;
   if (p->head.entry >= 0) { kind = 2; e = (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
   else if (p->wino) { kind = 2 + (unsigned)p->wino_m; e = (unsigned)p->wino->entry; mt = (unsigned)p->wino->MT; ki = (unsigned)p->wino->KI; }
-  else if (p->entry >= 0) { kind = 1; e = (unsigned)p->entry; mt = (unsigned)p->MT; ki = (unsigned)p->KI; }
+  else if (p->entry >= 0) { kind = 1; e = (unsigned)p->entry; mt = (unsigned)p->MT; ki = (unsigned)p->KI; }   // (entry distinguishes fp16 packs)
   else return 0;   // direct kernel: reads the Caffe layout
   return kind | (e << 8) | (mt << 24) | (ki << 44);
 }
@@ -927,6 +1023,9 @@ extern "C" double mscnn_conv2d_plan_flops(const mscnn_conv_plan* p) {
   if (!p) return 0;
   const mscnn_conv_desc& d = p->d;
   return 2.0 * d.N * d.Cout * p->Ho * p->Wo * (double)(d.Cin / d.group) * d.Kh * d.Kw;
+}
+extern "C" const char* mscnn_conv2d_plan_dtype(const mscnn_conv_plan* p) {
+  return (p && !p->wino && p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant == 200) ? "f16" : "f32";
 }
 extern "C" double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* p) {
   if (!p) return 0;
@@ -976,8 +1075,12 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   const long total = (long)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  pack_weights_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, p->d.Cout, p->d.Cin, k.KH * k.KW, k.BM, k.CK,
-                                                                 p->MT, p->KI);
+  if (k.variant == 200)
+    pack_weights_f16_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, reinterpret_cast<_Float16*>(packed), p->d.Cout, p->d.Cin,
+                                                                       k.KH * k.KW, k.BM, k.CK, p->MT, p->KI);
+  else
+    pack_weights_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, packed, p->d.Cout, p->d.Cin, k.KH * k.KW, k.BM, k.CK,
+                                                                   p->MT, p->KI);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

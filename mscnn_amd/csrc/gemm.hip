@@ -182,6 +182,125 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmArgs a) {
   }
 }
 
+// ---- fp16-operand variant (MSCNN_CONV_ALGO_F16's counterpart for InnerProduct; no reference counterpart) --------------------
+// y = x[M,K] (fp32, rounded to fp16 while it is staged) * w16[N,K]^T (fp16, converted once by mscnn_inner_product_pack_f16),
+// v_mfma_f32_32x32x16_f16 with fp32 accumulators.  At small M (a few hundred ROIs) fc6 is bound by streaming its weights
+// once: fp16 weights halve those bytes (caltech fc6: 134 -> 67 MB).  LDS rows are [row][BK + 8] halves: the 80-byte stride
+// puts the 16-byte operand reads of 32 consecutive rows on distinct bank groups.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDH = BK + 8;
+
+__global__ __launch_bounds__(256) void pack_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ w16, long count) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < count; i += (long)gridDim.x * 256) w16[i] = (_Float16)w[i];
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm16_tn_kernel(GemmArgs a) {
+  static_assert(BM * BN == 128 * 128 && BM % 64 == 0 && BN % 64 == 0, "4 waves of 64 x 64");
+  __shared__ __attribute__((aligned(16))) _Float16 ldsX[BM * LDH];
+  __shared__ __attribute__((aligned(16))) _Float16 ldsW[BN * LDH];
+  const _Float16* w16 = reinterpret_cast<const _Float16*>(a.w);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  constexpr int WN = BN / 64;
+  const int wm = wave / WN, wn = wave % WN;
+  constexpr int XV = BM * (BK / 4) / 256;       // float4 (4 k) per thread of the x tile
+  constexpr int WV = BN * (BK / 8) / 256;       // half8 (8 k) per thread of the w tile
+
+  long it, it_end;
+  wg_range(a.total_iters, a.G, blockIdx.x, it, it_end);
+  const int xs_row0 = tid >> 3, xs_k = (tid & 7) * 4;       // x: 8 float4 per row
+  const int ws_row0 = tid >> 2, ws_k = (tid & 3) * 8;       // w: 4 half8 per row
+
+  while (it < it_end) {
+    const int t = (int)(it / a.KI);
+    const int k0 = (int)(it % a.KI);
+    const int k1 = (int)min((long)a.KI, k0 + (it_end - it));
+    const int nt = t / a.MT, mt = t % a.MT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 rx[XV];
+    f16x8 rw[WV];
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int m = m0 + xs_row0 + 32 * i, k = kc * BK + xs_k;
+        rx[i] = (m < a.M && k < a.K) ? *reinterpret_cast<const float4*>(a.x + (long)m * a.K + k) : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < WV; ++i) {
+        const int n = n0 + ws_row0 + 64 * i, k = kc * BK + ws_k;
+        f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        rw[i] = (n < a.N && k < a.K) ? *reinterpret_cast<const f16x8*>(w16 + (long)n * a.K + k) : z;
+      }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        f16x4 h = {(_Float16)rx[i].x, (_Float16)rx[i].y, (_Float16)rx[i].z, (_Float16)rx[i].w};
+        *reinterpret_cast<f16x4*>(&ldsX[(xs_row0 + 32 * i) * LDH + xs_k]) = h;
+      }
+#pragma unroll
+      for (int i = 0; i < WV; ++i) *reinterpret_cast<f16x8*>(&ldsW[(ws_row0 + 64 * i) * LDH + ws_k]) = rw[i];
+    };
+
+    load_chunk(k0);
+    for (int kc = k0; kc < k1; ++kc) {
+      __syncthreads();
+      store_chunk();
+      __syncthreads();
+      if (kc + 1 < k1) load_chunk(kc + 1);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        f16x8 av[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const f16x8*>(&ldsX[(wm * 64 + i * 32 + l31) * LDH + ks * 16 + khalf * 8]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const f16x8*>(&ldsW[(wn * 64 + j * 32 + l31) * LDH + ks * 16 + khalf * 8]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+
+    const bool full = (k0 == 0 && k1 == a.KI);
+    float* slab = a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int nl = wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          if (full) {
+            const int m = m0 + ml, n = n0 + nl;
+            if (m < a.M && n < a.N) {
+              float v = acc[i][j][r];
+              if (a.bias) v += a.bias[n];
+              if (a.relu) v = v > 0.f ? v : 0.f;
+              a.y[(long)m * a.N + n] = v;
+            }
+          } else {
+            slab[ml * BN + nl] = acc[i][j][r];
+          }
+        }
+      }
+    it += (k1 - k0);
+    __syncthreads();
+  }
+}
+
 // Small-N path (cls_pred N = 5, bbox_pred N = 20, K = 4096): one workgroup per row m.  The row of x is held in registers
 // (K / 256 values per thread), every output n is a register dot product + wave reduction, the 4 wave partials of all N
 // outputs are combined after ONE barrier.  W (N x K) is re-read by every workgroup out of L2.
@@ -264,6 +383,31 @@ using namespace mscnn;
 static float* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
 
+extern "C" int mscnn_inner_product_f16_supported(int N, int K) { return N >= 64 && K % 8 == 0; }
+
+extern "C" int mscnn_inner_product_pack_f16(const float* w, void* w16, int N, int K, void* stream) {
+  MSCNN_REQUIRE(w && w16 && N > 0 && K > 0, "inner_product pack: bad argument");
+  const long count = (long)N * K;
+  long blocks = (count + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  pack_f16_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, static_cast<_Float16*>(w16), count);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+static int inner_product_gemm(const float* x, const void* w, bool w_is_f16, const float* bias, float* y, int M, int N, int K, int relu,
+                              hipStream_t st);
+
+extern "C" int mscnn_inner_product_fwd_f16(const float* x, const void* w16, const float* bias, float* y, int M, int N, int K, int relu,
+                                           void* stream) {
+  MSCNN_REQUIRE(M >= 0 && N > 0 && K > 0, "inner_product: bad shape M=%d N=%d K=%d", M, N, K);
+  if (M == 0) return MSCNN_OK;
+  MSCNN_REQUIRE(x && w16 && y, "inner_product: null pointer");
+  MSCNN_REQUIRE(mscnn_inner_product_f16_supported(N, K) && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(w16) % 16 == 0,
+                "inner_product f16: needs N >= 64, K %% 8 == 0 and 16-byte aligned operands (N=%d K=%d)", N, K);
+  return inner_product_gemm(x, w16, true, bias, y, M, N, K, relu, as_stream(stream));
+}
+
 extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
                                            int relu, void* stream) {
   MSCNN_REQUIRE(M >= 0 && N > 0 && K > 0, "inner_product: bad shape M=%d N=%d K=%d", M, N, K);
@@ -280,8 +424,13 @@ extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const
     MSCNN_POST_LAUNCH();
     return MSCNN_OK;
   }
+  return inner_product_gemm(x, w, false, bias, y, M, N, K, relu, st);
+}
+
+static int inner_product_gemm(const float* x, const void* w, bool w_is_f16, const float* bias, float* y, int M, int N, int K, int relu,
+                              hipStream_t st) {
   GemmArgs a;
-  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.x = x; a.w = static_cast<const float*>(w); a.bias = bias; a.y = y;
   a.M = M; a.N = N; a.K = K; a.relu = relu;
   // tile shape: 64-row tiles when they waste fewer padded ROI rows (M = 700: 704 instead of 768 rows, -8 % MFMA work)
   const bool m64 = cdiv(M, 64) * 64 < cdiv(M, 128) * 128 && N >= 256;
@@ -300,8 +449,13 @@ extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const
     g_ws_bytes = need;
   }
   a.ws = g_ws;
-  if (m64) gemm_tn_kernel<64, 256><<<a.G, 256, 0, st>>>(a);
-  else gemm_tn_kernel<128, 128><<<a.G, 256, 0, st>>>(a);
+  if (w_is_f16) {
+    if (m64) gemm16_tn_kernel<64, 256><<<a.G, 256, 0, st>>>(a);
+    else gemm16_tn_kernel<128, 128><<<a.G, 256, 0, st>>>(a);
+  } else {
+    if (m64) gemm_tn_kernel<64, 256><<<a.G, 256, 0, st>>>(a);
+    else gemm_tn_kernel<128, 128><<<a.G, 256, 0, st>>>(a);
+  }
   MSCNN_POST_LAUNCH();
   if (m64) gemm_fixup_kernel<64, 256><<<a.MT * a.NT * 4, 256, 0, st>>>(a);
   else gemm_fixup_kernel<128, 128><<<a.MT * a.NT * 4, 256, 0, st>>>(a);

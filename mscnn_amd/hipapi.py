@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
 
 
 # mscnn_conv_algo
-ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_F2, ALGO_WINO_F3 = 0, 1, 2, 3
+ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_F2, ALGO_WINO_F3, ALGO_F16 = 0, 1, 2, 3, 4
 
 
 MAX_HEADS = 16
@@ -61,6 +61,11 @@ def lib():
         L.mscnn_version.restype = C.c_char_p
         L.mscnn_conv2d_plan_kernel.restype = C.c_char_p
         L.mscnn_conv2d_plan_kernel.argtypes = [C.c_void_p]
+        L.mscnn_conv2d_plan_dtype.restype = C.c_char_p
+        L.mscnn_conv2d_plan_dtype.argtypes = [C.c_void_p]
+        L.mscnn_inner_product_f16_supported.argtypes = [C.c_int, C.c_int]
+        L.mscnn_inner_product_pack_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.mscnn_inner_product_fwd_f16.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
         for f in ("mscnn_conv2d_plan_flops", "mscnn_conv2d_plan_executed_flops"):
             getattr(L, f).restype = C.c_double
             getattr(L, f).argtypes = [C.c_void_p]
@@ -150,6 +155,10 @@ class ConvPlan:
     @property
     def kernel(self):
         return lib().mscnn_conv2d_plan_kernel(self._p).decode()
+
+    @property
+    def dtype(self):
+        return lib().mscnn_conv2d_plan_dtype(self._p).decode()
 
     @property
     def flops(self):
@@ -243,6 +252,19 @@ def inner_product(x, w, bias=None, relu=False):
     Nn = w.shape[0]
     y = torch.empty((M, Nn), dtype=torch.float32, device=x.device)
     _check(lib().mscnn_inner_product_fwd_f32(_dev(x), _dev(w), _dev(bias), _dev(y), M, Nn, K, int(relu), _stream()))
+    return y
+
+
+def inner_product_f16(x, w, bias=None, relu=False):
+    """fp16-operand InnerProduct: w is converted once to fp16 (here per call), x on the fly, fp32 accumulate."""
+    M = x.shape[0]
+    Nn, K = w.shape[0], w[0].numel()
+    if not lib().mscnn_inner_product_f16_supported(Nn, K):
+        raise MscnnError(f"inner_product f16 needs N >= 64 and K % 8 == 0 (N={Nn}, K={K})")
+    w16 = torch.empty(Nn * K, dtype=torch.float16, device=x.device)
+    _check(lib().mscnn_inner_product_pack_f16(_dev(w), _dev(w16), Nn, K, _stream()))
+    y = torch.empty((M, Nn), dtype=torch.float32, device=x.device)
+    _check(lib().mscnn_inner_product_fwd_f16(_dev(x), _dev(w16), _dev(bias), _dev(y), M, Nn, K, int(relu), _stream()))
     return y
 
 

@@ -76,6 +76,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   virtual bool FusePool2x2(Blob<Dtype>* pooled_top);
   virtual double ForwardFlops() const;
   const char* kernel_name() const;
+  const char* dtype() const;              // "f32" | "f16": MFMA operand type of the planned kernel
   // --- extensions of this build (no reference counterpart) ---
   // Algorithm of this layer (mscnn_conv_algo in include/mscnn_hip.h: 0 auto, 1 direct, 2 / 3 Winograd F(2x2) / F(3x3));
   // Net::CalibrateNumerics sets 1 on layers whose Winograd result strays from the direct sum on representative data.
@@ -162,7 +163,12 @@ class ReLULayer : public Layer<Dtype> {
 template <typename Dtype>
 class InnerProductLayer : public Layer<Dtype> {
  public:
-  explicit InnerProductLayer(const LayerParameter& param) : Layer<Dtype>(param), relu_(false) {}
+  explicit InnerProductLayer(const LayerParameter& param) : Layer<Dtype>(param), relu_(false), f16_(false), w16_dirty_(true) {}
+  // fp16-operand mode (no reference counterpart): weights kept as an fp16 copy, fp32 accumulate; layers the fp16 kernel does
+  // not cover (N < 64) keep running fp32.  dtype() says what the last Forward really used.
+  void set_f16(bool on) { f16_ = on; w16_dirty_ = true; }
+  const char* dtype() const { return used_f16_ ? "f16" : "f32"; }
+  virtual void OnWeightsChanged() { w16_dirty_ = true; }
   virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   virtual inline const char* type() const { return "InnerProduct"; }
@@ -175,6 +181,8 @@ class InnerProductLayer : public Layer<Dtype> {
   virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   int M_, K_, N_;
   bool bias_term_, relu_;
+  bool f16_, w16_dirty_, used_f16_ = false;
+  DeviceBuffer w16_;
 };
 
 // include/caffe/layers/concat_layer.hpp (channel axis)

@@ -157,6 +157,21 @@ int mscnn_net_set_conv_tuning(mscnn_net* n, int layer, int variant, int grid, in
       if (auto* c = conv_of(n, l)) c->set_tuning(variant, grid, flags);
   });
 }
+int mscnn_net_set_precision(mscnn_net* n, const char* dtype) {
+  return guarded([&] {
+    const std::string d = dtype ? dtype : "";
+    CHECK(d == "f32" || d == "f16") << "precision must be f32 or f16, not '" << d << "'";
+    for (size_t l = 0; l < n->net->layers().size(); ++l) {
+      if (auto* c = conv_of(n, (int)l)) c->set_algo(d == "f16" ? 4 : 0);
+      if (auto* ip = dynamic_cast<caffe::InnerProductLayer<float>*>(n->net->layers()[l].get())) ip->set_f16(d == "f16");
+    }
+  });
+}
+const char* mscnn_net_layer_dtype(const mscnn_net* n, int l) {
+  if (auto* c = conv_of(n, l)) return c->dtype();
+  if (auto* ip = dynamic_cast<caffe::InnerProductLayer<float>*>(n->net->layers()[l].get())) return ip->dtype();
+  return "f32";
+}
 int mscnn_net_calibrate_numerics(mscnn_net* n, double tol, int* num_switched) {
   return guarded([&] {
     const std::vector<int> sw = n->net->CalibrateNumerics(tol);

@@ -164,7 +164,7 @@ void ConvolutionLayer<Dtype>::Plan(int n, int h, int w) {
 
 template <typename Dtype>
 void ConvolutionLayer<Dtype>::set_algo(int algo) {
-  CHECK(algo >= 0 && algo <= 3) << "unknown mscnn_conv_algo " << algo;
+  CHECK(algo >= 0 && algo <= 4) << "unknown mscnn_conv_algo " << algo;
   if (algo == algo_) return;
   algo_ = algo;
   if (plan_) { mscnn_conv2d_plan_destroy(plan_); plan_ = nullptr; }
@@ -238,6 +238,8 @@ template <typename Dtype>
 double ConvolutionLayer<Dtype>::ForwardFlops() const { return plan_ ? mscnn_conv2d_plan_flops(plan_) : 0; }
 template <typename Dtype>
 const char* ConvolutionLayer<Dtype>::kernel_name() const { return plan_ ? mscnn_conv2d_plan_kernel(plan_) : ""; }
+template <typename Dtype>
+const char* ConvolutionLayer<Dtype>::dtype() const { return plan_ ? mscnn_conv2d_plan_dtype(plan_) : "f32"; }
 
 template <typename Dtype>
 void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
@@ -400,6 +402,17 @@ void InnerProductLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const
 }
 template <typename Dtype>
 void InnerProductLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  used_f16_ = f16_ && mscnn_inner_product_f16_supported(N_, K_);
+  if (used_f16_) {
+    void* w16 = w16_.Reserve((size_t)N_ * K_ * 2);
+    if (w16_dirty_) {
+      MSCNN_CHECK(mscnn_inner_product_pack_f16(this->blobs_[0]->gpu_data(), w16, N_, K_, S()));
+      w16_dirty_ = false;
+    }
+    MSCNN_CHECK(mscnn_inner_product_fwd_f16(bottom[0]->gpu_data(), w16, bias_term_ ? this->blobs_[1]->gpu_data() : nullptr,
+                                            top[0]->mutable_gpu_data(), M_, N_, K_, relu_ ? 1 : 0, S()));
+    return;
+  }
   MSCNN_CHECK(mscnn_inner_product_fwd_f32(bottom[0]->gpu_data(), this->blobs_[0]->gpu_data(),
                                           bias_term_ ? this->blobs_[1]->gpu_data() : nullptr, top[0]->mutable_gpu_data(), M_, N_, K_,
                                           relu_ ? 1 : 0, S()));

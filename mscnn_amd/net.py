@@ -30,7 +30,7 @@ def lib():
         C.CDLL(os.path.join(_HERE, "libmscnn_hip.so"), mode=C.RTLD_GLOBAL)
         L = C.CDLL(LIB_PATH)
         for f in ("mscnn_net_last_error", "mscnn_net_layer_name", "mscnn_net_layer_type", "mscnn_net_layer_bottom",
-                  "mscnn_net_layer_top", "mscnn_net_layer_kernel", "mscnn_net_layer_param_text", "mscnn_net_blob_name", "mscnn_net_output_name"):
+                  "mscnn_net_layer_top", "mscnn_net_layer_kernel", "mscnn_net_layer_dtype", "mscnn_net_layer_param_text", "mscnn_net_blob_name", "mscnn_net_output_name"):
             getattr(L, f).restype = C.c_char_p
         L.mscnn_net_layer_flops.restype = C.c_double
         L.mscnn_net_layer_executed_flops.restype = C.c_double
@@ -44,6 +44,7 @@ def lib():
             "mscnn_net_create_from_file": [cs, ci, vp], "mscnn_net_create_from_string": [cs, ci, vp], "mscnn_net_destroy": [vp],
             "mscnn_net_create_from_string_ex": [cs, ci, C.c_uint, vp],
             "mscnn_net_layer_executed_flops": [vp, ci], "mscnn_net_set_conv_profiling": [vp, ci], "mscnn_net_layer_stage_ms": [vp, ci, vp],
+            "mscnn_net_set_precision": [vp, cs], "mscnn_net_layer_dtype": [vp, ci],
             "mscnn_net_set_conv_algo": [vp, ci, ci], "mscnn_net_set_conv_tuning": [vp, ci, ci, ci, ci],
             "mscnn_net_calibrate_numerics": [vp, C.c_double, vp], "mscnn_net_layer_calibration_err": [vp, ci],
             "mscnn_net_load_caffemodel": [vp, cs], "mscnn_net_set_stream": [vp], "mscnn_net_num_layers": [vp],
@@ -147,6 +148,13 @@ class Net:
         out = (C.c_float * 3)()
         lib().mscnn_net_layer_stage_ms(self._h, i, out)
         return tuple(out)
+
+    def set_precision(self, dtype):
+        """"f32" (default, reference parity) or "f16" (fp16 MFMA operands, fp32 accumulate: BASELINE config 5)."""
+        _check(lib().mscnn_net_set_precision(self._h, dtype.encode()))
+
+    def layer_dtype(self, i):
+        return lib().mscnn_net_layer_dtype(self._h, i).decode()
 
     def set_conv_algo(self, layer, algo):
         i = layer if isinstance(layer, int) else self.layer_names.index(layer)

@@ -366,6 +366,73 @@ def test_cascade_deploys_whole_net(model, size, cls_id, org_hw):
     assert seen == (3 if "proposals_3rd" in n.blob_names else 1)
 
 
+def _match_fraction(dets, dref, iou_min, dscore):
+    if len(dets) == 0 or len(dref) == 0:
+        return 1.0 if len(dets) == len(dref) else 0.0
+    a = np.stack([dets[:, 0], dets[:, 1], dets[:, 0] + dets[:, 2], dets[:, 1] + dets[:, 3]], 1)
+    b = np.stack([dref[:, 0], dref[:, 1], dref[:, 0] + dref[:, 2], dref[:, 1] + dref[:, 3]], 1)
+    m = iou_xyxy(a, b)
+    j = m.argmax(1)
+    return float(((m[np.arange(len(a)), j] >= iou_min) & (np.abs(dets[:, 4] - dref[j, 4]) <= dscore)).mean())
+
+
+@pytest.mark.parametrize("model,size,org_hw", [("caltech/mscnn-7s-480", dict(height=240, width=320, max_nms_num=300), (480, 640)),
+                                                ("kitti_car/mscnn-7s-576", dict(height=192, width=640, max_nms_num=300), (375, 1242))])
+def test_f16_precision_mode_tolerance_policy(model, size, org_hw):
+    """BASELINE config 5 (fp16 MFMA convolutions; the reference has no counterpart, include/caffe/common.hpp:41-44).  Policy:
+    (a) every trunk / sub-net blob within 1e-2 of the fp32 HIP path AND of the CPU oracle, relative to the blob's rms;
+    (b) final detections against the fp32 HIP path and against the oracle's own run: >= 95 % matched at IoU >= 0.95 with
+        |dscore| <= 5e-3, detection counts within 5 %;
+    (c) the integer / selection layers stay exact given identical inputs (BoxOutput on the fp16 net's own head blobs)."""
+    from oracle import pynet, pyoracle as orc
+    txt = zoo.prototxt(model, **size)
+    H, W = size["height"], size["width"]
+    x = synth.frame(H, W, org_hw=org_hw)
+    kw = dict(cls_id=2, ratios=(H / float(org_hw[0]), W / float(org_hw[1])), org_hw=org_hw)
+    nets = {}
+    for dt in ("f32", "f16"):
+        n = mnet.Net(prototxt_text=txt)
+        ws = synth.load_into(n, "mid")
+        n.set_precision(dt)
+        n.set_blob("data", x)
+        n.forward()
+        nets[dt] = n
+    n32, n16 = nets["f32"], nets["f16"]
+    names = n16.layer_names
+    conv16 = [nm for i, nm in enumerate(names) if n16.layer_dtype(i) == "f16"]
+    assert {"conv1_2", "conv4_2", "conv5_3", "conv6_1", "roi_c1", "fc6"} <= set(conv16), conv16
+    assert all(n16.layer_dtype(names.index(nm)) == "f32" for nm in names if nm.startswith("LFCN_") or nm in ("cls_pred", "bbox_pred"))
+    assert all(n32.layer_dtype(i) == "f32" for i in range(len(names)))
+    layers = layer_list(n16)
+    ref = pynet.forward(layers, ws, {"data": x})
+
+    def rms_err(a, b):
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64).reshape(a.shape)
+        return float(np.abs(a - b).max() / max(np.sqrt((b ** 2).mean()), 1e-6))
+    for b in ("conv1_2", "conv2_2", "conv3_3", "conv4_3", "conv5_3", "conv6_1"):
+        e32, eor = rms_err(n16.get_blob(b), n32.get_blob(b)), rms_err(n16.get_blob(b), ref[b])
+        assert e32 < 1e-2 and eor < 1e-2, (b, e32, eor)
+    # (c) selection exact on identical inputs
+    bo = [l for l in layers if l[1] == "BoxOutput"][0]
+    r2 = pynet.forward([bo], ws, {b: n16.get_blob(b) for b in bo[2]})
+    assert np.array_equal(n16.get_blob("proposals"), r2["proposals"])
+    # sub-net on the fp16 net's own ROI features: fp16 roi_c1 / fc6 against the oracle
+    sub = layers[[l[0] for l in layers].index("roi_pool") + 1:]
+    r3 = pynet.forward(sub, ws, {"roi_pool": n16.get_blob("roi_pool")})
+    for b in ("roi_c1", "fc6", "cls_pred", "bbox_pred"):
+        assert rms_err(n16.get_blob(b), r3[b]) < 1e-2, b
+    # (b) detections
+    d16, _, R16 = n16.detect(**kw)
+    d32, _, R32 = n32.detect(**kw)
+    Rr = ref["proposals"].shape[0]
+    dor, _ = orc.detections(ref["bbox_pred"], ref["cls_pred"], ref["proposals_score"].reshape(Rr, 6), **kw)
+    for name, dref in (("fp32 HIP path", d32), ("CPU oracle", dor)):
+        frac = _match_fraction(d16, dref, 0.95, 5e-3)
+        print(f"f16 vs {name}: {len(d16)} / {len(dref)} detections, matched {frac:.3f}")
+        assert frac >= 0.95, (name, frac)
+        assert abs(len(d16) - len(dref)) <= max(2, 0.05 * len(dref)), name
+
+
 def test_set_image_preprocessing():
     """Net-level pre-processing (run_mscnn_detection.m:64-69 on the device): a 375x1242-like uint8 RGB frame -> the input blob,
     bit-identical to the oracle's restatement, from host memory and from a device tensor."""

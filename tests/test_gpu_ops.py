@@ -359,6 +359,87 @@ def test_conv_identity_asymmetric(hip):
     assert np.array_equal(y, exp)
 
 
+# ---- fp16-operand kernels (MSCNN_CONV_ALGO_F16, BASELINE config 5; no reference counterpart) -----------------------------------
+def _fp16_exact(a):
+    """Values a fp16 MFMA operand represents exactly: with them the fp16 kernel computes the same products as the fp32 oracle
+    (11 + 11 mantissa bits fit fp32), so any layout / indexing bug shows at the 1e-4 bar instead of hiding in rounding noise."""
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+F16_CASES = [   # N, Cin, H, W, Cout, pad, pooled
+    (1, 16, 8, 16, 128, 1, False),        # one exact 128x128 tile (8 x 16 patch), one k-step
+    (1, 32, 12, 40, 130, 1, False),       # ragged tiles, Cout ragged, two chunks
+    (1, 24, 13, 21, 64, 1, False),        # Cin % 16 != 0 (zero-filled channels), Cout = 64 -> 64x256 tiles
+    (1, 3, 16, 48, 64, 1, True),          # conv1_1 shape: 3 channels in a 16-channel step, fused pooling
+    (2, 48, 18, 36, 96, 1, True),         # batch 2, fused 2x2 pooling
+    (1, 64, 36, 120, 256, 1, False),      # conv5-like plane: persistent grid with stream-K split tiles + fix-up
+    (1, 40, 9, 16, 32, 0, False),         # pad 0
+]
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+def test_conv_f16_planes(hip, orc, case):
+    N, Cin, H, W, Cout, pad, pooled = case
+    rng = np.random.default_rng(31)
+    x = _fp16_exact(rng.standard_normal((N, Cin, H, W)))
+    w = _fp16_exact(rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9)))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), relu=True, algo=hip.ALGO_F16)
+    assert plan.kernel.startswith("igemm16_") and plan.dtype == "f16", plan.kernel
+    assert hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad)).dtype == "f32"
+    plan.pack(dev(w))
+    Ho, Wo = plan.out_shape()[2:]
+    yp = torch.full((N, Cout, (Ho + 1) // 2, (Wo + 1) // 2), float("nan"), device="cuda") if pooled else None
+    y = plan.forward(dev(x), dev(b), pool_out=yp).cpu().numpy()
+    ref = orc.relu(orc.conv2d(x, w, b, (pad, pad)))
+    close(y, ref)
+    if pooled:
+        assert plan.can_pool and np.array_equal(yp.cpu().numpy(), orc.pool2d(y, (2, 2), (0, 0), (2, 2), "MAX"))
+    # general fp32 data: only rounding of the operands to fp16 separates the two (relative 2^-11 per operand, averaged over K)
+    x2 = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w2 = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    plan.pack(dev(w2))
+    y2 = plan.forward(dev(x2), dev(b)).cpu().numpy()
+    ref2 = orc.relu(orc.conv2d(x2, w2, b, (pad, pad)))
+    scale = float(np.sqrt((ref2.astype(np.float64) ** 2).mean()))
+    assert np.abs(y2 - ref2).max() / max(scale, 1e-6) < 5e-3
+
+
+@pytest.mark.parametrize("case", [(33, 64, 7, 7, 48, 0), (20, 40, 7, 5, 130, 0), (16, 32, 8, 4, 64, 1), (150, 1024, 8, 4, 512, 1)])
+def test_conv_f16_roi_maps(hip, orc, case):
+    """roi_c1 in fp16 mode: ROI-mode tiles (several whole ROI maps per tile), ROI count changing between calls."""
+    R, Cin, H, W, Cout, pad = case
+    rng = np.random.default_rng(32)
+    x = _fp16_exact(np.maximum(rng.standard_normal((R, Cin, H, W)), 0))
+    w = _fp16_exact(rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9)))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    plan = hip.ConvPlan(R, Cin, H, W, Cout, 3, 3, (pad, pad), relu=True, algo=hip.ALGO_F16)
+    assert plan.kernel.startswith("igemm16_") and "roi" in plan.kernel, plan.kernel
+    plan.pack(dev(w))
+    ref = orc.relu(orc.conv2d(x, w, b, (pad, pad)))
+    close(plan.forward(dev(x), dev(b)).cpu().numpy(), ref)
+    plan.set_batch(R - 5)
+    close(plan.forward(dev(x[:R - 5]), dev(b)).cpu().numpy(), ref[:R - 5])
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 2048, 16384), (150, 2048, 16384), (700, 4096, 12800), (33, 64, 72), (257, 320, 1000)])
+def test_inner_product_f16(hip, M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn((M, K), device="cuda", generator=g).half().float()
+    w = (torch.randn((N, K), device="cuda", generator=g) * (2.0 / K) ** 0.5).half().float()
+    b = torch.randn(N, device="cuda", generator=g)
+    y = hip.inner_product_f16(x, w, b, relu=True)
+    ref = torch.relu(x.double() @ w.double().t() + b.double())
+    err = ((y.double() - ref).abs() / torch.clamp(ref.abs(), min=1.0)).max().item()
+    assert err < 1e-4, err                                   # fp16-exact operands: only the fp32 accumulation order differs
+    x2 = torch.randn((M, K), device="cuda", generator=g)
+    y2 = hip.inner_product_f16(x2, w, b)
+    ref2 = x2.double() @ w.double().t() + b.double()
+    assert ((y2.double() - ref2).abs().max() / ref2.pow(2).mean().sqrt()).item() < 5e-3
+    with pytest.raises(hip.MscnnError):
+        hip.inner_product_f16(x[:, :K - 4].contiguous(), w[:, :K - 4].contiguous())     # K % 8 != 0: the fp32 entry point's job
+
+
 # ------------------------------------------------------------------ inner product
 @pytest.mark.parametrize("M,N,K", [(1, 5, 64), (7, 20, 4096), (3, 128, 256), (130, 192, 1000), (257, 4096, 800), (1, 4096, 12800),
                                    (3, 10, 9000), (5, 70, 33), (700, 20, 4096), (150, 512, 260), (700, 320, 1000)])
