@@ -78,6 +78,7 @@ def _full_size_parity(net, x, blobs, kw, dtype="f32"):
     dets, ids, _ = net.detect(**kw)
     dref, _ = orc.detections(blobs["bbox_pred"], blobs["cls_pred"], blobs["proposals_score"].reshape(Rr, 6), **kw)
     matched = 1.0 if len(dets) == len(dref) == 0 else 0.0
+    diag = {}
     if len(dets) and len(dref):
         a = np.stack([dets[:, 0], dets[:, 1], dets[:, 0] + dets[:, 2], dets[:, 1] + dets[:, 3]], 1)
         b = np.stack([dref[:, 0], dref[:, 1], dref[:, 0] + dref[:, 2], dref[:, 1] + dref[:, 3]], 1)
@@ -86,7 +87,11 @@ def _full_size_parity(net, x, blobs, kw, dtype="f32"):
         inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
         iou = inter / ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])[:, None] + ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :] - inter)
         j = iou.argmax(1)
-        matched = float(((iou[np.arange(len(a)), j] >= iou_min) & (np.abs(dets[:, 4] - dref[j, 4]) <= dscore)).mean())
+        best_iou, ds = iou[np.arange(len(a)), j], np.abs(dets[:, 4] - dref[j, 4])
+        matched = float(((best_iou >= iou_min) & (ds <= dscore)).mean())
+        diag = {"iou_min": round(float(best_iou.min()), 4), "iou_p05": round(float(np.quantile(best_iou, 0.05)), 4),
+                "dscore_p50": float(f"{np.median(ds):.3g}"), "dscore_p95": float(f"{np.quantile(ds, 0.95):.3g}"),
+                "dscore_max": float(f"{ds.max():.3g}")}
     slack = 0.05 if f16 else 0.02
     ok = (max(errs.values()) < bound and abs(Rg - Rr) <= max(2, slack * Rr) and matched >= need
           and abs(len(dets) - len(dref)) <= max(2, slack * len(dref)))
@@ -94,7 +99,9 @@ def _full_size_parity(net, x, blobs, kw, dtype="f32"):
             "policy": ("fp16 operands: blob error / rms(blob) < 1e-2; detections matched at IoU >= 0.95, |dscore| <= 5e-3, >= 95 %" if f16 else
                        "fp32: |a - b| / max(1, |b|) < 1e-4; detections matched at IoU >= 0.99, |dscore| <= 1e-4, >= 98 %"),
             "proposals_gpu": int(Rg), "proposals_reference": int(Rr), "detections_gpu": int(len(dets)),
-            "detections_reference": int(len(dref)), "detections_matched": round(matched, 4)}
+            "detections_reference": int(len(dref)), "detections_matched": round(matched, 4), "detections_diag": diag,
+            "subnet_err_vs_reference_cpu": {b: float(f"{err(net.get_blob(b), blobs[b]):.3g}") for b in ("cls_pred", "bbox_pred")
+                                            if Rg == Rr and np.array_equal(net.get_blob("proposals"), blobs["proposals"].reshape(Rg, 5, 1, 1))}}
 
 
 def _cpu_model():
