@@ -59,6 +59,8 @@ struct Cfg {
   // accumulators; blobs stay fp32 in HBM.  A k-step is 16 input channels of one tap: a lane holds 8 consecutive channels, so
   // both LDS tiles are channel-innermost 16-byte units: A [tap][kg][BM][8], B [kg][patch pixel][8]  (kg = 8-channel group).
   static constexpr bool F16 = F16_ != 0;
+  // PF_ == 3: as PF_ == 1, compiled for 4 workgroups per CU (<= 128 VGPRs; the 1x1 VEC kernel fits: 127, no scratch)
+  static constexpr int MIN_WG_PER_CU = PF_ == 3 ? 4 : 2;
   static constexpr int KG = CK_ / 8;
   // VEC: 1x1 kernel over planes of exactly 128-pixel rows (the Winograd GEMM operands): the B tile is CK contiguous
   // 512-byte rows, staged with b128 loads / ds_write_b128 and no per-element offset table
@@ -230,7 +232,7 @@ __device__ __forceinline__ float max2(float a, float b) { return b > a ? b : a; 
 constexpr float kNegMax = -3.402823466e+38f;
 
 template <class C>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs a) {
   __shared__ __attribute__((aligned(16))) float ldsA[C::A_LDS_FLOATS];
   __shared__ __attribute__((aligned(16))) float ldsB[C::B_LDS_FLOATS];
 
@@ -781,6 +783,8 @@ const KernelEntry kTable[] = {
     {"igemm_128x128_k1x1_ck32_vec_nopn", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 105, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1, 1>>},
 #endif
+    {"igemm_128x128_k1x1_ck32_vec_occ4", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 106, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 3, 1>>,
+     igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 3, 1>>},
     {"igemm_128x128_k1x1_ck64_vec", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 102, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>},
     {"igemm_128x256_k1x1_ck32_vec", 128, 256, 1, 1, 32, 128, 2, 0, 0, 0, 1, 8, 103, igemm_kernel<Cfg<128, 256, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>,
@@ -973,10 +977,10 @@ static void plan_shape(mscnn_conv_plan* p) {
   if (!genv && tiles >= 2 * G) {
     // the 1x1 GEMM kernel (32 KB LDS, 166 VGPRs) also fits 3 per CU: try that range first (measured G = 750 vs 500 on the
     // 25-plane GEMMs: conv4_2 259 vs 266 us, conv3_2 332 vs 339, conv2_2 496 vs 510)
-    const long tops[2] = {(k.KH == 1 && k.BN == 128 && k.CK < 64) ? 768 : G, G};
+    const long tops[3] = {k.variant == 106 ? 1024 : 0, (k.KH == 1 && k.BN == 128 && k.CK < 64) ? 768 : 0, G};
     bool found = false;
-    for (int c = 0; c < 2 && !found; ++c)
-      for (long g2 = tops[c]; g2 >= tops[c] - tops[c] / 16 && g2 * 2 <= tiles; --g2)
+    for (int c = 0; c < 3 && !found; ++c)
+      for (long g2 = tops[c]; g2 > 0 && g2 >= tops[c] - tops[c] / 16 && g2 * 2 <= tiles; --g2)
         if (tiles % g2 == 0) { G = g2; found = true; break; }
   }
   p->G = (int)G;

@@ -32,7 +32,7 @@ __device__ __forceinline__ void wg_range(long total, int G, int g, long& b, long
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {      // (min 3 workgroups / CU was tried: 168 VGPRs + 176 B scratch)
   static_assert(BM * BN == 128 * 128 && BM % 64 == 0 && BN % 64 == 0, "4 waves of 64 x 64");
   __shared__ __attribute__((aligned(16))) float ldsX[BM * LDK];
   __shared__ __attribute__((aligned(16))) float ldsW[BN * LDK];

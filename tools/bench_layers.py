@@ -27,6 +27,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS probe)")
 ap.add_argument("--ab", default="", help="knob=v1,v2,...  with knob in {algo, variant, grid, flags}")
+ap.add_argument("--fixed", default="", help="other knobs held fixed, e.g. variant=107,grid=1000")
 a = ap.parse_args()
 knob, vals = None, [0]
 if a.ab:
@@ -43,6 +44,9 @@ for name, N, Cin, H, W, Cout, k, pad in LAYERS:
     plans = []
     for v in vals:
         kw = dict(algo=0, tune_variant=0, tune_grid=0, tune_flags=0)
+        names = {"algo": "algo", "variant": "tune_variant", "grid": "tune_grid", "flags": "tune_flags"}
+        for kv in filter(None, a.fixed.split(",")):
+            kw[names[kv.split("=")[0]]] = int(kv.split("=")[1])
         if knob:
             kw[{"algo": "algo", "variant": "tune_variant", "grid": "tune_grid", "flags": "tune_flags"}[knob]] = v
         p = hip.ConvPlan(N, Cin, H, W, Cout, k, k, (pad, pad), relu=True, **kw)
