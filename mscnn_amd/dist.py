@@ -54,12 +54,24 @@ def shard(num_images, rank, world):
     return list(range(rank, num_images, world))
 
 
-def split_packs(gathered, world, cap):
-    """world concatenated packs (bytes-like) -> [(dets float64 [D,5], ids int32 [D], R)] per rank."""
+def split_packs(gathered, world, cap, copy=True):
+    """world concatenated packs (bytes-like) -> [(dets float64 [D,5], ids int32 [D], R)] per rank.  The layout is the one
+    mscnn_net_detect_device writes (include/mscnn_net.h; C callers use mscnn_net_unpack_detections); here the rows are numpy
+    VIEWS of the gathered buffer (copy=False: valid until the next gather) so that the per-step host cost stays a few us."""
     pb = mnet.detect_pack_bytes(cap)
     buf = np.frombuffer(gathered, np.uint8) if not isinstance(gathered, np.ndarray) else gathered.reshape(-1)
     assert buf.size == world * pb, (buf.size, world, pb)
-    return [mnet.unpack_detections(buf[r * pb:(r + 1) * pb], cap) for r in range(world)]
+    rows = max(cap, 1)
+    out = []
+    for r in range(world):
+        p = buf[r * pb:(r + 1) * pb]
+        D, R, c, _ = (int(v) for v in p[:16].view(np.int32))
+        if c != cap or not (0 <= D <= R <= cap):
+            raise DistError(f"rank {r}: corrupt detection pack ({D} detections, {R} ROIs, written for capacity {c}, read with {cap})")
+        dets = p[16:16 + 40 * D].view(np.float64).reshape(D, 5)
+        ids = p[16 + 40 * rows:16 + 40 * rows + 4 * D].view(np.int32)
+        out.append((dets.copy(), ids.copy(), R) if copy else (dets, ids, R))
+    return out
 
 
 class RcclGather:
@@ -83,7 +95,7 @@ class RcclGather:
         out = C.c_void_p()
         _dcheck(dist_lib().mscnn_dist_all_gather(self._h, C.c_void_p(pack_dev_ptr), C.c_void_p(stream or 0), C.byref(out)))
         host = (C.c_ubyte * (self.world * self.pack_bytes)).from_address(out.value)
-        return split_packs(np.frombuffer(host, np.uint8), self.world, self.cap)
+        return split_packs(np.frombuffer(host, np.uint8), self.world, self.cap, copy=False)      # views of the pinned buffer
 
     def barrier(self, stream=None):
         _dcheck(dist_lib().mscnn_dist_barrier(self._h, C.c_void_p(stream or 0)))
