@@ -226,10 +226,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # launched by torch.distributed.run (even with one rank): take the multi-GPU path -- process group, direct RCCL gather
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     assert torch.cuda.is_available(), "bench.py needs a MI355X"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -247,7 +249,7 @@ def main():
     kw = dict(cls_id=cfg["cls_id"], ratios=(H / cfg["org_hw"][0], W / cfg["org_hw"][1]), org_hw=cfg["org_hw"])
     cap = int(zoo.MODELS[args.model][0].get("max_nms_num", 2000))          # BoxOutput's top-K bounds the ROI count
     gather, gather_kind = None, "none"
-    if world > 1:
+    if dist is not None:
         from mscnn_amd import dist as mdist
 
         def exchange(b):
@@ -281,7 +283,7 @@ def main():
         return dets
 
     def sync():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -302,7 +304,7 @@ def main():
         step_s.append(time.perf_counter() - ts)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -419,7 +421,7 @@ def main():
         result["stage_ms"] = {k: round(v, 3) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1]) if v > 0.0005}
         if parity_ok is False:
             rc = 3
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         if hasattr(gather, "close"):
             gather.close()

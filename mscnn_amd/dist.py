@@ -83,9 +83,14 @@ class RcclGather:
         self.cap, self.world, self.rank = cap, world, rank
         self.pack_bytes = mnet.detect_pack_bytes(cap)
         idb = (C.c_ubyte * 128)()
-        if rank == 0:
-            _dcheck(L.mscnn_dist_unique_id(idb))
-        raw = exchange_id(bytes(idb))
+        # every rank takes part in the exchange whatever happened on rank 0, so that a failure there raises everywhere
+        # instead of leaving the other ranks waiting
+        mine = b""
+        if rank == 0 and L.mscnn_dist_unique_id(idb) == 0:
+            mine = bytes(idb)
+        raw = exchange_id(mine)
+        if len(raw) != 128:
+            raise DistError("rank 0 could not create the RCCL rendezvous id: " + L.mscnn_dist_last_error().decode())
         idb = (C.c_ubyte * 128).from_buffer_copy(raw)
         self._h = C.c_void_p()
         _dcheck(L.mscnn_dist_init(idb, rank, world, device, self.pack_bytes, C.byref(self._h)))

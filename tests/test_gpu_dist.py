@@ -39,6 +39,28 @@ def test_rccl_gather_world1_is_bit_identical_to_single_gpu_detect():
     gather.close()
 
 
+def test_bench_under_the_launcher_takes_the_distributed_path(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, RANK / MASTER_* in the environment), with the one
+    rank a single-GPU box allows: process group, id exchange over the store, direct RCCL gather, barrier, max-over-ranks."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a MI355X")
+    import json
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29671", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--model", "caltech/mscnn-7s-480", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 50 and d["config"]["gather"].startswith("libmscnn_dist"), d["config"]
+    # the second route to the same bytes (kept for the case the direct communicator cannot be set up)
+    from bench import _CudaPtr
+    t = torch.arange(64, dtype=torch.uint8, device="cuda")
+    v = torch.as_tensor(_CudaPtr(t.data_ptr(), 64), device="cuda")
+    assert v.data_ptr() == t.data_ptr() and torch.equal(v, t)
+
+
 def test_cpp_multi_gpu_host_driver(tmp_path):
     """mscnn_amd/detect_multi_gpu (host/tools/detect_multi_gpu.cpp): threads + net replicas + RCCL gather through the C ABIs."""
     if not torch.cuda.is_available():
