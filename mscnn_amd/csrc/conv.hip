@@ -60,7 +60,8 @@ struct Cfg {
   // both LDS tiles are channel-innermost 16-byte units: A [tap][kg][BM][8], B [kg][patch pixel][8]  (kg = 8-channel group).
   static constexpr bool F16 = F16_ != 0;
   // PF_ == 3: as PF_ == 1, compiled for 4 workgroups per CU (<= 128 VGPRs; the 1x1 VEC kernel fits: 127, no scratch)
-  static constexpr int MIN_WG_PER_CU = PF_ == 3 ? 4 : 2;
+  // PF_ == 4 (fp16 kernels, whose inner loop does not use PF): compiled for 3 workgroups per CU (168 VGPRs, 16 B of scratch)
+  static constexpr int MIN_WG_PER_CU = PF_ == 3 ? 4 : PF_ == 4 ? 3 : 2;
   static constexpr int KG = CK_ / 8;
   // VEC: 1x1 kernel over planes of exactly 128-pixel rows (the Winograd GEMM operands): the B tile is CK contiguous
   // 512-byte rows, staged with b128 loads / ds_write_b128 and no per-element offset table
@@ -810,6 +811,13 @@ const KernelEntry kTable[] = {
     ENTRY16(128, 128, 2, 2, 16),
     ENTRY16(128, 128, 2, 2, 32),
     ENTRY16(64, 256, 1, 4, 32),
+#define ENTRY16_OCC3(BM, BN, WGM, WGN, TW)                                                                                   \
+  {"igemm16_" #BM "x" #BN "_k3x3_tw" #TW "_occ3", BM, BN, 3, 3, 16, TW, BN / TW, 0, 0, 0, 1, (BM * BN) / 4096, 201,            \
+   igemm_kernel<Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 4, 0, 0, 1>>, igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 4, 0, 0, 1>>, \
+   Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 4, 0, 0, 1>::CAN_POOL ? igemm_fixup_pool_kernel<Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 4, 0, 0, 1>> : nullptr}
+    ENTRY16_OCC3(128, 128, 2, 2, 16),
+    ENTRY16_OCC3(128, 128, 2, 2, 32),
+    ENTRY16_OCC3(64, 256, 1, 4, 32),
     ROI_ENTRY16(7, 7, 0),
     ROI_ENTRY16(7, 5, 0),
     ROI_ENTRY16(8, 4, 1),
@@ -926,9 +934,11 @@ static void plan_shape(mscnn_conv_plan* p) {
   for (int i = 0; i < kTableN; ++i) {
     const KernelEntry& k = kTable[i];
     if (k.KH != d.Kh || k.KW != d.Kw) continue;
-    if ((k.variant == 200) != want16) continue;
+    const bool is16 = k.variant == 200 || k.variant == 201;
+    if (is16 != want16) continue;
+    if (is16 && k.RH == 0 && k.variant != (tv - 1 == 201 ? 201 : 200)) continue;        // tune_variant 202 selects the 3-per-CU build
     const bool is256 = (k.BM == 128 && k.BN == 256);
-    if (k.KH == 3 && k.KW == 3 && k.RH == 0 && k.variant != 200) {
+    if (k.KH == 3 && k.KW == 3 && k.RH == 0 && !is16) {
       if (is256 && k.variant == 0) continue;                  // (kept for reference; superseded by variant 3)
       if (k.variant != ((d.Cin <= 4 && d.Cout <= 64 && !venv) ? 50 : want)) continue;
     }
@@ -968,7 +978,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   const long tiles = (long)p->MT * p->NT;
   // grid: G workgroups (default 2 per CU; 3 for the 128x128 tiles whose 43 KB of LDS and 168 VGPRs allow it)
   const int genv = tune_env("MSCNN_TUNE_GRID", d.tune_grid);   // tuning knob
-  long G = genv > 0 ? genv : ((k.BM == 128 && k.BN == 128 && k.KH == 3) ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
+  long G = genv > 0 ? genv : ((k.BM == 128 && k.BN == 128 && k.KH == 3 && k.variant != 200) || k.variant == 201 ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
   if (tiles * p->KI / 4 < G) G = tiles * p->KI / 4;         // never less than ~4 chunks per workgroup
   if (G < 1) G = 1;
   // A slightly smaller grid that divides the tile count exactly needs no stream-K phase and no fix-up launch at all (the 25
@@ -986,7 +996,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->G = (int)G;
   p->full_q = (int)(tiles / G);                               // data-parallel phase
   p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
-  p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * (k.variant == 200 ? sizeof(_Float16) : sizeof(float));
+  p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * ((k.variant == 200 || k.variant == 201) ? sizeof(_Float16) : sizeof(float));
   p->ws_bytes = (size_t)p->G * kSlabsPerWg * k.BM * k.BN * sizeof(float);
 }
 
@@ -1029,7 +1039,7 @@ extern "C" double mscnn_conv2d_plan_flops(const mscnn_conv_plan* p) {
   return 2.0 * d.N * d.Cout * p->Ho * p->Wo * (double)(d.Cin / d.group) * d.Kh * d.Kw;
 }
 extern "C" const char* mscnn_conv2d_plan_dtype(const mscnn_conv_plan* p) {
-  return (p && !p->wino && p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant == 200) ? "f16" : "f32";
+  return (p && !p->wino && p->head.entry < 0 && p->entry >= 0 && (kTable[p->entry].variant == 200 || kTable[p->entry].variant == 201)) ? "f16" : "f32";
 }
 extern "C" double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* p) {
   if (!p) return 0;
@@ -1079,7 +1089,7 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   const long total = (long)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (k.variant == 200)
+  if (k.variant == 200 || k.variant == 201)
     pack_weights_f16_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, reinterpret_cast<_Float16*>(packed), p->d.Cout, p->d.Cin,
                                                                        k.KH * k.KW, k.BM, k.CK, p->MT, p->KI);
   else

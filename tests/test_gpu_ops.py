@@ -377,15 +377,17 @@ F16_CASES = [   # N, Cin, H, W, Cout, pad, pooled
 ]
 
 
+@pytest.mark.parametrize("tune_variant", [0, 202])          # 202: the 3-workgroups-per-CU build of the same kernels
 @pytest.mark.parametrize("case", F16_CASES)
-def test_conv_f16_planes(hip, orc, case):
+def test_conv_f16_planes(hip, orc, case, tune_variant):
     N, Cin, H, W, Cout, pad, pooled = case
     rng = np.random.default_rng(31)
     x = _fp16_exact(rng.standard_normal((N, Cin, H, W)))
     w = _fp16_exact(rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9)))
     b = rng.standard_normal(Cout).astype(np.float32)
-    plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), relu=True, algo=hip.ALGO_F16)
+    plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), relu=True, algo=hip.ALGO_F16, tune_variant=tune_variant)
     assert plan.kernel.startswith("igemm16_") and plan.dtype == "f16", plan.kernel
+    assert plan.kernel.endswith("_occ3") == (tune_variant == 202)
     assert hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad)).dtype == "f32"
     plan.pack(dev(w))
     Ho, Wo = plan.out_shape()[2:]
