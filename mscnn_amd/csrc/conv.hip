@@ -936,7 +936,15 @@ static void plan_shape(mscnn_conv_plan* p) {
     if (k.KH != d.Kh || k.KW != d.Kw) continue;
     const bool is16 = k.variant == 200 || k.variant == 201;
     if (is16 != want16) continue;
-    if (is16 && k.RH == 0 && k.variant != (tv - 1 == 201 ? 201 : 200)) continue;        // tune_variant 202 selects the 3-per-CU build
+    if (is16 && k.RH == 0) {
+      // 2 workgroups / CU (172 VGPRs, grid 512) or the 3-per-CU build (168 VGPRs + 16 B scratch, grid 768): measured on the
+      // 7s-576 trunk (profiles/r02_ab_f16_occ3.txt) the latter wins where there are thousands of tiles (conv1_2 208 -> 195 us,
+      // conv2_1 104 -> 83, conv2_2 165 -> 147) and loses on the 540 / 1080-tile layers (conv4_2 134 -> 161).  tune_variant
+      // 201 / 202 force one of them.
+      const long t16 = (long)cdiv(d.Cout, k.BM) * d.N * cdiv(p->Ho, k.TH) * cdiv(p->Wo, k.TW);
+      const int pick = tv - 1 == 201 ? 201 : tv - 1 == 200 ? 200 : (t16 >= 2000 ? 201 : 200);
+      if (k.variant != pick) continue;
+    }
     const bool is256 = (k.BM == 128 && k.BN == 256);
     if (k.KH == 3 && k.KW == 3 && k.RH == 0 && !is16) {
       if (is256 && k.variant == 0) continue;                  // (kept for reference; superseded by variant 3)
