@@ -895,6 +895,12 @@ static bool wino_plan(mscnn_conv_plan* p) {
   g->d.N = planes; g->d.H = (int)(T_pad / 128); g->d.W = 128; g->d.Kh = g->d.Kw = 1; g->d.pad_h = g->d.pad_w = 0; g->d.relu = 0;
   g->d.algo = MSCNN_CONV_ALGO_DIRECT;
   plan_shape(g);
+  // the 4-workgroups-per-CU build of the GEMM (127 VGPRs) on a grid of 1000: measured +4..9 % where the 25 planes have >= 3000
+  // tiles (conv2_2, conv3_x), -2 % on the 1500-tile layers and roi_c1 (profiles/r02_ab_gemm_occupancy4.txt)
+  if (g->entry >= 0 && g->d.tune_variant == 0 && (long)g->MT * g->NT >= 3000 && ((long)g->MT * g->NT) % 1000 == 0) {
+    g->d.tune_variant = 107;
+    plan_shape(g);
+  }
   if (g->entry < 0 || g->wino || g->head.entry >= 0) { delete g; return false; }
   p->wino_m = m;
   p->wino = g;
