@@ -899,6 +899,7 @@ static bool wino_plan(mscnn_conv_plan* p) {
   // tiles (conv2_2, conv3_x), -2 % on the 1500-tile layers and roi_c1 (profiles/r02_ab_gemm_occupancy4.txt)
   if (g->entry >= 0 && g->d.tune_variant == 0 && (long)g->MT * g->NT >= 3000 && ((long)g->MT * g->NT) % 1000 == 0) {
     g->d.tune_variant = 107;
+    g->d.tune_grid = 1000;
     plan_shape(g);
   }
   if (g->entry < 0 || g->wino || g->head.entry >= 0) { delete g; return false; }
