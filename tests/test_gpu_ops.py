@@ -128,6 +128,9 @@ WINO_CASES = [   # N, Cin, H, W, Cout, pad
     (2, 24, 10, 14, 32, 1),       # batch 2
     (1, 8, 9, 16, 16, 0),         # pad 0 (Ho = H - 2)
     (1, 320, 18, 60, 320, 1),     # chosen by the default heuristic (conv6_1-like plane), stream-K split of the 1x1 GEMM
+    (2, 24, 20, 100, 32, 1),      # 34 tile columns, batch 2: the LDS-staged input transform (>= 32 tile columns), ragged block
+    (1, 16, 11, 290, 24, 1),      # 97 tile columns = 1.5 blocks of 64, 4 tile rows (one block row), odd sizes
+    (1, 8, 30, 96, 16, 0),        # pad 0, 32 tile columns exactly, 10 tile rows = 2.5 block rows
 ]
 
 
