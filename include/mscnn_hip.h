@@ -76,7 +76,7 @@ typedef struct {
   /* Tuning knobs for A/B measurements (tools/bench_layers.py); 0 = the measured default.  None changes results beyond
    * fp32 rounding.  tune_variant: igemm tile variant (value + 1, so that 0 keeps the default); tune_grid: workgroups of the
    * persistent igemm / head kernels; tune_flags: bit 0 = no XCD-aware workgroup map, bit 1 = proposal heads on the 32-row
-   * igemm tile instead of the M = 4 head kernel, bit 3 = thread-per-tile Winograd input transform instead of the LDS-staged one. */
+   * igemm tile instead of the M = 4 head kernel. */
   int tune_variant, tune_grid, tune_flags;
 } mscnn_conv_desc;
 

@@ -11,9 +11,8 @@ int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, i
 
 // V[xinu][ci][t] = (B^T d B)[xi][nu],  d = the 4x4 input patch of output tile t = (n, ty, tx) (zero outside the image);
 // t < T real tiles, row stride T_pad (columns T..T_pad are written as zeros).
-// per_tile_loads: the thread-per-tile plane kernel instead of the LDS-staged one (A/B switch, mscnn_conv_desc::tune_flags bit 3).
 int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
-                         int tiles_w, int T_pad, hipStream_t st, bool per_tile_loads = false);
+                         int tiles_w, int T_pad, hipStream_t st);
 
 // y[n][co][2ty + i][2tx + j] = (A^T m A)[i][j] + bias[co], optional ReLU;  m[xi][nu] = M[xinu][co][t].
 // y_pool != nullptr: also write max over the tile's (in-plane) outputs to y_pool[n][co][ty][tx] (fused 2x2/2 max pooling).

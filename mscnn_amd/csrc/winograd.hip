@@ -334,60 +334,6 @@ __global__ __launch_bounds__(256) void wino33_input_plane_kernel(const float* __
   }
 }
 
-// The same transform with the input staged through LDS.  The thread-per-tile kernel above reads its 5x5 patch with 25 loads
-// whose lanes are 12 bytes apart (a third of every fetched cache line per instruction): measured 2.1-3.5 TB/s of the ~6 the
-// chip streams.  Here a workgroup owns 4 tile rows x 64 tile columns of one channel: the 5 input rows of every tile row
-// (194 floats each) are loaded as contiguous runs -- whole cache lines -- into LDS with the zero border filled in, then every
-// thread takes its patch from LDS at a 3-float lane stride (gcd(3, 32) = 1: conflict-free) and writes the 25 planes exactly as
-// before (64 consecutive tiles = 256 contiguous bytes per plane and wave).
-constexpr int kItCols = 64, kItRows = 4, kItW = 3 * kItCols + 2;     // tiles per block row / tile rows per block / staged floats per input row
-__global__ __launch_bounds__(256) void wino33_input_plane_lds_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int Cin,
-                                                                     int H, int W, int pad_h, int pad_w, int tiles_h, int tiles_w,
-                                                                     int T, int T_pad) {
-  __shared__ float sm[kItRows][5][kItW];
-  const int tid = threadIdx.x;
-  const int ci = blockIdx.z, gr0 = blockIdx.y * kItRows, tx0 = blockIdx.x * kItCols;
-  const int rows_total = N * tiles_h;
-  const int w_first = 3 * tx0 - pad_w;
-  for (int idx = tid; idx < kItRows * 5 * kItW; idx += 256) {
-    const int r = idx / (5 * kItW), rem = idx % (5 * kItW), i = rem / kItW, c = rem % kItW;
-    const int gr = gr0 + r;
-    float v = 0.f;
-    if (gr < rows_total) {
-      const int n = gr / tiles_h, ty = gr % tiles_h;
-      const int h = 3 * ty - pad_h + i, w = w_first + c;
-      if (h >= 0 && h < H && w >= 0 && w < W) v = x[(((long)n * Cin + ci) * H + h) * W + w];
-    }
-    sm[r][i][c] = v;
-  }
-  __syncthreads();
-  const long plane_stride = (long)Cin * T_pad;
-  const int tr = tid / kItCols, tc = tid % kItCols;
-  const int gr = gr0 + tr, tx = tx0 + tc;
-  if (gr < rows_total && tx < tiles_w) {
-    float r[5][5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const float col[5] = {sm[tr][0][3 * tc + j], sm[tr][1][3 * tc + j], sm[tr][2][3 * tc + j], sm[tr][3][3 * tc + j], sm[tr][4][3 * tc + j]};
-      float o[5];
-      bt5(col, o);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) r[i][j] = o[i];
-    }
-    float* dst = V + (long)ci * T_pad + (long)gr * tiles_w + tx;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      float o[5];
-      bt5(r[i], o);
-#pragma unroll
-      for (int j = 0; j < 5; ++j) dst[(i * 5 + j) * plane_stride] = o[j];
-    }
-  }
-  // GEMM padding columns T .. T_pad of this channel's planes: written (as zeros) by the channel's first block
-  if (blockIdx.x == 0 && blockIdx.y == 0)
-    for (int i = tid; i < 25 * (T_pad - T); i += 256) V[(i / (T_pad - T)) * plane_stride + (long)ci * T_pad + T + i % (T_pad - T)] = 0.f;
-}
-
 __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                             float* __restrict__ y, int N, int Cout, int Ho, int Wo, int tiles_h,
                                                             int tiles_w, int T, int T_pad, int relu) {
@@ -527,15 +473,12 @@ int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, i
 }
 
 int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
-                         int tiles_w, int T_pad, hipStream_t st, bool per_tile_loads) {
+                         int tiles_w, int T_pad, hipStream_t st) {
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T_pad, 256), Cin);
   if (m == 3 && H * W <= kW33MaxHW) {
     dim3 g3(cdiv(N, kW33Rois), cdiv(Cin, kW33Ch));
     wino33_input_kernel<<<g3, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
-  } else if (m == 3 && tiles_w >= 32 && Cin <= 65535 && !per_tile_loads) {
-    dim3 gl(cdiv(tiles_w, kItCols), cdiv(N * tiles_h, kItRows), Cin);
-    wino33_input_plane_lds_kernel<<<gl, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
   } else if (m == 3) {
     wino33_input_plane_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
   } else wino_input_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
