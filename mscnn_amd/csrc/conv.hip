@@ -1008,6 +1008,10 @@ static void plan_shape(mscnn_conv_plan* p) {
       for (long g2 = tops[c]; g2 > 0 && g2 >= tops[c] - tops[c] / 16 && g2 * 2 <= tiles; --g2)
         if (tiles % g2 == 0) { G = g2; found = true; break; }
   }
+  // the 25-plane GEMMs of the small layers (conv5_x of 7s-576: 400 tiles on 768 slots): one whole tile per workgroup beats
+  // the stream-K split + fix-up launch (78 vs 91 us; profiles/r02_ab_nosplit.txt).  Not so below 256 tiles (conv6_1: 100
+  // tiles, 45 vs 40 us) nor for the 3x3 / fp16 kernels (measured slower).
+  if (!genv && k.KH == 1 && k.variant >= 101 && tiles >= 256 && tiles <= 768) G = tiles;
   p->G = (int)G;
   p->full_q = (int)(tiles / G);                               // data-parallel phase
   p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
