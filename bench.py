@@ -364,7 +364,8 @@ def main():
             "kernel": ("igemm_kernel<Cfg<...,F16>> (igemm16_*): direct 3x3 implicit GEMM on v_mfma_f32_32x32x16_f16, operands rounded to "
                        "fp16 while staged into LDS, fp32 accumulate (+ its stream-K fix-up)") if args.dtype == "f16" else
                       "igemm_kernel<Cfg<128,128,2,2,1,1,32,128,...,vec>> -- the 25 batched [Cout x Cin] x [Cin x tiles] GEMMs of the "
-                      "Winograd F(3x3,3x3) layers (+ its stream-K fix-up where a grid does not divide the tiles)",
+                      "Winograd F(3x3,3x3) layers (two builds of the same kernel: 3 workgroups / CU, and 4 / CU for the >= 3000-tile "
+                      "layers; + its stream-K fix-up where a grid does not divide the tiles)",
             "flops_note": "achieved = FLOPs the kernel's MFMAs execute for the real problem (2 * 25 * Cout * Cin * tiles per launch) / "
                           "its HIP-event time on the net's stream, summed over its launches of one image",
             "launches_per_image": len(wino), "avg_launch_us": round(1e3 * g_ms / max(len(wino), 1), 1),

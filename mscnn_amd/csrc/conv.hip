@@ -381,8 +381,6 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
     const int t_e = t, k0_e = k0, k1_e = k1, mt_e = mt;
     more = false;
     for (int kc = k0_e; kc < k1_e; ++kc) {
-      if (C::PF == 2) __builtin_amdgcn_s_setprio(3);   // staging phase: get through the barriers quickly
-      if (C::PF < 12 || C::PF == 14 || kc == k0_e) {      // (PF >= 11: timing ablations only, results are wrong by construction)
       __syncthreads();                 // everyone finished reading the previous chunk
 #pragma unroll
       for (int i = 0; i < C::A_PER_T; ++i)
@@ -404,14 +402,12 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
           if (C::B_ELEMS % 256 == 0 || tid + i * 256 < C::B_ELEMS) ldsB[tid + i * 256] = rb[i];
       }
       __syncthreads();
-      }
       if (kc + 1 < k1_e) {
-        if (C::PF < 11 || C::PF == 14) MSCNN_LOAD_CHUNK(kc + 1);   // in flight while this chunk is multiplied
+        MSCNN_LOAD_CHUNK(kc + 1);   // in flight while this chunk is multiplied
       } else if constexpr (C::PREFETCH_NEXT) {
         more = next_segment();                                     // (overwrites t, k0, k1, mt, geo, xsrc, g_off, ...)
         if (more) MSCNN_LOAD_CHUNK(k0);
       }
-      if (C::PF == 2) __builtin_amdgcn_s_setprio(0);
       if constexpr (C::F16) {
         // unit (16 B) indices: A [tap][kg][BM], B [kg][CH_STRIDE]; this lane's k-group inside a 16-channel step = khalf
         const f16x8* a16 = reinterpret_cast<const f16x8*>(ldsA) + khalf * C::BM + wm * C::WM + l31;
@@ -468,10 +464,9 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
           _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni) bv[buf][ni] = bRd[ni][cp_ * 2 * C::CH_STRIDE + kh_ * C::ROWS + kw_]; \
         }
         MSCNN_LDS_GROUP(0, 0);
-        if constexpr (C::PF == 13 || C::PF == 15) MSCNN_LDS_GROUP(1, 1);   // ablation: operands loaded once, MFMA-only loop
         static_for<0, S>([&](auto sc) {
           constexpr int s = decltype(sc)::value;
-          if constexpr (s + 1 < S && C::PF != 13 && C::PF != 15) MSCNN_LDS_GROUP(s + 1, (s + 1) & 1);
+          if constexpr (s + 1 < S) MSCNN_LDS_GROUP(s + 1, (s + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);      // pin: next group's ds_reads are issued BEFORE this group's MFMAs
 #pragma unroll
           for (int mi = 0; mi < C::MI; ++mi)
@@ -489,9 +484,7 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
     const int t = t_e, k0 = k0_e, k1 = k1_e, mt = mt_e;
     (void)t;
     const bool full = (k0 == 0 && k1 == a.KI);
-    if (C::PF >= 14 && full) {
-      if (acc[0][0][0] == 12345.678f) a.y[tid] = acc[0][0][1];     // ablation: no epilogue (keeps acc live)
-    } else if (full) {
+    if (full) {
       const __amdgpu_buffer_rsrc_t ysrc = make_rsrc(geo.y_base(a), geo.y_bytes(a));
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi) {
@@ -767,37 +760,18 @@ const KernelEntry kTable[] = {
     ENTRY_PF(128, 128, 2, 2, 3, 3, 8, 16),
     ENTRY_PF(128, 128, 2, 2, 3, 3, 8, 32),
     ENTRY_PF(64, 256, 1, 4, 3, 3, 8, 32),
-#ifdef MSCNN_ABLATIONS
-    {"ablate_noload", 128, 128, 3, 3, 8, 16, 8, 0, 0, 0, 1, 4, 11, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 11>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 11>>},
-    {"igemm_128x128_k3x3_tw16_pf_prio", 128, 128, 3, 3, 8, 16, 8, 0, 0, 0, 1, 4, 2, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 2>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 2>>},
-    {"igemm_128x256_k3x3_tw32_pf", 128, 256, 3, 3, 8, 32, 8, 0, 0, 0, 1, 8, 3, igemm_kernel<Cfg<128, 256, 2, 2, 3, 3, 8, 32, 0, 0, 0, 1>>, igemm_fixup_kernel<Cfg<128, 256, 2, 2, 3, 3, 8, 32, 0, 0, 0, 1>>},
-    {"ablate_mfmaonly", 128, 128, 3, 3, 8, 16, 8, 0, 0, 0, 1, 4, 13, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 13>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 13>>},
-    {"ablate_nostage", 128, 128, 3, 3, 8, 16, 8, 0, 0, 0, 1, 4, 12, igemm_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 12>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 3, 3, 8, 16, 0, 0, 0, 12>>},
-#endif
     // 1x1 (the 16 batched GEMMs of the Winograd path; plane = [rows][128] so a tile is one 128-pixel row)
     {"igemm_128x128_k1x1_ck32_pf", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 0, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1>>},
     // variants 101 / 102: vectorised staging, planes of exactly 128-pixel rows only (Winograd GEMM)
     {"igemm_128x128_k1x1_ck32_vec", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 101, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>},
-#ifdef MSCNN_ABLATIONS
-    {"igemm_128x128_k1x1_ck32_vec_nopn", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 105, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1, 1>>,
-     igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1, 1>>},
-#endif
     {"igemm_128x128_k1x1_ck32_vec_occ4", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 106, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 3, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 3, 1>>},
     {"igemm_128x128_k1x1_ck64_vec", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 102, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 1, 1>>},
     {"igemm_128x256_k1x1_ck32_vec", 128, 256, 1, 1, 32, 128, 2, 0, 0, 0, 1, 8, 103, igemm_kernel<Cfg<128, 256, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>,
      igemm_fixup_kernel<Cfg<128, 256, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1, 1>>},
-#ifdef MSCNN_ABLATIONS
-    {"abl32_mfmaonly", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 123, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 13, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 13, 1>>},
-    {"abl32_noepi", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 124, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 14, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 14, 1>>},
-    {"abl32_mfmaonly_noepi", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 125, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 15, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 15, 1>>},
-    {"abl1x1_noload", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 111, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 11, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 11, 1>>},
-    {"abl1x1_nostage", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 112, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 12, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 12, 1>>},
-    {"abl1x1_mfmaonly", 128, 128, 1, 1, 64, 128, 1, 0, 0, 0, 1, 4, 113, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 13, 1>>, igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 64, 128, 0, 0, 0, 13, 1>>},
-#endif
     ENTRY(128, 256, 2, 2, 3, 3, 8, 32),     // variant 2 (selected with MSCNN_IGEMM_VARIANT=2): 64x128 wave tiles
     // fp16-operand variants (variant 200, mscnn_conv_desc::algo == MSCNN_CONV_ALGO_F16): trunk 3x3 planes and the ROI maps of roi_c1
 #define ENTRY16(BM, BN, WGM, WGN, TW)                                                                                        \

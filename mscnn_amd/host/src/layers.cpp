@@ -252,11 +252,11 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     weights_dirty_ = false;
   }
   // Transient workspace (stream-K slabs, Winograd V / M planes: up to 0.8 GB for conv2_2): the layers of a net run one after
-  // the other on one stream, so they all share ONE buffer per process (= per GPU) instead of 3 GB of per-layer buffers.
-  // One buffer per device; forwards of different nets on the same device must not overlap in time (they never do: one
-  // process per GPU, one stream).  (Leaked on purpose: a static destructor would call hipFree after the HIP runtime has been
-  // torn down.)
-  static DeviceBuffer* shared_ws[64] = {nullptr};
+  // the other on one stream, so all conv layers of a host THREAD share ONE buffer per device instead of 3 GB of per-layer
+  // buffers.  Thread-local like the Caffe singleton itself (a thread is a device context, common.cpp:13-20): two threads may
+  // drive nets on the same device without sharing scratch.  (Leaked on thread exit on purpose: a destructor could run after
+  // the HIP runtime has been torn down.)
+  static thread_local DeviceBuffer* shared_ws[64] = {nullptr};
   int dev = 0;
   HIP_CHECK(hipGetDevice(&dev));
   CHECK(dev >= 0 && dev < 64);
