@@ -789,6 +789,9 @@ const KernelEntry kTable[] = {
   {"igemm16_" #BM "x" #BN "_k3x3_tw" #TW "_occ3", BM, BN, 3, 3, 16, TW, BN / TW, 0, 0, 0, 1, (BM * BN) / 4096, 201,            \
    igemm_kernel<Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 4, 0, 0, 1>>, igemm_fixup_kernel<Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 4, 0, 0, 1>>, \
    Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 4, 0, 0, 1>::CAN_POOL ? igemm_fixup_pool_kernel<Cfg<BM, BN, WGM, WGN, 3, 3, 16, TW, 0, 0, 0, 4, 0, 0, 1>> : nullptr}
+    // 128 x 256 tiles = 64 x 128 per wave: 6 operand fragments per 8 MFMAs instead of 4 per 4 (the kernel is LDS-fed)
+    {"igemm16_128x256_k3x3_tw32", 128, 256, 3, 3, 16, 32, 8, 0, 0, 0, 1, 8, 202, igemm_kernel<Cfg<128, 256, 2, 2, 3, 3, 16, 32, 0, 0, 0, 0, 0, 0, 1>>,
+     igemm_fixup_kernel<Cfg<128, 256, 2, 2, 3, 3, 16, 32, 0, 0, 0, 0, 0, 0, 1>>, igemm_fixup_pool_kernel<Cfg<128, 256, 2, 2, 3, 3, 16, 32, 0, 0, 0, 0, 0, 0, 1>>},
     ENTRY16_OCC3(128, 128, 2, 2, 16),
     ENTRY16_OCC3(128, 128, 2, 2, 32),
     ENTRY16_OCC3(64, 256, 1, 4, 32),
@@ -915,7 +918,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   for (int i = 0; i < kTableN; ++i) {
     const KernelEntry& k = kTable[i];
     if (k.KH != d.Kh || k.KW != d.Kw) continue;
-    const bool is16 = k.variant == 200 || k.variant == 201;
+    const bool is16 = k.variant >= 200 && k.variant <= 202;
     if (is16 != want16) continue;
     if (is16 && k.RH == 0) {
       // 2 workgroups / CU (172 VGPRs, grid 512) or the 3-per-CU build (168 VGPRs + 16 B scratch, grid 768): measured on the
@@ -923,7 +926,7 @@ static void plan_shape(mscnn_conv_plan* p) {
       // conv2_1 104 -> 83, conv2_2 165 -> 147) and loses on the 540 / 1080-tile layers (conv4_2 134 -> 161).  tune_variant
       // 201 / 202 force one of them.
       const long t16 = (long)cdiv(d.Cout, k.BM) * d.N * cdiv(p->Ho, k.TH) * cdiv(p->Wo, k.TW);
-      const int pick = tv - 1 == 201 ? 201 : tv - 1 == 200 ? 200 : (t16 >= 2000 ? 201 : 200);
+      const int pick = (tv - 1 >= 200 && tv - 1 <= 202) ? tv - 1 : (t16 >= 2000 ? 201 : 200);
       if (k.variant != pick) continue;
     }
     const bool is256 = (k.BM == 128 && k.BN == 256);
@@ -989,7 +992,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->G = (int)G;
   p->full_q = (int)(tiles / G);                               // data-parallel phase
   p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
-  p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * ((k.variant == 200 || k.variant == 201) ? sizeof(_Float16) : sizeof(float));
+  p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * ((k.variant >= 200 && k.variant <= 202) ? sizeof(_Float16) : sizeof(float));
   p->ws_bytes = (size_t)p->G * kSlabsPerWg * k.BM * k.BN * sizeof(float);
 }
 
@@ -1032,7 +1035,7 @@ extern "C" double mscnn_conv2d_plan_flops(const mscnn_conv_plan* p) {
   return 2.0 * d.N * d.Cout * p->Ho * p->Wo * (double)(d.Cin / d.group) * d.Kh * d.Kw;
 }
 extern "C" const char* mscnn_conv2d_plan_dtype(const mscnn_conv_plan* p) {
-  return (p && !p->wino && p->head.entry < 0 && p->entry >= 0 && (kTable[p->entry].variant == 200 || kTable[p->entry].variant == 201)) ? "f16" : "f32";
+  return (p && !p->wino && p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202) ? "f16" : "f32";
 }
 extern "C" double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* p) {
   if (!p) return 0;
@@ -1082,7 +1085,7 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   const long total = (long)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (k.variant == 200 || k.variant == 201)
+  if (k.variant >= 200 && k.variant <= 202)
     pack_weights_f16_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, reinterpret_cast<_Float16*>(packed), p->d.Cout, p->d.Cin,
                                                                        k.KH * k.KW, k.BM, k.CK, p->MT, p->KI);
   else

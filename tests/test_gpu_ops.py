@@ -380,7 +380,7 @@ F16_CASES = [   # N, Cin, H, W, Cout, pad, pooled
 ]
 
 
-@pytest.mark.parametrize("tune_variant", [0, 202])          # 202: the 3-workgroups-per-CU build of the same kernels
+@pytest.mark.parametrize("tune_variant", [0, 202, 203])     # 202: the 3-workgroups-per-CU build, 203: 128 x 256 tiles
 @pytest.mark.parametrize("case", F16_CASES)
 def test_conv_f16_planes(hip, orc, case, tune_variant):
     N, Cin, H, W, Cout, pad, pooled = case
@@ -391,6 +391,7 @@ def test_conv_f16_planes(hip, orc, case, tune_variant):
     plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), relu=True, algo=hip.ALGO_F16, tune_variant=tune_variant)
     assert plan.kernel.startswith("igemm16_") and plan.dtype == "f16", plan.kernel
     assert plan.kernel.endswith("_occ3") == (tune_variant == 202)          # (these shapes are far below the 2000-tile switch)
+    assert ("128x256" in plan.kernel) == (tune_variant == 203)
     assert hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad)).dtype == "f32"
     plan.pack(dev(w))
     Ho, Wo = plan.out_shape()[2:]
