@@ -42,6 +42,8 @@ MODELS = {
 }
 DEFAULT_MODEL = "kitti_car/mscnn-7s-576"
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+FP32_MFMA_MEASURED_TFLOPS = 141.7      # MFMA-only loop on this part (tools/micro/mfma_valu_overlap.hip, profiles/r02_micro_mfma_valu_overlap.txt):
+                                        # what the pipe sustains at the clock it holds under fp32 MFMA load (SURVEY 8d asks for this reference too)
 FP16_MFMA_PEAK_TFLOPS = 2500.0         # dense fp16 / bf16 MFMA (cdna_hip_programming.md: ~2.5 PF; 16x the fp32 MFMA rate)
 # fp16 mode (BASELINE config 5; no reference counterpart): per-blob error relative to the blob's rms, detection matching
 # (a) blobs: max error / rms(blob) < 1e-2 against the reference's CPU path; (b) detections: fp16 noise (1e-3 .. 1e-2 of a score)
@@ -361,6 +363,8 @@ def main():
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+            **({"frac_of_measured_mfma_peak": round(achieved / FP32_MFMA_MEASURED_TFLOPS, 4),
+                "measured_mfma_peak": FP32_MFMA_MEASURED_TFLOPS} if args.dtype == "f32" else {}),
             "kernel": ("igemm_kernel<Cfg<...,F16>> (igemm16_*): direct 3x3 implicit GEMM on v_mfma_f32_32x32x16_f16, operands rounded to "
                        "fp16 while staged into LDS, fp32 accumulate (+ its stream-K fix-up)") if args.dtype == "f16" else
                       "igemm_kernel<Cfg<128,128,2,2,1,1,32,128,...,vec>> -- the 25 batched [Cout x Cin] x [Cin x tiles] GEMMs of the "
