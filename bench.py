@@ -217,8 +217,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default=DEFAULT_MODEL, choices=sorted(MODELS))
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
-                    help="f16: fp16 MFMA operands / fp32 accumulate for the 3x3 convolutions and fc6 (BASELINE config 5)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "f16x3"],
+                    help="f16: fp16 MFMA operands / fp32 accumulate for the 3x3 convolutions and fc6 (BASELINE config 5); "
+                         "f16x3: the Winograd plane GEMMs on the fp16 pipe with exactly split fp32 operands (fp32-grade: same "
+                         "parity gates as f32)")
     ap.add_argument("--regime", default="mid", choices=["dense", "mid", "sparse"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-layer tables (caffe time format) to stderr")
@@ -357,8 +359,8 @@ def main():
                 traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
                 tsrc = f"static: profiles/{tp} (rocprofv3 PMC passes of an earlier run of this command, not measured in this run)"
                 break
-        peak = FP16_MFMA_PEAK_TFLOPS if args.dtype == "f16" else FP32_MFMA_PEAK_TFLOPS
-        if args.dtype == "f16":
+        peak = FP16_MFMA_PEAK_TFLOPS if args.dtype in ("f16", "f16x3") else FP32_MFMA_PEAK_TFLOPS
+        if args.dtype != "f32":
             traffic, tsrc = None, None
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -367,11 +369,16 @@ def main():
                 "measured_mfma_peak": FP32_MFMA_MEASURED_TFLOPS} if args.dtype == "f32" else {}),
             "kernel": ("igemm_kernel<Cfg<...,F16>> (igemm16_*): direct 3x3 implicit GEMM on v_mfma_f32_32x32x16_f16, operands rounded to "
                        "fp16 while staged into LDS, fp32 accumulate (+ its stream-K fix-up)") if args.dtype == "f16" else
+                      ("x3_gemm_kernel<128|256> -- the 25 plane GEMMs of the Winograd F(3x3,3x3) layers on v_mfma_f32_32x32x16_f16 with "
+                       "every fp32 operand split exactly into fp16 hi + lo: three MFMAs per product pair (all three counted as "
+                       "executed FLOPs), fp32 accumulate") if args.dtype == "f16x3" else
                       "igemm_kernel<Cfg<128,128,2,2,1,1,32,128,...,vec>> -- the 25 batched [Cout x Cin] x [Cin x tiles] GEMMs of the "
                       "Winograd F(3x3,3x3) layers (two builds of the same kernel: 3 workgroups / CU, and 4 / CU for the >= 3000-tile "
                       "layers; + its stream-K fix-up where a grid does not divide the tiles)",
             "flops_note": "achieved = FLOPs the kernel's MFMAs execute for the real problem (2 * 25 * Cout * Cin * tiles per launch) / "
                           "its HIP-event time on the net's stream, summed over its launches of one image",
+            **({"fp32_equivalent_tflops": round(achieved / 3, 2),
+                "fp32_equivalent_vs_fp32_mfma_peak": round(achieved / 3 / FP32_MFMA_PEAK_TFLOPS, 4)} if args.dtype == "f16x3" else {}),
             "launches_per_image": len(wino), "avg_launch_us": round(1e3 * g_ms / max(len(wino), 1), 1),
             "executed_gflop_per_image": round(g_flops / 1e9, 2),
             "layers": [net.layer_names[i] for i in wino],
@@ -398,7 +405,7 @@ def main():
                               "p90": round(float(ss[int(round(0.90 * (len(ss) - 1)))]), 4), "min": round(float(ss[0]), 4),
                               "max": round(float(ss[-1]), 4), "note": "rank 0, wall time per step incl. the host sync at its end"},
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                  "config": {"workload": f"{args.model} {'fp16 MFMA operands / fp32 accumulate' if args.dtype == 'f16' else 'fp32'}, batch=1 per GPU, 1x3x{H}x{W} frame resident in HBM -> detections on host "
+                  "config": {"workload": f"{args.model} {'fp16 MFMA operands / fp32 accumulate' if args.dtype == 'f16' else 'fp32 (Winograd GEMMs as 3 x fp16 MFMA on split operands)' if args.dtype == 'f16x3' else 'fp32'}, batch=1 per GPU, 1x3x{H}x{W} frame resident in HBM -> detections on host "
                                          "(trunk + heads + BoxOutput + ROI pool + det sub-net + final NMS)",
                              "regime": args.regime, "mean_rois": round(Rm, 1), "mean_detections": round(float(np.mean(stats["D"])), 1),
                              "parallelism": f"image-parallel x{world}", "gather": gather_kind},

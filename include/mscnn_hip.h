@@ -64,7 +64,13 @@ typedef enum {
    * with fp32 accumulators, direct 3x3 implicit GEMM (no Winograd).  Blobs stay fp32.  Shapes without an fp16 kernel (stride,
    * groups, heads) run their fp32 kernel.  Tolerance policy: DESIGN.md (per-layer 5e-3 of the layer's scale; detections IoU >=
    * 0.95 and |dscore| <= 5e-3 against the fp32 path). */
-  MSCNN_CONV_ALGO_F16 = 4
+  MSCNN_CONV_ALGO_F16 = 4,
+  /* F(3x3,3x3) whose 25 plane GEMMs run on the fp16 MFMA pipe with every fp32 operand split exactly into two fp16 halves
+   * (x s = hi + lo, s a power of two taken from the tensor's max |x|, measured on the device each forward) and three products
+   * per pair, fp32 accumulators: 22-bit significands -- fp32-grade results (same 1e-4 parity bar as the fp32 kernels) at 16/3
+   * of the fp32 MFMA rate.  Opt-in; it replaces the plane GEMMs of the layers the AUTO heuristic runs as F(3x3,3x3); every other
+   * layer (and Cin not a multiple of 32) keeps its fp32 kernel.  mscnn_conv2d_plan_dtype() reports "f16x3". */
+  MSCNN_CONV_ALGO_WINO_F3_X3 = 5
 } mscnn_conv_algo;
 
 typedef struct {
@@ -76,7 +82,8 @@ typedef struct {
   /* Tuning knobs for A/B measurements (tools/bench_layers.py); 0 = the measured default.  None changes results beyond
    * fp32 rounding.  tune_variant: igemm tile variant (value + 1, so that 0 keeps the default); tune_grid: workgroups of the
    * persistent igemm / head kernels; tune_flags: bit 0 = no XCD-aware workgroup map, bit 1 = proposal heads on the 32-row
-   * igemm tile instead of the M = 4 head kernel. */
+   * igemm tile instead of the M = 4 head kernel, bit 2 = MSCNN_CONV_ALGO_WINO_F3_X3 wherever it is legal (default: only where
+   * the AUTO heuristic picks F(3x3,3x3)); tune_variant with WINO_F3_X3: 1 = 128-row, 2 = 256-row GEMM tiles. */
   int tune_variant, tune_grid, tune_flags;
 } mscnn_conv_desc;
 
@@ -89,7 +96,7 @@ MSCNN_API size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* plan);
 MSCNN_API const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* plan);
 /* Algorithmic FLOPs (2*MACs of the direct convolution the reference computes) of one forward call. */
 MSCNN_API double mscnn_conv2d_plan_flops(const mscnn_conv_plan* plan);
-/* "f32" | "f16": the arithmetic type of the plan's MFMA operands (accumulation is fp32 in both). */
+/* "f32" | "f16" | "f16x3": the arithmetic type of the plan's MFMA operands (accumulation is fp32 in all of them). */
 MSCNN_API const char* mscnn_conv2d_plan_dtype(const mscnn_conv_plan* plan);
 /* FLOPs the MFMA pipe really executes for the real (unpadded) problem: equal to the algorithmic count for the direct
  * kernels, 2 * planes * Cout * Cin * tiles for the Winograd forms (25/81 resp. 16/36 of it on exactly tiled planes). */
@@ -99,6 +106,15 @@ MSCNN_API double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* plan);
  * stream-K fix-up, output transform} in milliseconds (direct / head kernels: {0, total, 0}). */
 MSCNN_API int mscnn_conv2d_plan_set_profiling(mscnn_conv_plan* plan, int on);
 MSCNN_API int mscnn_conv2d_plan_stage_ms(const mscnn_conv_plan* plan, float ms_out[3]);
+/* max |x| hand-over between the layers of a chain (split-fp16 plans, MSCNN_CONV_ALGO_WINO_F3_X3).  Such a plan needs an upper
+ * bound of max |x| of its input; by default it measures it itself (one streaming pass over x per forward).
+ *   in_bound  (device, the bit pattern of a float >= max |x|; NULL = measure): read by this plan's forward instead;
+ *   out_amax  (device; NULL = off): the plan's forward does atomicMax(bits of max |y|) into it -- the caller zeroes it before
+ *             the forward.  Only the F(3x3,3x3) forms publish (mscnn_conv2d_plan_publishes_amax() == 1); for other plans a
+ *             non-NULL out_amax is MSCNN_ERR_UNSUPPORTED.
+ * A max-pooled or ROI-pooled copy of y is bounded by the same value. */
+MSCNN_API int mscnn_conv2d_plan_publishes_amax(const mscnn_conv_plan* plan);
+MSCNN_API int mscnn_conv2d_plan_set_amax_io(mscnn_conv_plan* plan, const uint32_t* in_bound, uint32_t* out_amax);
 /* Re-shape a plan for a new batch size N (ROI count changes per image, layer.hpp:451-456). */
 MSCNN_API int mscnn_conv2d_plan_set_batch(mscnn_conv_plan* plan, int N);
 /* Identifies the packed-weight layout the plan currently expects (0: none, the kernel reads the Caffe layout).

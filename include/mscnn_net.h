@@ -70,7 +70,10 @@ MSCNN_NET_API int mscnn_net_set_conv_algo(mscnn_net* net, int layer, int algo);
 MSCNN_NET_API int mscnn_net_set_conv_tuning(mscnn_net* net, int layer, int variant, int grid, int flags);
 /* Arithmetic of the MFMA layers of the whole net: "f32" (default: the path that matches the reference within 1e-4) or "f16"
  * (fp16 operands, fp32 accumulate, no reference counterpart -- BASELINE config 5): 3x3 stride-1 convolutions and InnerProduct
- * layers with N >= 64 switch, everything else keeps its fp32 kernel.  mscnn_net_layer_dtype: what layer i really runs. */
+ * layers with N >= 64 switch, everything else keeps its fp32 kernel.  "f16x3": the convolutions that run Winograd F(3x3,3x3)
+ * multiply their planes on the fp16 MFMA pipe with every fp32 operand split exactly into fp16 hi + lo (three products, fp32
+ * accumulate; MSCNN_CONV_ALGO_WINO_F3_X3) -- fp32-grade results held to the SAME parity gates as "f32", max |x| handed from
+ * layer to layer on the device.  mscnn_net_layer_dtype: what layer i really runs. */
 MSCNN_NET_API int mscnn_net_set_precision(mscnn_net* net, const char* dtype);
 MSCNN_NET_API const char* mscnn_net_layer_dtype(const mscnn_net* net, int layer);
 /* Numerical calibration (call after a forward on representative input): every Winograd convolution is re-computed with the

@@ -26,6 +26,7 @@
 #include "common.h"
 #include "headconv.h"
 #include "winograd.h"
+#include "wino_x3.h"
 #include <new>
 #include <type_traits>
 
@@ -825,6 +826,11 @@ struct mscnn_conv_plan {
   mscnn_conv_plan* wino = nullptr;
   int wino_m = 2;        // output tile edge: 2 = F(2x2,3x3) (16 planes), 3 = F(3x3,3x3) (25 planes; small ROI maps)
   int tiles_h = 0, tiles_w = 0, T_pad = 0;
+  // split-fp16 form of the F(3x3,3x3) path (MSCNN_CONV_ALGO_WINO_F3_X3, wino_x3.hip): x3.BM > 0, wino == nullptr.
+  // Workspace layout: [256 B device scalars][V16][M: 25 x Cout x T_pad floats]
+  mscnn::X3Plan x3;
+  const unsigned* amax_in = nullptr;   // mscnn_conv2d_plan_set_amax_io (kept across re-planning)
+  unsigned* amax_out = nullptr;
   // roofline accounting (mscnn_conv2d_plan_set_profiling): events around {input transform | GEMM | output transform}
   bool profiling = false;
   mutable hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -850,7 +856,10 @@ static bool wino_plan(mscnn_conv_plan* p) {
   const int algo = tune_env("MSCNN_CONV_ALGO", d.algo);
   if (algo == MSCNN_CONV_ALGO_DIRECT || d.Kh != 3 || d.Kw != 3 || d.stride_h != 1 || d.stride_w != 1 || d.group != 1) return false;
   if (p->Ho < 2 || p->Wo < 2) return false;
-  const bool force = algo == MSCNN_CONV_ALGO_WINO_F2 || algo == MSCNN_CONV_ALGO_WINO_F3;
+  const bool want_x3 = algo == MSCNN_CONV_ALGO_WINO_F3_X3;
+  // WINO_F3_X3 follows the AUTO heuristic (it replaces the GEMM of the layers that run F(3x3,3x3) anyway); tune_flags bit 2
+  // forces the form wherever it is legal, like WINO_F3 (tests)
+  const bool force = algo == MSCNN_CONV_ALGO_WINO_F2 || algo == MSCNN_CONV_ALGO_WINO_F3 || (want_x3 && (d.tune_flags & 4));
   const double intensity = (double)d.Cin * d.Cout / (d.Cin + d.Cout);
   // small maps (the ROI-pooled 7x7 / 7x5 / 8x4 inputs of roi_c1): F(3x3,3x3) -- a 5x5 output is 2x2 tiles x 25 multiplies
   // instead of 225 (measured 1293 -> see DESIGN.md); larger planes: F(2x2,3x3)
@@ -866,6 +875,14 @@ static bool wino_plan(mscnn_conv_plan* p) {
   const long T = (long)d.N * th * tw;
   const long T_pad = (T + 127) / 128 * 128;
   if ((double)T_pad * (d.Cin > d.Cout ? d.Cin : d.Cout) * 4.0 >= 2.0e9) return false;   // one transform plane per 32-bit window
+  // the split-fp16 GEMM where the caller asked for it and the shape is one the fp32 heuristic sends to F(3x3,3x3) anyway
+  if (want_x3 && m == 3 && x3_plan(d.Cin, d.Cout, T_pad, d.tune_variant, &p->x3)) {
+    p->wino_m = 3;
+    p->tiles_h = th; p->tiles_w = tw; p->T_pad = (int)T_pad;
+    p->packed_bytes = p->x3.packed_bytes;
+    p->ws_bytes = p->x3.scal_bytes + p->x3.v_bytes + (size_t)25 * d.Cout * T_pad * sizeof(float);
+    return true;
+  }
   mscnn_conv_plan* g = new (std::nothrow) mscnn_conv_plan();
   if (!g) return false;
   g->d = d;
@@ -903,6 +920,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   }
   delete p->wino;
   p->wino = nullptr;
+  p->x3 = mscnn::X3Plan();
   if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0 || d.Cin > 2048) return;   // KI <= 256
   const bool want16 = tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_F16 && d.Kh == 3 && d.Kw == 3;
   if (!want16 && wino_plan(p)) return;
@@ -1017,6 +1035,7 @@ extern "C" size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* p) { retur
 extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (!p) return "";
   if (p->head.entry >= 0) return head_kernel_name(p->head);
+  if (p->x3.BM) return p->x3.BM == 256 ? "winograd_f3x3_3x3_x3f16_256" : "winograd_f3x3_3x3_x3f16_128";
   if (p->wino) return p->wino_m == 3 ? "winograd_f3x3_3x3" : "winograd_f2x2_3x3";
   return p->entry < 0 ? "direct_f32" : kTable[p->entry].name;
 }
@@ -1024,6 +1043,7 @@ extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_p
   if (!p) return 0;
   unsigned long long kind, e, mt, ki;
   if (p->head.entry >= 0) { kind = 2; e = (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
+  else if (p->x3.BM) { kind = 6; e = (unsigned)p->x3.BM; mt = (unsigned)p->x3.MT; ki = (unsigned)p->x3.KG; }
   else if (p->wino) { kind = 2 + (unsigned)p->wino_m; e = (unsigned)p->wino->entry; mt = (unsigned)p->wino->MT; ki = (unsigned)p->wino->KI; }
   else if (p->entry >= 0) { kind = 1; e = (unsigned)p->entry; mt = (unsigned)p->MT; ki = (unsigned)p->KI; }   // (entry distinguishes fp16 packs)
   else return 0;   // direct kernel: reads the Caffe layout
@@ -1035,13 +1055,14 @@ extern "C" double mscnn_conv2d_plan_flops(const mscnn_conv_plan* p) {
   return 2.0 * d.N * d.Cout * p->Ho * p->Wo * (double)(d.Cin / d.group) * d.Kh * d.Kw;
 }
 extern "C" const char* mscnn_conv2d_plan_dtype(const mscnn_conv_plan* p) {
+  if (p && p->x3.BM) return "f16x3";
   return (p && !p->wino && p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202) ? "f16" : "f32";
 }
 extern "C" double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* p) {
   if (!p) return 0;
-  if (!p->wino) return mscnn_conv2d_plan_flops(p);
+  if (!p->wino && !p->x3.BM) return mscnn_conv2d_plan_flops(p);
   const mscnn_conv_desc& d = p->d;
-  const double planes = p->wino_m == 3 ? 25.0 : 16.0;
+  const double planes = (p->wino_m == 3 ? 25.0 : 16.0) * (p->x3.BM ? 3.0 : 1.0);    // x3: three fp16 MFMA products per pair
   return 2.0 * planes * d.Cout * d.Cin * ((double)d.N * p->tiles_h * p->tiles_w);
 }
 extern "C" int mscnn_conv2d_plan_set_profiling(mscnn_conv_plan* p, int on) {
@@ -1061,6 +1082,19 @@ extern "C" int mscnn_conv2d_plan_stage_ms(const mscnn_conv_plan* p, float ms_out
   for (int i = 0; i < 3; ++i) MSCNN_HIP_TRY(hipEventElapsedTime(&ms_out[i], p->ev[i], p->ev[i + 1]));
   return MSCNN_OK;
 }
+extern "C" int mscnn_conv2d_plan_publishes_amax(const mscnn_conv_plan* p) {
+  return p && (p->x3.BM || (p->wino && p->wino_m == 3)) ? 1 : 0;
+}
+extern "C" int mscnn_conv2d_plan_set_amax_io(mscnn_conv_plan* p, const uint32_t* in_bound, uint32_t* out_amax) {
+  MSCNN_REQUIRE(p, "conv plan: null");
+  if (out_amax && !mscnn_conv2d_plan_publishes_amax(p)) {
+    set_error("conv plan: kernel %s does not publish max |y|", mscnn_conv2d_plan_kernel(p));
+    return MSCNN_ERR_UNSUPPORTED;
+  }
+  p->amax_in = in_bound;
+  p->amax_out = out_amax;
+  return MSCNN_OK;
+}
 extern "C" int mscnn_conv2d_plan_set_batch(mscnn_conv_plan* p, int N) {
   MSCNN_REQUIRE(p && N >= 0, "conv plan: bad batch");
   p->d.N = N;
@@ -1073,6 +1107,10 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   if (p->head.entry >= 0) {
     MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
     return head_pack(p->d, p->head, w, packed, as_stream(stream));
+  }
+  if (p->x3.BM) {
+    MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
+    return x3_pack_weights(p->x3, w, packed, as_stream(stream));
   }
   if (p->wino) {
     MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
@@ -1132,7 +1170,7 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
 
 extern "C" int mscnn_conv2d_plan_can_pool(const mscnn_conv_plan* p) {
   if (!p || p->head.entry >= 0) return 0;
-  if (p->wino) return p->wino_m == 2 || (p->tiles_h % 2 == 0 && p->tiles_w % 2 == 0 && p->d.H > 8);
+  if (p->wino || p->x3.BM) return p->wino_m == 2 || (p->tiles_h % 2 == 0 && p->tiles_w % 2 == 0 && p->d.H > 8);
   return p->entry >= 0 && kTable[p->entry].fix_pool_fn != nullptr;
 }
 
@@ -1154,6 +1192,32 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
   MSCNN_REQUIRE(x && y, "conv: null pointer");
   hipStream_t st = as_stream(stream);
 #define MSCNN_STAGE_EVENT(i) do { if (p->profiling) MSCNN_HIP_TRY(hipEventRecord(p->ev[i], st)); } while (0)
+  if (p->x3.BM) {        // split-fp16 Winograd: {amax + input transform | GEMM | output transform}
+    MSCNN_REQUIRE(packed, "conv: Winograd path needs packed weights (mscnn_conv2d_pack_weights)");
+    if (!workspace || workspace_bytes < p->ws_bytes) {
+      set_error("conv(winograd x3): workspace %zu < %zu", workspace_bytes, p->ws_bytes);
+      return MSCNN_ERR_WORKSPACE;
+    }
+    unsigned char* wsb = static_cast<unsigned char*>(workspace);
+    const unsigned* scal = p->amax_in ? p->amax_in : reinterpret_cast<unsigned*>(wsb);
+    void* V16 = wsb + p->x3.scal_bytes;
+    float* M = reinterpret_cast<float*>(wsb + p->x3.scal_bytes + p->x3.v_bytes);
+    MSCNN_STAGE_EVENT(0);
+    int rc = p->amax_in ? MSCNN_OK : x3_amax(x, (long)d.N * d.Cin * d.H * d.W, reinterpret_cast<unsigned*>(wsb), st);
+    if (rc != MSCNN_OK) return rc;
+    rc = x3_input_transform(p->x3, x, V16, scal, d.N, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, st);
+    if (rc != MSCNN_OK) return rc;
+    MSCNN_STAGE_EVENT(1);
+    rc = x3_gemm(p->x3, packed, V16, M, scal, (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 1) ? 0 : 1, st);
+    if (rc != MSCNN_OK) return rc;
+    MSCNN_STAGE_EVENT(2);
+    rc = wino_output_transform(3, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st,
+                               p->amax_out);
+    if (rc != MSCNN_OK) return rc;
+    MSCNN_STAGE_EVENT(3);
+    p->ev_valid = p->profiling;
+    return MSCNN_OK;
+  }
   if (!p->wino) {        // one-stage kernels: {0, total, 0}
     MSCNN_STAGE_EVENT(0); MSCNN_STAGE_EVENT(1);
     const int rc = conv_forward_single(p, x, w, packed, bias, y, y_pool, workspace, workspace_bytes, st);
@@ -1180,7 +1244,8 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
     rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
     if (rc != MSCNN_OK) return rc;
     MSCNN_STAGE_EVENT(2);
-    rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st);
+    rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st,
+                               p->wino_m == 3 ? p->amax_out : nullptr);
     if (rc != MSCNN_OK) return rc;
     MSCNN_STAGE_EVENT(3);
     p->ev_valid = p->profiling;

@@ -1,0 +1,33 @@
+// Internal interface of wino_x3.hip: Winograd F(3x3,3x3) whose 25 plane GEMMs run on the fp16 MFMA pipe with every fp32
+// operand split exactly into two fp16 halves (x * s = hi + lo, s a power of two chosen from the tensor's max |x|) and
+// three products per pair (hi*hi + hi*lo + lo*hi, fp32 accumulators): 22-bit significands, fp32-grade results at 16/3 of the
+// fp32 MFMA rate.  Opt-in (MSCNN_CONV_ALGO_WINO_F3_X3); see wino_x3.hip for layouts and the error analysis.
+#pragma once
+#include "common.h"
+
+namespace mscnn {
+
+struct X3Plan {
+  int Cin = 0, Cout = 0, KG = 0, Cout_pad = 0, BM = 0, MT = 0, NT = 0;
+  long T_pad = 0;
+  size_t packed_bytes = 0;   // header + U16
+  size_t v_bytes = 0;        // V16 planes
+  size_t scal_bytes = 256;   // device scalars (amax of the input) in front of the workspace
+};
+
+// false when the shape is not covered (Cin not a multiple of 32, planes beyond the 32-bit buffer window)
+bool x3_plan(int Cin, int Cout, long T_pad, int tune_variant, X3Plan* out);
+
+int x3_pack_weights(const X3Plan& p, const float* w, void* packed, hipStream_t st);
+
+// scal <- max |x| over the n floats of x (device scalar, written as the float's bit pattern)
+int x3_amax(const float* x, long n, unsigned* scal, hipStream_t st);
+
+// V16[plane][part][kg][t][8] = split(s * (B^T d B)); H * W <= 64: the ROI-map form (tiles of one ROI are consecutive t)
+int x3_input_transform(const X3Plan& p, const float* x, void* V16, const unsigned* scal, int N, int H, int W, int pad_h,
+                       int pad_w, int tiles_h, int tiles_w, hipStream_t st);
+
+// M[plane][co][t] (fp32, the layout of the fp32 Winograd path) = (U V)(plane) / (s_U s_V)
+int x3_gemm(const X3Plan& p, const void* packed, const void* V16, float* M, const unsigned* scal, int xcd_map, hipStream_t st);
+
+}  // namespace mscnn

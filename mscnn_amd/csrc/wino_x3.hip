@@ -1,0 +1,463 @@
+// Winograd F(3x3,3x3) with split-fp16 plane GEMMs for gfx950 (opt-in: MSCNN_CONV_ALGO_WINO_F3_X3).
+//
+// The fp32 MFMA pipe (v_mfma_f32_32x32x2_f32) runs at 1/16 of the fp16 pipe (v_mfma_f32_32x32x16_f16).  An fp32 number x
+// with |x * s| < 2^15 (s a power of two) splits EXACTLY into two fp16 numbers up to 22 significant bits:
+//     hi = fp16(x s),  lo = fp16(x s - hi),   |x s - hi - lo| <= max(2^-22 |x s|, 2^-25)
+// (fp16 has an 11-bit significand; lo is the exact remainder rounded once more; below 2^-14 lo is a denormal with quantum
+// 2^-24).  A product of two such numbers is then  a b = (ah bh + ah bl + al bh) + O(2^-22 |a b|): three fp16 MFMAs whose
+// partial products are exact in the fp32 accumulator (11 x 11 bits), summed in fp32 exactly like the fp32 MFMA does.  The result
+// carries a 2^-21 relative error per product against 2^-24 for fp32 operands -- far inside the 1e-4 parity bound and below the
+// rounding of the Winograd transforms themselves (measured: tests/test_gpu_ops.py::test_conv_winograd_x3*) -- at
+// 16/3 of the fp32 MFMA rate.
+//
+// Scales.  Weights: s_U from max |g| of the layer at pack time (|G g G^T| <= 2.25 max|g|), stored as 1/s_U in the header of
+// the packed buffer.  Activations: s_V from max |x| of THIS forward's input, measured on the device by x3_amax (one streaming
+// pass; |B^T d B| <= 36 max|d|) -- a frame can never overflow the fp16 range, whatever its statistics.  Both are powers of
+// two, so scaling and un-scaling are exact.
+//
+// Layouts (16-byte units of 8 halves = one lane's MFMA operand, kg = 8-channel group):
+//     U16[plane][part][kg][Cout_pad][8]     part 0 = hi, 1 = lo
+//     V16[plane][part][kg][T_pad][8]        t = tile index (n, ty, tx), T_pad a multiple of 128
+// so an A / B tile of the GEMM is, per (part, kg), one contiguous run of BM / 128 units: staged with b128 buffer loads and
+// ds_write_b128, read back with one conflict-free ds_read_b128 per operand.  M comes out in the fp32 path's layout
+// [plane][Cout][T_pad] so the output transforms (winograd.hip) are shared.
+#include "wino_x3.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr size_t kHdrBytes = 256;      // packed weights: float[0] = 1 / s_U, uint[1] = bits of max |g|
+constexpr unsigned kOob = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// s = 2^(14 - floor(log2(bound))): bound * s in [2^14, 2^15).  bound == 0 (all-zero tensor) -> 1.
+__device__ __forceinline__ void pow2_scale(float bound, float* s, float* inv) {
+  int e = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 127;
+  if (bound == 0.f) e = 14;
+  e = e < -100 ? -100 : (e > 110 ? 110 : e);
+  *s = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+  *inv = __uint_as_float((unsigned)(127 - 14 + e) << 23);
+}
+
+__device__ __forceinline__ void split16(float v, _Float16* hi, _Float16* lo) {
+  const _Float16 h = (_Float16)v;
+  *hi = h;
+  *lo = (_Float16)(v - (float)h);
+}
+
+// ---- max |x| -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  __shared__ unsigned s_m[4];
+  unsigned m = 0;
+  const long n4 = n >> 2;
+  const uint4* x4 = reinterpret_cast<const uint4*>(x);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const uint4 v = x4[i];
+    m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(x[(n4 << 2) + threadIdx.x]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));
+}
+
+// ---- weights: U = G g G^T, scaled, split ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void x3_weight_kernel(const float* __restrict__ w, unsigned char* __restrict__ packed, int Cout,
+                                                        int Cin, int Cout_pad, int KG) {
+  const float amax = __uint_as_float(reinterpret_cast<const unsigned*>(packed)[1]);
+  float s, inv;
+  pow2_scale(2.25f * amax, &s, &inv);
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(packed)[0] = inv;
+  _Float16* U = reinterpret_cast<_Float16*>(packed + kHdrBytes);
+  const long part_stride = (long)KG * Cout_pad * 8, plane_stride = 2 * part_stride;
+  const long total = (long)Cout_pad * KG * 8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int co = (int)(i % Cout_pad), ci = (int)(i / Cout_pad);
+    const bool live = co < Cout && ci < Cin;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[a][b] = live ? w[((long)co * Cin + ci) * 9 + a * 3 + b] : 0.f;
+    float t[5][3];   // G g  (the same expressions as wino33_weight_kernel: identical U before the split)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      t[0][b] = 0.5f * g[0][b];
+      t[1][b] = -0.5f * (g[0][b] + g[1][b] + g[2][b]);
+      t[2][b] = (-g[0][b] + g[1][b] - g[2][b]) * (1.f / 6.f);
+      t[3][b] = g[0][b] * (1.f / 6.f) + g[1][b] * (1.f / 3.f) + g[2][b] * (2.f / 3.f);
+      t[4][b] = g[2][b];
+    }
+    _Float16* dst = U + ((long)(ci >> 3) * Cout_pad + co) * 8 + (ci & 7);
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      const float x0 = t[a][0], x1 = t[a][1], x2 = t[a][2];
+      const float u[5] = {0.5f * x0, -0.5f * (x0 + x1 + x2), (-x0 + x1 - x2) * (1.f / 6.f),
+                          x0 * (1.f / 6.f) + x1 * (1.f / 3.f) + x2 * (2.f / 3.f), x2};
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        _Float16 hi, lo;
+        split16(u[b] * s, &hi, &lo);
+        dst[(a * 5 + b) * plane_stride] = hi;
+        dst[(a * 5 + b) * plane_stride + part_stride] = lo;
+      }
+    }
+  }
+}
+
+// ---- input transform -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bt5(const float d[5], float r[5]) {      // B^T of winograd.hip
+  r[0] = 2.f * d[0] - d[1] - 2.f * d[2] + d[3];
+  r[1] = -2.f * d[1] - d[2] + d[3];
+  r[2] = 2.f * d[1] - 3.f * d[2] + d[3];
+  r[3] = d[3] - d[1];
+  r[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+}
+
+// d (5x5 patch, registers) -> 25 scaled, split values in the LDS transpose buffer sh[part][plane][q][c] (halves)
+__device__ __forceinline__ void transform_split_store(const float d[5][5], float s, _Float16* sh, int q, int c) {
+  float r[5][5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float col[5] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j]};
+    float o[5];
+    bt5(col, o);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r[i][j] = o[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    float o[5];
+    bt5(r[i], o);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      _Float16 hi, lo;
+      split16(o[j] * s, &hi, &lo);
+      sh[(((i * 5 + j)) * 32 + q) * 8 + c] = hi;
+      sh[((25 + (i * 5 + j)) * 32 + q) * 8 + c] = lo;
+    }
+  }
+}
+
+// LDS transpose buffer -> V16: 50 runs (plane, part) of nq consecutive 16-byte units starting at tile t0
+__device__ __forceinline__ void flush_units(const _Float16* sh, uint4* V16, int KG, long T_pad, int kg, long t0, int nq, int tid) {
+  for (int u = tid; u < 50 * 32; u += 256) {
+    const int q = u & 31, pp = u >> 5;          // pp = part * 25 + plane
+    if (q >= nq) continue;
+    const int part = pp / 25, plane = pp % 25;
+    V16[((long)(plane * 2 + part) * KG + kg) * T_pad + t0 + q] = reinterpret_cast<const uint4*>(sh)[pp * 32 + q];
+  }
+}
+
+// whole image planes: workgroup = 8 channels (one kg) x 32 consecutive tiles; a wave is 2 channels x 32 tiles
+__global__ __launch_bounds__(256) void x3_input_plane_kernel(const float* __restrict__ x, uint4* __restrict__ V16,
+                                                             const unsigned* __restrict__ scal, int N, int Cin, int H, int W,
+                                                             int pad_h, int pad_w, int tiles_h, int tiles_w, int T, long T_pad,
+                                                             int KG) {
+  __shared__ __attribute__((aligned(16))) _Float16 sh[2 * 25 * 32 * 8];
+  const int tid = threadIdx.x, q = tid & 31, c = tid >> 5;
+  const int kg = blockIdx.y;
+  const long t0 = (long)blockIdx.x * 32;
+  const int t = (int)t0 + q, ci = kg * 8 + c;
+  float s, inv;
+  pow2_scale(36.f * __uint_as_float(scal[0]), &s, &inv);
+  float d[5][5];
+  if (t < T) {
+    const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
+    const float* src = x + ((long)n * Cin + ci) * H * W;
+    const int h0 = 3 * ty - pad_h, w0 = 3 * tx - pad_w;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int h = h0 + i;
+      const bool hok = h >= 0 && h < H;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int wv = w0 + j;
+        d[i][j] = (hok && wv >= 0 && wv < W) ? src[h * W + wv] : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) d[i][j] = 0.f;
+  }
+  transform_split_store(d, s, sh, q, c);
+  __syncthreads();
+  flush_units(sh, V16, KG, T_pad, kg, t0, 32, tid);
+}
+
+// ROI maps (H * W <= 64; roi_c1): workgroup = 8 channels x nr ROIs (nr * tiles-per-ROI <= 32); the nr x 8 maps are staged
+// through LDS with coalesced loads (8 channels of one ROI are one contiguous run), then thread = (channel, roi, tile)
+constexpr int kRoiMaxHW = 64, kRoiMax = 8;
+
+__global__ __launch_bounds__(256) void x3_input_roi_kernel(const float* __restrict__ x, uint4* __restrict__ V16,
+                                                           const unsigned* __restrict__ scal, int N, int Cin, int H, int W,
+                                                           int pad_h, int pad_w, int tiles_h, int tiles_w, int T, long T_pad,
+                                                           int KG, int nr) {
+  __shared__ __attribute__((aligned(16))) _Float16 sh[2 * 25 * 32 * 8];
+  __shared__ __attribute__((aligned(16))) float sm[kRoiMax * 8 * kRoiMaxHW];
+  const int tid = threadIdx.x;
+  const int kg = blockIdx.y, c0 = kg * 8;
+  const int r0 = blockIdx.x * nr;
+  const int HW = H * W, tpr = tiles_h * tiles_w;
+  const int run = 8 * HW;
+  for (int rl = 0; rl < nr; ++rl) {
+    const int r = r0 + rl;
+    if (r >= N) break;
+    const float* src = x + ((long)r * Cin + c0) * HW;
+    float* dst = sm + rl * (8 * HW);
+    if ((run & 3) == 0 && ((((long)r * Cin + c0) * HW) & 3) == 0) {
+      for (int i = tid; i < run / 4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+      for (int i = tid; i < run; i += 256) dst[i] = src[i];
+    }
+  }
+  __syncthreads();
+  float s, inv;
+  pow2_scale(36.f * __uint_as_float(scal[0]), &s, &inv);
+  const int nq = nr * tpr;                       // <= 32
+  const int q = tid & 31, c = tid >> 5;
+  if (q < nq) {
+    const int rl = q / tpr, tl = q % tpr;
+    float d[5][5];
+    if (r0 + rl < N) {
+      const int ty = tl / tiles_w, tx = tl % tiles_w;
+      const float* map = sm + (rl * 8 + c) * HW;
+      const int h0 = 3 * ty - pad_h, w0 = 3 * tx - pad_w;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int h = h0 + i;
+        const bool hok = h >= 0 && h < H;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int wv = w0 + j;
+          d[i][j] = (hok && wv >= 0 && wv < W) ? map[h * W + wv] : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) d[i][j] = 0.f;
+    }
+    transform_split_store(d, s, sh, q, c);
+  }
+  __syncthreads();
+  const long t0 = (long)r0 * tpr;
+  int live = (int)min((long)nq, (long)T - t0);   // the last block's missing ROIs are not written here ...
+  if (live < 0) live = 0;
+  flush_units(sh, V16, KG, T_pad, kg, t0, live, tid);
+  if (blockIdx.x == gridDim.x - 1) {             // ... the GEMM's padding columns T .. T_pad are zeros
+    const int padn = (int)(T_pad - T);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int u = tid; u < 50 * padn; u += 256) V16[((long)(u / padn) * KG + kg) * T_pad + T + u % padn] = z;
+  }
+}
+
+// ---- the 25 plane GEMMs ------------------------------------------------------------------------------------------------------
+struct X3Args {
+  const void* U; const void* V; float* M; const unsigned* scal; const float* hdr;
+  int Cout, Cout_pad, KG, KI, MT, NT, tiles, xcd_map;
+  unsigned T_pad;
+};
+
+// Workgroup = BM x 128 tile of one plane, 4 waves as 2 x 2, wave tile (BM/2) x 64 = MI x 2 MFMA blocks.  A k-chunk is 32
+// channels (4 kg, two k = 16 MFMA steps): LDS A [part][kgl][BM] + B [part][kgl][128] units (BM 256: 48 KB, BM 128: 32 KB),
+// next chunk prefetched into registers while the current one is multiplied.  Per k-step a wave reads 2 MI + 4 operands (1 KB
+// each) for 6 MI MFMAs of 32 cycles: 64 B/clk (BM 256) / 85 B/clk (BM 128) per workgroup against the LDS's 256 B/clk.
+template <int BM>
+__global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
+  constexpr int MI = BM / 64, NI = 2, WM = BM / 2, AU = BM / 32, BU = 4;
+  __shared__ uint4 ldsA[2 * 4 * BM];
+  __shared__ uint4 ldsB[2 * 4 * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: XCD x (workgroups b == x mod 8) walks one contiguous range of (plane, nt, mt): the plane's U stays in
+  // that XCD's L2 and the MT workgroups that share a V tile run next to each other
+  int ti = (int)blockIdx.x;
+  if (a.xcd_map) {
+    const int xcd = ti % 8, gq = a.tiles / 8, gr = a.tiles % 8;
+    ti = xcd * gq + min(xcd, gr) + ti / 8;
+  }
+  const int per_plane = a.MT * a.NT;
+  const int plane = ti / per_plane, rem = ti % per_plane;
+  const int nt = rem / a.MT, mt = rem % a.MT;
+
+  const unsigned a_bytes = 50u * (unsigned)a.KG * (unsigned)a.Cout_pad * 16u;
+  const unsigned v_bytes = 50u * (unsigned)a.KG * a.T_pad * 16u;
+  const __amdgpu_buffer_rsrc_t asrc = make_rsrc(a.U, a_bytes), bsrc = make_rsrc(a.V, v_bytes);
+  // unit u = tid + 256 i of a tile: (part, kgl, row) with row fastest
+  unsigned a_off[AU], b_off[BU];
+#pragma unroll
+  for (int i = 0; i < AU; ++i) {
+    const int u = tid + 256 * i, part = u / (4 * BM), kgl = (u / BM) % 4, row = u % BM;
+    a_off[i] = ((unsigned)((plane * 2 + part) * a.KG + kgl) * (unsigned)a.Cout_pad + (unsigned)(mt * BM + row)) * 16u;
+  }
+#pragma unroll
+  for (int i = 0; i < BU; ++i) {
+    const int u = tid + 256 * i, part = u / 512, kgl = (u / 128) % 4, col = u % 128;
+    b_off[i] = ((unsigned)((plane * 2 + part) * a.KG + kgl) * a.T_pad + (unsigned)(nt * 128 + col)) * 16u;
+  }
+  const unsigned a_step = 4u * (unsigned)a.Cout_pad * 16u, b_step = 4u * a.T_pad * 16u;   // one k-chunk further
+
+  uint4 ra[AU], rb[BU];
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < AU; ++i)
+      ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(asrc, a_off[i], (unsigned)kc * a_step, 0));
+#pragma unroll
+    for (int i = 0; i < BU; ++i)
+      rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, b_off[i], (unsigned)kc * b_step, 0));
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  load_chunk(0);
+  for (int kc = 0; kc < a.KI; ++kc) {
+#pragma unroll
+    for (int i = 0; i < AU; ++i) ldsA[tid + 256 * i] = ra[i];
+#pragma unroll
+    for (int i = 0; i < BU; ++i) ldsB[tid + 256 * i] = rb[i];
+    __syncthreads();
+    if (kc + 1 < a.KI) load_chunk(kc + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kgl = 2 * s + khalf;
+      f16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        ah[mi] = __builtin_bit_cast(f16x8, ldsA[kgl * BM + wm * WM + mi * 32 + l31]);
+        al[mi] = __builtin_bit_cast(f16x8, ldsA[(4 + kgl) * BM + wm * WM + mi * 32 + l31]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        bh[ni] = __builtin_bit_cast(f16x8, ldsB[kgl * 128 + wn * 64 + ni * 32 + l31]);
+        bl[ni] = __builtin_bit_cast(f16x8, ldsB[(4 + kgl) * 128 + wn * 64 + ni * 32 + l31]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: un-scale (exact: powers of two), store M[plane][co][t]
+  float sv, inv_v;
+  pow2_scale(36.f * __uint_as_float(a.scal[0]), &sv, &inv_v);
+  const float inv = inv_v * a.hdr[0];
+  const unsigned m_bytes = 25u * (unsigned)a.Cout * a.T_pad * 4u;
+  const __amdgpu_buffer_rsrc_t msrc = make_rsrc(a.M, m_bytes);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int co0 = mt * BM + wm * WM + mi * 32 + 4 * khalf;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const unsigned voff = ((unsigned)(plane * a.Cout + co0) * a.T_pad + (unsigned)(nt * 128 + wn * 64 + ni * 32 + l31)) * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        const unsigned vo = (co0 + row < a.Cout) ? voff : kOob;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[mi][ni][r] * inv), msrc, vo,
+                                              (unsigned)row * a.T_pad * 4u, 0);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+namespace mscnn {
+
+bool x3_plan(int Cin, int Cout, long T_pad, int tune_variant, X3Plan* out) {
+  if (Cin % 32 != 0 || Cin < 32 || T_pad % 128 != 0) return false;
+  X3Plan p;
+  p.Cin = Cin; p.Cout = Cout; p.KG = Cin / 8; p.T_pad = T_pad;
+  p.NT = (int)(T_pad / 128);
+  // 256-row tiles halve the LDS and L2 traffic per MFMA; they need enough tiles to fill 512 workgroup slots
+  const long tiles256 = 25L * (Cout / 256) * p.NT;
+  p.BM = (tune_variant == 1) ? 128 : (tune_variant == 2 && Cout % 256 == 0) ? 256 : (Cout % 256 == 0 && tiles256 >= 1024) ? 256 : 128;
+  p.MT = cdiv(Cout, p.BM);
+  p.Cout_pad = p.MT * p.BM;
+  const double u_bytes = 50.0 * p.KG * p.Cout_pad * 16.0, v_bytes = 50.0 * p.KG * (double)T_pad * 16.0;
+  const double m_bytes = 25.0 * Cout * (double)T_pad * 4.0;
+  if (u_bytes >= 4.0e9 || v_bytes >= 4.0e9 || m_bytes >= 4.0e9) return false;     // 32-bit buffer windows
+  p.packed_bytes = kHdrBytes + (size_t)u_bytes;
+  p.v_bytes = (size_t)v_bytes;
+  *out = p;
+  return true;
+}
+
+int x3_amax(const float* x, long n, unsigned* scal, hipStream_t st) {
+  MSCNN_HIP_TRY(hipMemsetAsync(scal, 0, 16, st));
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  amax_kernel<<<(int)blocks, 256, 0, st>>>(x, n, scal);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+int x3_pack_weights(const X3Plan& p, const float* w, void* packed, hipStream_t st) {
+  unsigned* hdr = static_cast<unsigned*>(packed);
+  int rc = x3_amax(w, (long)p.Cout * p.Cin * 9, hdr + 1, st);
+  if (rc != MSCNN_OK) return rc;
+  const long total = (long)p.Cout_pad * p.KG * 8;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  x3_weight_kernel<<<(int)blocks, 256, 0, st>>>(w, static_cast<unsigned char*>(packed), p.Cout, p.Cin, p.Cout_pad, p.KG);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+int x3_input_transform(const X3Plan& p, const float* x, void* V16, const unsigned* scal, int N, int H, int W, int pad_h,
+                       int pad_w, int tiles_h, int tiles_w, hipStream_t st) {
+  const int T = N * tiles_h * tiles_w;
+  if (H * W <= kRoiMaxHW && tiles_h * tiles_w <= 32) {
+    int nr = 32 / (tiles_h * tiles_w);
+    if (nr > kRoiMax) nr = kRoiMax;
+    dim3 grid(cdiv(N, nr), p.KG);
+    x3_input_roi_kernel<<<grid, 256, 0, st>>>(x, static_cast<uint4*>(V16), scal, N, p.Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T,
+                                              p.T_pad, p.KG, nr);
+  } else {
+    dim3 grid((unsigned)(p.T_pad / 32), p.KG);
+    x3_input_plane_kernel<<<grid, 256, 0, st>>>(x, static_cast<uint4*>(V16), scal, N, p.Cin, H, W, pad_h, pad_w, tiles_h, tiles_w,
+                                                T, p.T_pad, p.KG);
+  }
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+int x3_gemm(const X3Plan& p, const void* packed, const void* V16, float* M, const unsigned* scal, int xcd_map, hipStream_t st) {
+  X3Args a;
+  a.U = static_cast<const unsigned char*>(packed) + kHdrBytes;
+  a.V = V16; a.M = M; a.scal = scal; a.hdr = static_cast<const float*>(packed);
+  a.Cout = p.Cout; a.Cout_pad = p.Cout_pad; a.KG = p.KG; a.KI = p.KG / 4; a.MT = p.MT; a.NT = p.NT;
+  a.tiles = 25 * p.MT * p.NT; a.xcd_map = xcd_map; a.T_pad = (unsigned)p.T_pad;
+  if (p.BM == 256) x3_gemm_kernel<256><<<a.tiles, 256, 0, st>>>(a);
+  else x3_gemm_kernel<128><<<a.tiles, 256, 0, st>>>(a);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+}  // namespace mscnn

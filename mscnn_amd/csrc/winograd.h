@@ -17,6 +17,7 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
 // y[n][co][2ty + i][2tx + j] = (A^T m A)[i][j] + bias[co], optional ReLU;  m[xi][nu] = M[xinu][co][t].
 // y_pool != nullptr: also write max over the tile's (in-plane) outputs to y_pool[n][co][ty][tx] (fused 2x2/2 max pooling).
 int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
-                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st);
+                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st, unsigned* amax = nullptr);
+// amax != nullptr (m == 3 only): atomicMax of the bit pattern of max |y| into *amax (the caller zeroes it before the forward)
 
 }  // namespace mscnn

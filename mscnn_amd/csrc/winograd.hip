@@ -334,12 +334,21 @@ __global__ __launch_bounds__(256) void wino33_input_plane_kernel(const float* __
   }
 }
 
+// max |y| of a layer's output for the split-fp16 consumer (wino_x3.hip): wave maximum of the bit patterns, one atomic per wave
+// and only when it would raise the value already there (a stale read only costs a redundant atomic: the value is monotonic)
+__device__ __forceinline__ void publish_amax(unsigned m, unsigned* amax) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
+}
+
 __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                             float* __restrict__ y, int N, int Cout, int Ho, int Wo, int tiles_h,
-                                                            int tiles_w, int T, int T_pad, int relu) {
+                                                            int tiles_w, int T, int T_pad, int relu, unsigned* __restrict__ amax) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int co = blockIdx.y;
-  if (t >= T) return;
+  unsigned am = 0;
+  if (t < T) {
   const long plane_stride = (long)Cout * T_pad;
   const float* src = M + (long)co * T_pad + t;
   float r[3][5];   // A^T m
@@ -369,8 +378,11 @@ __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restr
       float u = v[j];
       if (relu) u = u > 0.f ? u : 0.f;
       dst[oh * Wo + ow] = u;
+      am = max(am, __float_as_uint(u) & 0x7fffffffu);
     }
   }
+  }
+  if (amax) publish_amax(am, amax);
 }
 
 
@@ -386,12 +398,14 @@ __device__ __forceinline__ void at5(const float m[5], float o[3]) {
 
 __global__ __launch_bounds__(256) void wino33_output_pool_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                                  float* __restrict__ y, float* __restrict__ yp, int N, int Cout,
-                                                                 int Ho, int Wo, int tiles_h, int tiles_w, int T_pad, int relu) {
+                                                                 int Ho, int Wo, int tiles_h, int tiles_w, int T_pad, int relu,
+                                                                 unsigned* __restrict__ amax) {
   const int sw = tiles_w / 2, sh = tiles_h / 2;
   const int S = N * sh * sw;
   const int sidx = blockIdx.x * 256 + threadIdx.x;
   const int co = blockIdx.y;
-  if (sidx >= S) return;
+  unsigned am = 0;
+  if (sidx < S) {
   const int sx = sidx % sw, sy = (sidx / sw) % sh, n = sidx / (sw * sh);
   const long plane_stride = (long)Cout * T_pad;
   const float b = bias ? bias[co] : 0.f;
@@ -430,7 +444,9 @@ __global__ __launch_bounds__(256) void wino33_output_pool_kernel(const float* __
     for (int j = 0; j < 6; ++j) {
       float v = out[i][j];
       if (relu) v = v > 0.f ? v : 0.f;
-      out[i][j] = (oh0 + i < Ho && ow0 + j < Wo) ? v : -3.402823466e+38f;
+      const bool in = oh0 + i < Ho && ow0 + j < Wo;
+      if (in) am = max(am, __float_as_uint(v) & 0x7fffffffu);
+      out[i][j] = in ? v : -3.402823466e+38f;
     }
     const int oh = oh0 + i;
     if (oh >= Ho) continue;
@@ -456,6 +472,8 @@ __global__ __launch_bounds__(256) void wino33_output_pool_kernel(const float* __
       if (out[2 * pi + 1][2 * pj + 1] > m) m = out[2 * pi + 1][2 * pj + 1];
       pd[ph * Wp + pw] = m;
     }
+  }
+  if (amax) publish_amax(am, amax);
 }
 
 }  // namespace
@@ -487,15 +505,16 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
 }
 
 int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
-                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st) {
+                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st, unsigned* amax) {
+  MSCNN_REQUIRE(!amax || m == 3, "winograd: max |y| is published by the F(3x3,3x3) output transforms only");
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T, 256), Cout);
   if (m == 3 && y_pool) {
     MSCNN_REQUIRE(tiles_h % 2 == 0 && tiles_w % 2 == 0, "winograd F(3x3,3x3): fused pooling needs even tile counts");
     dim3 gp(cdiv((long)N * (tiles_h / 2) * (tiles_w / 2), 256), Cout);
-    wino33_output_pool_kernel<<<gp, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T_pad, relu);
+    wino33_output_pool_kernel<<<gp, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T_pad, relu, amax);
   } else if (m == 3) {
-    wino33_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu);
+    wino33_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu, amax);
   } else {
     wino_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu);
   }

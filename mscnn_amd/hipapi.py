@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
 
 
 # mscnn_conv_algo
-ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_F2, ALGO_WINO_F3, ALGO_F16 = 0, 1, 2, 3, 4
+ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_F2, ALGO_WINO_F3, ALGO_F16, ALGO_WINO_F3_X3 = 0, 1, 2, 3, 4, 5
 
 
 MAX_HEADS = 16

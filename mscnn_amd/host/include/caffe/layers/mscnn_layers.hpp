@@ -91,6 +91,14 @@ class ConvolutionLayer : public Layer<Dtype> {
   // max |y - y_direct| / max(1, |y_direct|) of the current algorithm against the direct kernel on the given bottom
   // (device scratch only; the layer's tops are not touched).  0 when the layer already runs a direct kernel.
   double ErrorAgainstDirect(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  // max |x| hand-over for the split-fp16 algorithm (mscnn_conv2d_plan_set_amax_io), wired by the Net: `out` is this layer's
+  // slot (written when some consumer asked for it: set_amax_wanted), `src` / `in` the layer whose output bounds this layer's
+  // bottom and its slot.  A hand-over is used only for forwards the Net marks trusted (the producer ran in the same call).
+  void set_amax_io(const ConvolutionLayer* src, const unsigned* in, unsigned* out) { amax_src_ = src; amax_in_ = in; amax_out_ = out; }
+  const ConvolutionLayer* amax_src() const { return amax_src_; }
+  void set_amax_wanted(bool on) { amax_wanted_ = on; }
+  void set_amax_trusted(bool on) { amax_trusted_ = on; }
+  bool publishes_amax() const;
  protected:
   MSCNN_NO_CPU_PATH("Convolution")
   virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
@@ -104,6 +112,10 @@ class ConvolutionLayer : public Layer<Dtype> {
   DeviceBuffer packed_, workspace_;
   int algo_, tune_[3];
   bool profiling_;
+  const ConvolutionLayer* amax_src_ = nullptr;
+  const unsigned* amax_in_ = nullptr;
+  unsigned* amax_out_ = nullptr;
+  bool amax_wanted_ = false, amax_trusted_ = false;
 };
 
 // include/caffe/layers/deconv_layer.hpp -- transposed conv; the depthwise case of the "-2x" nets has its own kernel

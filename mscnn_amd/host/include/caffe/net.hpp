@@ -28,7 +28,7 @@ class Net {
   explicit Net(const NetParameter& param, Phase phase = TEST);
   explicit Net(const string& param_file, Phase phase);
   Net(const NetParameter& param, Phase phase, bool fusion);
-  virtual ~Net() {}
+  virtual ~Net();
 
   const vector<Blob<Dtype>*>& Forward(Dtype* loss = NULL);
   const vector<Blob<Dtype>*>& ForwardPrefilled(Dtype* loss = NULL) { return Forward(loss); }
@@ -77,6 +77,11 @@ class Net {
  protected:
   void Init(const NetParameter& param);
   void ApplyFusion();
+  // max |x| hand-over for split-fp16 convolutions (ConvolutionLayer::set_amax_io): one device slot per layer; a blob's bound
+  // follows it through Split / in-place ReLU / Dropout / MAX pooling / ROIPooling / Concat of blobs with one common source.
+  void WireAmax();
+  void* amax_slots_ = nullptr;
+  vector<int> amax_src_;          // convolution layer -> the convolution layer whose max |y| bounds its bottom, or -1
 
   string name_;
   Phase phase_;

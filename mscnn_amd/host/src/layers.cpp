@@ -164,10 +164,14 @@ void ConvolutionLayer<Dtype>::Plan(int n, int h, int w) {
 
 template <typename Dtype>
 void ConvolutionLayer<Dtype>::set_algo(int algo) {
-  CHECK(algo >= 0 && algo <= 4) << "unknown mscnn_conv_algo " << algo;
+  CHECK(algo >= 0 && algo <= 5) << "unknown mscnn_conv_algo " << algo;
   if (algo == algo_) return;
   algo_ = algo;
   if (plan_) { mscnn_conv2d_plan_destroy(plan_); plan_ = nullptr; }
+}
+template <typename Dtype>
+bool ConvolutionLayer<Dtype>::publishes_amax() const {
+  return plan_ && amax_wanted_ && amax_out_ && mscnn_conv2d_plan_publishes_amax(plan_);
 }
 template <typename Dtype>
 void ConvolutionLayer<Dtype>::set_tuning(int variant, int grid, int flags) {
@@ -264,6 +268,11 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
   const size_t wbytes = mscnn_conv2d_workspace_bytes(plan_);
   void* ws = wbytes ? shared_ws[dev]->Reserve(wbytes) : nullptr;
   const float* bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
+  {
+    const bool pub = amax_wanted_ && amax_out_ && mscnn_conv2d_plan_publishes_amax(plan_);
+    const bool handed = amax_trusted_ && amax_src_ && amax_in_ && amax_src_->publishes_amax();
+    MSCNN_CHECK(mscnn_conv2d_plan_set_amax_io(plan_, handed ? amax_in_ : nullptr, pub ? amax_out_ : nullptr));
+  }
   float* pooled = nullptr;
   if (pooled_top_) {
     // the fused-away Pooling layer's Reshape would run AFTER this Forward (layer.hpp:451-456): shape its top here, so that a

@@ -5,12 +5,14 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <set>
 #include <sstream>
 #include <utility>
 
+#include "../../../include/mscnn_hip.h"
 #include "caffe/layer_factory.hpp"
 #include "caffe/layers/mscnn_layers.hpp"
 #include "caffe/net.hpp"
@@ -202,7 +204,39 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
   calib_err_.assign(layers_.size(), 0.0);
   layer_ms_.assign(layers_.size(), 0.f);
   if (fusion_) ApplyFusion();
+  WireAmax();
   LOG(INFO) << "Network initialization done.";
+}
+
+template <typename Dtype>
+Net<Dtype>::~Net() {
+  if (amax_slots_) (void)hipFree(amax_slots_);
+}
+
+template <typename Dtype>
+void Net<Dtype>::WireAmax() {
+  // (the slots are allocated by the first forward that has a split-fp16 layer: building a net needs no device)
+  amax_src_.assign(layers_.size(), -1);
+  vector<int> src(blobs_.size(), -1);           // blob id -> convolution layer whose max |y| bounds the blob
+  for (size_t i = 0; i < layers_.size(); ++i) {
+    const string t = layers_[i]->type();
+    ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
+    int s = -1;
+    if (c) {
+      const int b = bottom_id_vecs_[i].empty() ? -1 : src[bottom_id_vecs_[i][0]];
+      amax_src_[i] = b;
+      s = (int)i;
+    } else if (t == "Split" || t == "ReLU" || t == "Dropout" || t == "ROIPooling" ||
+               (t == "Pooling" && layers_[i]->layer_param().pooling_param().pool() == PoolingParameter_PoolMethod_MAX)) {
+      // max |.| never grows through these (ReLU with a negative slope in [-1, 1] included)
+      s = bottom_id_vecs_[i].empty() ? -1 : src[bottom_id_vecs_[i][0]];
+      if (t == "ReLU" && std::fabs(layers_[i]->layer_param().relu_param().negative_slope()) > 1) s = -1;
+    } else if (t == "Concat" && !bottom_id_vecs_[i].empty()) {
+      s = src[bottom_id_vecs_[i][0]];
+      for (size_t b = 1; b < bottom_id_vecs_[i].size(); ++b) if (src[bottom_id_vecs_[i][b]] != s) s = -1;
+    }
+    for (size_t k = 0; k < top_id_vecs_[i].size(); ++k) src[top_id_vecs_[i][k]] = s;
+  }
 }
 
 // Conv / InnerProduct followed by an in-place ReLU on its top (every trunk conv of the deploy nets): the ReLU is
@@ -318,6 +352,33 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   CHECK_LT(end, (int)layers_.size());
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing_) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
+  {
+    // split-fp16 convolutions take the bound of their input from the producing convolution when it runs in this same call
+    // from the top (slots zeroed here, once); a partial range makes them measure it themselves
+    bool any = false;
+    for (size_t i = 0; i < layers_.size(); ++i)
+      if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) c->set_amax_wanted(false);
+    for (size_t i = 0; i < layers_.size(); ++i) {
+      ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
+      if (!c) continue;
+      c->set_amax_trusted(start == 0);
+      if (c->algo() == MSCNN_CONV_ALGO_WINO_F3_X3 && amax_src_[i] >= 0 && start == 0) {
+        static_cast<ConvolutionLayer<Dtype>*>(layers_[amax_src_[i]].get())->set_amax_wanted(true);
+        any = true;
+      }
+    }
+    if (any && !amax_slots_) {
+      HIP_CHECK(hipMalloc(&amax_slots_, sizeof(unsigned) * layers_.size()));
+      unsigned* slots = static_cast<unsigned*>(amax_slots_);
+      for (size_t i = 0; i < layers_.size(); ++i)
+        if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) {
+          const int b = amax_src_[i];
+          c->set_amax_io(b >= 0 ? static_cast<const ConvolutionLayer<Dtype>*>(layers_[b].get()) : nullptr, b >= 0 ? slots + b : nullptr,
+                         slots + i);
+        }
+    }
+    if (any) HIP_CHECK(hipMemsetAsync(amax_slots_, 0, sizeof(unsigned) * layers_.size(), (hipStream_t)Caffe::stream()));
+  }
   for (int i = start; i <= end; ++i) {
     bool run = !fused_away_[i];
     if (fused_away_[i]) {

@@ -150,7 +150,8 @@ class Net:
         return tuple(out)
 
     def set_precision(self, dtype):
-        """"f32" (default, reference parity) or "f16" (fp16 MFMA operands, fp32 accumulate: BASELINE config 5)."""
+        """"f32" (default, reference parity), "f16" (fp16 MFMA operands, fp32 accumulate: BASELINE config 5) or "f16x3" (the
+        Winograd plane GEMMs on the fp16 pipe with exactly split operands: fp32-grade, same parity gates as "f32")."""
         _check(lib().mscnn_net_set_precision(self._h, dtype.encode()))
 
     def layer_dtype(self, i):

@@ -48,9 +48,11 @@ FULL_SIZE = [
 ]
 
 
-def check_net(model, size, regime, cls_id, org_hw=(375, 1242), backend=None):
+def check_net(model, size, regime, cls_id, org_hw=(375, 1242), backend=None, precision=None):
     from oracle import pynet, pyoracle as orc
     n = mnet.Net(prototxt_text=zoo.prototxt(model, **size))
+    if precision:
+        n.set_precision(precision)
     ws = synth.load_into(n, regime)
     H, W = n.blob_shape("data")[2:]
     x = synth.frame(H, W, org_hw=org_hw)
@@ -58,6 +60,9 @@ def check_net(model, size, regime, cls_id, org_hw=(375, 1242), backend=None):
     n.forward()
     layers = layer_list(n)
     report = {}
+    if precision:
+        report["layers_" + precision] = sum(n.layer_dtype(i) == precision for i in range(len(n.layer_names)))
+        assert report["layers_" + precision] >= 3, report
 
     # (1) end-to-end oracle run (its own intermediate values)
     ref = pynet.forward(layers, ws, {"data": x}, backend=backend)
@@ -131,6 +136,31 @@ def test_net_layerwise_and_end_to_end(model, size, regime, cls_id):
     if not torch.cuda.is_available():
         pytest.fail("needs a MI355X")
     check_net(model, size, regime, cls_id)
+
+
+@pytest.mark.parametrize("model,size,regime,cls_id", [CONFIGS[0], CONFIGS[2]])
+def test_net_x3_precision_same_gates_as_fp32(model, size, regime, cls_id):
+    """set_precision("f16x3") (split-fp16 Winograd GEMMs, max |x| handed from layer to layer on the device) is held to exactly
+    the fp32 gates of check_net: per-layer 1e-4 against the oracle, selection layers bit-exact, >= 98 % matched detections."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a MI355X")
+    rep = check_net(model, size, regime, cls_id, precision="f16x3")
+    print("\nX3", model, {k: (f"{v:.1e}" if isinstance(v, float) else v) for k, v in rep.items()})
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("model,size,regime,cls_id,org_hw", [FULL_SIZE[0], FULL_SIZE[3]])
+def test_full_size_parity_x3_vs_reference(model, size, regime, cls_id, org_hw):
+    """The f16x3 mode at BASELINE sizes against the reference's own CPU layers, fp32 gates."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a MI355X")
+    from oracle import pyref
+    if not pyref.available():
+        pytest.fail("oracle/_ref/libmscnn_ref.so did not travel to this box")
+    rep = check_net(model, size, regime, cls_id, org_hw, backend=pyref, precision="f16x3")
+    worst = max(v for k, v in rep.items() if isinstance(v, float) and k != "matched")
+    print(f"\nFULLSIZE-X3 {model} {regime}: R {rep['R']}/{rep['R_ref']} dets {rep['dets']}/{rep['dets_ref']} matched {rep['matched']} "
+          f"x3 layers {rep['layers_f16x3']} worst per-blob err {worst:.2e}")
 
 
 @pytest.mark.slow
