@@ -108,11 +108,14 @@ MSCNN_API int mscnn_conv2d_plan_set_profiling(mscnn_conv_plan* plan, int on);
 MSCNN_API int mscnn_conv2d_plan_stage_ms(const mscnn_conv_plan* plan, float ms_out[3]);
 /* max |x| hand-over between the layers of a chain (split-fp16 plans, MSCNN_CONV_ALGO_WINO_F3_X3).  Such a plan needs an upper
  * bound of max |x| of its input; by default it measures it itself (one streaming pass over x per forward).
- *   in_bound  (device, the bit pattern of a float >= max |x|; NULL = measure): read by this plan's forward instead;
- *   out_amax  (device; NULL = off): the plan's forward does atomicMax(bits of max |y|) into it -- the caller zeroes it before
- *             the forward.  Only the F(3x3,3x3) forms publish (mscnn_conv2d_plan_publishes_amax() == 1); for other plans a
+ * Both are DEVICE arrays of MSCNN_AMAX_SLOTS uint32 holding float bit patterns; the value they stand for is their maximum
+ * (thousands of workgroups publishing into one address would serialise, so each takes one of the slots):
+ *   in_bound  (max over the slots >= max |x|; NULL = measure): read by this plan's forward instead;
+ *   out_amax  (NULL = off): the plan's forward does atomicMax(bits of a partial max |y|) into the slots -- the caller zeroes
+ *             them before the forward.  Only the F(3x3,3x3) forms publish (mscnn_conv2d_plan_publishes_amax() == 1); for other plans a
  *             non-NULL out_amax is MSCNN_ERR_UNSUPPORTED.
  * A max-pooled or ROI-pooled copy of y is bounded by the same value. */
+#define MSCNN_AMAX_SLOTS 1024
 MSCNN_API int mscnn_conv2d_plan_publishes_amax(const mscnn_conv_plan* plan);
 MSCNN_API int mscnn_conv2d_plan_set_amax_io(mscnn_conv_plan* plan, const uint32_t* in_bound, uint32_t* out_amax);
 /* Re-shape a plan for a new batch size N (ROI count changes per image, layer.hpp:451-456). */

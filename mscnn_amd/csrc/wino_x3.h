@@ -12,7 +12,7 @@ struct X3Plan {
   long T_pad = 0;
   size_t packed_bytes = 0;   // header + U16
   size_t v_bytes = 0;        // V16 planes
-  size_t scal_bytes = 256;   // device scalars (amax of the input) in front of the workspace
+  size_t scal_bytes = 4096;  // kAmaxSlots partial maxima of |x| in front of the workspace (when the plan measures them itself)
 };
 
 // false when the shape is not covered (Cin not a multiple of 32, planes beyond the 32-bit buffer window)
@@ -20,7 +20,7 @@ bool x3_plan(int Cin, int Cout, long T_pad, int tune_variant, X3Plan* out);
 
 int x3_pack_weights(const X3Plan& p, const float* w, void* packed, hipStream_t st);
 
-// scal <- max |x| over the n floats of x (device scalar, written as the float's bit pattern)
+// scal[0 .. kAmaxSlots) <- partial maxima (bit patterns) of |x| over the n floats of x; their maximum is max |x|
 int x3_amax(const float* x, long n, unsigned* scal, hipStream_t st);
 
 // V16[plane][part][kg][t][8] = split(s * (B^T d B)); H * W <= 64: the ROI-map form (tiles of one ROI are consecutive t)

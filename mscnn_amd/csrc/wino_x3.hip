@@ -22,13 +22,14 @@
 // ds_write_b128, read back with one conflict-free ds_read_b128 per operand.  M comes out in the fp32 path's layout
 // [plane][Cout][T_pad] so the output transforms (winograd.hip) are shared.
 #include "wino_x3.h"
+#include "winograd.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr size_t kHdrBytes = 256;      // packed weights: float[0] = 1 / s_U, uint[1] = bits of max |g|
+constexpr size_t kHdrBytes = 8192;     // packed weights: float[0] = 1 / s_U; bytes 4096.. = the kAmaxSlots partial maxima of |g|
 constexpr unsigned kOob = 0x80000000u;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -50,6 +51,20 @@ __device__ __forceinline__ void split16(float v, _Float16* hi, _Float16* lo) {
   *lo = (_Float16)(v - (float)h);
 }
 
+// max over the kAmaxSlots published partial maxima (winograd.hip publish_amax / amax_kernel below): 4 loads per thread, served by
+// the L2.  Every thread of the 256-thread workgroup must call this; returns the float whose bit pattern is the maximum.
+__device__ __forceinline__ float bound_from_slots(const unsigned* __restrict__ slots) {
+  __shared__ unsigned s_b[4];
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < mscnn::kAmaxSlots / 256; ++i) m = max(m, slots[threadIdx.x + 256 * i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = m;
+  __syncthreads();
+  return __uint_as_float(max(max(s_b[0], s_b[1]), max(s_b[2], s_b[3])));
+}
+
 // ---- max |x| -----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
   __shared__ unsigned s_m[4];
@@ -65,13 +80,13 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
   if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(out, max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));
+  if (threadIdx.x == 0) atomicMax(out + (blockIdx.x & (mscnn::kAmaxSlots - 1)), max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])));
 }
 
 // ---- weights: U = G g G^T, scaled, split ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void x3_weight_kernel(const float* __restrict__ w, unsigned char* __restrict__ packed, int Cout,
                                                         int Cin, int Cout_pad, int KG) {
-  const float amax = __uint_as_float(reinterpret_cast<const unsigned*>(packed)[1]);
+  const float amax = bound_from_slots(reinterpret_cast<const unsigned*>(packed + kHdrBytes / 2));
   float s, inv;
   pow2_scale(2.25f * amax, &s, &inv);
   if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(packed)[0] = inv;
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(256) void x3_input_plane_kernel(const float* __rest
   const long t0 = (long)blockIdx.x * 32;
   const int t = (int)t0 + q, ci = kg * 8 + c;
   float s, inv;
-  pow2_scale(36.f * __uint_as_float(scal[0]), &s, &inv);
+  pow2_scale(36.f * bound_from_slots(scal), &s, &inv);
   float d[5][5];
   if (t < T) {
     const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
@@ -220,9 +235,8 @@ __global__ __launch_bounds__(256) void x3_input_roi_kernel(const float* __restri
       for (int i = tid; i < run; i += 256) dst[i] = src[i];
     }
   }
-  __syncthreads();
   float s, inv;
-  pow2_scale(36.f * __uint_as_float(scal[0]), &s, &inv);
+  pow2_scale(36.f * bound_from_slots(scal), &s, &inv);       // (its barrier also publishes the staged maps)
   const int nq = nr * tpr;                       // <= 32
   const int q = tid & 31, c = tid >> 5;
   if (q < nq) {
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
 
   // epilogue: un-scale (exact: powers of two), store M[plane][co][t]
   float sv, inv_v;
-  pow2_scale(36.f * __uint_as_float(a.scal[0]), &sv, &inv_v);
+  pow2_scale(36.f * bound_from_slots(a.scal), &sv, &inv_v);
   const float inv = inv_v * a.hdr[0];
   const unsigned m_bytes = 25u * (unsigned)a.Cout * a.T_pad * 4u;
   const __amdgpu_buffer_rsrc_t msrc = make_rsrc(a.M, m_bytes);
@@ -409,9 +423,9 @@ bool x3_plan(int Cin, int Cout, long T_pad, int tune_variant, X3Plan* out) {
 }
 
 int x3_amax(const float* x, long n, unsigned* scal, hipStream_t st) {
-  MSCNN_HIP_TRY(hipMemsetAsync(scal, 0, 16, st));
+  MSCNN_HIP_TRY(hipMemsetAsync(scal, 0, sizeof(unsigned) * kAmaxSlots, st));
   long blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > kAmaxSlots) blocks = kAmaxSlots;       // one atomic per slot
   if (blocks < 1) blocks = 1;
   amax_kernel<<<(int)blocks, 256, 0, st>>>(x, n, scal);
   MSCNN_POST_LAUNCH();
@@ -420,7 +434,7 @@ int x3_amax(const float* x, long n, unsigned* scal, hipStream_t st) {
 
 int x3_pack_weights(const X3Plan& p, const float* w, void* packed, hipStream_t st) {
   unsigned* hdr = static_cast<unsigned*>(packed);
-  int rc = x3_amax(w, (long)p.Cout * p.Cin * 9, hdr + 1, st);
+  int rc = x3_amax(w, (long)p.Cout * p.Cin * 9, hdr + kHdrBytes / 8, st);
   if (rc != MSCNN_OK) return rc;
   const long total = (long)p.Cout_pad * p.KG * 8;
   long blocks = (total + 255) / 256;

@@ -5,6 +5,8 @@
 
 namespace mscnn {
 
+constexpr int kAmaxSlots = 1024;   // == MSCNN_AMAX_SLOTS (mscnn_hip.h)
+
 // U[xi*4+nu] = (G g G^T)[xi][nu] for every (co, ci), written in the igemm packed layout of a 1x1 convolution with
 // per-"image" weights:  wp[xinu][mt][kc][ck][BM]  (zero padded in Cout and Cin).
 int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, int BM, int CK, int MT, int KI, hipStream_t st);
@@ -18,6 +20,7 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
 // y_pool != nullptr: also write max over the tile's (in-plane) outputs to y_pool[n][co][ty][tx] (fused 2x2/2 max pooling).
 int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
                           int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st, unsigned* amax = nullptr);
-// amax != nullptr (m == 3 only): atomicMax of the bit pattern of max |y| into *amax (the caller zeroes it before the forward)
+// amax != nullptr (m == 3 only): max |y| is published as bit patterns into amax[0 .. kAmaxSlots) (atomicMax, one slot per
+// workgroup; the caller zeroes the slots before the forward and takes the maximum over them)
 
 }  // namespace mscnn

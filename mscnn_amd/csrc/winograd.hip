@@ -334,12 +334,18 @@ __global__ __launch_bounds__(256) void wino33_input_plane_kernel(const float* __
   }
 }
 
-// max |y| of a layer's output for the split-fp16 consumer (wino_x3.hip): wave maximum of the bit patterns, one atomic per wave
-// and only when it would raise the value already there (a stale read only costs a redundant atomic: the value is monotonic)
+// max |y| of a layer's output for the split-fp16 consumer (wino_x3.hip): the workgroup's maximum of the bit patterns goes, with
+// ONE fire-and-forget atomic, into one of kAmaxSlots slots chosen by the workgroup id -- thousands of workgroups hitting a
+// single address cost 45 us per layer (measured), spread over 1024 addresses they cost nothing measurable; the consumer takes
+// the maximum over the slots.  Every thread of the workgroup must call this.
 __device__ __forceinline__ void publish_amax(unsigned m, unsigned* amax) {
+  __shared__ unsigned s_am[4];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
+  if ((threadIdx.x & 63) == 0) s_am[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(amax + ((blockIdx.y * gridDim.x + blockIdx.x) & (mscnn::kAmaxSlots - 1)), max(max(s_am[0], s_am[1]), max(s_am[2], s_am[3])));
 }
 
 __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,

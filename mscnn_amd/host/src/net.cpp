@@ -368,16 +368,16 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
       }
     }
     if (any && !amax_slots_) {
-      HIP_CHECK(hipMalloc(&amax_slots_, sizeof(unsigned) * layers_.size()));
+      HIP_CHECK(hipMalloc(&amax_slots_, sizeof(unsigned) * MSCNN_AMAX_SLOTS * layers_.size()));
       unsigned* slots = static_cast<unsigned*>(amax_slots_);
       for (size_t i = 0; i < layers_.size(); ++i)
         if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) {
           const int b = amax_src_[i];
-          c->set_amax_io(b >= 0 ? static_cast<const ConvolutionLayer<Dtype>*>(layers_[b].get()) : nullptr, b >= 0 ? slots + b : nullptr,
-                         slots + i);
+          c->set_amax_io(b >= 0 ? static_cast<const ConvolutionLayer<Dtype>*>(layers_[b].get()) : nullptr,
+                         b >= 0 ? slots + (size_t)b * MSCNN_AMAX_SLOTS : nullptr, slots + i * MSCNN_AMAX_SLOTS);
         }
     }
-    if (any) HIP_CHECK(hipMemsetAsync(amax_slots_, 0, sizeof(unsigned) * layers_.size(), (hipStream_t)Caffe::stream()));
+    if (any) HIP_CHECK(hipMemsetAsync(amax_slots_, 0, sizeof(unsigned) * MSCNN_AMAX_SLOTS * layers_.size(), (hipStream_t)Caffe::stream()));
   }
   for (int i = start; i <= end; ++i) {
     bool run = !fused_away_[i];
