@@ -154,6 +154,17 @@ MSCNN_API int mscnn_inner_product_fwd_f32(const float* x, const float* w, const 
 /* fp16-operand InnerProduct (the counterpart of MSCNN_CONV_ALGO_F16; no reference counterpart): w16 = the weights converted
  * once to fp16 [N][K] (mscnn_inner_product_pack_f16, N * K * 2 bytes), x rounded to fp16 on its way into LDS, fp32 accumulate.
  * Needs N >= 64 and K % 8 == 0 (mscnn_inner_product_f16_supported); smaller layers stay on the fp32 entry point. */
+/* Split-fp16 InnerProduct (fp32-grade: see MSCNN_CONV_ALGO_WINO_F3_X3): w packed once into exactly split fp16 hi + lo units
+ * (mscnn_inner_product_x3_pack, mscnn_inner_product_x3_packed_bytes), x split on the device every forward with the scale taken
+ * from max |x| -- handed over in in_bound (MSCNN_AMAX_SLOTS uint32, see mscnn_conv2d_plan_set_amax_io) or, when NULL, measured.
+ * Three fp16 MFMAs per operand pair, fp32 accumulate, K cut into ranges whose partial sums are added in a fixed order.
+ * Needs N >= 128 and K % 32 == 0. */
+MSCNN_API int mscnn_inner_product_x3_supported(int N, int K);
+MSCNN_API size_t mscnn_inner_product_x3_packed_bytes(int N, int K);
+MSCNN_API size_t mscnn_inner_product_x3_workspace_bytes(int M, int N, int K);
+MSCNN_API int mscnn_inner_product_x3_pack(const float* w, void* packed, int N, int K, void* stream);
+MSCNN_API int mscnn_inner_product_x3_fwd(const float* x, const void* packed, const float* bias, float* y, int M, int N, int K, int relu,
+                               const uint32_t* in_bound, void* workspace, size_t workspace_bytes, void* stream);
 MSCNN_API int mscnn_inner_product_f16_supported(int N, int K);
 MSCNN_API int mscnn_inner_product_pack_f16(const float* w, void* w16, int N, int K, void* stream);
 MSCNN_API int mscnn_inner_product_fwd_f16(const float* x, const void* w16, const float* bias, float* y, int M, int N, int K, int relu,

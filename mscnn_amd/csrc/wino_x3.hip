@@ -281,6 +281,9 @@ struct X3Args {
   const void* U; const void* V; float* M; const unsigned* scal; const float* hdr;
   int Cout, Cout_pad, KG, KI, MT, NT, tiles, xcd_map;
   unsigned T_pad;
+  int planes;        // 25 (Winograd), 1 (InnerProduct)
+  int ks;            // k-split: > 0 = every tile is cut into ks ranges of KI / ks chunks whose raw accumulators go to
+  float* slabs;      //          slabs[((plane * NT + nt) * MT + mt) * ks + s][BM][128] (summed in s order by x3_fixup_kernel); 0 = off
 };
 
 // Workgroup = BM x 128 tile of one plane, 4 waves as 2 x 2, wave tile (BM/2) x 64 = MI x 2 MFMA blocks.  A k-chunk is 32
@@ -303,12 +306,14 @@ __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
     const int xcd = ti % 8, gq = a.tiles / 8, gr = a.tiles % 8;
     ti = xcd * gq + min(xcd, gr) + ti / 8;
   }
-  const int per_plane = a.MT * a.NT;
+  const int ks = a.ks > 0 ? a.ks : 1;
+  const int per_plane = a.MT * a.NT * ks;
   const int plane = ti / per_plane, rem = ti % per_plane;
-  const int nt = rem / a.MT, mt = rem % a.MT;
+  const int nt = rem / (a.MT * ks), ksi = (rem / a.MT) % ks, mt = rem % a.MT;    // mt fastest: the workgroups sharing a B tile
+  const int kc0 = ksi * (a.KI / ks), kc1 = kc0 + a.KI / ks;
 
-  const unsigned a_bytes = 50u * (unsigned)a.KG * (unsigned)a.Cout_pad * 16u;
-  const unsigned v_bytes = 50u * (unsigned)a.KG * a.T_pad * 16u;
+  const unsigned a_bytes = 2u * (unsigned)a.planes * (unsigned)a.KG * (unsigned)a.Cout_pad * 16u;
+  const unsigned v_bytes = 2u * (unsigned)a.planes * (unsigned)a.KG * a.T_pad * 16u;
   const __amdgpu_buffer_rsrc_t asrc = make_rsrc(a.U, a_bytes), bsrc = make_rsrc(a.V, v_bytes);
   // unit u = tid + 256 i of a tile: (part, kgl, row) with row fastest
   unsigned a_off[AU], b_off[BU];
@@ -342,14 +347,14 @@ __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  load_chunk(0);
-  for (int kc = 0; kc < a.KI; ++kc) {
+  load_chunk(kc0);
+  for (int kc = kc0; kc < kc1; ++kc) {
 #pragma unroll
     for (int i = 0; i < AU; ++i) ldsA[tid + 256 * i] = ra[i];
 #pragma unroll
     for (int i = 0; i < BU; ++i) ldsB[tid + 256 * i] = rb[i];
     __syncthreads();
-    if (kc + 1 < a.KI) load_chunk(kc + 1);
+    if (kc + 1 < kc1) load_chunk(kc + 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int kgl = 2 * s + khalf;
@@ -376,11 +381,23 @@ __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
     __syncthreads();
   }
 
+  if (a.ks > 0) {      // raw partial sums; x3_fixup_kernel adds the ks slabs of a tile in order, un-scales, adds the bias
+    float* slab = a.slabs + ((size_t)((plane * a.NT + nt) * a.MT + mt) * ks + ksi) * (BM * 128);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float* sp = slab + (wm * WM + mi * 32 + 4 * khalf) * 128 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sp[((r & 3) + 8 * (r >> 2)) * 128] = acc[mi][ni][r];
+      }
+    return;
+  }
   // epilogue: un-scale (exact: powers of two), store M[plane][co][t]
   float sv, inv_v;
   pow2_scale(36.f * bound_from_slots(a.scal), &sv, &inv_v);
   const float inv = inv_v * a.hdr[0];
-  const unsigned m_bytes = 25u * (unsigned)a.Cout * a.T_pad * 4u;
+  const unsigned m_bytes = (unsigned)a.planes * (unsigned)a.Cout * a.T_pad * 4u;
   const __amdgpu_buffer_rsrc_t msrc = make_rsrc(a.M, m_bytes);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -395,6 +412,65 @@ __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[mi][ni][r] * inv), msrc, vo,
                                               (unsigned)row * a.T_pad * 4u, 0);
       }
+    }
+  }
+}
+
+// ---- InnerProduct: y[M][N] = x[M][K] w[N][K]^T + bias on the same GEMM kernel (A = the rows of x, B = the rows of w) ----------
+// fp32 rows x[R][K] -> split units out[part][kg][R_pad][8], scaled by 2^e from the bound in `slots`; rows R .. R_pad are zeros.
+// Thread = (row, kg): 32 contiguous bytes in, 2 x 16 bytes out; a wave covers 8 rows x 8 kg (256-byte runs in, 128-byte out).
+__global__ __launch_bounds__(256) void x3_split_rows_kernel(const float* __restrict__ x, uint4* __restrict__ out,
+                                                            const unsigned* __restrict__ slots, int R, int K, int R_pad, float* inv_out) {
+  float s, inv;
+  pow2_scale(bound_from_slots(slots), &s, &inv);
+  if (inv_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *inv_out = inv;
+  const int KG = K / 8;
+  const int row = blockIdx.y * 32 + (threadIdx.x >> 3), kg = blockIdx.x * 8 + (threadIdx.x & 7);
+  if (row >= R_pad || kg >= KG) return;
+  f16x8 hi, lo;
+  if (row < R) {
+    const float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * K + kg * 8);
+    const float4 b = *reinterpret_cast<const float4*>(x + (size_t)row * K + kg * 8 + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      _Float16 h, l;
+      split16(v[i] * s, &h, &l);
+      hi[i] = h; lo[i] = l;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { hi[i] = (_Float16)0.f; lo[i] = (_Float16)0.f; }
+  }
+  out[(size_t)kg * R_pad + row] = __builtin_bit_cast(uint4, hi);
+  out[((size_t)KG + kg) * R_pad + row] = __builtin_bit_cast(uint4, lo);
+}
+
+// y[row][col] = relu?((sum over the ks slabs of the tile, in order) * inv_x * inv_w + bias[col]); one workgroup per 128 x 128 tile
+__global__ __launch_bounds__(256) void x3_fixup_kernel(const float* __restrict__ slabs, const float* __restrict__ inv_x,
+                                                       const float* __restrict__ inv_w, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int M, int N, int MT, int ks, int relu) {
+  const int mt = blockIdx.x % MT, nt = blockIdx.x / MT;
+  const float inv = inv_x[0] * inv_w[0];
+  const float* base = slabs + (size_t)(nt * MT + mt) * ks * (128 * 128);
+#pragma unroll 1
+  for (int j = 0; j < 16; ++j) {
+    const int i = (j * 256 + threadIdx.x) * 4;       // 4 consecutive columns of one row
+    const int r = i / 128, c = i % 128;
+    const int row = mt * 128 + r, col = nt * 128 + c;
+    if (row >= M) continue;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < ks; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(base + (size_t)s * (128 * 128) + i);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    float o[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (col + q >= N) continue;
+      float t = o[q] + (bias ? bias[col + q] : 0.f);
+      if (relu) t = t > 0.f ? t : 0.f;
+      y[(size_t)row * N + col + q] = t;
     }
   }
 }
@@ -468,6 +544,7 @@ int x3_gemm(const X3Plan& p, const void* packed, const void* V16, float* M, cons
   a.V = V16; a.M = M; a.scal = scal; a.hdr = static_cast<const float*>(packed);
   a.Cout = p.Cout; a.Cout_pad = p.Cout_pad; a.KG = p.KG; a.KI = p.KG / 4; a.MT = p.MT; a.NT = p.NT;
   a.tiles = 25 * p.MT * p.NT; a.xcd_map = xcd_map; a.T_pad = (unsigned)p.T_pad;
+  a.planes = 25; a.ks = 0; a.slabs = nullptr;
   if (p.BM == 256) x3_gemm_kernel<256><<<a.tiles, 256, 0, st>>>(a);
   else x3_gemm_kernel<128><<<a.tiles, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
@@ -475,3 +552,85 @@ int x3_gemm(const X3Plan& p, const void* packed, const void* V16, float* M, cons
 }
 
 }  // namespace mscnn
+
+// ---- C ABI: InnerProduct on the split-fp16 GEMM -------------------------------------------------------------------------------
+using namespace mscnn;
+
+namespace {
+struct IpShape { int KG, KI, N_pad, NT, M_pad, MT, ks; size_t x_bytes, slab_bytes; };
+IpShape ip_shape(int M, int N, int K) {
+  IpShape s;
+  s.KG = K / 8; s.KI = K / 32;
+  s.N_pad = (N + 127) / 128 * 128; s.NT = s.N_pad / 128;
+  s.M_pad = (M + 127) / 128 * 128; s.MT = s.M_pad / 128;
+  s.ks = 1;      // enough workgroups for 256 CUs x 3: cut K (the slabs are summed in order: deterministic)
+  for (int k = 1; k <= 16; ++k)
+    if (s.KI % k == 0) { s.ks = k; if ((long)s.MT * s.NT * k >= 768) break; }
+  s.x_bytes = (size_t)2 * s.KG * s.M_pad * 16;
+  s.slab_bytes = (size_t)s.MT * s.NT * s.ks * 128 * 128 * sizeof(float);
+  return s;
+}
+}  // namespace
+
+extern "C" int mscnn_inner_product_x3_supported(int N, int K) { return N >= 128 && K % 32 == 0 && K >= 32; }
+
+extern "C" size_t mscnn_inner_product_x3_packed_bytes(int N, int K) {
+  return kHdrBytes + (size_t)2 * (K / 8) * ((N + 127) / 128 * 128) * 16;
+}
+
+extern "C" size_t mscnn_inner_product_x3_workspace_bytes(int M, int N, int K) {
+  const IpShape s = ip_shape(M, N, K);
+  return 8192 + s.x_bytes + s.slab_bytes;
+}
+
+extern "C" int mscnn_inner_product_x3_pack(const float* w, void* packed, int N, int K, void* stream) {
+  MSCNN_REQUIRE(w && packed && mscnn_inner_product_x3_supported(N, K), "inner_product x3 pack: bad argument (N=%d K=%d)", N, K);
+  hipStream_t st = as_stream(stream);
+  unsigned char* pk = static_cast<unsigned char*>(packed);
+  unsigned* slots = reinterpret_cast<unsigned*>(pk + kHdrBytes / 2);
+  int rc = x3_amax(w, (long)N * K, slots, st);
+  if (rc != MSCNN_OK) return rc;
+  const int N_pad = (N + 127) / 128 * 128;
+  dim3 grid(cdiv(K / 8, 8), cdiv(N_pad, 32));
+  x3_split_rows_kernel<<<grid, 256, 0, st>>>(w, reinterpret_cast<uint4*>(pk + kHdrBytes), slots, N, K, N_pad, reinterpret_cast<float*>(pk));
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+extern "C" int mscnn_inner_product_x3_fwd(const float* x, const void* packed, const float* bias, float* y, int M, int N, int K,
+                                          int relu, const uint32_t* in_bound, void* workspace, size_t workspace_bytes, void* stream) {
+  MSCNN_REQUIRE(M >= 0 && N > 0 && K > 0, "inner_product: bad shape M=%d N=%d K=%d", M, N, K);
+  if (M == 0) return MSCNN_OK;
+  MSCNN_REQUIRE(x && packed && y && mscnn_inner_product_x3_supported(N, K) && reinterpret_cast<uintptr_t>(x) % 16 == 0,
+                "inner_product x3: needs N >= 128, K %% 32 == 0, 16-byte aligned x (N=%d K=%d)", N, K);
+  const IpShape s = ip_shape(M, N, K);
+  if (!workspace || workspace_bytes < 8192 + s.x_bytes + s.slab_bytes) {
+    set_error("inner_product x3: workspace %zu < %zu", workspace_bytes, 8192 + s.x_bytes + s.slab_bytes);
+    return MSCNN_ERR_WORKSPACE;
+  }
+  MSCNN_REQUIRE((double)s.x_bytes < 4.0e9 && 2.0 * s.KG * s.N_pad * 16.0 < 4.0e9, "inner_product x3: operand beyond the 32-bit window");
+  hipStream_t st = as_stream(stream);
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  unsigned* slots = reinterpret_cast<unsigned*>(ws);
+  float* inv_x = reinterpret_cast<float*>(ws + 4096);
+  uint4* X16 = reinterpret_cast<uint4*>(ws + 8192);
+  float* slabs = reinterpret_cast<float*>(ws + 8192 + s.x_bytes);
+  if (!in_bound) {
+    const int rc = x3_amax(x, (long)M * K, slots, st);
+    if (rc != MSCNN_OK) return rc;
+  }
+  dim3 grid(cdiv(s.KG, 8), cdiv(s.M_pad, 32));
+  x3_split_rows_kernel<<<grid, 256, 0, st>>>(x, X16, in_bound ? in_bound : slots, M, K, s.M_pad, inv_x);
+  MSCNN_POST_LAUNCH();
+  const unsigned char* pk = static_cast<const unsigned char*>(packed);
+  X3Args a;
+  a.U = X16; a.V = pk + kHdrBytes; a.M = nullptr; a.scal = nullptr; a.hdr = nullptr;
+  a.Cout = M; a.Cout_pad = s.M_pad; a.KG = s.KG; a.KI = s.KI; a.MT = s.MT; a.NT = s.NT;
+  a.tiles = s.MT * s.NT * s.ks; a.xcd_map = 1; a.T_pad = (unsigned)s.N_pad;
+  a.planes = 1; a.ks = s.ks; a.slabs = slabs;
+  x3_gemm_kernel<128><<<a.tiles, 256, 0, st>>>(a);
+  MSCNN_POST_LAUNCH();
+  x3_fixup_kernel<<<s.MT * s.NT, 256, 0, st>>>(slabs, inv_x, reinterpret_cast<const float*>(pk), bias, y, M, N, s.MT, s.ks, relu);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}

@@ -64,6 +64,13 @@ def lib():
         L.mscnn_conv2d_plan_dtype.restype = C.c_char_p
         L.mscnn_conv2d_plan_dtype.argtypes = [C.c_void_p]
         L.mscnn_inner_product_f16_supported.argtypes = [C.c_int, C.c_int]
+        L.mscnn_inner_product_x3_supported.argtypes = [C.c_int, C.c_int]
+        L.mscnn_inner_product_x3_packed_bytes.restype = C.c_size_t
+        L.mscnn_inner_product_x3_packed_bytes.argtypes = [C.c_int, C.c_int]
+        L.mscnn_inner_product_x3_workspace_bytes.restype = C.c_size_t
+        L.mscnn_inner_product_x3_workspace_bytes.argtypes = [C.c_int] * 3
+        L.mscnn_inner_product_x3_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.mscnn_inner_product_x3_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.mscnn_inner_product_pack_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mscnn_inner_product_fwd_f16.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
         for f in ("mscnn_conv2d_plan_flops", "mscnn_conv2d_plan_executed_flops"):
@@ -252,6 +259,23 @@ def inner_product(x, w, bias=None, relu=False):
     Nn = w.shape[0]
     y = torch.empty((M, Nn), dtype=torch.float32, device=x.device)
     _check(lib().mscnn_inner_product_fwd_f32(_dev(x), _dev(w), _dev(bias), _dev(y), M, Nn, K, int(relu), _stream()))
+    return y
+
+
+def inner_product_x3(x, w, bias=None, relu=False, packed=None):
+    """Split-fp16 InnerProduct (fp32-grade): w [N][K] is packed into exactly split fp16 hi + lo units, x is split on the device
+    with a scale from its measured max |x|; three fp16 MFMAs per operand pair, fp32 accumulate."""
+    M, K = x.shape[0], int(x.numel() // max(x.shape[0], 1))
+    Nn = w.shape[0]
+    if not lib().mscnn_inner_product_x3_supported(Nn, K):
+        raise MscnnError(f"inner_product x3 needs N >= 128 and K % 32 == 0 (N={Nn}, K={K})")
+    if packed is None:
+        packed = torch.empty(lib().mscnn_inner_product_x3_packed_bytes(Nn, K), dtype=torch.uint8, device=x.device)
+        _check(lib().mscnn_inner_product_x3_pack(_dev(w), _dev(packed), Nn, K, _stream()))
+    wb = lib().mscnn_inner_product_x3_workspace_bytes(M, Nn, K)
+    ws = torch.empty(wb, dtype=torch.uint8, device=x.device)
+    y = torch.empty((M, Nn), dtype=torch.float32, device=x.device)
+    _check(lib().mscnn_inner_product_x3_fwd(_dev(x), _dev(packed), _dev(bias), _dev(y), M, Nn, K, int(relu), None, _dev(ws), wb, _stream()))
     return y
 
 

@@ -179,7 +179,13 @@ class InnerProductLayer : public Layer<Dtype> {
   // fp16-operand mode (no reference counterpart): weights kept as an fp16 copy, fp32 accumulate; layers the fp16 kernel does
   // not cover (N < 64) keep running fp32.  dtype() says what the last Forward really used.
   void set_f16(bool on) { f16_ = on; w16_dirty_ = true; }
-  const char* dtype() const { return used_f16_ ? "f16" : "f32"; }
+  // split-fp16 mode ("f16x3": fp32-grade, mscnn_inner_product_x3_*); max |x| comes from the convolution that produced the
+  // bottom when the Net wired one (set_amax_in) and ran it in the same forward (set_amax_trusted), else it is measured
+  void set_x3(bool on) { x3_ = on; w16_dirty_ = true; }
+  bool x3() const { return x3_; }
+  void set_amax_in(const ConvolutionLayer<Dtype>* src, const unsigned* in) { amax_src_ = src; amax_in_ = in; }
+  void set_amax_trusted(bool on) { amax_trusted_ = on; }
+  const char* dtype() const { return used_x3_ ? "f16x3" : used_f16_ ? "f16" : "f32"; }
   virtual void OnWeightsChanged() { w16_dirty_ = true; }
   virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
@@ -194,7 +200,10 @@ class InnerProductLayer : public Layer<Dtype> {
   int M_, K_, N_;
   bool bias_term_, relu_;
   bool f16_, w16_dirty_, used_f16_ = false;
-  DeviceBuffer w16_;
+  bool x3_ = false, used_x3_ = false, amax_trusted_ = false;
+  const ConvolutionLayer<Dtype>* amax_src_ = nullptr;
+  const unsigned* amax_in_ = nullptr;
+  DeviceBuffer w16_, x3_ws_;
 };
 
 // include/caffe/layers/concat_layer.hpp (channel axis)

@@ -163,7 +163,7 @@ int mscnn_net_set_precision(mscnn_net* n, const char* dtype) {
     CHECK(d == "f32" || d == "f16" || d == "f16x3") << "precision must be f32, f16 or f16x3, not '" << d << "'";
     for (size_t l = 0; l < n->net->layers().size(); ++l) {
       if (auto* c = conv_of(n, (int)l)) c->set_algo(d == "f16" ? 4 : d == "f16x3" ? 5 : 0);
-      if (auto* ip = dynamic_cast<caffe::InnerProductLayer<float>*>(n->net->layers()[l].get())) ip->set_f16(d == "f16");
+      if (auto* ip = dynamic_cast<caffe::InnerProductLayer<float>*>(n->net->layers()[l].get())) { ip->set_f16(d == "f16"); ip->set_x3(d == "f16x3"); }
     }
   });
 }

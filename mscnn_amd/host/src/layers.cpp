@@ -411,6 +411,21 @@ void InnerProductLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const
 }
 template <typename Dtype>
 void InnerProductLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  used_x3_ = x3_ && mscnn_inner_product_x3_supported(N_, K_);
+  if (used_x3_) {
+    void* pk = w16_.Reserve(mscnn_inner_product_x3_packed_bytes(N_, K_));
+    if (w16_dirty_) {
+      MSCNN_CHECK(mscnn_inner_product_x3_pack(this->blobs_[0]->gpu_data(), pk, N_, K_, S()));
+      w16_dirty_ = false;
+    }
+    const size_t wb = mscnn_inner_product_x3_workspace_bytes(M_, N_, K_);
+    const bool handed = amax_trusted_ && amax_src_ && amax_in_ && amax_src_->publishes_amax();
+    MSCNN_CHECK(mscnn_inner_product_x3_fwd(bottom[0]->gpu_data(), pk, bias_term_ ? this->blobs_[1]->gpu_data() : nullptr,
+                                           top[0]->mutable_gpu_data(), M_, N_, K_, relu_ ? 1 : 0, handed ? amax_in_ : nullptr,
+                                           x3_ws_.Reserve(wb), wb, S()));
+    used_f16_ = false;
+    return;
+  }
   used_f16_ = f16_ && mscnn_inner_product_f16_supported(N_, K_);
   if (used_f16_) {
     void* w16 = w16_.Reserve((size_t)N_ * K_ * 2);

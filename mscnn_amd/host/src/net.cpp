@@ -226,6 +226,8 @@ void Net<Dtype>::WireAmax() {
       const int b = bottom_id_vecs_[i].empty() ? -1 : src[bottom_id_vecs_[i][0]];
       amax_src_[i] = b;
       s = (int)i;
+    } else if (t == "InnerProduct") {
+      amax_src_[i] = bottom_id_vecs_[i].empty() ? -1 : src[bottom_id_vecs_[i][0]];      // (its own output bounds nothing)
     } else if (t == "Split" || t == "ReLU" || t == "Dropout" || t == "ROIPooling" ||
                (t == "Pooling" && layers_[i]->layer_param().pooling_param().pool() == PoolingParameter_PoolMethod_MAX)) {
       // max |.| never grows through these (ReLU with a negative slope in [-1, 1] included)
@@ -359,6 +361,13 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
     for (size_t i = 0; i < layers_.size(); ++i)
       if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) c->set_amax_wanted(false);
     for (size_t i = 0; i < layers_.size(); ++i) {
+      if (InnerProductLayer<Dtype>* ip = dynamic_cast<InnerProductLayer<Dtype>*>(layers_[i].get())) {
+        ip->set_amax_trusted(start == 0);
+        if (ip->x3() && amax_src_[i] >= 0 && start == 0) {
+          static_cast<ConvolutionLayer<Dtype>*>(layers_[amax_src_[i]].get())->set_amax_wanted(true);
+          any = true;
+        }
+      }
       ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
       if (!c) continue;
       c->set_amax_trusted(start == 0);
@@ -375,6 +384,9 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
           const int b = amax_src_[i];
           c->set_amax_io(b >= 0 ? static_cast<const ConvolutionLayer<Dtype>*>(layers_[b].get()) : nullptr,
                          b >= 0 ? slots + (size_t)b * MSCNN_AMAX_SLOTS : nullptr, slots + i * MSCNN_AMAX_SLOTS);
+        } else if (InnerProductLayer<Dtype>* ip = dynamic_cast<InnerProductLayer<Dtype>*>(layers_[i].get())) {
+          const int b = amax_src_[i];
+          if (b >= 0) ip->set_amax_in(static_cast<const ConvolutionLayer<Dtype>*>(layers_[b].get()), slots + (size_t)b * MSCNN_AMAX_SLOTS);
         }
     }
     if (any) HIP_CHECK(hipMemsetAsync(amax_slots_, 0, sizeof(unsigned) * MSCNN_AMAX_SLOTS * layers_.size(), (hipStream_t)Caffe::stream()));

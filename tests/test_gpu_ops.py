@@ -538,6 +538,28 @@ def test_inner_product_f16(hip, M, N, K):
         hip.inner_product_f16(x[:, :K - 4].contiguous(), w[:, :K - 4].contiguous())     # K % 8 != 0: the fp32 entry point's job
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 2048, 16384), (150, 2048, 16384), (700, 4096, 12800), (33, 128, 96), (257, 320, 1024), (129, 4096, 800)])
+def test_inner_product_x3(hip, orc, M, N, K):
+    """Split-fp16 InnerProduct against the float64 product: the fp32 bound (1e-4), and no worse than 3x the fp32 MFMA kernel's
+    own error + 2e-6; ragged M (rows padded to 128) and N (320 = 2.5 tiles), k-split slabs summed in order."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.relu(torch.randn((M, K), device="cuda", generator=g)) * 3.0
+    w = torch.randn((N, K), device="cuda", generator=g) * (2.0 / K) ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    ref = torch.relu(x.double() @ w.double().t() + b.double())
+    y3 = hip.inner_product_x3(x, w, b, relu=True)
+    y32 = hip.inner_product(x, w, b, relu=True)
+    e3 = ((y3.double() - ref).abs() / torch.clamp(ref.abs(), min=1.0)).max().item()
+    e32 = ((y32.double() - ref).abs() / torch.clamp(ref.abs(), min=1.0)).max().item()
+    print(f"ip x3 err {e3:.2e}  fp32 err {e32:.2e}")
+    assert e3 < 1e-4 and e3 <= 3 * e32 + 2e-6, (e3, e32)
+    assert torch.equal(y3, hip.inner_product_x3(x, w, b, relu=True))           # deterministic (no atomics in the k-split)
+    y0 = hip.inner_product_x3(torch.zeros_like(x), w, b)                         # all-zero input: scale 1, y = bias
+    assert torch.equal(y0, b[None, :].expand(M, N))
+    with pytest.raises(hip.MscnnError):
+        hip.inner_product_x3(x[:, :K - 4].contiguous(), w[:, :K - 4].contiguous())
+
+
 # ------------------------------------------------------------------ inner product
 @pytest.mark.parametrize("M,N,K", [(1, 5, 64), (7, 20, 4096), (3, 128, 256), (130, 192, 1000), (257, 4096, 800), (1, 4096, 12800),
                                    (3, 10, 9000), (5, 70, 33), (700, 20, 4096), (150, 512, 260), (700, 320, 1000)])
