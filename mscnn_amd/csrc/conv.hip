@@ -27,6 +27,7 @@
 #include "headconv.h"
 #include "winograd.h"
 #include "wino_x3.h"
+#include "x3_device.h"
 #include <new>
 #include <type_traits>
 
@@ -46,6 +47,9 @@ struct IgemmArgs {
   unsigned w_img_bytes;  // per-image weight stride in bytes (0: one weight set; Winograd GEMM: one U matrix per "image")
   int full_q;          // whole tiles per workgroup in the data-parallel phase (tile t = g + j * G, j < full_q)
   long total_iters;    // iterations (tile, chunk) of the stream-K phase: the remaining tiles [full_q * G, MT * NT)
+  // split-fp16 (X3) kernels: kAmaxSlots partial maxima bounding |x| (scale of the activations), 1 / s_w of the packed weights
+  const unsigned* amax_in; const float* w_inv;
+  unsigned* amax_out;  // != nullptr: every kernel of the family publishes max |y| into these slots (x3_device.h)
 };
 constexpr int kSlabsPerWg = 2;   // stream-K tail partial, stream-K head partial
 
@@ -60,6 +64,14 @@ struct Cfg {
   // accumulators; blobs stay fp32 in HBM.  A k-step is 16 input channels of one tap: a lane holds 8 consecutive channels, so
   // both LDS tiles are channel-innermost 16-byte units: A [tap][kg][BM][8], B [kg][patch pixel][8]  (kg = 8-channel group).
   static constexpr bool F16 = F16_ != 0;
+  // X3 (F16_ == 2): the F16 kernel with every fp32 operand split exactly into fp16 hi + lo (x3_device.h) and three MFMAs per
+  // pair -- fp32-grade results.  Both LDS tiles and the packed weights carry a second, "lo" copy behind the "hi" one.
+  static constexpr bool X3 = F16_ == 2;
+  static constexpr int PARTS = X3 ? 2 : 1;
+  // kernels whose output may feed a split-fp16 layer publish max |y| (IgemmArgs::amax_out): the fp32 and X3 3x3 kernels; not
+  // the Winograd GEMM (its output transform does) nor the reduced-precision fp16 mode (registers: the occupancy-bound builds
+  // would spill)
+  static constexpr bool PUBLISH = VEC_ == 0 && F16_ != 1;
   // PF_ == 3: as PF_ == 1, compiled for 4 workgroups per CU (<= 128 VGPRs; the 1x1 VEC kernel fits: 127, no scratch)
   // PF_ == 4 (fp16 kernels, whose inner loop does not use PF): compiled for 3 workgroups per CU (168 VGPRs, 16 B of scratch)
   static constexpr int MIN_WG_PER_CU = PF_ == 3 ? 4 : PF_ == 4 ? 3 : 2;
@@ -86,13 +98,14 @@ struct Cfg {
   static constexpr int CH_STRIDE = ROI ? IPT * IPH * IPW : PH * PW;     // LDS floats per channel
   static constexpr int TAPS = KH * KW;
   static constexpr int A_ELEMS = TAPS * CK * BM;
-  static constexpr int A_VEC4 = (F16_ ? A_ELEMS / 2 : A_ELEMS) / 4;      // float4s of one chunk's packed weight slab
+  static constexpr int A_VEC4 = (F16_ ? A_ELEMS / 2 * PARTS : A_ELEMS) / 4;      // float4s of one chunk's packed weight slab
   static constexpr int A_PER_T = (A_VEC4 + 255) / 256;
   static constexpr int B_ELEMS = CK * CH_STRIDE;
   static constexpr int B_PER_T = F16_ ? 1 : (B_ELEMS + 255) / 256;
   static constexpr int B_UNITS = (CK_ / 8) * CH_STRIDE;                  // F16: 16-byte units (8 channels of one patch pixel)
   static constexpr int BU_PER_T = F16_ ? (B_UNITS + 255) / 256 : 1;
-  static constexpr int A_LDS_FLOATS = F16_ ? A_ELEMS / 2 : A_ELEMS, B_LDS_FLOATS = F16_ ? B_ELEMS / 2 : B_ELEMS;
+  static constexpr int A_LDS_FLOATS = F16_ ? A_ELEMS / 2 * PARTS : A_ELEMS, B_LDS_FLOATS = F16_ ? B_ELEMS / 2 * PARTS : B_ELEMS;
+  static constexpr int A_UNITS = TAPS * (CK_ / 8) * BM_;                 // F16: 16-byte units of one part of the A tile
   static constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
   static constexpr int FIX_SPLIT = (BM * BN) / 4096;                    // fix-up workgroups per tile
   // fused 2x2 max pooling in the epilogue: a 32-pixel MFMA block is two 16-pixel rows (TW 16) or one row whose partner
@@ -151,6 +164,34 @@ __global__ __launch_bounds__(256) void pack_weights_f16_kernel(const float* __re
     const int mt = (int)r;
     const int co = mt * BM + m, ci = kc * CK + kg * 8 + e;
     wp[i] = (_Float16)((co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * taps + tap] : 0.f);
+  }
+}
+
+// X3 kernels: the F16 layout twice -- wp[mt][kc][part][tap][kg][BM][8], part 0 = hi, 1 = lo of w * s_w (exact split,
+// x3_device.h); s_w = the power of two from max |w| found in the slots at hdr + 4096 bytes, 1 / s_w is left in hdr[0].
+__global__ __launch_bounds__(256) void pack_weights_x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, float* __restrict__ hdr,
+                                                              int Cout, int Cin, int taps, int BM, int CK, int MT, int KI) {
+  float s, inv;
+  mscnn::pow2_scale(mscnn::bound_from_slots(reinterpret_cast<const unsigned*>(hdr) + 1024), &s, &inv);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = inv;
+  const long total = (long)MT * KI * taps * CK * BM;
+  const int KG = CK / 8;
+  const long part_stride = (long)taps * CK * BM;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long r = i;
+    const int e = (int)(r % 8); r /= 8;
+    const int m = (int)(r % BM); r /= BM;
+    const int kg = (int)(r % KG); r /= KG;
+    const int tap = (int)(r % taps); r /= taps;
+    const int kc = (int)(r % KI); r /= KI;
+    const int mt = (int)r;
+    const int co = mt * BM + m, ci = kc * CK + kg * 8 + e;
+    const float v = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * taps + tap] : 0.f;
+    _Float16 hi, lo;
+    mscnn::split16(v * s, &hi, &lo);
+    const long chunk = i / part_stride, within = i % part_stride;      // chunk = (mt, kc)
+    wp[chunk * 2 * part_stride + within] = hi;
+    wp[chunk * 2 * part_stride + part_stride + within] = lo;
   }
 }
 
@@ -264,6 +305,13 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
   float4* aWr = reinterpret_cast<float4*>(ldsA) + tid;
 
   const int plane = a.H * a.W;
+  float x3_s = 1.f, x3_inv = 1.f;
+  if constexpr (C::X3) {
+    float inv_x;
+    mscnn::pow2_scale(mscnn::bound_from_slots(a.amax_in), &x3_s, &inv_x);
+    x3_inv = inv_x * a.w_inv[0];
+  }
+  unsigned am = 0;                                // max |y| (bit pattern) of everything this workgroup stores
   const bool ragged_c = (a.Cin % C::CK) != 0;    // last chunk has fewer than CK real channels (conv1_1: Cin = 3)
   const __amdgpu_buffer_rsrc_t wsrc =
       make_rsrc(a.wp, (unsigned)((long)a.MT * a.KI * C::A_LDS_FLOATS * 4) + (a.w_img_bytes ? (unsigned)(a.N - 1) * a.w_img_bytes : 0u));
@@ -389,10 +437,21 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
       if constexpr (C::F16) {
 #pragma unroll
         for (int i = 0; i < C::BU_PER_T; ++i) {
-          f16x8 h;
+          f16x8 h, l;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) h[j] = (_Float16)rh[i][j];            // round to nearest even
-          if (C::B_UNITS % 256 == 0 || tid + i * 256 < C::B_UNITS) reinterpret_cast<f16x8*>(ldsB)[tid + i * 256] = h;
+          for (int j = 0; j < 8; ++j) {
+            if constexpr (C::X3) {
+              _Float16 hh, ll;
+              mscnn::split16(rh[i][j] * x3_s, &hh, &ll);
+              h[j] = hh; l[j] = ll;
+            } else {
+              h[j] = (_Float16)rh[i][j];            // round to nearest even
+            }
+          }
+          if (C::B_UNITS % 256 == 0 || tid + i * 256 < C::B_UNITS) {
+            reinterpret_cast<f16x8*>(ldsB)[tid + i * 256] = h;
+            if constexpr (C::X3) reinterpret_cast<f16x8*>(ldsB)[C::B_UNITS + tid + i * 256] = l;
+          }
         }
       } else if constexpr (C::VEC) {
 #pragma unroll
@@ -427,6 +486,20 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
               for (int mi = 0; mi < C::MI; ++mi) av[mi] = a16[((kh * C::KW + kw) * C::KG + 2 * ks) * C::BM + mi * 32];
 #pragma unroll
               for (int ni = 0; ni < C::NI; ++ni) bv[ni] = b16[2 * ks * C::CH_STRIDE + poff[ni] + kh * C::ROWS + kw];
+              if constexpr (C::X3) {
+                f16x8 al[C::MI], bl[C::NI];
+#pragma unroll
+                for (int mi = 0; mi < C::MI; ++mi) al[mi] = a16[C::A_UNITS + ((kh * C::KW + kw) * C::KG + 2 * ks) * C::BM + mi * 32];
+#pragma unroll
+                for (int ni = 0; ni < C::NI; ++ni) bl[ni] = b16[C::B_UNITS + 2 * ks * C::CH_STRIDE + poff[ni] + kh * C::ROWS + kw];
+#pragma unroll
+                for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+                  for (int ni = 0; ni < C::NI; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                  }
+              }
 #pragma unroll
               for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
@@ -480,6 +553,14 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
       }
     }
 
+    if constexpr (C::X3) {      // un-scale (exact: a power of two) before the epilogue / the partial-sum slab
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= x3_inv;
+    }
     {
     const TileGeo<C>& geo = geo_e;
     const int t = t_e, k0 = k0_e, k1 = k1_e, mt = mt_e;
@@ -506,6 +587,7 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
             const unsigned vo = (co0 + (r & 3) + 8 * (r >> 2) < a.Cout) ? voff : kOob;   // Cout < BM (proposal heads)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, vo,
                                                   (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)co_stride * 4u, 0);
+            if constexpr (C::PUBLISH) { if (vo != kOob) am = max(am, __builtin_bit_cast(unsigned, v) & 0x7fffffffu); }
             if constexpr (C::CAN_POOL) acc[mi][ni][r] = o >= 0 ? v : kNegMax;     // kept for the pooling pass below
           }
         }
@@ -556,6 +638,7 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
     __syncthreads();   // LDS is re-used by the next segment's first stores
   }
 #undef MSCNN_LOAD_CHUNK
+  if constexpr (C::PUBLISH) { if (a.amax_out) mscnn::publish_amax(am, a.amax_out, blockIdx.x); }
 }
 
 // Sums the partial slabs of every tile that was split across workgroups, in k order (deterministic), + bias + ReLU.
@@ -596,6 +679,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
   geo.decode(a, nt);
   float* ybase = geo.y_base(a);
   const int co_stride = a.Ho * a.Wo;
+  unsigned am = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = part * 4096 + (j * 256 + threadIdx.x) * 4;     // 4 consecutive pixels of one output channel row
@@ -616,8 +700,10 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
       float r = vals[q] + bv;
       if (a.relu) r = r > 0.f ? r : 0.f;
       ybase[(long)co * co_stride + o] = r;
+      am = max(am, __builtin_bit_cast(unsigned, r) & 0x7fffffffu);
     }
   }
+  if (a.amax_out) mscnn::publish_amax(am, a.amax_out, 512u + blockIdx.x);
 }
 
 // Fix-up with fused 2x2 max pooling: a thread owns one pooling window (4 pixels of one channel) of a split tile.
@@ -659,6 +745,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_pool_kernel(IgemmArgs a) {
     const int co_stride = a.Ho * a.Wo, pstride = a.Hp * a.Wp;
     float* pbase = a.yp + (long)geo.img * a.Cout * pstride;
     constexpr int WPT = C::BN / 4;                        // pooling windows per channel row of the tile
+    unsigned am = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int q = j * 256 + threadIdx.x;                // window index inside this workgroup's 4096-element part
@@ -685,9 +772,11 @@ __global__ __launch_bounds__(256) void igemm_fixup_pool_kernel(IgemmArgs a) {
         if (a.relu) r = r > 0.f ? r : 0.f;
         ybase[(long)co * co_stride + h * a.Wo + w] = r;
         mx = max2(mx, r);
+        am = max(am, __builtin_bit_cast(unsigned, r) & 0x7fffffffu);
       }
       if (oh < a.Ho && ow < a.Wo) pbase[(long)co * pstride + (oh >> 1) * a.Wp + (ow >> 1)] = mx;
     }
+    if (a.amax_out) mscnn::publish_amax(am, a.amax_out, 512u + blockIdx.x);
   }
 }
 
@@ -793,6 +882,10 @@ const KernelEntry kTable[] = {
     // 128 x 256 tiles = 64 x 128 per wave: 6 operand fragments per 8 MFMAs instead of 4 per 4 (the kernel is LDS-fed)
     {"igemm16_128x256_k3x3_tw32", 128, 256, 3, 3, 16, 32, 8, 0, 0, 0, 1, 8, 202, igemm_kernel<Cfg<128, 256, 2, 2, 3, 3, 16, 32, 0, 0, 0, 0, 0, 0, 1>>,
      igemm_fixup_kernel<Cfg<128, 256, 2, 2, 3, 3, 16, 32, 0, 0, 0, 0, 0, 0, 1>>, igemm_fixup_pool_kernel<Cfg<128, 256, 2, 2, 3, 3, 16, 32, 0, 0, 0, 0, 0, 0, 1>>},
+    // split-fp16 (X3, fp32-grade) direct 3x3 kernel for the layers the Winograd heuristic leaves direct (conv1_2, conv2_1):
+    // variant 210.  64 x 256 tiles: 59 KB of LDS (hi + lo of both operands), two workgroups per CU
+    {"igemm16x3_64x256_k3x3_tw32", 64, 256, 3, 3, 16, 32, 8, 0, 0, 0, 1, 4, 210, igemm_kernel<Cfg<64, 256, 1, 4, 3, 3, 16, 32, 0, 0, 0, 0, 0, 0, 2>>,
+     igemm_fixup_kernel<Cfg<64, 256, 1, 4, 3, 3, 16, 32, 0, 0, 0, 0, 0, 0, 2>>, igemm_fixup_pool_kernel<Cfg<64, 256, 1, 4, 3, 3, 16, 32, 0, 0, 0, 0, 0, 0, 2>>},
     ENTRY16_OCC3(128, 128, 2, 2, 16),
     ENTRY16_OCC3(128, 128, 2, 2, 32),
     ENTRY16_OCC3(64, 256, 1, 4, 32),
@@ -829,6 +922,7 @@ struct mscnn_conv_plan {
   // split-fp16 form of the F(3x3,3x3) path (MSCNN_CONV_ALGO_WINO_F3_X3, wino_x3.hip): x3.BM > 0, wino == nullptr.
   // Workspace layout: [256 B device scalars][V16][M: 25 x Cout x T_pad floats]
   mscnn::X3Plan x3;
+  size_t x3d_hdr_off = 0, x3d_slots_off = 0;   // X3 direct kernel: header behind the packed weights, own-amax slots behind the slabs
   const unsigned* amax_in = nullptr;   // mscnn_conv2d_plan_set_amax_io (kept across re-planning)
   unsigned* amax_out = nullptr;
   // roofline accounting (mscnn_conv2d_plan_set_profiling): events around {input transform | GEMM | output transform}
@@ -924,6 +1018,9 @@ static void plan_shape(mscnn_conv_plan* p) {
   if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0 || d.Cin > 2048) return;   // KI <= 256
   const bool want16 = tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_F16 && d.Kh == 3 && d.Kw == 3;
   if (!want16 && wino_plan(p)) return;
+  // WINO_F3_X3 on a layer the Winograd heuristic leaves direct: the split-fp16 direct kernel (conv1_2, conv2_1)
+  const bool wantx3 = tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_WINO_F3_X3 && d.Kh == 3 && d.Kw == 3 && d.Cin % 16 == 0 &&
+                      (long)d.H * d.W >= 4096;
   // 32-bit buffer offsets: every tensor window the kernel addresses must stay below 2 GiB
   const double win_x = (double)d.Cin * d.H * d.W * 4.0, win_y = (double)d.Cout * p->Ho * p->Wo * 4.0;
   // choose the table entry with the least padded work; an ROI-mode entry wins whenever it matches the image shape
@@ -938,6 +1035,7 @@ static void plan_shape(mscnn_conv_plan* p) {
     if (k.KH != d.Kh || k.KW != d.Kw) continue;
     const bool is16 = k.variant >= 200 && k.variant <= 202;
     if (is16 != want16) continue;
+    if ((k.variant == 210) != wantx3) continue;
     if (is16 && k.RH == 0) {
       // 2 workgroups / CU (172 VGPRs, grid 512) or the 3-per-CU build (168 VGPRs + 16 B scratch, grid 768): measured on the
       // 7s-576 trunk (profiles/r02_ab_f16_occ3.txt) the latter wins where there are thousands of tiles (conv1_2 208 -> 195 us,
@@ -948,7 +1046,7 @@ static void plan_shape(mscnn_conv_plan* p) {
       if (k.variant != pick) continue;
     }
     const bool is256 = (k.BM == 128 && k.BN == 256);
-    if (k.KH == 3 && k.KW == 3 && k.RH == 0 && !is16) {
+    if (k.KH == 3 && k.KW == 3 && k.RH == 0 && !is16 && k.variant != 210) {
       if (is256 && k.variant == 0) continue;                  // (kept for reference; superseded by variant 3)
       if (k.variant != ((d.Cin <= 4 && d.Cout <= 64 && !venv) ? 50 : want)) continue;
     }
@@ -1012,6 +1110,12 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->total_iters = (tiles - (long)p->full_q * G) * p->KI;     // stream-K phase over the remainder tiles
   p->packed_bytes = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * ((k.variant >= 200 && k.variant <= 202) ? sizeof(_Float16) : sizeof(float));
   p->ws_bytes = (size_t)p->G * kSlabsPerWg * k.BM * k.BN * sizeof(float);
+  if (k.variant == 210) {      // hi + lo halves, then [8 KB header: 1 / s_w, slots of max |w|]; workspace tail: slots of max |x|
+    p->x3d_hdr_off = (size_t)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM * 2 * sizeof(_Float16);
+    p->packed_bytes = p->x3d_hdr_off + 8192;
+    p->x3d_slots_off = p->ws_bytes;
+    p->ws_bytes += 4096;
+  }
 }
 
 extern "C" int mscnn_conv2d_plan_create(const mscnn_conv_desc* desc, mscnn_conv_plan** plan_out) {
@@ -1055,12 +1159,13 @@ extern "C" double mscnn_conv2d_plan_flops(const mscnn_conv_plan* p) {
   return 2.0 * d.N * d.Cout * p->Ho * p->Wo * (double)(d.Cin / d.group) * d.Kh * d.Kw;
 }
 extern "C" const char* mscnn_conv2d_plan_dtype(const mscnn_conv_plan* p) {
-  if (p && p->x3.BM) return "f16x3";
+  if (p && (p->x3.BM || (!p->wino && p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant == 210))) return "f16x3";
   return (p && !p->wino && p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202) ? "f16" : "f32";
 }
 extern "C" double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* p) {
   if (!p) return 0;
-  if (!p->wino && !p->x3.BM) return mscnn_conv2d_plan_flops(p);
+  if (!p->wino && !p->x3.BM)
+    return mscnn_conv2d_plan_flops(p) * ((p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant == 210) ? 3.0 : 1.0);
   const mscnn_conv_desc& d = p->d;
   const double planes = (p->wino_m == 3 ? 25.0 : 16.0) * (p->x3.BM ? 3.0 : 1.0);    // x3: three fp16 MFMA products per pair
   return 2.0 * planes * d.Cout * d.Cin * ((double)d.N * p->tiles_h * p->tiles_w);
@@ -1083,7 +1188,9 @@ extern "C" int mscnn_conv2d_plan_stage_ms(const mscnn_conv_plan* p, float ms_out
   return MSCNN_OK;
 }
 extern "C" int mscnn_conv2d_plan_publishes_amax(const mscnn_conv_plan* p) {
-  return p && (p->x3.BM || (p->wino && p->wino_m == 3)) ? 1 : 0;
+  // the F(3x3,3x3) output transforms and every kernel of the implicit-GEMM family (main + fix-up) publish
+  return p && (p->x3.BM || (p->wino && p->wino_m == 3) ||
+               (!p->wino && p->head.entry < 0 && p->entry >= 0 && !(kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202))) ? 1 : 0;
 }
 extern "C" int mscnn_conv2d_plan_set_amax_io(mscnn_conv_plan* p, const uint32_t* in_bound, uint32_t* out_amax) {
   MSCNN_REQUIRE(p, "conv plan: null");
@@ -1123,7 +1230,14 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   const long total = (long)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  if (k.variant >= 200 && k.variant <= 202)
+  if (k.variant == 210) {
+    unsigned char* pk = reinterpret_cast<unsigned char*>(packed);
+    float* hdr = reinterpret_cast<float*>(pk + p->x3d_hdr_off);
+    const int rc = x3_amax(w, (long)p->d.Cout * p->d.Cin * k.KH * k.KW, reinterpret_cast<unsigned*>(hdr) + 1024, as_stream(stream));
+    if (rc != MSCNN_OK) return rc;
+    pack_weights_x3_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, reinterpret_cast<_Float16*>(packed), hdr, p->d.Cout, p->d.Cin,
+                                                                      k.KH * k.KW, k.BM, k.CK, p->MT, p->KI);
+  } else if (k.variant >= 200 && k.variant <= 202)
     pack_weights_f16_kernel<<<(int)blocks, 256, 0, as_stream(stream)>>>(w, reinterpret_cast<_Float16*>(packed), p->d.Cout, p->d.Cin,
                                                                        k.KH * k.KW, k.BM, k.CK, p->MT, p->KI);
   else
@@ -1159,6 +1273,22 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
     return MSCNN_ERR_BAD_ARG;
   }
   a.xcd_map = (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 1) ? 0 : 1;
+  a.amax_in = nullptr; a.w_inv = nullptr;
+  a.amax_out = nt_major ? nullptr : p->amax_out;          // (nt_major: the nested Winograd GEMM -- its output transform publishes)
+  if (k.variant == 210) {
+    if (!workspace || workspace_bytes < p->ws_bytes) {
+      set_error("conv(x3): workspace %zu < %zu", workspace_bytes, p->ws_bytes);
+      return MSCNN_ERR_WORKSPACE;
+    }
+    a.w_inv = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(packed) + p->x3d_hdr_off);
+    a.amax_in = p->amax_in;
+    if (!a.amax_in) {      // nobody handed max |x| over: one streaming pass
+      unsigned* slots = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(workspace) + p->x3d_slots_off);
+      const int rc = x3_amax(x, (long)d.N * d.Cin * d.H * d.W, slots, st);
+      if (rc != MSCNN_OK) return rc;
+      a.amax_in = slots;
+    }
+  }
   k.main_fn<<<p->G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   if (split) {

@@ -23,6 +23,7 @@
 // [plane][Cout][T_pad] so the output transforms (winograd.hip) are shared.
 #include "wino_x3.h"
 #include "winograd.h"
+#include "x3_device.h"
 
 namespace {
 
@@ -36,34 +37,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-// s = 2^(14 - floor(log2(bound))): bound * s in [2^14, 2^15).  bound == 0 (all-zero tensor) -> 1.
-__device__ __forceinline__ void pow2_scale(float bound, float* s, float* inv) {
-  int e = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 127;
-  if (bound == 0.f) e = 14;
-  e = e < -100 ? -100 : (e > 110 ? 110 : e);
-  *s = __uint_as_float((unsigned)(127 + 14 - e) << 23);
-  *inv = __uint_as_float((unsigned)(127 - 14 + e) << 23);
-}
-
-__device__ __forceinline__ void split16(float v, _Float16* hi, _Float16* lo) {
-  const _Float16 h = (_Float16)v;
-  *hi = h;
-  *lo = (_Float16)(v - (float)h);
-}
-
-// max over the kAmaxSlots published partial maxima (winograd.hip publish_amax / amax_kernel below): 4 loads per thread, served by
-// the L2.  Every thread of the 256-thread workgroup must call this; returns the float whose bit pattern is the maximum.
-__device__ __forceinline__ float bound_from_slots(const unsigned* __restrict__ slots) {
-  __shared__ unsigned s_b[4];
-  unsigned m = 0;
-#pragma unroll
-  for (int i = 0; i < mscnn::kAmaxSlots / 256; ++i) m = max(m, slots[threadIdx.x + 256 * i]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = m;
-  __syncthreads();
-  return __uint_as_float(max(max(s_b[0], s_b[1]), max(s_b[2], s_b[3])));
-}
+using mscnn::pow2_scale; using mscnn::split16; using mscnn::bound_from_slots;
 
 // ---- max |x| -----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {

@@ -5,8 +5,6 @@
 
 namespace mscnn {
 
-constexpr int kAmaxSlots = 1024;   // == MSCNN_AMAX_SLOTS (mscnn_hip.h)
-
 // U[xi*4+nu] = (G g G^T)[xi][nu] for every (co, ci), written in the igemm packed layout of a 1x1 convolution with
 // per-"image" weights:  wp[xinu][mt][kc][ck][BM]  (zero padded in Cout and Cin).
 int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, int BM, int CK, int MT, int KI, hipStream_t st);

@@ -18,6 +18,7 @@
 // All transform kernels are HBM-bound streaming kernels: one thread per (channel, tile), tiles fastest, so every transform
 // plane is read / written as contiguous runs.
 #include "winograd.h"
+#include "x3_device.h"
 
 namespace {
 
@@ -334,20 +335,6 @@ __global__ __launch_bounds__(256) void wino33_input_plane_kernel(const float* __
   }
 }
 
-// max |y| of a layer's output for the split-fp16 consumer (wino_x3.hip): the workgroup's maximum of the bit patterns goes, with
-// ONE fire-and-forget atomic, into one of kAmaxSlots slots chosen by the workgroup id -- thousands of workgroups hitting a
-// single address cost 45 us per layer (measured), spread over 1024 addresses they cost nothing measurable; the consumer takes
-// the maximum over the slots.  Every thread of the workgroup must call this.
-__device__ __forceinline__ void publish_amax(unsigned m, unsigned* amax) {
-  __shared__ unsigned s_am[4];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0) s_am[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    atomicMax(amax + ((blockIdx.y * gridDim.x + blockIdx.x) & (mscnn::kAmaxSlots - 1)), max(max(s_am[0], s_am[1]), max(s_am[2], s_am[3])));
-}
-
 __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                             float* __restrict__ y, int N, int Cout, int Ho, int Wo, int tiles_h,
                                                             int tiles_w, int T, int T_pad, int relu, unsigned* __restrict__ amax) {
@@ -388,7 +375,7 @@ __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restr
     }
   }
   }
-  if (amax) publish_amax(am, amax);
+  if (amax) mscnn::publish_amax(am, amax, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 
@@ -479,7 +466,7 @@ __global__ __launch_bounds__(256) void wino33_output_pool_kernel(const float* __
       pd[ph * Wp + pw] = m;
     }
   }
-  if (amax) publish_amax(am, amax);
+  if (amax) mscnn::publish_amax(am, amax, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 }  // namespace

@@ -24,6 +24,7 @@ class ConvDesc(C.Structure):
 
 
 # mscnn_conv_algo
+AMAX_SLOTS = 1024
 ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_F2, ALGO_WINO_F3, ALGO_F16, ALGO_WINO_F3_X3 = 0, 1, 2, 3, 4, 5
 
 
@@ -61,6 +62,8 @@ def lib():
         L.mscnn_version.restype = C.c_char_p
         L.mscnn_conv2d_plan_kernel.restype = C.c_char_p
         L.mscnn_conv2d_plan_kernel.argtypes = [C.c_void_p]
+        L.mscnn_conv2d_plan_publishes_amax.argtypes = [C.c_void_p]
+        L.mscnn_conv2d_plan_set_amax_io.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mscnn_conv2d_plan_dtype.restype = C.c_char_p
         L.mscnn_conv2d_plan_dtype.argtypes = [C.c_void_p]
         L.mscnn_inner_product_f16_supported.argtypes = [C.c_int, C.c_int]
@@ -201,6 +204,15 @@ class ConvPlan:
         self.w = w
         if self.packed is not None:
             _check(lib().mscnn_conv2d_pack_weights(self._p, _dev(w), _dev(self.packed), _stream()))
+
+    @property
+    def publishes_amax(self):
+        return bool(lib().mscnn_conv2d_plan_publishes_amax(self._p))
+
+    def set_amax_io(self, in_bound=None, out_amax=None):
+        """max |x| hand-over (mscnn_conv2d_plan_set_amax_io): int32 device tensors of AMAX_SLOTS float bit patterns."""
+        self._amax = (in_bound, out_amax)      # keep them alive
+        _check(lib().mscnn_conv2d_plan_set_amax_io(self._p, _dev(in_bound), _dev(out_amax)))
 
     @property
     def can_pool(self):

@@ -229,6 +229,77 @@ def test_conv_winograd_x3(hip, orc, case, relu):
     assert not hip.ConvPlan(1, 32, 64, 64, 32, 3, 3, (1, 1), algo=hip.ALGO_WINO_F3_X3).kernel.startswith("winograd")
 
 
+X3_DIRECT_CASES = [   # N, Cin, H, W, Cout, tune_grid: layers the Winograd heuristic leaves direct (conv1_2 / conv2_1 class)
+    (1, 64, 64, 96, 64, 0),        # one M tile, fused pooling
+    (2, 32, 70, 130, 130, 0),      # batch 2, odd sizes, ragged Cout (3 M tiles of 64)
+    (1, 48, 65, 97, 128, 0),       # Cin = 48: three 16-channel chunks
+    (2, 64, 72, 200, 128, 100),    # grid of 100 over 252 tiles: 2 whole tiles per workgroup + a stream-K phase with fix-up
+]
+
+
+@pytest.mark.parametrize("case", X3_DIRECT_CASES)
+def test_conv_direct_x3(hip, orc, case):
+    """Split-fp16 direct 3x3 implicit GEMM (the igemm template with hi + lo operand tiles, variant 210) -- the form
+    MSCNN_CONV_ALGO_WINO_F3_X3 selects where the Winograd heuristic stays direct: 1e-4 against the oracle, no worse than 3x the
+    fp32 MFMA kernel's error + 2e-6, fused 2x2 pooling bit-identical to pooling y, and max |y| published exactly."""
+    N, Cin, H, W, Cout, grid = case
+    rng = np.random.default_rng(31)
+    x = np.maximum(rng.standard_normal((N, Cin, H, W)), 0).astype(np.float32) * 4.0
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True, algo=hip.ALGO_WINO_F3_X3, tune_grid=grid)
+    assert plan.kernel == "igemm16x3_64x256_k3x3_tw32" and plan.dtype == "f16x3" and plan.can_pool and plan.publishes_amax
+    assert plan.executed_flops == 3 * plan.flops
+    plan.pack(dev(w))
+    slots = torch.zeros(hip.AMAX_SLOTS, dtype=torch.int32, device="cuda")
+    plan.set_amax_io(None, slots)
+    yp = torch.full((N, Cout, (H + 1) // 2, (W + 1) // 2), float("nan"), device="cuda")
+    y = plan.forward(dev(x), dev(b), pool_out=yp)
+    assert torch.equal(yp, hip.pool2d(y, (2, 2), (0, 0), (2, 2)))
+    assert slots.max().item() == y.abs().max().view(torch.int32).item()              # published max |y|, bit pattern
+    ref = orc.relu(orc.conv2d(x, w, b, (1, 1)))
+    close(y.cpu().numpy(), ref)
+    p32 = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_grid=grid)
+    p32.pack(dev(w))
+    s32 = torch.zeros(hip.AMAX_SLOTS, dtype=torch.int32, device="cuda")
+    p32.set_amax_io(None, s32)
+    y32 = p32.forward(dev(x), dev(b))
+    assert s32.max().item() == y32.abs().max().view(torch.int32).item()              # the fp32 kernels publish too
+    truth = torch.relu(torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                                  padding=1)).numpy()
+    e3 = float((np.abs(y.cpu().numpy() - truth) / np.maximum(1, np.abs(truth))).max())
+    e32 = float((np.abs(y32.cpu().numpy() - truth) / np.maximum(1, np.abs(truth))).max())
+    print(f"direct x3 err {e3:.2e}  fp32 igemm err {e32:.2e}")
+    assert e3 <= 3 * e32 + 2e-6
+    # handed-over bound instead of the plan's own max |x| pass: any upper bound gives the same result up to the split's rounding
+    bound = torch.zeros(hip.AMAX_SLOTS, dtype=torch.int32, device="cuda")
+    bound[7] = torch.tensor(float(np.abs(x).max()) * 1.7, dtype=torch.float32).view(torch.int32)
+    plan.set_amax_io(bound, None)
+    close(plan.forward(dev(x), dev(b)).cpu().numpy(), ref)
+
+
+def test_winograd_layers_publish_amax(hip):
+    """The F(3x3,3x3) output transforms (plain and fused-pooling, fp32 and x3 GEMM) publish the exact max |y|."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((1, 64, 24, 48), device="cuda", generator=g)
+    w = torch.randn((96, 64, 3, 3), device="cuda", generator=g) * 0.05
+    b = torch.randn(96, device="cuda", generator=g)
+    for algo, flags in ((hip.ALGO_WINO_F3, 0), (hip.ALGO_WINO_F3_X3, 4)):
+        for pooled in (False, True):
+            plan = hip.ConvPlan(1, 64, 24, 48, 96, 3, 3, (1, 1), relu=False, algo=algo, tune_flags=flags)
+            assert plan.publishes_amax
+            plan.pack(w)
+            slots = torch.zeros(hip.AMAX_SLOTS, dtype=torch.int32, device="cuda")
+            plan.set_amax_io(None, slots)
+            yp = torch.empty((1, 96, 12, 24), device="cuda") if pooled else None
+            y = plan.forward(x, b, pool_out=yp)
+            assert slots.max().item() == y.abs().max().view(torch.int32).item(), (algo, pooled)
+    head = hip.ConvPlan(1, 512, 36, 60, 9, 5, 5, (2, 2))
+    assert not head.publishes_amax
+    with pytest.raises(hip.MscnnError):
+        head.set_amax_io(None, torch.zeros(hip.AMAX_SLOTS, dtype=torch.int32, device="cuda"))
+
+
 @pytest.mark.parametrize("case", [(20, 64, 7, 7, 48, 0), (33, 32, 7, 5, 130, 0), (16, 32, 8, 4, 32, 1), (50, 1024, 7, 7, 512, 0)])
 def test_conv_winograd_x3_roi_maps(hip, orc, case):
     """Split-fp16 F(3x3,3x3) on the ROI-pooled maps (roi_c1), incl. a changing ROI count; 1e-4 against the oracle."""
