@@ -951,6 +951,7 @@ static bool wino_plan(mscnn_conv_plan* p) {
   if (algo == MSCNN_CONV_ALGO_DIRECT || d.Kh != 3 || d.Kw != 3 || d.stride_h != 1 || d.stride_w != 1 || d.group != 1) return false;
   if (p->Ho < 2 || p->Wo < 2) return false;
   const bool want_x3 = algo == MSCNN_CONV_ALGO_WINO_F3_X3;
+  if (want_x3 && (d.tune_flags & 8)) return false;        // A/B: the split-fp16 direct kernel instead
   // WINO_F3_X3 follows the AUTO heuristic (it replaces the GEMM of the layers that run F(3x3,3x3) anyway); tune_flags bit 2
   // forces the form wherever it is legal, like WINO_F3 (tests)
   const bool force = algo == MSCNN_CONV_ALGO_WINO_F2 || algo == MSCNN_CONV_ALGO_WINO_F3 || (want_x3 && (d.tune_flags & 4));
@@ -963,7 +964,10 @@ static bool wino_plan(mscnn_conv_plan* p) {
   // Threshold for F(3x3,3x3): conv2_2 (intensity 64) 523 vs 642 us direct, conv2_1 (43) 375 vs 383 (tie -> direct), conv1_2
   // (32) 1175 vs 762.  WINO_F2 selects F(2x2,3x3) on planes for A/B runs and tests.
   const int m = (roi_map || algo != MSCNN_CONV_ALGO_WINO_F2) ? 3 : 2, planes = m == 3 ? 25 : 16;
-  if (!force && (intensity < (m == 3 ? 60.0 : 100.0) || (!roi_map && d.H * d.W < 256))) return false;
+  // (split-fp16: the direct kernel runs at ~800 TFLOP/s executed, so Winograd -- HBM-bound on its V / M planes -- only pays from
+  // conv3_1 up: measured conv2_2 (64) 415 vs 311 us direct, conv3_1 (85) 159 vs 175, conv3_2 (128) 225 vs 269)
+  const double wino_min = want_x3 && d.Cin % 16 == 0 ? 80.0 : (m == 3 ? 60.0 : 100.0);
+  if (!force && (intensity < wino_min || (!roi_map && d.H * d.W < 256))) return false;
   if (roi_map && d.N < 8) return false;
   const int th = cdiv(p->Ho, m), tw = cdiv(p->Wo, m);
   const long T = (long)d.N * th * tw;

@@ -155,8 +155,7 @@ __global__ __launch_bounds__(256) void x3_input_plane_kernel(const float* __rest
   const int kg = blockIdx.y;
   const long t0 = (long)blockIdx.x * 32;
   const int t = (int)t0 + q, ci = kg * 8 + c;
-  float s, inv;
-  pow2_scale(36.f * bound_from_slots(scal), &s, &inv);
+  const unsigned slot_m = mscnn::slots_partial(scal);                  // in flight together with the patch loads below
   float d[5][5];
   if (t < T) {
     const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
@@ -178,6 +177,8 @@ __global__ __launch_bounds__(256) void x3_input_plane_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 5; ++j) d[i][j] = 0.f;
   }
+  float s, inv;
+  pow2_scale(36.f * mscnn::slots_finish(slot_m), &s, &inv);
   transform_split_store(d, s, sh, q, c);
   __syncthreads();
   flush_units(sh, V16, KG, T_pad, kg, t0, 32, tid);
@@ -192,25 +193,29 @@ __global__ __launch_bounds__(256) void x3_input_roi_kernel(const float* __restri
                                                            int pad_h, int pad_w, int tiles_h, int tiles_w, int T, long T_pad,
                                                            int KG, int nr) {
   __shared__ __attribute__((aligned(16))) _Float16 sh[2 * 25 * 32 * 8];
-  __shared__ __attribute__((aligned(16))) float sm[kRoiMax * 8 * kRoiMaxHW];
+  extern __shared__ __attribute__((aligned(16))) float sm[];          // nr * 8 * H * W floats
   const int tid = threadIdx.x;
+  const unsigned slot_m = mscnn::slots_partial(scal);                  // in flight while the maps are staged
   const int kg = blockIdx.y, c0 = kg * 8;
   const int r0 = blockIdx.x * nr;
   const int HW = H * W, tpr = tiles_h * tiles_w;
-  const int run = 8 * HW;
-  for (int rl = 0; rl < nr; ++rl) {
-    const int r = r0 + rl;
-    if (r >= N) break;
-    const float* src = x + ((long)r * Cin + c0) * HW;
-    float* dst = sm + rl * (8 * HW);
-    if ((run & 3) == 0 && ((((long)r * Cin + c0) * HW) & 3) == 0) {
-      for (int i = tid; i < run / 4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
-    } else {
-      for (int i = tid; i < run; i += 256) dst[i] = src[i];
+  const int run = 8 * HW;                        // contiguous floats per ROI (its 8 channels)
+  const int live_r = min(nr, N - r0);
+  if ((run & 3) == 0 && (((long)Cin * HW) & 3) == 0 && (((long)c0 * HW) & 3) == 0) {
+    // one flat loop over (roi, float4) so that all 256 threads have loads in flight (98 float4 per ROI for 7x7 maps)
+    const int per = run / 4;
+    for (int i = tid; i < live_r * per; i += 256) {
+      const int rl = i / per, e = i % per;
+      reinterpret_cast<float4*>(sm + rl * run)[e] = reinterpret_cast<const float4*>(x + ((long)(r0 + rl) * Cin + c0) * HW)[e];
+    }
+  } else {
+    for (int i = tid; i < live_r * run; i += 256) {
+      const int rl = i / run, e = i % run;
+      sm[rl * run + e] = x[((long)(r0 + rl) * Cin + c0) * HW + e];
     }
   }
   float s, inv;
-  pow2_scale(36.f * bound_from_slots(scal), &s, &inv);       // (its barrier also publishes the staged maps)
+  pow2_scale(36.f * mscnn::slots_finish(slot_m), &s, &inv);  // (its barrier also publishes the staged maps)
   const int nq = nr * tpr;                       // <= 32
   const int q = tid & 31, c = tid >> 5;
   if (q < nq) {
@@ -501,7 +506,7 @@ int x3_input_transform(const X3Plan& p, const float* x, void* V16, const unsigne
     int nr = 32 / (tiles_h * tiles_w);
     if (nr > kRoiMax) nr = kRoiMax;
     dim3 grid(cdiv(N, nr), p.KG);
-    x3_input_roi_kernel<<<grid, 256, 0, st>>>(x, static_cast<uint4*>(V16), scal, N, p.Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T,
+    x3_input_roi_kernel<<<grid, 256, sizeof(float) * nr * 8 * H * W, st>>>(x, static_cast<uint4*>(V16), scal, N, p.Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T,
                                               p.T_pad, p.KG, nr);
   } else {
     dim3 grid((unsigned)(p.T_pad / 32), p.KG);

@@ -25,6 +25,21 @@ __device__ __forceinline__ void split16(float v, _Float16* hi, _Float16* lo) {
 
 // max over the kAmaxSlots published partial maxima: 4 loads per thread, served by the L2.  Every thread of the 256-thread
 // workgroup must call this (it contains a barrier); returns the float whose bit pattern is the maximum.
+// Two halves so that a kernel can put the slot loads in flight first and reduce them after its own global loads were issued.
+__device__ __forceinline__ unsigned slots_partial(const unsigned* __restrict__ slots) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < kAmaxSlots / 256; ++i) m = max(m, slots[threadIdx.x + 256 * i]);
+  return m;
+}
+__device__ __forceinline__ float slots_finish(unsigned m) {
+  __shared__ unsigned s_b[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = m;
+  __syncthreads();
+  return __uint_as_float(max(max(s_b[0], s_b[1]), max(s_b[2], s_b[3])));
+}
 __device__ __forceinline__ float bound_from_slots(const unsigned* __restrict__ slots) {
   __shared__ unsigned s_b[4];
   unsigned m = 0;
