@@ -463,9 +463,9 @@ bool x3_plan(int Cin, int Cout, long T_pad, int tune_variant, X3Plan* out) {
   X3Plan p;
   p.Cin = Cin; p.Cout = Cout; p.KG = Cin / 8; p.T_pad = T_pad;
   p.NT = (int)(T_pad / 128);
-  // 256-row tiles halve the LDS and L2 traffic per MFMA; they need enough tiles to fill 512 workgroup slots
-  const long tiles256 = 25L * (Cout / 256) * p.NT;
-  p.BM = (tune_variant == 1) ? 128 : (tune_variant == 2 && Cout % 256 == 0) ? 256 : (Cout % 256 == 0 && tiles256 >= 1024) ? 256 : 128;
+  // 256-row tiles (tune_variant 2) halve the LDS and L2 traffic per MFMA but sit at 234 VGPRs; measured equal or slower on every
+  // layer of the 7s-576 net (conv4_2 GEMM 87 vs 94 us, roi_c1 233 vs 244, conv3_2 109 vs 107): 128 rows is the default
+  p.BM = (tune_variant == 2 && Cout % 256 == 0) ? 256 : 128;
   p.MT = cdiv(Cout, p.BM);
   p.Cout_pad = p.MT * p.BM;
   const double u_bytes = 50.0 * p.KG * p.Cout_pad * 16.0, v_bytes = 50.0 * p.KG * (double)T_pad * 16.0;
