@@ -674,6 +674,29 @@ def test_roipool_wide_rois(hip, orc):
         assert np.array_equal(y, orc.roipool(feat, rois, 7, 7, 0.25, pad))
 
 
+@pytest.mark.parametrize("bias", [False, True])
+def test_deconv_upsample2x_and_roipool_on_it(hip, orc, bias):
+    """The "-2x" nets' detection sub-net input: the depthwise 4x4 / stride 2 / pad 1 Deconvolution (one thread per 2x2 output quad)
+    against the oracle (1e-6) and bit-identical to the generic depthwise kernel's tap order, then ROI pooling on the up-sampled
+    map incl. ROIs wider than the 128-column LDS buffer (pooled in column segments), bit-exact against the oracle."""
+    rng = np.random.default_rng(23)
+    N, C, H, W = 2, 32, 30, 90
+    x = np.maximum(rng.standard_normal((N, C, H, W)), 0).astype(np.float32)
+    w = (orc.bilinear_filler((C, 1, 4, 4)) * rng.uniform(0.5, 1.5, (C, 1, 1, 1))).astype(np.float32)      # per-channel gains
+    b = rng.standard_normal(C).astype(np.float32) if bias else None
+    up = hip.deconv_depthwise(dev(x), dev(w), None if b is None else dev(b), (1, 1), (2, 2))
+    close(up.cpu().numpy(), orc.deconv2d(x, w, b, (1, 1), (2, 2), group=C), 1e-6)
+    scale = 0.25
+    rois = _random_rois(rng, 120, 2 * H / scale, 2 * W / scale, batch=N)
+    rois[0] = [0, -900, -900, -700, -700]                                   # fully outside
+    rois[1] = [1, 0, 0, 2 * W / scale - 1, 2 * H / scale - 1]               # the whole map: 180 columns = 2 segments
+    rois[2] = [0, -40, -40, 200, 150]
+    rois[3] = [1, 600, 100, 2 * W / scale + 80, 2 * H / scale + 50]
+    for pad in (0.0, 0.25):
+        y = hip.roipool(up, dev(rois), 7, 5, scale, pad)
+        assert np.array_equal(y.cpu().numpy(), orc.roipool(up.cpu().numpy(), rois, 7, 5, scale, pad))
+
+
 def test_roipool_concat_window(hip, orc):
     rng = np.random.default_rng(8)
     feat = rng.standard_normal((1, 16, 18, 60)).astype(np.float32)
