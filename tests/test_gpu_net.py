@@ -341,15 +341,19 @@ CASCADES = [   # model, reduced input, cls_id, original image size
 ]
 
 
-@pytest.mark.parametrize("model,size,cls_id,org_hw", CASCADES)
-def test_cascade_deploys_whole_net(model, size, cls_id, org_hw):
+@pytest.mark.parametrize("model,size,cls_id,org_hw,precision",
+                         [c + (None,) for c in CASCADES] + [CASCADES[0] + ("f16x3",), CASCADES[3] + ("f16x3",)])
+def test_cascade_deploys_whole_net(model, size, cls_id, org_hw, precision):
     """The reference's cascade / CityPersons / WiderFace deploy nets (the generated prototxts are checked against the shipped
     files in tests/test_prototxt.py) forwarded on the GPU: trunk + heads end to end within 1e-4 of the oracle, then EVERY layer
     from BoxOutput on with the device's own bottoms (DecodeBBox chains, stage-wise re-pooling, ROIAlign + AVE pooling, the
     third-stage ensemble, Softmax, Eltwise) bit-exact for selection / sampling layers and 1e-4 for GEMM layers, and the cascade
-    drivers' final stage (run_cascademscnn.m:84-127) on each cascade output against its oracle."""
+    drivers' final stage (run_cascademscnn.m:84-127) on each cascade output against its oracle.  precision "f16x3": the same
+    assertions with the split-fp16 kernels (every stage's roi_c1 / fc6 included)."""
     from oracle import pynet, pyoracle as orc
     n = mnet.Net(prototxt_text=zoo.prototxt(model, **size))
+    if precision:
+        n.set_precision(precision)
     ws = synth.load_into(n, "mid")
     H, W = n.blob_shape("data")[2:]
     x = synth.frame(H, W)
@@ -364,6 +368,8 @@ def test_cascade_deploys_whole_net(model, size, cls_id, org_hw):
             assert rel_err(n.get_blob(l[3][0]), ref[l[3][0]]) < 1e-4, l[0]
     R = n.blob_shape("proposals")[0]
     assert R > 8, R
+    if precision:
+        assert sum(n.layer_dtype(i) == precision for i in range(len(n.layer_names))) >= 6
     relu_inplace = {l[2][0] for l in layers if l[1] == "ReLU" and l[2] == l[3]}
     for l in layers[ip:]:
         if l[1] in ("Split", "ReLU", "Dropout"):
