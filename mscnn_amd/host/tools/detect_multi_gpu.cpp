@@ -5,7 +5,7 @@
 // RCCL all-gather per step of the device-resident detection packs (include/mscnn_dist.h).  Everything goes through the two C
 // ABIs (include/mscnn_net.h, include/mscnn_dist.h); no Python, no torch.
 //
-//   detect_multi_gpu <deploy.prototxt> [--gpus G] [--images K] [--caffemodel file] [--cls-id c] [--cap n]
+//   detect_multi_gpu <deploy.prototxt> [--gpus G] [--images K] [--caffemodel file] [--precision f32|f16|f16x3] [--cls-id c] [--cap n]
 //
 // Without a caffemodel the replicas get identical seeded He-normal weights (a throughput / plumbing run; every replica must
 // then produce the same detections for the same image, which rank 0 checks on the gathered packs of the first step).
@@ -27,7 +27,7 @@
 namespace {
 
 struct Options {
-  std::string prototxt, caffemodel;
+  std::string prototxt, caffemodel, precision = "f32";
   int gpus = 0, images = 16, cls_id = 2, cap = 2000;
 };
 
@@ -91,6 +91,7 @@ void worker(int rank, int world, const Options& opt, const unsigned char* id, st
   mscnn_net* net = nullptr;
   NET_CHECK(mscnn_net_create_from_file(opt.prototxt.c_str(), rank, &net));            // also binds this thread to device `rank`
   if (!opt.caffemodel.empty()) NET_CHECK(mscnn_net_load_caffemodel(net, opt.caffemodel.c_str()));
+  if (opt.precision != "f32") NET_CHECK(mscnn_net_set_precision(net, opt.precision.c_str()));      // "f16" | "f16x3"
   else seed_weights(net, rank);
   int dims[8], nd = 0;
   NET_CHECK(mscnn_net_blob_shape(net, "data", dims, &nd));
@@ -154,12 +155,13 @@ int main(int argc, char** argv) {
     if (a == "--gpus") opt.gpus = std::atoi(next());
     else if (a == "--images") opt.images = std::atoi(next());
     else if (a == "--caffemodel") opt.caffemodel = next();
+    else if (a == "--precision") opt.precision = next();
     else if (a == "--cls-id") opt.cls_id = std::atoi(next());
     else if (a == "--cap") opt.cap = std::atoi(next());
     else if (opt.prototxt.empty()) opt.prototxt = a;
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
   }
-  if (opt.prototxt.empty()) { fprintf(stderr, "usage: %s deploy.prototxt [--gpus G] [--images K] [--caffemodel f] [--cls-id c] [--cap n]\n", argv[0]); return 1; }
+  if (opt.prototxt.empty()) { fprintf(stderr, "usage: %s deploy.prototxt [--gpus G] [--images K] [--caffemodel f] [--precision p] [--cls-id c] [--cap n]\n", argv[0]); return 1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "no HIP device\n"); return 1; }
   const int world = opt.gpus > 0 ? (opt.gpus < ndev ? opt.gpus : ndev) : ndev;
