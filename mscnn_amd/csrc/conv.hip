@@ -23,6 +23,11 @@
 //     fix-up kernel adds the (at most few) slabs of such tiles in k order (deterministic), then bias + ReLU.
 //   * epilogue fuses bias and ReLU; stores are 128-B runs along W.
 // Shapes the MFMA path does not cover (stride > 1, groups, Cin < 8) use direct_conv_kernel.
+//
+// The same template has two more operand types (Cfg::F16 / Cfg::X3): fp16 operands rounded while they are staged (the
+// reduced-precision mode, MSCNN_CONV_ALGO_F16), and the split-fp16 form (MSCNN_CONV_ALGO_WINO_F3_X3 on layers that stay direct:
+// every fp32 operand as fp16 hi + lo, three MFMAs per pair, fp32-grade; x3_device.h, wino_x3.hip).  Every kernel of the family
+// can publish max |y| of what it stores for a split-fp16 consumer (IgemmArgs::amax_out).
 #include "common.h"
 #include "headconv.h"
 #include "winograd.h"
@@ -920,7 +925,7 @@ struct mscnn_conv_plan {
   int wino_m = 2;        // output tile edge: 2 = F(2x2,3x3) (16 planes), 3 = F(3x3,3x3) (25 planes; small ROI maps)
   int tiles_h = 0, tiles_w = 0, T_pad = 0;
   // split-fp16 form of the F(3x3,3x3) path (MSCNN_CONV_ALGO_WINO_F3_X3, wino_x3.hip): x3.BM > 0, wino == nullptr.
-  // Workspace layout: [256 B device scalars][V16][M: 25 x Cout x T_pad floats]
+  // Workspace layout: [4 KB: max |x| slots, used when nobody hands the bound over][V16][M: 25 x Cout x T_pad floats]
   mscnn::X3Plan x3;
   size_t x3d_hdr_off = 0, x3d_slots_off = 0;   // X3 direct kernel: header behind the packed weights, own-amax slots behind the slabs
   const unsigned* amax_in = nullptr;   // mscnn_conv2d_plan_set_amax_io (kept across re-planning)
