@@ -392,7 +392,10 @@ def main():
         # dominant kernel = the MFMA GEMM of the F(3x3,3x3) layers: one launch per layer
         g_flops, g_ms = float(xflops[wino].sum()), float(stage[wino, 1].sum())
         achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-        blk_ms = float(lay_ms[idx].sum())
+        # (per-layer device time: the plan's own stage events where it has them -- they bracket exactly the layer's kernels; the
+        # net-level per-layer events also contain the host's launch gap after each per-layer synchronisation)
+        dev_ms = np.where(stage.sum(axis=1) > 0, stage.sum(axis=1), lay_ms)
+        blk_ms = float(dev_ms[idx].sum())
         blk_exec = float(xflops[idx].sum()) / (blk_ms * 1e-3) / 1e12
         blk_alg = float(flops[idx].sum()) / (blk_ms * 1e-3) / 1e12
         conv_idx = [i for i, t in enumerate(net.layer_types) if t == "Convolution"]
