@@ -91,8 +91,8 @@ void worker(int rank, int world, const Options& opt, const unsigned char* id, st
   mscnn_net* net = nullptr;
   NET_CHECK(mscnn_net_create_from_file(opt.prototxt.c_str(), rank, &net));            // also binds this thread to device `rank`
   if (!opt.caffemodel.empty()) NET_CHECK(mscnn_net_load_caffemodel(net, opt.caffemodel.c_str()));
-  if (opt.precision != "f32") NET_CHECK(mscnn_net_set_precision(net, opt.precision.c_str()));      // "f16" | "f16x3"
   else seed_weights(net, rank);
+  if (opt.precision != "f32") NET_CHECK(mscnn_net_set_precision(net, opt.precision.c_str()));      // "f16" | "f16x3"
   int dims[8], nd = 0;
   NET_CHECK(mscnn_net_blob_shape(net, "data", dims, &nd));
   const int H = dims[2], W = dims[3];
