@@ -64,8 +64,6 @@ class Layer {
   // A producer that can write its top straight into channels [c_offset, c_offset + C) of a wider blob (the top of the
   // Concat that would otherwise copy it) returns true and does so from then on; its own top blob is then not written.
   virtual bool SetOutputWindow(Blob<Dtype>* target, int c_total, int c_offset) { return false; }
-  // A small convolution that may join a grouped launch (the proposal heads; ConvolutionLayer::PrepareGroupMember)
-  virtual bool IsGroupCandidate() const { return false; }
   // Algorithmic FLOPs of the last Forward (0 for bandwidth layers), for roofline accounting.
   virtual double ForwardFlops() const { return 0; }
 

@@ -91,13 +91,6 @@ class ConvolutionLayer : public Layer<Dtype> {
   // max |y - y_direct| / max(1, |y_direct|) of the current algorithm against the direct kernel on the given bottom
   // (device scratch only; the layer's tops are not touched).  0 when the layer already runs a direct kernel.
   double ErrorAgainstDirect(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
-  // Grouped launch of the proposal heads (mscnn_conv2d_fwd_group_f32): the Net defers the heads to the last one and runs every
-  // kernel family in one launch.  PrepareGroupMember plans / packs exactly like Forward_gpu and hands out what the group call
-  // needs; false when the planned kernel is not a head kernel (the layer then runs on its own).
-  struct GroupMember { const mscnn_conv_plan* plan; const float* x; const float* packed; const float* bias; float* y; };
-  virtual bool IsGroupCandidate() const { return num_output_ <= 12 && group_ == 1 && stride_h_ == 1 && stride_w_ == 1 && !pooled_top_; }
-  bool PrepareGroupMember(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top, GroupMember* m);
-  static void* SharedWorkspace(size_t bytes);       // the per-thread, per-device transient workspace all conv layers share
   // max |x| hand-over for the split-fp16 algorithm (mscnn_conv2d_plan_set_amax_io), wired by the Net: `out` is this layer's
   // slot (written when some consumer asked for it: set_amax_wanted), `src` / `in` the layer whose output bounds this layer's
   // bottom and its slot.  A hand-over is used only for forwards the Net marks trusted (the producer ran in the same call).

@@ -80,10 +80,6 @@ class Net {
   // max |x| hand-over for split-fp16 convolutions (ConvolutionLayer::set_amax_io): one device slot per layer; a blob's bound
   // follows it through Split / in-place ReLU / Dropout / MAX pooling / ROIPooling / Concat of blobs with one common source.
   void WireAmax();
-  // Proposal heads (small convolutions consumed only by BoxOutput layers): deferred to the last of them and launched per
-  // kernel family in one grouped call (ConvolutionLayer::PrepareGroupMember, mscnn_conv2d_fwd_group_f32)
-  vector<int> head_layers_;
-  void RunHeadGroup(const vector<int>& pending);
   void* amax_slots_ = nullptr;
   vector<int> amax_src_;          // convolution layer -> the convolution layer whose max |y| bounds its bottom, or -1
 

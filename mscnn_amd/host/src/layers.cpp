@@ -245,38 +245,6 @@ const char* ConvolutionLayer<Dtype>::kernel_name() const { return plan_ ? mscnn_
 template <typename Dtype>
 const char* ConvolutionLayer<Dtype>::dtype() const { return plan_ ? mscnn_conv2d_plan_dtype(plan_) : "f32"; }
 
-// Transient workspace (stream-K slabs, Winograd V / M planes: up to 0.8 GB for conv2_2): the layers of a net run one after
-// the other on one stream, so all conv layers of a host THREAD share ONE buffer per device instead of 3 GB of per-layer
-// buffers.  Thread-local like the Caffe singleton itself (a thread is a device context, common.cpp:13-20): two threads may
-// drive nets on the same device without sharing scratch.  (Leaked on thread exit on purpose: a destructor could run after
-// the HIP runtime has been torn down.)
-template <typename Dtype>
-void* ConvolutionLayer<Dtype>::SharedWorkspace(size_t bytes) {
-  static thread_local DeviceBuffer* shared_ws[64] = {nullptr};
-  int dev = 0;
-  HIP_CHECK(hipGetDevice(&dev));
-  CHECK(dev >= 0 && dev < 64);
-  if (!shared_ws[dev]) shared_ws[dev] = new DeviceBuffer();
-  return bytes ? shared_ws[dev]->Reserve(bytes) : nullptr;
-}
-
-template <typename Dtype>
-bool ConvolutionLayer<Dtype>::PrepareGroupMember(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top, GroupMember* m) {
-  Plan(bottom[0]->num(), bottom[0]->height(), bottom[0]->width());
-  if (std::string(mscnn_conv2d_plan_kernel(plan_)).compare(0, 8, "head4x4_") != 0 || bottom[0]->num() == 0) return false;
-  const float* w = this->blobs_[0]->gpu_data();
-  const size_t pbytes = mscnn_conv2d_packed_weight_bytes(plan_);
-  float* packed = pbytes ? static_cast<float*>(packed_.Reserve(pbytes)) : nullptr;
-  if (weights_dirty_) {
-    MSCNN_CHECK(mscnn_conv2d_pack_weights(plan_, w, packed, S()));
-    weights_dirty_ = false;
-  }
-  m->plan = plan_; m->x = bottom[0]->gpu_data(); m->packed = packed;
-  m->bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
-  m->y = top[0]->mutable_gpu_data();
-  return true;
-}
-
 template <typename Dtype>
 void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
   Plan(bottom[0]->num(), bottom[0]->height(), bottom[0]->width());
@@ -287,8 +255,18 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     MSCNN_CHECK(mscnn_conv2d_pack_weights(plan_, w, packed, S()));
     weights_dirty_ = false;
   }
+  // Transient workspace (stream-K slabs, Winograd V / M planes: up to 0.8 GB for conv2_2): the layers of a net run one after
+  // the other on one stream, so all conv layers of a host THREAD share ONE buffer per device instead of 3 GB of per-layer
+  // buffers.  Thread-local like the Caffe singleton itself (a thread is a device context, common.cpp:13-20): two threads may
+  // drive nets on the same device without sharing scratch.  (Leaked on thread exit on purpose: a destructor could run after
+  // the HIP runtime has been torn down.)
+  static thread_local DeviceBuffer* shared_ws[64] = {nullptr};
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  CHECK(dev >= 0 && dev < 64);
+  if (!shared_ws[dev]) shared_ws[dev] = new DeviceBuffer();
   const size_t wbytes = mscnn_conv2d_workspace_bytes(plan_);
-  void* ws = SharedWorkspace(wbytes);
+  void* ws = wbytes ? shared_ws[dev]->Reserve(wbytes) : nullptr;
   const float* bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
   {
     const bool pub = amax_wanted_ && amax_out_ && mscnn_conv2d_plan_publishes_amax(plan_);

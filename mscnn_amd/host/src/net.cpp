@@ -5,7 +5,6 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdlib>
-#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -280,25 +279,6 @@ void Net<Dtype>::ApplyFusion() {
     if (!clean) continue;
     if (layers_[prod]->FusePool2x2(top_vecs_[i][0])) { fused_away_[i] = true; fused_producers_[i].push_back(prod); }
   }
-  // Proposal heads: convolutions whose top is read by BoxOutput layers only.  Their inputs are all there once the trunk is
-  // done; ForwardFromTo defers them to the last one and launches each kernel family once (the low-resolution heads are pure
-  // launch latency on their own).
-  for (size_t i = 0; i < layers_.size(); ++i) {
-    if (string(layers_[i]->type()) != "Convolution" || !layers_[i]->IsGroupCandidate() || top_vecs_[i].size() != 1) continue;
-    bool ok = true, any = false;
-    for (size_t l = 0; l < layers_.size() && ok; ++l) {
-      if (l == i) continue;
-      for (Blob<Dtype>* b : bottom_vecs_[l])
-        if (b == top_vecs_[i][0]) {
-          if (string(layers_[l]->type()) == "BoxOutput" && l > i) any = true;
-          else if (!(fused_away_[l] && string(layers_[l]->type()) == "ReLU")) ok = false;
-        }
-      for (Blob<Dtype>* t : top_vecs_[l]) if (t == top_vecs_[i][0] && !fused_away_[l]) ok = false;
-    }
-    for (int oi : net_output_blob_indices_) if (blobs_[oi].get() == top_vecs_[i][0]) ok = false;
-    if (ok && any) head_layers_.push_back((int)i);
-  }
-  if (head_layers_.size() < 2) head_layers_.clear();
   // Channel Concat whose bottoms all come straight from ROIPooling layers (roi_pool_org + roi_pool_ctx -> roi_pool): the
   // producers write their channel window of the concatenated blob and the copy layer disappears (concat_layer.cu:28-46
   // moves R x 1024 x 49 floats per image otherwise).  The individual ROIPooling tops are then not materialised.
@@ -411,27 +391,7 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
     }
     if (any) HIP_CHECK(hipMemsetAsync(amax_slots_, 0, sizeof(unsigned) * MSCNN_AMAX_SLOTS * layers_.size(), (hipStream_t)Caffe::stream()));
   }
-  // the heads inside [start, end]: all but the last are deferred to the last one
-  int last_head = -1;
-  for (int h : head_layers_) if (h >= start && h <= end) last_head = std::max(last_head, h);
-  vector<int> pending;
   for (int i = start; i <= end; ++i) {
-    if (last_head >= 0 && std::find(head_layers_.begin(), head_layers_.end(), i) != head_layers_.end()) {
-      pending.push_back(i);
-      if (i != last_head) {
-        layers_[i]->Reshape(bottom_vecs_[i], top_vecs_[i]);
-        layer_ms_[i] = 0.f;
-        continue;
-      }
-      if (timing_) HIP_CHECK(hipEventRecord(e0, (hipStream_t)Caffe::stream()));
-      RunHeadGroup(pending);
-      if (timing_) {
-        HIP_CHECK(hipEventRecord(e1, (hipStream_t)Caffe::stream()));
-        HIP_CHECK(hipEventSynchronize(e1));
-        HIP_CHECK(hipEventElapsedTime(&layer_ms_[i], e0, e1));
-      }
-      continue;
-    }
     bool run = !fused_away_[i];
     if (fused_away_[i]) {
       // A fused-away layer's work is done by its producer(s).  When a partial range starts after one of them (the reference
@@ -457,38 +417,6 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   }
   if (timing_) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
   return 0;
-}
-
-template <typename Dtype>
-void Net<Dtype>::RunHeadGroup(const vector<int>& pending) {
-  typedef typename ConvolutionLayer<Dtype>::GroupMember Member;
-  std::map<string, vector<std::pair<int, Member> > > families;       // kernel name -> (layer, what the group call needs)
-  for (int i : pending) {
-    ConvolutionLayer<Dtype>* c = static_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
-    c->Reshape(bottom_vecs_[i], top_vecs_[i]);
-    Member m;
-    if (c->PrepareGroupMember(bottom_vecs_[i], top_vecs_[i], &m)) families[c->kernel_name()].push_back(std::make_pair(i, m));
-    else layers_[i]->Forward(bottom_vecs_[i], top_vecs_[i]);            // not a head kernel after all: on its own
-  }
-  for (typename std::map<string, vector<std::pair<int, Member> > >::iterator f = families.begin(); f != families.end(); ++f) {
-    const vector<std::pair<int, Member> >& mem = f->second;
-    for (size_t b = 0; b < mem.size(); b += 4) {
-      const int n = (int)std::min<size_t>(4, mem.size() - b);
-      const mscnn_conv_plan* plans[4]; const float* xs[4]; const float* pk[4]; const float* bs[4]; float* ys[4];
-      for (int k = 0; k < n; ++k) {
-        const Member& m = mem[b + k].second;
-        plans[k] = m.plan; xs[k] = m.x; pk[k] = m.packed; bs[k] = m.bias; ys[k] = m.y;
-      }
-      const size_t wb = n > 1 ? mscnn_conv2d_group_workspace_bytes(plans, n) : 0;
-      if (wb == 0) {
-        for (int k = 0; k < n; ++k) layers_[mem[b + k].first]->Forward(bottom_vecs_[mem[b + k].first], top_vecs_[mem[b + k].first]);
-        continue;
-      }
-      void* ws = ConvolutionLayer<Dtype>::SharedWorkspace(wb);
-      const int rc = mscnn_conv2d_fwd_group_f32(plans, xs, pk, bs, ys, n, ws, wb, Caffe::stream());
-      CHECK_EQ(rc, 0) << mscnn_last_error();
-    }
-  }
 }
 
 template <typename Dtype>
