@@ -136,17 +136,6 @@ MSCNN_API int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* plan, const float
                               const float* bias, float* y, float* y_pool, void* workspace, size_t workspace_bytes,
                               void* stream);
 
-/* Several convolutions in ONE launch: the 7 / 8 proposal heads of a deploy net (LFCN_*: Cout <= 12, kernels 5x5 / 7x7 / 3x5 /
- * 5x7) are small and all runnable once the trunk is done; launched one by one the low-resolution levels are pure launch latency.
- * plans[0..n) (n <= 4) must have selected the same head kernel (mscnn_conv2d_plan_kernel equal, "head4x4_..."); x / packed / bias
- * / y are per-plan device pointers (bias[i] may be NULL).  mscnn_conv2d_group_workspace_bytes returns 0 when the plans cannot be
- * grouped -- run them one by one then.  Results are bit-identical to the individual calls only up to the stream-K split points
- * (each member gets its share of one grid): same 1e-4 bound. */
-MSCNN_API size_t mscnn_conv2d_group_workspace_bytes(const mscnn_conv_plan* const* plans, int n);
-MSCNN_API int mscnn_conv2d_fwd_group_f32(const mscnn_conv_plan* const* plans, const float* const* x, const float* const* packed,
-                               const float* const* bias, float* const* y, int n, void* workspace, size_t workspace_bytes,
-                               void* stream);
-
 /* ReLU -- ReLULayer::Forward_gpu (relu_layer.cu:9-26); in place allowed (y == x). */
 MSCNN_API int mscnn_relu_fwd_f32(const float* x, float* y, size_t count, float negative_slope, void* stream);
 

@@ -1307,33 +1307,6 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
   return MSCNN_OK;
 }
 
-// Proposal heads of one kernel family in one launch (headconv.hip: head_forward_group)
-static int group_items(const mscnn_conv_plan* const* plans, const float* const* x, const float* const* packed, const float* const* bias,
-                       float* const* y, int n, HeadGroupItem* items) {
-  if (n < 1 || n > 4 || !plans) return 0;
-  for (int i = 0; i < n; ++i) {
-    const mscnn_conv_plan* p = plans[i];
-    if (!p || p->head.entry < 0 || p->d.N == 0) return 0;
-    items[i].d = &p->d; items[i].hp = &p->head; items[i].Ho = p->Ho; items[i].Wo = p->Wo;
-    items[i].x = x ? x[i] : nullptr; items[i].packed = packed ? packed[i] : nullptr; items[i].bias = bias ? bias[i] : nullptr;
-    items[i].y = y ? y[i] : nullptr;
-  }
-  return n;
-}
-extern "C" size_t mscnn_conv2d_group_workspace_bytes(const mscnn_conv_plan* const* plans, int n) {
-  HeadGroupItem items[4];
-  if (!group_items(plans, nullptr, nullptr, nullptr, nullptr, n, items)) return 0;
-  return head_group_workspace_bytes(items, n);
-}
-extern "C" int mscnn_conv2d_fwd_group_f32(const mscnn_conv_plan* const* plans, const float* const* x, const float* const* packed,
-                                          const float* const* bias, float* const* y, int n, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
-  HeadGroupItem items[4];
-  MSCNN_REQUIRE(x && packed && y && group_items(plans, x, packed, bias, y, n, items) == n,
-                "conv group: 1..4 non-empty plans that run a proposal-head kernel are needed");
-  return head_forward_group(items, n, workspace, workspace_bytes, as_stream(stream));
-}
-
 extern "C" int mscnn_conv2d_plan_can_pool(const mscnn_conv_plan* p) {
   if (!p || p->head.entry >= 0) return 0;
   if (p->wino || p->x3.BM) return p->wino_m == 2 || (p->tiles_h % 2 == 0 && p->tiles_w % 2 == 0 && p->d.H > 8);

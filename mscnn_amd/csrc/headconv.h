@@ -17,13 +17,4 @@ int head_pack(const mscnn_conv_desc& d, const HeadPlan& hp, const float* w, floa
 int head_forward(const mscnn_conv_desc& d, const HeadPlan& hp, int Ho, int Wo, const float* x, const float* packed,
                  const float* bias, float* y, void* workspace, size_t workspace_bytes, hipStream_t st);
 
-// Several heads that selected the same kernel (hp->entry equal) in ONE main launch + ONE fix-up launch; each member's grid is
-// its share of 512 workgroups.  head_group_workspace_bytes: 0 when the plans cannot be grouped (n outside 1..4, different kernels).
-struct HeadGroupItem {
-  const mscnn_conv_desc* d; const HeadPlan* hp; int Ho, Wo;
-  const float* x; const float* packed; const float* bias; float* y;
-};
-size_t head_group_workspace_bytes(const HeadGroupItem* items, int n);
-int head_forward_group(const HeadGroupItem* items, int n, void* workspace, size_t workspace_bytes, hipStream_t st);
-
 }  // namespace mscnn

@@ -43,22 +43,6 @@ struct HeadArgs {
   long total_iters;
 };
 
-// Several heads in one launch: the proposal heads of a net are 7 / 8 small convolutions whose inputs are all ready once the trunk
-// is done; launched one by one the small levels (18 x 60, 9 x 30 maps) are pure launch latency (30-40 us each for < 0.5 GFLOP).
-// Workgroup b belongs to head i with first[i] <= b < first[i + 1] (main kernel: stream-K workgroups, fix-up: tile x channel
-// workgroups); each head's G is its share of one grid, so all heads finish together.
-constexpr int kMaxGroup = 4;
-struct HeadGroupArgs {
-  HeadArgs h[kMaxGroup];
-  int first[kMaxGroup + 1];
-};
-__device__ __forceinline__ int group_member(const HeadGroupArgs& g, int b) {
-  int i = 0;
-#pragma unroll
-  for (int j = 1; j < kMaxGroup; ++j) if (b >= g.first[j]) i = j;
-  return i;
-}
-
 template <int KH_, int KW_, int NQ_, int CK_>
 struct HCfg {
   static constexpr int KH = KH_, KW = KW_, NQ = NQ_, CK = CK_, TH = 16, TW = 32, BN = TH * TW;
@@ -123,13 +107,11 @@ __device__ __forceinline__ void lds_group(const float* b0, const float* b1, floa
 }
 
 template <class C>
-__global__ __launch_bounds__(256, 2) void head_kernel(HeadGroupArgs grp) {
+__global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
   __shared__ __attribute__((aligned(16))) float ldsA[C::A_ELEMS];
   __shared__ float ldsB[C::B_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int member = group_member(grp, (int)blockIdx.x);
-  const HeadArgs a = grp.h[member];
-  const int wg = (int)blockIdx.x - grp.first[member];
+  const int wg = blockIdx.x;
   long it, it_end;
   wg_range(a.total_iters, a.G, wg, it, it_end);
 
@@ -265,13 +247,10 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadGroupArgs grp) {
 // Adds the partial slabs of every tile that was split across workgroups, in k order, + bias (+ ReLU).
 // One workgroup per (tile, output channel): 512 pixels, a float2 per thread, slab loads four deep.
 template <class C>
-__global__ __launch_bounds__(256) void head_fixup_kernel(HeadGroupArgs grp) {
+__global__ __launch_bounds__(256) void head_fixup_kernel(HeadArgs a) {
   __shared__ const float* s_slab[256];
   __shared__ int s_n;
-  const int member = group_member(grp, (int)blockIdx.x);
-  const HeadArgs a = grp.h[member];
-  const int bid = (int)blockIdx.x - grp.first[member];
-  const int t = bid / a.Cout, co = bid % a.Cout;
+  const int t = blockIdx.x / a.Cout, co = blockIdx.x % a.Cout;
   if (threadIdx.x == 0) {
     const long its = (long)t * a.KI, ite = its + a.KI;
     int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
@@ -322,7 +301,7 @@ __global__ __launch_bounds__(256) void head_fixup_kernel(HeadGroupArgs grp) {
   if (ow + 1 < a.Wo) yrow[ow + 1] = r1;
 }
 
-typedef void (*HeadFn)(HeadGroupArgs);
+typedef void (*HeadFn)(HeadArgs);
 struct HeadEntry {
   const char* name;
   int KH, KW, NQ, CK, AREGS, SLAB;
@@ -383,71 +362,18 @@ int head_pack(const mscnn_conv_desc& d, const HeadPlan& hp, const float* w, floa
 
 int head_forward(const mscnn_conv_desc& d, const HeadPlan& hp, int Ho, int Wo, const float* x, const float* packed,
                  const float* bias, float* y, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const HeadEntry& k = kHeads[hp.entry];
   if (!workspace || workspace_bytes < hp.ws_bytes) {
     set_error("conv(head): workspace %zu < %zu", workspace_bytes, hp.ws_bytes);
     return MSCNN_ERR_WORKSPACE;
   }
-  HeadGroupItem it = {&d, &hp, Ho, Wo, x, packed, bias, y};
-  return head_forward_group(&it, 1, workspace, workspace_bytes, st);
-}
-
-// Workgroups per member of a group: its share (by stream-K iterations) of one grid of 512, at least ~2 chunks each
-static void group_grids(const HeadGroupItem* items, int n, int* G) {
-  long total = 0;
-  for (int i = 0; i < n; ++i) total += items[i].hp->total_iters;
-  for (int i = 0; i < n; ++i) {
-    if (n == 1) { G[i] = items[i].hp->G; continue; }
-    long g = (512 * items[i].hp->total_iters + total - 1) / total;
-    if (items[i].hp->total_iters / 2 < g) g = items[i].hp->total_iters / 2;
-    G[i] = (int)(g < 1 ? 1 : g);
-  }
-}
-
-size_t head_group_workspace_bytes(const HeadGroupItem* items, int n) {
-  if (n < 1 || n > kMaxGroup) return 0;
-  for (int i = 0; i < n; ++i)
-    if (!items[i].hp || items[i].hp->entry < 0 || items[i].hp->entry != items[0].hp->entry) return 0;
-  int G[kMaxGroup];
-  group_grids(items, n, G);
-  size_t bytes = 0;
-  for (int i = 0; i < n; ++i) bytes += (size_t)G[i] * 2 * kHeads[items[0].hp->entry].SLAB * sizeof(float);
-  return bytes;
-}
-
-int head_forward_group(const HeadGroupItem* items, int n, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  const size_t need = head_group_workspace_bytes(items, n);
-  MSCNN_REQUIRE(need > 0, "conv(head group): 1..%d plans that selected the same head kernel are needed", kMaxGroup);
-  if (!workspace || workspace_bytes < need) {
-    set_error("conv(head group): workspace %zu < %zu", workspace_bytes, need);
-    return MSCNN_ERR_WORKSPACE;
-  }
-  const HeadEntry& k = kHeads[items[0].hp->entry];
-  int G[kMaxGroup];
-  group_grids(items, n, G);
-  HeadGroupArgs g, gf;
-  float* ws = static_cast<float*>(workspace);
-  int first = 0, first_fix = 0;
-  for (int i = 0; i < kMaxGroup; ++i) {
-    const int j = i < n ? i : n - 1;               // unused members repeat the last one (never selected: first[] beyond the grid)
-    const mscnn_conv_desc& d = *items[j].d;
-    const HeadPlan& hp = *items[j].hp;
-    HeadArgs a;
-    a.x = items[j].x; a.wp = items[j].packed; a.bias = items[j].bias; a.y = items[j].y; a.ws = ws;
-    a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.Ho = items[j].Ho; a.Wo = items[j].Wo; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
-    a.NTH = hp.NTH; a.NTW = hp.NTW; a.KI = hp.KI; a.G = G[j]; a.relu = d.relu; a.total_iters = hp.total_iters;
-    g.h[i] = a; gf.h[i] = a;
-    g.first[i] = first; gf.first[i] = first_fix;
-    if (i < n) {
-      MSCNN_REQUIRE(items[i].x && items[i].packed && items[i].y, "conv(head group): null pointer");
-      first += G[i]; first_fix += hp.tiles * d.Cout;
-      ws += (size_t)G[i] * 2 * k.SLAB;
-    }
-  }
-  g.first[kMaxGroup] = first; gf.first[kMaxGroup] = first_fix;
-  for (int i = n; i < kMaxGroup; ++i) { g.first[i] = 0x7fffffff; gf.first[i] = 0x7fffffff; }
-  k.main_fn<<<first, 256, 0, st>>>(g);
+  HeadArgs a;
+  a.x = x; a.wp = packed; a.bias = bias; a.y = y; a.ws = static_cast<float*>(workspace);
+  a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.Ho = Ho; a.Wo = Wo; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
+  a.NTH = hp.NTH; a.NTW = hp.NTW; a.KI = hp.KI; a.G = hp.G; a.relu = d.relu; a.total_iters = hp.total_iters;
+  k.main_fn<<<hp.G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
-  k.fix_fn<<<first_fix, 256, 0, st>>>(gf);
+  k.fix_fn<<<hp.tiles * d.Cout, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

@@ -64,9 +64,6 @@ def lib():
         L.mscnn_conv2d_plan_kernel.argtypes = [C.c_void_p]
         L.mscnn_conv2d_plan_publishes_amax.argtypes = [C.c_void_p]
         L.mscnn_conv2d_plan_set_amax_io.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.mscnn_conv2d_group_workspace_bytes.restype = C.c_size_t
-        L.mscnn_conv2d_group_workspace_bytes.argtypes = [C.c_void_p, C.c_int]
-        L.mscnn_conv2d_fwd_group_f32.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.mscnn_conv2d_plan_dtype.restype = C.c_char_p
         L.mscnn_conv2d_plan_dtype.argtypes = [C.c_void_p]
         L.mscnn_inner_product_f16_supported.argtypes = [C.c_int, C.c_int]
@@ -237,21 +234,6 @@ class ConvPlan:
                 self._p = None
         except Exception:
             pass
-
-
-def conv2d_group(plans, xs, biases=None):
-    """Several proposal-head convolutions (ConvPlan objects that selected the same head kernel, weights packed) in one launch."""
-    n = len(plans)
-    P = (C.c_void_p * n)(*[p._p for p in plans])
-    wb = lib().mscnn_conv2d_group_workspace_bytes(P, n)
-    if not wb:
-        raise MscnnError("these plans cannot be grouped (1..4 plans with the same head kernel)")
-    ys = [torch.empty(p.out_shape(), dtype=torch.float32, device=x.device) for p, x in zip(plans, xs)]
-    ws = torch.empty(wb, dtype=torch.uint8, device=xs[0].device)
-    arr = lambda ts: (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])      # noqa: E731
-    _check(lib().mscnn_conv2d_fwd_group_f32(P, arr(xs), arr([p.packed for p in plans]), arr(biases or [None] * n), arr(ys), n,
-                                            _dev(ws), wb, _stream()))
-    return ys
 
 
 def conv2d(x, w, bias=None, pad=(0, 0), stride=(1, 1), group=1, relu=False, algo=ALGO_AUTO):

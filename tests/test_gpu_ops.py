@@ -122,37 +122,6 @@ def test_conv(hip, orc, case, relu):
     close(y, ref)
 
 
-@pytest.mark.parametrize("k,cout", [((5, 5), 9), ((7, 7), 9), ((5, 3), 7), ((7, 5), 6)])
-def test_conv_head_group_launch(hip, orc, k, cout):
-    """The proposal heads of several net levels in ONE launch (+ one fix-up launch): each member against the oracle (1e-4) and
-    against its own individual launch; a group of one; plans that cannot be grouped are refused."""
-    rng = np.random.default_rng(41)
-    kh, kw = k
-    shapes = [(1, 64, 36, 120), (1, 64, 18, 60), (2, 64, 9, 30), (1, 40, 5, 15)]      # four "levels", batch 2 and ragged Cin among them
-    plans, xs, ws, bs = [], [], [], []
-    for (N, Cin, H, W) in shapes:
-        plans.append(hip.ConvPlan(N, Cin, H, W, cout, kh, kw, (kh // 2, kw // 2)))
-        assert plans[-1].kernel.startswith("head4x4_")
-        xs.append(np.maximum(rng.standard_normal((N, Cin, H, W)), 0).astype(np.float32))
-        ws.append((rng.standard_normal((cout, Cin, kh, kw)) * np.sqrt(2.0 / (Cin * kh * kw))).astype(np.float32))
-        bs.append(rng.standard_normal(cout).astype(np.float32))
-        plans[-1].pack(dev(ws[-1]))
-    dx, db = [dev(x) for x in xs], [dev(b) for b in bs]
-    ys = hip.conv2d_group(plans, dx, db)
-    for i in range(len(shapes)):
-        ref = orc.conv2d(xs[i], ws[i], bs[i], (kh // 2, kw // 2))
-        close(ys[i].cpu().numpy(), ref)
-        close(ys[i].cpu().numpy(), plans[i].forward(dx[i], db[i]).cpu().numpy())
-    y1 = hip.conv2d_group(plans[:1], dx[:1], db[:1])[0]
-    assert torch.equal(y1, plans[0].forward(dx[0], db[0]))                        # a group of one IS the individual launch
-    y2 = hip.conv2d_group(plans[1:3], dx[1:3], None)                               # no bias
-    close(y2[0].cpu().numpy(), orc.conv2d(xs[1], ws[1], None, (kh // 2, kw // 2)))
-    other = hip.ConvPlan(1, 64, 18, 60, cout, kw, kh, (kw // 2, kh // 2)) if kh != kw else hip.ConvPlan(1, 64, 18, 60, 64, 3, 3, (1, 1))
-    other.pack(dev(np.zeros((other.desc.Cout, 64, other.desc.Kh, other.desc.Kw), np.float32)))
-    with pytest.raises(hip.MscnnError):
-        hip.conv2d_group([plans[1], other], [dx[1], dx[1]])                        # another kernel family in the group
-
-
 WINO_CASES = [   # N, Cin, H, W, Cout, pad
     (1, 16, 8, 12, 24, 1),        # exact 2x2 tiles
     (1, 40, 13, 21, 130, 1),      # odd H and W: partial tiles at the bottom / right edge, Cout ragged
