@@ -927,6 +927,7 @@ struct mscnn_conv_plan {
   // split-fp16 form of the F(3x3,3x3) path (MSCNN_CONV_ALGO_WINO_F3_X3, wino_x3.hip): x3.BM > 0, wino == nullptr.
   // Workspace layout: [4 KB: max |x| slots, used when nobody hands the bound over][V16][M: 25 x Cout x T_pad floats]
   mscnn::X3Plan x3;
+  mscnn::X3HeadPlan x3h;       // x3h.rows > 0: proposal head as one split-fp16 GEMM + shift-and-add (wino_x3.hip); per image
   size_t x3d_hdr_off = 0, x3d_slots_off = 0;   // X3 direct kernel: header behind the packed weights, own-amax slots behind the slabs
   const unsigned* amax_in = nullptr;   // mscnn_conv2d_plan_set_amax_io (kept across re-planning)
   unsigned* amax_out = nullptr;
@@ -1016,6 +1017,15 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->packed_bytes = 0;
   p->ws_bytes = 0;
   p->head.entry = -1;
+  p->x3h = mscnn::X3HeadPlan();
+  // split-fp16 mode: a small-Cout K x K head is ONE dense GEMM over the taps + a shift-and-add (M = taps * Cout instead of Cout)
+  if (tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_WINO_F3_X3 && d.stride_h == 1 && d.stride_w == 1 && d.group == 1 &&
+      d.Cout <= 12 && d.Kh * d.Kw > 1 && d.N > 0 && !(d.tune_flags & 2) &&
+      x3_head_plan(d.Cin, d.Cout, d.Kh, d.Kw, (long)d.H * d.W, &p->x3h)) {
+    p->packed_bytes = p->x3h.packed_bytes;
+    p->ws_bytes = 4096 + p->x3h.x_bytes + p->x3h.t_bytes;
+    return;
+  }
   if (head_plan(d, p->Ho, p->Wo, &p->head)) {
     p->packed_bytes = p->head.packed_bytes;
     p->ws_bytes = p->head.ws_bytes;
@@ -1147,6 +1157,7 @@ extern "C" size_t mscnn_conv2d_packed_weight_bytes(const mscnn_conv_plan* p) { r
 extern "C" size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* p) { return p ? p->ws_bytes : 0; }
 extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (!p) return "";
+  if (p->x3h.rows) return "head_gemm_shiftadd_x3f16";
   if (p->head.entry >= 0) return head_kernel_name(p->head);
   if (p->x3.BM) return p->x3.BM == 256 ? "winograd_f3x3_3x3_x3f16_256" : "winograd_f3x3_3x3_x3f16_128";
   if (p->wino) return p->wino_m == 3 ? "winograd_f3x3_3x3" : "winograd_f2x2_3x3";
@@ -1155,7 +1166,8 @@ extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
 extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_plan* p) {
   if (!p) return 0;
   unsigned long long kind, e, mt, ki;
-  if (p->head.entry >= 0) { kind = 2; e = (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
+  if (p->x3h.rows) { kind = 7; e = (unsigned)p->x3h.rows_pad; mt = 0; ki = (unsigned)p->x3h.KG; }
+  else if (p->head.entry >= 0) { kind = 2; e = (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
   else if (p->x3.BM) { kind = 6; e = (unsigned)p->x3.BM; mt = (unsigned)p->x3.MT; ki = (unsigned)p->x3.KG; }
   else if (p->wino) { kind = 2 + (unsigned)p->wino_m; e = (unsigned)p->wino->entry; mt = (unsigned)p->wino->MT; ki = (unsigned)p->wino->KI; }
   else if (p->entry >= 0) { kind = 1; e = (unsigned)p->entry; mt = (unsigned)p->MT; ki = (unsigned)p->KI; }   // (entry distinguishes fp16 packs)
@@ -1168,11 +1180,13 @@ extern "C" double mscnn_conv2d_plan_flops(const mscnn_conv_plan* p) {
   return 2.0 * d.N * d.Cout * p->Ho * p->Wo * (double)(d.Cin / d.group) * d.Kh * d.Kw;
 }
 extern "C" const char* mscnn_conv2d_plan_dtype(const mscnn_conv_plan* p) {
+  if (p && p->x3h.rows) return "f16x3";
   if (p && (p->x3.BM || (!p->wino && p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant == 210))) return "f16x3";
   return (p && !p->wino && p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202) ? "f16" : "f32";
 }
 extern "C" double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* p) {
   if (!p) return 0;
+  if (p->x3h.rows) return 3.0 * mscnn_conv2d_plan_flops(p);
   if (!p->wino && !p->x3.BM)
     return mscnn_conv2d_plan_flops(p) * ((p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant == 210) ? 3.0 : 1.0);
   const mscnn_conv_desc& d = p->d;
@@ -1198,7 +1212,7 @@ extern "C" int mscnn_conv2d_plan_stage_ms(const mscnn_conv_plan* p, float ms_out
 }
 extern "C" int mscnn_conv2d_plan_publishes_amax(const mscnn_conv_plan* p) {
   // the F(3x3,3x3) output transforms and every kernel of the implicit-GEMM family (main + fix-up) publish
-  return p && (p->x3.BM || (p->wino && p->wino_m == 3) ||
+  return p && !p->x3h.rows && (p->x3.BM || (p->wino && p->wino_m == 3) ||
                (!p->wino && p->head.entry < 0 && p->entry >= 0 && !(kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202))) ? 1 : 0;
 }
 extern "C" int mscnn_conv2d_plan_set_amax_io(mscnn_conv_plan* p, const uint32_t* in_bound, uint32_t* out_amax) {
@@ -1220,6 +1234,10 @@ extern "C" int mscnn_conv2d_plan_set_batch(mscnn_conv_plan* p, int N) {
 
 extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* w, float* packed, void* stream) {
   MSCNN_REQUIRE(p, "conv pack: null plan");
+  if (p->x3h.rows) {
+    MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
+    return x3_head_pack(p->x3h, w, packed, as_stream(stream));
+  }
   if (p->head.entry >= 0) {
     MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
     return head_pack(p->d, p->head, w, packed, as_stream(stream));
@@ -1308,7 +1326,7 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
 }
 
 extern "C" int mscnn_conv2d_plan_can_pool(const mscnn_conv_plan* p) {
-  if (!p || p->head.entry >= 0) return 0;
+  if (!p || p->head.entry >= 0 || p->x3h.rows) return 0;
   if (p->wino || p->x3.BM) return p->wino_m == 2 || (p->tiles_h % 2 == 0 && p->tiles_w % 2 == 0 && p->d.H > 8);
   return p->entry >= 0 && kTable[p->entry].fix_pool_fn != nullptr;
 }
@@ -1397,6 +1415,19 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
 static int conv_forward_single(const mscnn_conv_plan* p, const float* x, const float* w, const float* packed, const float* bias,
                                float* y, float* y_pool, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const mscnn_conv_desc& d = p->d;
+  if (p->x3h.rows) {
+    MSCNN_REQUIRE(packed, "conv: head kernel needs packed weights (mscnn_conv2d_pack_weights)");
+    if (!workspace || workspace_bytes < p->ws_bytes) {
+      set_error("conv(head x3): workspace %zu < %zu", workspace_bytes, p->ws_bytes);
+      return MSCNN_ERR_WORKSPACE;
+    }
+    for (int n = 0; n < d.N; ++n) {      // (the deploy nets run batch 1; images share the workspace one after the other)
+      const int rc = x3_head_forward(p->x3h, x + (size_t)n * d.Cin * d.H * d.W, packed, bias, y + (size_t)n * d.Cout * p->Ho * p->Wo, d.H,
+                                     d.W, p->Ho, p->Wo, d.pad_h, d.pad_w, d.relu, d.N == 1 ? p->amax_in : nullptr, workspace, st);
+      if (rc != MSCNN_OK) return rc;
+    }
+    return MSCNN_OK;
+  }
   if (p->head.entry >= 0) {
     MSCNN_REQUIRE(packed, "conv: head kernel needs packed weights (mscnn_conv2d_pack_weights)");
     return head_forward(d, p->head, p->Ho, p->Wo, x, packed, bias, y, workspace, workspace_bytes, st);

@@ -15,6 +15,17 @@ struct X3Plan {
   size_t scal_bytes = 4096;  // kAmaxSlots partial maxima of |x| in front of the workspace (when the plan measures them itself)
 };
 
+// Proposal heads (small Cout, K x K, stride 1) as ONE GEMM T[tap * Cout + co][pixel] + a shift-and-add over the taps (wino_x3.hip)
+struct X3HeadPlan {
+  int Cin = 0, Cout = 0, KH = 0, KW = 0, KG = 0, rows = 0, rows_pad = 0;
+  long T_pad = 0;
+  size_t packed_bytes = 0, x_bytes = 0, t_bytes = 0;     // workspace = 4096 (own max |x| slots) + x_bytes + t_bytes
+};
+bool x3_head_plan(int Cin, int Cout, int KH, int KW, long HW, X3HeadPlan* out);
+int x3_head_pack(const X3HeadPlan& p, const float* w, void* packed, hipStream_t st);
+int x3_head_forward(const X3HeadPlan& p, const float* x, const void* packed, const float* bias, float* y, int H, int W, int Ho, int Wo,
+                    int pad_h, int pad_w, int relu, const unsigned* in_bound, void* ws, hipStream_t st);
+
 // false when the shape is not covered (Cin not a multiple of 32, planes beyond the 32-bit buffer window)
 bool x3_plan(int Cin, int Cout, long T_pad, int tune_variant, X3Plan* out);
 

@@ -260,7 +260,8 @@ struct X3Args {
   const void* U; const void* V; float* M; const unsigned* scal; const float* hdr;
   int Cout, Cout_pad, KG, KI, MT, NT, tiles, xcd_map;
   unsigned T_pad;
-  int planes;        // 25 (Winograd), 1 (InnerProduct)
+  int planes;        // 25 (Winograd), 1 (InnerProduct, proposal heads)
+  float bound_mult;  // max |B operand| <= bound_mult * (max over the scal slots): 36 behind the Winograd transform, 1 otherwise
   int ks;            // k-split: > 0 = every tile is cut into ks ranges of KI / ks chunks whose raw accumulators go to
   float* slabs;      //          slabs[((plane * NT + nt) * MT + mt) * ks + s][BM][128] (summed in s order by x3_fixup_kernel); 0 = off
 };
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
   }
   // epilogue: un-scale (exact: powers of two), store M[plane][co][t]
   float sv, inv_v;
-  pow2_scale(36.f * bound_from_slots(a.scal), &sv, &inv_v);
+  pow2_scale(a.bound_mult * bound_from_slots(a.scal), &sv, &inv_v);
   const float inv = inv_v * a.hdr[0];
   const unsigned m_bytes = (unsigned)a.planes * (unsigned)a.Cout * a.T_pad * 4u;
   const __amdgpu_buffer_rsrc_t msrc = make_rsrc(a.M, m_bytes);
@@ -454,9 +455,135 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const float* __restrict__
   }
 }
 
+// ---- proposal heads as a GEMM + shift-and-add ---------------------------------------------------------------------------------
+// A K x K convolution with a handful of output channels over 512 input channels (LFCN_*: Cout 6..9, 5x5 / 7x7 / 3x5 / 5x7) is a
+// poor MFMA shape as a convolution (M = Cout), but  y[co][p] = sum_tap ( sum_c w[co][c][tap] x[c][p + off(tap)] )  is ONE dense
+// GEMM  T[tap * Cout + co][p] = W'[tap * Cout + co][c] x[c][p]  (M = taps * Cout = 225 / 441 rows, K = Cin, N = pixels: no patch, no
+// halo, x is its own B operand) followed by a shift-and-add over the taps -- the transposed view of im2col + GEMM (col2im after the
+// GEMM instead of im2col before it).  Same multiplies as the direct form; T is taps * Cout * H * W floats (30 MB for the 7x7 head on
+// conv4_3).  In the split-fp16 arithmetic: x split once per layer into the GEMM's B layout, W' packed once.
+// x [Cin][HW] fp32 -> X16[part][kg][T_pad][8]: thread = (pixel, kg), 8 coalesced channel-row loads, one 16-byte unit per part
+__global__ __launch_bounds__(256) void x3_split_planes_kernel(const float* __restrict__ x, uint4* __restrict__ X16,
+                                                              const unsigned* __restrict__ slots, int Cin, int HW, unsigned T_pad) {
+  float s, inv;
+  pow2_scale(bound_from_slots(slots), &s, &inv);
+  const unsigned t = blockIdx.x * 256 + threadIdx.x;
+  const int kg = blockIdx.y, KG = Cin / 8;
+  if (t >= T_pad) return;
+  f16x8 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = t < (unsigned)HW ? x[(size_t)(kg * 8 + i) * HW + t] : 0.f;
+    _Float16 h, l;
+    split16(v * s, &h, &l);
+    hi[i] = h; lo[i] = l;
+  }
+  X16[(size_t)kg * T_pad + t] = __builtin_bit_cast(uint4, hi);
+  X16[((size_t)KG + kg) * T_pad + t] = __builtin_bit_cast(uint4, lo);
+}
+
+// w [Cout][Cin][taps] -> W16[part][kg][rows_pad][8], row = tap * Cout + co; scale from the slots behind the header
+__global__ __launch_bounds__(256) void x3_head_weight_kernel(const float* __restrict__ w, unsigned char* __restrict__ packed, int Cout,
+                                                             int Cin, int taps, int rows_pad) {
+  float s, inv;
+  pow2_scale(bound_from_slots(reinterpret_cast<const unsigned*>(packed + kHdrBytes / 2)), &s, &inv);
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(packed)[0] = inv;
+  _Float16* W16 = reinterpret_cast<_Float16*>(packed + kHdrBytes);
+  const int KG = Cin / 8;
+  const long part_stride = (long)KG * rows_pad * 8, total = (long)rows_pad * Cin;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int row = (int)(i % rows_pad), ci = (int)(i / rows_pad);
+    const int tap = row / Cout, co = row % Cout;
+    const float v = row < taps * Cout ? w[((long)co * Cin + ci) * taps + tap] : 0.f;
+    _Float16 hi, lo;
+    split16(v * s, &hi, &lo);
+    const long o = ((long)(ci >> 3) * rows_pad + row) * 8 + (ci & 7);
+    W16[o] = hi;
+    W16[part_stride + o] = lo;
+  }
+}
+
+// y[co][oy][ox] = bias[co] + sum over taps (kh, kw ascending) of T[tap * Cout + co][(oy + kh - ph) * W + ox + kw - pw], taps that fall
+// outside the map skipped (zero padding); thread = (co, output pixel), lanes along ox: every T row is read as contiguous runs
+__global__ __launch_bounds__(256) void x3_head_shift_add_kernel(const float* __restrict__ T, const float* __restrict__ bias,
+                                                                float* __restrict__ y, int Cout, int H, int W, int Ho, int Wo, int KH,
+                                                                int KW, int ph, int pw, unsigned T_pad, int relu) {
+  const int p = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
+  if (p >= Ho * Wo) return;
+  const int oy = p / Wo, ox = p % Wo;
+  float acc = bias ? bias[co] : 0.f;
+  for (int kh = 0; kh < KH; ++kh) {
+    const int iy = oy + kh - ph;
+    if (iy < 0 || iy >= H) continue;
+    for (int kw = 0; kw < KW; ++kw) {
+      const int ix = ox + kw - pw;
+      if (ix < 0 || ix >= W) continue;
+      acc += T[(size_t)((kh * KW + kw) * Cout + co) * T_pad + (unsigned)(iy * W + ix)];
+    }
+  }
+  if (relu) acc = acc > 0.f ? acc : 0.f;
+  y[((size_t)co * Ho + oy) * Wo + ox] = acc;
+}
+
 }  // namespace
 
 namespace mscnn {
+
+bool x3_head_plan(int Cin, int Cout, int KH, int KW, long HW, X3HeadPlan* out) {
+  if (Cin % 32 != 0 || Cin < 32 || Cout < 1 || Cout > 16 || KH * KW < 2 || KH * KW > 64 || HW < 1) return false;
+  X3HeadPlan p;
+  p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.KG = Cin / 8;
+  p.rows = KH * KW * Cout;
+  p.rows_pad = (p.rows + 127) / 128 * 128;
+  p.T_pad = (HW + 127) / 128 * 128;
+  const double w_bytes = 2.0 * p.KG * p.rows_pad * 16.0, x_bytes = 2.0 * p.KG * (double)p.T_pad * 16.0, t_bytes = (double)p.rows * p.T_pad * 4.0;
+  if (w_bytes >= 4.0e9 || x_bytes >= 4.0e9 || t_bytes >= 4.0e9) return false;
+  p.packed_bytes = kHdrBytes + (size_t)w_bytes;
+  p.x_bytes = (size_t)x_bytes;
+  p.t_bytes = (size_t)t_bytes;
+  *out = p;
+  return true;
+}
+
+int x3_head_pack(const X3HeadPlan& p, const float* w, void* packed, hipStream_t st) {
+  unsigned* hdr = static_cast<unsigned*>(packed);
+  const int rc = x3_amax(w, (long)p.Cout * p.Cin * p.KH * p.KW, hdr + kHdrBytes / 8, st);
+  if (rc != MSCNN_OK) return rc;
+  long blocks = ((long)p.rows_pad * p.Cin + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  x3_head_weight_kernel<<<(int)blocks, 256, 0, st>>>(w, static_cast<unsigned char*>(packed), p.Cout, p.Cin, p.KH * p.KW, p.rows_pad);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+// one image: x [Cin][H][W] -> y [Cout][Ho][Wo].  ws: [4 KB own slots][X16][T]
+int x3_head_forward(const X3HeadPlan& p, const float* x, const void* packed, const float* bias, float* y, int H, int W, int Ho, int Wo,
+                    int pad_h, int pad_w, int relu, const unsigned* in_bound, void* ws, hipStream_t st) {
+  unsigned char* wsb = static_cast<unsigned char*>(ws);
+  unsigned* own = reinterpret_cast<unsigned*>(wsb);
+  uint4* X16 = reinterpret_cast<uint4*>(wsb + 4096);
+  float* T = reinterpret_cast<float*>(wsb + 4096 + p.x_bytes);
+  const int HW = H * W;
+  if (!in_bound) {
+    const int rc = x3_amax(x, (long)p.Cin * HW, own, st);
+    if (rc != MSCNN_OK) return rc;
+  }
+  const unsigned* slots = in_bound ? in_bound : own;
+  x3_split_planes_kernel<<<dim3((unsigned)(p.T_pad / 256 + (p.T_pad % 256 ? 1 : 0)), p.KG), 256, 0, st>>>(x, X16, slots, p.Cin, HW, (unsigned)p.T_pad);
+  MSCNN_POST_LAUNCH();
+  const unsigned char* pk = static_cast<const unsigned char*>(packed);
+  X3Args a;
+  a.U = pk + kHdrBytes; a.V = X16; a.M = T; a.scal = slots; a.hdr = reinterpret_cast<const float*>(pk);
+  a.Cout = p.rows; a.Cout_pad = p.rows_pad; a.KG = p.KG; a.KI = p.KG / 4; a.MT = p.rows_pad / 128; a.NT = (int)(p.T_pad / 128);
+  a.tiles = a.MT * a.NT; a.xcd_map = 1; a.T_pad = (unsigned)p.T_pad;
+  a.planes = 1; a.ks = 0; a.slabs = nullptr; a.bound_mult = 1.f;
+  x3_gemm_kernel<128><<<a.tiles, 256, 0, st>>>(a);
+  MSCNN_POST_LAUNCH();
+  x3_head_shift_add_kernel<<<dim3(cdiv(Ho * Wo, 256), p.Cout), 256, 0, st>>>(T, bias, y, p.Cout, H, W, Ho, Wo, p.KH, p.KW, pad_h, pad_w,
+                                                                             (unsigned)p.T_pad, relu);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
 
 bool x3_plan(int Cin, int Cout, long T_pad, int tune_variant, X3Plan* out) {
   if (Cin % 32 != 0 || Cin < 32 || T_pad % 128 != 0) return false;
@@ -523,7 +650,7 @@ int x3_gemm(const X3Plan& p, const void* packed, const void* V16, float* M, cons
   a.V = V16; a.M = M; a.scal = scal; a.hdr = static_cast<const float*>(packed);
   a.Cout = p.Cout; a.Cout_pad = p.Cout_pad; a.KG = p.KG; a.KI = p.KG / 4; a.MT = p.MT; a.NT = p.NT;
   a.tiles = 25 * p.MT * p.NT; a.xcd_map = xcd_map; a.T_pad = (unsigned)p.T_pad;
-  a.planes = 25; a.ks = 0; a.slabs = nullptr;
+  a.planes = 25; a.ks = 0; a.slabs = nullptr; a.bound_mult = 36.f;
   if (p.BM == 256) x3_gemm_kernel<256><<<a.tiles, 256, 0, st>>>(a);
   else x3_gemm_kernel<128><<<a.tiles, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
@@ -606,7 +733,7 @@ extern "C" int mscnn_inner_product_x3_fwd(const float* x, const void* packed, co
   a.U = X16; a.V = pk + kHdrBytes; a.M = nullptr; a.scal = nullptr; a.hdr = nullptr;
   a.Cout = M; a.Cout_pad = s.M_pad; a.KG = s.KG; a.KI = s.KI; a.MT = s.MT; a.NT = s.NT;
   a.tiles = s.MT * s.NT * s.ks; a.xcd_map = 1; a.T_pad = (unsigned)s.N_pad;
-  a.planes = 1; a.ks = s.ks; a.slabs = slabs;
+  a.planes = 1; a.ks = s.ks; a.slabs = slabs; a.bound_mult = 1.f;
   x3_gemm_kernel<128><<<a.tiles, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   x3_fixup_kernel<<<s.MT * s.NT, 256, 0, st>>>(slabs, inv_x, reinterpret_cast<const float*>(pk), bias, y, M, N, s.MT, s.ks, relu);

@@ -122,6 +122,40 @@ def test_conv(hip, orc, case, relu):
     close(y, ref)
 
 
+@pytest.mark.parametrize("case", [(1, 64, 36, 120, 9, (5, 5)), (1, 128, 18, 60, 9, (7, 7)), (2, 64, 12, 20, 7, (5, 3)), (1, 96, 13, 21, 6, (7, 5)),
+                                  (1, 512, 9, 30, 9, (5, 5)), (1, 32, 7, 9, 12, (3, 3))])
+def test_conv_head_x3_gemm_shiftadd(hip, orc, case):
+    """Proposal heads in the split-fp16 mode: ONE dense GEMM T[tap * Cout + co][pixel] over the taps (M = taps * Cout instead of Cout)
+    + a shift-and-add with the zero padding of the convolution -- against the oracle's direct convolution (1e-4) and no worse than 3x
+    the fp32 head kernel + 2e-6; borders smaller than the kernel, batch 2, ReLU, handed-over max |x|."""
+    N, Cin, H, W, Cout, (kh, kw) = case
+    rng = np.random.default_rng(43)
+    x = np.maximum(rng.standard_normal((N, Cin, H, W)), 0).astype(np.float32) * 2
+    w = (rng.standard_normal((Cout, Cin, kh, kw)) * np.sqrt(2.0 / (Cin * kh * kw))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    plan = hip.ConvPlan(N, Cin, H, W, Cout, kh, kw, (kh // 2, kw // 2), algo=hip.ALGO_WINO_F3_X3)
+    assert plan.kernel == "head_gemm_shiftadd_x3f16" and plan.dtype == "f16x3" and not plan.can_pool and not plan.publishes_amax
+    plan.pack(dev(w))
+    y = plan.forward(dev(x), dev(b)).cpu().numpy()
+    ref = orc.conv2d(x, w, b, (kh // 2, kw // 2))
+    close(y, ref)
+    p32 = hip.ConvPlan(N, Cin, H, W, Cout, kh, kw, (kh // 2, kw // 2))
+    p32.pack(dev(w))
+    y32 = p32.forward(dev(x), dev(b)).cpu().numpy()
+    truth = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                       padding=(kh // 2, kw // 2)).numpy()
+    m = lambda a: float((np.abs(a - truth) / np.maximum(1, np.abs(truth))).max())      # noqa: E731
+    print(f"head x3 err {m(y):.2e}  fp32 head kernel err {m(y32):.2e}")
+    assert m(y) <= 3 * m(y32) + 2e-6
+    pr = hip.ConvPlan(N, Cin, H, W, Cout, kh, kw, (kh // 2, kw // 2), relu=True, algo=hip.ALGO_WINO_F3_X3)
+    pr.pack(dev(w))
+    if N == 1:
+        bound = torch.zeros(hip.AMAX_SLOTS, dtype=torch.int32, device="cuda")
+        bound[3] = torch.tensor(float(np.abs(x).max()) * 1.3, dtype=torch.float32).view(torch.int32)
+        pr.set_amax_io(bound, None)
+    close(pr.forward(dev(x), dev(b)).cpu().numpy(), np.maximum(ref, 0))
+
+
 WINO_CASES = [   # N, Cin, H, W, Cout, pad
     (1, 16, 8, 12, 24, 1),        # exact 2x2 tiles
     (1, 40, 13, 21, 130, 1),      # odd H and W: partial tiles at the bottom / right edge, Cout ragged
