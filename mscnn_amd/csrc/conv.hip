@@ -1023,7 +1023,7 @@ static void plan_shape(mscnn_conv_plan* p) {
       d.Cout <= 12 && d.Kh * d.Kw > 1 && d.N > 0 && !(d.tune_flags & 2) &&
       x3_head_plan(d.Cin, d.Cout, d.Kh, d.Kw, (long)d.H * d.W, &p->x3h)) {
     p->packed_bytes = p->x3h.packed_bytes;
-    p->ws_bytes = 4096 + p->x3h.x_bytes + p->x3h.t_bytes;
+    p->ws_bytes = 4096 + p->x3h.t_bytes;
     return;
   }
   if (head_plan(d, p->Ho, p->Wo, &p->head)) {

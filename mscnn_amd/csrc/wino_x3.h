@@ -19,7 +19,7 @@ struct X3Plan {
 struct X3HeadPlan {
   int Cin = 0, Cout = 0, KH = 0, KW = 0, KG = 0, rows = 0, rows_pad = 0;
   long T_pad = 0;
-  size_t packed_bytes = 0, x_bytes = 0, t_bytes = 0;     // workspace = 4096 (own max |x| slots) + x_bytes + t_bytes
+  size_t packed_bytes = 0, t_bytes = 0;     // workspace = 4096 (own max |x| slots) + t_bytes
 };
 bool x3_head_plan(int Cin, int Cout, int KH, int KW, long HW, X3HeadPlan* out);
 int x3_head_pack(const X3HeadPlan& p, const float* w, void* packed, hipStream_t st);

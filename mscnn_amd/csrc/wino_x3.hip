@@ -262,6 +262,7 @@ struct X3Args {
   unsigned T_pad;
   int planes;        // 25 (Winograd), 1 (InnerProduct, proposal heads)
   float bound_mult;  // max |B operand| <= bound_mult * (max over the scal slots): 36 behind the Winograd transform, 1 otherwise
+  int hw;            // BF32 kernels: V is the fp32 tensor x[K][hw] itself (split while it is staged), columns >= hw are zeros
   int ks;            // k-split: > 0 = every tile is cut into ks ranges of KI / ks chunks whose raw accumulators go to
   float* slabs;      //          slabs[((plane * NT + nt) * MT + mt) * ks + s][BM][128] (summed in s order by x3_fixup_kernel); 0 = off
 };
@@ -270,9 +271,11 @@ struct X3Args {
 // channels (4 kg, two k = 16 MFMA steps): LDS A [part][kgl][BM] + B [part][kgl][128] units (BM 256: 48 KB, BM 128: 32 KB),
 // next chunk prefetched into registers while the current one is multiplied.  Per k-step a wave reads 2 MI + 4 operands (1 KB
 // each) for 6 MI MFMAs of 32 cycles: 64 B/clk (BM 256) / 85 B/clk (BM 128) per workgroup against the LDS's 256 B/clk.
-template <int BM>
+// BF32: the B operand is staged from fp32 (8 coalesced channel-row loads per 16-byte unit, scaled and split in registers -- no
+// separate split pass, no X16 in HBM; the proposal heads, whose B is the feature map itself)
+template <int BM, bool BF32 = false>
 __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
-  constexpr int MI = BM / 64, NI = 2, WM = BM / 2, AU = BM / 32, BU = 4;
+  constexpr int MI = BM / 64, NI = 2, WM = BM / 2, AU = BM / 32, BU = 4, BFU = 2;
   __shared__ uint4 ldsA[2 * 4 * BM];
   __shared__ uint4 ldsB[2 * 4 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -292,8 +295,10 @@ __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
   const int nt = rem / (a.MT * ks), ksi = (rem / a.MT) % ks, mt = rem % a.MT;    // mt fastest: the workgroups sharing a B tile
   const int kc0 = ksi * (a.KI / ks), kc1 = kc0 + a.KI / ks;
 
+  float sx = 1.f, inv_x = 1.f;
+  if constexpr (BF32) pow2_scale(a.bound_mult * bound_from_slots(a.scal), &sx, &inv_x);
   const unsigned a_bytes = 2u * (unsigned)a.planes * (unsigned)a.KG * (unsigned)a.Cout_pad * 16u;
-  const unsigned v_bytes = 2u * (unsigned)a.planes * (unsigned)a.KG * a.T_pad * 16u;
+  const unsigned v_bytes = BF32 ? (unsigned)a.KG * 8u * (unsigned)a.hw * 4u : 2u * (unsigned)a.planes * (unsigned)a.KG * a.T_pad * 16u;
   const __amdgpu_buffer_rsrc_t asrc = make_rsrc(a.U, a_bytes), bsrc = make_rsrc(a.V, v_bytes);
   // unit u = tid + 256 i of a tile: (part, kgl, row) with row fastest
   unsigned a_off[AU], b_off[BU];
@@ -307,16 +312,34 @@ __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
     const int u = tid + 256 * i, part = u / 512, kgl = (u / 128) % 4, col = u % 128;
     b_off[i] = ((unsigned)((plane * 2 + part) * a.KG + kgl) * a.T_pad + (unsigned)(nt * 128 + col)) * 16u;
   }
-  const unsigned a_step = 4u * (unsigned)a.Cout_pad * 16u, b_step = 4u * a.T_pad * 16u;   // one k-chunk further
+  const unsigned a_step = 4u * (unsigned)a.Cout_pad * 16u, b_step = BF32 ? 32u * (unsigned)a.hw * 4u : 4u * a.T_pad * 16u;   // one k-chunk further
+  // BF32: unit u = tid + 256 i (i < 2) = (kgl = u / 128, column u % 128): 8 channels kgl * 8 .. + 7 of pixel nt * 128 + column
+  unsigned f_off[BFU];
+  if constexpr (BF32) {
+#pragma unroll
+    for (int i = 0; i < BFU; ++i) {
+      const int u = tid + 256 * i, kgl = u / 128, t = nt * 128 + u % 128;
+      f_off[i] = t < a.hw ? ((unsigned)(kgl * 8) * (unsigned)a.hw + (unsigned)t) * 4u : kOob;
+    }
+  }
 
   uint4 ra[AU], rb[BU];
+  float rf[BFU][8];
   auto load_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < AU; ++i)
       ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(asrc, a_off[i], (unsigned)kc * a_step, 0));
+    if constexpr (BF32) {
 #pragma unroll
-    for (int i = 0; i < BU; ++i)
-      rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, b_off[i], (unsigned)kc * b_step, 0));
+      for (int i = 0; i < BFU; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          rf[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bsrc, f_off[i], (unsigned)kc * b_step + (unsigned)j * (unsigned)a.hw * 4u, 0));
+    } else {
+#pragma unroll
+      for (int i = 0; i < BU; ++i)
+        rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, b_off[i], (unsigned)kc * b_step, 0));
+    }
   };
 
   f32x16 acc[MI][NI];
@@ -331,8 +354,23 @@ __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
   for (int kc = kc0; kc < kc1; ++kc) {
 #pragma unroll
     for (int i = 0; i < AU; ++i) ldsA[tid + 256 * i] = ra[i];
+    if constexpr (BF32) {
 #pragma unroll
-    for (int i = 0; i < BU; ++i) ldsB[tid + 256 * i] = rb[i];
+      for (int i = 0; i < BFU; ++i) {
+        f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          _Float16 hh, ll;
+          split16(rf[i][j] * sx, &hh, &ll);
+          h[j] = hh; l[j] = ll;
+        }
+        ldsB[tid + 256 * i] = __builtin_bit_cast(uint4, h);            // [part 0][kgl][column]
+        ldsB[512 + tid + 256 * i] = __builtin_bit_cast(uint4, l);      // [part 1][kgl][column]
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BU; ++i) ldsB[tid + 256 * i] = rb[i];
+    }
     __syncthreads();
     if (kc + 1 < kc1) load_chunk(kc + 1);
 #pragma unroll
@@ -374,8 +412,8 @@ __global__ __launch_bounds__(256, 2) void x3_gemm_kernel(X3Args a) {
     return;
   }
   // epilogue: un-scale (exact: powers of two), store M[plane][co][t]
-  float sv, inv_v;
-  pow2_scale(a.bound_mult * bound_from_slots(a.scal), &sv, &inv_v);
+  float sv, inv_v = inv_x;
+  if constexpr (!BF32) pow2_scale(a.bound_mult * bound_from_slots(a.scal), &sv, &inv_v);
   const float inv = inv_v * a.hdr[0];
   const unsigned m_bytes = (unsigned)a.planes * (unsigned)a.Cout * a.T_pad * 4u;
   const __amdgpu_buffer_rsrc_t msrc = make_rsrc(a.M, m_bytes);
@@ -461,27 +499,7 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const float* __restrict__
 // GEMM  T[tap * Cout + co][p] = W'[tap * Cout + co][c] x[c][p]  (M = taps * Cout = 225 / 441 rows, K = Cin, N = pixels: no patch, no
 // halo, x is its own B operand) followed by a shift-and-add over the taps -- the transposed view of im2col + GEMM (col2im after the
 // GEMM instead of im2col before it).  Same multiplies as the direct form; T is taps * Cout * H * W floats (30 MB for the 7x7 head on
-// conv4_3).  In the split-fp16 arithmetic: x split once per layer into the GEMM's B layout, W' packed once.
-// x [Cin][HW] fp32 -> X16[part][kg][T_pad][8]: thread = (pixel, kg), 8 coalesced channel-row loads, one 16-byte unit per part
-__global__ __launch_bounds__(256) void x3_split_planes_kernel(const float* __restrict__ x, uint4* __restrict__ X16,
-                                                              const unsigned* __restrict__ slots, int Cin, int HW, unsigned T_pad) {
-  float s, inv;
-  pow2_scale(bound_from_slots(slots), &s, &inv);
-  const unsigned t = blockIdx.x * 256 + threadIdx.x;
-  const int kg = blockIdx.y, KG = Cin / 8;
-  if (t >= T_pad) return;
-  f16x8 hi, lo;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float v = t < (unsigned)HW ? x[(size_t)(kg * 8 + i) * HW + t] : 0.f;
-    _Float16 h, l;
-    split16(v * s, &h, &l);
-    hi[i] = h; lo[i] = l;
-  }
-  X16[(size_t)kg * T_pad + t] = __builtin_bit_cast(uint4, hi);
-  X16[((size_t)KG + kg) * T_pad + t] = __builtin_bit_cast(uint4, lo);
-}
-
+// conv4_3).  In the split-fp16 arithmetic: W' packed once, x split by the GEMM itself while it stages its B tile (BF32).
 // w [Cout][Cin][taps] -> W16[part][kg][rows_pad][8], row = tap * Cout + co; scale from the slots behind the header
 __global__ __launch_bounds__(256) void x3_head_weight_kernel(const float* __restrict__ w, unsigned char* __restrict__ packed, int Cout,
                                                              int Cin, int taps, int rows_pad) {
@@ -536,10 +554,9 @@ bool x3_head_plan(int Cin, int Cout, int KH, int KW, long HW, X3HeadPlan* out) {
   p.rows = KH * KW * Cout;
   p.rows_pad = (p.rows + 127) / 128 * 128;
   p.T_pad = (HW + 127) / 128 * 128;
-  const double w_bytes = 2.0 * p.KG * p.rows_pad * 16.0, x_bytes = 2.0 * p.KG * (double)p.T_pad * 16.0, t_bytes = (double)p.rows * p.T_pad * 4.0;
+  const double w_bytes = 2.0 * p.KG * p.rows_pad * 16.0, x_bytes = (double)Cin * HW * 4.0, t_bytes = (double)p.rows * p.T_pad * 4.0;
   if (w_bytes >= 4.0e9 || x_bytes >= 4.0e9 || t_bytes >= 4.0e9) return false;
   p.packed_bytes = kHdrBytes + (size_t)w_bytes;
-  p.x_bytes = (size_t)x_bytes;
   p.t_bytes = (size_t)t_bytes;
   *out = p;
   return true;
@@ -556,28 +573,25 @@ int x3_head_pack(const X3HeadPlan& p, const float* w, void* packed, hipStream_t 
   return MSCNN_OK;
 }
 
-// one image: x [Cin][H][W] -> y [Cout][Ho][Wo].  ws: [4 KB own slots][X16][T]
+// one image: x [Cin][H][W] -> y [Cout][Ho][Wo].  ws: [4 KB own slots][T]
 int x3_head_forward(const X3HeadPlan& p, const float* x, const void* packed, const float* bias, float* y, int H, int W, int Ho, int Wo,
                     int pad_h, int pad_w, int relu, const unsigned* in_bound, void* ws, hipStream_t st) {
   unsigned char* wsb = static_cast<unsigned char*>(ws);
   unsigned* own = reinterpret_cast<unsigned*>(wsb);
-  uint4* X16 = reinterpret_cast<uint4*>(wsb + 4096);
-  float* T = reinterpret_cast<float*>(wsb + 4096 + p.x_bytes);
+  float* T = reinterpret_cast<float*>(wsb + 4096);
   const int HW = H * W;
   if (!in_bound) {
     const int rc = x3_amax(x, (long)p.Cin * HW, own, st);
     if (rc != MSCNN_OK) return rc;
   }
   const unsigned* slots = in_bound ? in_bound : own;
-  x3_split_planes_kernel<<<dim3((unsigned)(p.T_pad / 256 + (p.T_pad % 256 ? 1 : 0)), p.KG), 256, 0, st>>>(x, X16, slots, p.Cin, HW, (unsigned)p.T_pad);
-  MSCNN_POST_LAUNCH();
   const unsigned char* pk = static_cast<const unsigned char*>(packed);
   X3Args a;
-  a.U = pk + kHdrBytes; a.V = X16; a.M = T; a.scal = slots; a.hdr = reinterpret_cast<const float*>(pk);
+  a.U = pk + kHdrBytes; a.V = x; a.hw = HW; a.M = T; a.scal = slots; a.hdr = reinterpret_cast<const float*>(pk);
   a.Cout = p.rows; a.Cout_pad = p.rows_pad; a.KG = p.KG; a.KI = p.KG / 4; a.MT = p.rows_pad / 128; a.NT = (int)(p.T_pad / 128);
   a.tiles = a.MT * a.NT; a.xcd_map = 1; a.T_pad = (unsigned)p.T_pad;
   a.planes = 1; a.ks = 0; a.slabs = nullptr; a.bound_mult = 1.f;
-  x3_gemm_kernel<128><<<a.tiles, 256, 0, st>>>(a);
+  x3_gemm_kernel<128, true><<<a.tiles, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   x3_head_shift_add_kernel<<<dim3(cdiv(Ho * Wo, 256), p.Cout), 256, 0, st>>>(T, bias, y, p.Cout, H, W, Ho, Wo, p.KH, p.KW, pad_h, pad_w,
                                                                              (unsigned)p.T_pad, relu);
@@ -650,7 +664,7 @@ int x3_gemm(const X3Plan& p, const void* packed, const void* V16, float* M, cons
   a.V = V16; a.M = M; a.scal = scal; a.hdr = static_cast<const float*>(packed);
   a.Cout = p.Cout; a.Cout_pad = p.Cout_pad; a.KG = p.KG; a.KI = p.KG / 4; a.MT = p.MT; a.NT = p.NT;
   a.tiles = 25 * p.MT * p.NT; a.xcd_map = xcd_map; a.T_pad = (unsigned)p.T_pad;
-  a.planes = 25; a.ks = 0; a.slabs = nullptr; a.bound_mult = 36.f;
+  a.planes = 25; a.ks = 0; a.slabs = nullptr; a.bound_mult = 36.f; a.hw = 0;
   if (p.BM == 256) x3_gemm_kernel<256><<<a.tiles, 256, 0, st>>>(a);
   else x3_gemm_kernel<128><<<a.tiles, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
@@ -733,7 +747,7 @@ extern "C" int mscnn_inner_product_x3_fwd(const float* x, const void* packed, co
   a.U = X16; a.V = pk + kHdrBytes; a.M = nullptr; a.scal = nullptr; a.hdr = nullptr;
   a.Cout = M; a.Cout_pad = s.M_pad; a.KG = s.KG; a.KI = s.KI; a.MT = s.MT; a.NT = s.NT;
   a.tiles = s.MT * s.NT * s.ks; a.xcd_map = 1; a.T_pad = (unsigned)s.N_pad;
-  a.planes = 1; a.ks = s.ks; a.slabs = slabs; a.bound_mult = 1.f;
+  a.planes = 1; a.ks = s.ks; a.slabs = slabs; a.bound_mult = 1.f; a.hw = 0;
   x3_gemm_kernel<128><<<a.tiles, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   x3_fixup_kernel<<<s.MT * s.NT, 256, 0, st>>>(slabs, inv_x, reinterpret_cast<const float*>(pk), bias, y, M, N, s.MT, s.ks, relu);
