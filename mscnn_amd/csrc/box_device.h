@@ -65,8 +65,10 @@ __device__ __forceinline__ u64 readlane64(u64 v, int lane) {
 // Waves 1-3 stream the NEXT chunk's 64 mask rows (words c+1.. only) from L2 into the other half of a double buffer in LDS
 // meanwhile: lane = word, one row per load instruction (coalesced), all of a thread's rows in flight at once.
 // W = words per row actually used (<= 64).  `buf` = dynamic LDS of 2 * 64 * W u64.  Result: lane c of wave 0 returns the
-// keep-word of chunk c.
-__device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, int wpr, int W, u64* buf) {
+// keep-word of chunk c.  `removed_init` (optional, W words): boxes already suppressed from outside -- by the kept boxes of
+// earlier tiles in the tiled path of nms_large.h; they are neither kept nor do they suppress anything.
+__device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, int wpr, int W, u64* buf,
+                                           const u64* __restrict__ removed_init = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunks = (n + 63) >> 6;
   // rows r = r0, r0 + rstep, ... of chunk c -> buffer b; this thread moves word `lane` of each
@@ -92,6 +94,7 @@ __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, 
   fill(0, 0, wave, 4);
   __syncthreads();
   u64 removed = 0, mykeep = 0;
+  if (removed_init != nullptr && wave == 0 && lane < W) removed = removed_init[lane];
   for (int c = 0; c < nchunks; ++c) {
     const u64* cur_rows = buf + (size_t)(c & 1) * 64 * W;
     if (wave != 0) {

@@ -21,8 +21,13 @@
 //                             the diagonal block, then OR of the kept rows (prefetched one chunk ahead);
 //                             finally popcount-prefix compaction and emission of the output rows.
 // No MFMA anywhere here: integer / compare work, wave-level scans and ballots.
+//
+// More than kMaxK = 4032 candidates into NMS (max_nms_num 0 -- the caffe.proto default, "no cap" -- or > 4032 while the heads
+// have that many anchors): steps 2-4 are replaced by a global-memory bitonic sort of all keys and the tiled greedy NMS of
+// nms_large.h (same predicate, same order: the same rows).  The deploy files of the reference set 2000-3000 and never get here.
 #include "common.h"
 #include "box_device.h"
+#include "nms_large.h"
 #include <cfloat>
 
 namespace {
@@ -56,7 +61,7 @@ struct DecodeArgs {
 };
 
 // workspace counters
-enum { CNT_CAND = 0, CNT_ROWS = 1, CNT_REAL = 2, CNT_K = 3, CNT_WORDS = 8 };
+enum { CNT_CAND = 0, CNT_ROWS = 1, CNT_REAL = 2, CNT_K = 3, CNT_BIG = 4 /* + BIG_STATE_WORDS */, CNT_WORDS = 8 };
 
 __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a, u64* __restrict__ keys,
                                                             float4* __restrict__ box_by_anchor,
@@ -277,6 +282,60 @@ __global__ __launch_bounds__(256) void nms_scan_emit_kernel(const u64* __restric
   if (tid == 0) { cnt[CNT_ROWS] = row0 + kept_total; cnt[CNT_CAND] = 0; }
 }
 
+// ---- large path (nms_large.h) ----------------------------------------------------------------------------------------------
+struct RoiTr {
+  typedef float4 Box;
+  struct Params { float thr; int mode; };
+  static __device__ __forceinline__ bool over(const float4& a, const float4& b, const Params& p) {
+    return box_iou(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, p.mode) > p.thr;      // == nms_mask_kernel's test (a earlier)
+  }
+};
+
+// keys sorted descending (zero padding last): the first K = min(n, max_nms_num) rows, boxes gathered by anchor id
+__global__ __launch_bounds__(256) void big_gather_kernel(const u64* __restrict__ keys, const float4* __restrict__ box_by_anchor,
+                                                         const float* __restrict__ score_by_anchor,
+                                                         float4* __restrict__ sorted_box, float* __restrict__ sorted_score,
+                                                         int* __restrict__ sorted_aid, int* __restrict__ cnt, int max_nms_num) {
+  int K = cnt[CNT_CAND];
+  if (max_nms_num > 0 && K > max_nms_num) K = max_nms_num;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) cnt[CNT_K] = K;
+  if (i >= K) return;
+  const int aid = (int)(unsigned)(keys[i] & 0xffffffffull);
+  sorted_box[i] = box_by_anchor[aid];
+  sorted_score[i] = score_by_anchor[aid];
+  sorted_aid[i] = aid;
+}
+
+// rows of the kept boxes (kept_idx ascending = descending score), one workgroup
+__global__ __launch_bounds__(256) void big_emit_kernel(EmitArgs e, const int* __restrict__ kept_idx, int* __restrict__ cnt) {
+  int kept_total = cnt[CNT_BIG + BIG_NKEPT];
+  if (e.max_post > 0 && kept_total > e.max_post) kept_total = e.max_post;       // :184-186
+  const int row0 = cnt[CNT_ROWS];
+  for (int local = threadIdx.x; local < kept_total; local += 256) {
+    const int row = row0 + local;
+    if (row >= e.cap) continue;
+    const int k = kept_idx[local];
+    const float4 b = e.sorted_box[k];
+    float* r = e.rois + 5 * (size_t)row;
+    r[0] = (float)e.image; r[1] = b.x; r[2] = b.y; r[3] = b.x + b.z; r[4] = b.y + b.w;   // :201-210
+    if (e.props) {
+      float* q = e.props + 6 * (size_t)row;
+      q[0] = (float)e.image; q[1] = b.x; q[2] = b.y; q[3] = b.x + b.z; q[4] = b.y + b.w; q[5] = e.sorted_score[k];
+    }
+    if (e.aids) e.aids[row] = e.sorted_aid[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { cnt[CNT_ROWS] = row0 + kept_total; cnt[CNT_CAND] = 0; cnt[CNT_BIG + BIG_NKEPT] = 0; }
+}
+
+// stand-alone NMS, large n: keep bytes from the kept list
+__global__ __launch_bounds__(256) void big_keep_bytes_kernel(const int* __restrict__ kept_idx, const int* __restrict__ state,
+                                                             unsigned char* __restrict__ keep_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < state[BIG_NKEPT]) keep_out[kept_idx[i]] = 1;
+}
+
 __global__ void boxoutput_finish_kernel(int* __restrict__ cnt, float* rois, float* props, int* aids, int* count_out) {
   const int rows = cnt[CNT_ROWS];
   if (rows <= 0) {   // box_output_layer.cpp:195-199, :214-218
@@ -304,23 +363,32 @@ __global__ __launch_bounds__(256) void nms_scan_bytes_kernel(const u64* __restri
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t cnt, keys, box, score, sbox, sscore, said, mask, total;
-  int anchors, wpr;
+  size_t cnt, keys, box, score, sbox, sscore, said, mask, rinit, kidx, kbox, total;
+  int anchors, wpr, kcap, sortP;
+  bool big;
 };
 
-WsLayout layout_for(int anchors) {
+// kcap = host-side bound on the boxes that enter NMS; above kMaxK the large path's buffers are sized for it
+WsLayout layout_for(int anchors, int max_nms_num) {
   WsLayout L;
   L.anchors = anchors;
   L.wpr = kMaxK / 64;
+  L.kcap = (max_nms_num > 0 && max_nms_num < anchors) ? max_nms_num : anchors;
+  L.big = L.kcap > kMaxK;
+  L.sortP = L.big ? big_sort_pow2(anchors) : 0;
+  const size_t rows = L.big ? (size_t)L.kcap : (size_t)kMaxK;
   size_t o = 0;
   L.cnt = o; o += align_up(CNT_WORDS * sizeof(int), 256);
-  L.keys = o; o += align_up((size_t)anchors * sizeof(u64), 256);
+  L.keys = o; o += align_up((L.big ? (size_t)L.sortP : (size_t)anchors) * sizeof(u64), 256);
   L.box = o; o += align_up((size_t)anchors * sizeof(float4), 256);
   L.score = o; o += align_up((size_t)anchors * sizeof(float), 256);
-  L.sbox = o; o += align_up((size_t)kMaxK * sizeof(float4), 256);
-  L.sscore = o; o += align_up((size_t)kMaxK * sizeof(float), 256);
-  L.said = o; o += align_up((size_t)kMaxK * sizeof(int), 256);
+  L.sbox = o; o += align_up(rows * sizeof(float4), 256);
+  L.sscore = o; o += align_up(rows * sizeof(float), 256);
+  L.said = o; o += align_up(rows * sizeof(int), 256);
   L.mask = o; o += align_up((size_t)kMaxK * L.wpr * sizeof(u64), 256);
+  L.rinit = o; o += L.big ? align_up(64 * sizeof(u64), 256) : 0;
+  L.kidx = o; o += L.big ? align_up(rows * sizeof(int), 256) : 0;
+  L.kbox = o; o += L.big ? align_up(rows * sizeof(float4), 256) : 0;
   L.total = o;
   return L;
 }
@@ -344,18 +412,14 @@ static int check_desc(const mscnn_boxoutput_desc* d) {
   MSCNN_REQUIRE(d->field_whr > 0 && d->field_xyr > 0, "boxoutput: field_whr / field_xyr must be > 0");
   const int anchors = total_anchors(d);
   MSCNN_REQUIRE(anchors > 0, "boxoutput: no anchors");
-  const int k = (d->max_nms_num > 0) ? d->max_nms_num : anchors;
-  if (k > kMaxK && anchors > kMaxK) {
-    set_error("boxoutput: max_nms_num %d (anchors %d) exceeds the %d-box NMS bitmap of this build", d->max_nms_num, anchors,
-              kMaxK);
-    return MSCNN_ERR_UNSUPPORTED;
-  }
+  MSCNN_REQUIRE(d->max_nms_num >= 0 && d->max_post_nms_num >= 0, "boxoutput: negative max_nms_num / max_post_nms_num");
+  MSCNN_REQUIRE(anchors <= (1 << 26), "boxoutput: %d anchors", anchors);
   return MSCNN_OK;
 }
 
 extern "C" size_t mscnn_boxoutput_workspace_bytes(const mscnn_boxoutput_desc* desc) {
   if (check_desc(desc) != MSCNN_OK) return 0;
-  return layout_for(total_anchors(desc)).total;
+  return layout_for(total_anchors(desc), desc->max_nms_num).total;
 }
 
 extern "C" int mscnn_boxoutput_max_rows(const mscnn_boxoutput_desc* desc) {
@@ -375,7 +439,7 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
   MSCNN_REQUIRE(heads_host && rois_out && count_out_dev && workspace, "boxoutput: null pointer");
   MSCNN_REQUIRE(cap >= 1, "boxoutput: cap must be >= 1");
   const int anchors = total_anchors(d);
-  const WsLayout L = layout_for(anchors);
+  const WsLayout L = layout_for(anchors, d->max_nms_num);
   if (workspace_bytes < L.total) {
     set_error("boxoutput: workspace %zu < %zu", workspace_bytes, L.total);
     return MSCNN_ERR_WORKSPACE;
@@ -410,12 +474,31 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
   for (int k = 0; k < 4; ++k) { a.mean[k] = d->bbox_mean[k]; a.stdv[k] = d->bbox_std[k]; }
 
   MSCNN_HIP_TRY(hipMemsetAsync(cnt, 0, CNT_WORDS * sizeof(int), st));
-  const int kcap = (d->max_nms_num > 0 && d->max_nms_num < anchors) ? d->max_nms_num : anchors;
+  const int kcap = L.kcap;
   const int kblocks = cdiv(kcap < kMaxK ? kcap : kMaxK, 64);
   for (int img = 0; img < d->num; ++img) {
     a.image = img;
+    if (L.big) MSCNN_HIP_TRY(hipMemsetAsync(keys, 0, (size_t)L.sortP * sizeof(u64), st));     // zero keys = padding, sorts last
     decode_filter_kernel<<<cdiv(anchors, 256), 256, 0, st>>>(a, keys, box, score, cnt);
     MSCNN_POST_LAUNCH();
+    if (L.big) {
+      // every candidate sorted in HBM, the first K = min(n, max_nms_num) gathered, tiled greedy NMS, rows from the kept list
+      MSCNN_HIP_TRY(big_sort_desc(keys, L.sortP, st));
+      big_gather_kernel<<<cdiv(kcap, 256), 256, 0, st>>>(keys, box, score, sbox, sscore, said, cnt, d->max_nms_num);
+      MSCNN_POST_LAUNCH();
+      const float thr = d->iou_thr;
+      const int mode = d->nms_mode;
+      auto launch_mask = [&](const float4* tile, const int* tile_n) {
+        nms_mask_kernel<<<dim3(kTileWords, kTileWords), 64, 0, st>>>(tile, tile_n, 0, thr, mode, mask, kTileWords);
+      };
+      MSCNN_HIP_TRY((big_nms_tiles<RoiTr>(sbox, cnt + CNT_K, 0, kcap, RoiTr::Params{thr, mode}, mask,
+                                          reinterpret_cast<u64*>(ws + L.rinit), reinterpret_cast<int*>(ws + L.kidx),
+                                          reinterpret_cast<float4*>(ws + L.kbox), cnt + CNT_BIG, launch_mask, st)));
+      EmitArgs eb{sbox, sscore, said, rois_out, props_out, anchor_ids_out, cap, img, d->max_post_nms_num};
+      big_emit_kernel<<<1, 256, 0, st>>>(eb, reinterpret_cast<const int*>(ws + L.kidx), cnt);
+      MSCNN_POST_LAUNCH();
+      continue;
+    }
     select_sort_kernel<<<1, kSortThreads, 0, st>>>(keys, box, score, sbox, sscore, said, cnt, d->max_nms_num);
     MSCNN_POST_LAUNCH();
     nms_mask_kernel<<<dim3(kblocks, kblocks), 64, 0, st>>>(sbox, cnt + CNT_K, 0, d->iou_thr, d->nms_mode, mask, L.wpr);
@@ -429,8 +512,24 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
   return MSCNN_OK;
 }
 
+namespace {
+struct NmsBigLayout { size_t mask, rinit, state, kidx, kbox, total; };
+NmsBigLayout nms_big_layout(int n) {
+  NmsBigLayout L;
+  size_t o = 0;
+  L.mask = o; o += align_up((size_t)kMaxK * kTileWords * sizeof(u64), 256);
+  L.rinit = o; o += align_up(64 * sizeof(u64), 256);
+  L.state = o; o += 256;
+  L.kidx = o; o += align_up((size_t)n * sizeof(int), 256);
+  L.kbox = o; o += align_up((size_t)n * sizeof(float4), 256);
+  L.total = o;
+  return L;
+}
+}  // namespace
+
 extern "C" size_t mscnn_nms_workspace_bytes(int n) {
   if (n <= 0) return 256;
+  if (n > kMaxK) return nms_big_layout(n).total;
   const size_t wpr = (size_t)(n + 63) / 64;
   return align_up((size_t)n * wpr * sizeof(u64), 256);
 }
@@ -440,16 +539,30 @@ extern "C" int mscnn_nms_greedy_f32(const float* boxes_xywh, int n, float iou_th
   MSCNN_REQUIRE(n >= 0 && nms_mode >= 0 && nms_mode <= 2, "nms: bad argument");
   if (n == 0) return MSCNN_OK;
   MSCNN_REQUIRE(boxes_xywh && keep_out && workspace, "nms: null pointer");
-  if (n > kMaxK) {
-    set_error("nms: n %d exceeds %d", n, kMaxK);
-    return MSCNN_ERR_UNSUPPORTED;
-  }
   MSCNN_REQUIRE(reinterpret_cast<uintptr_t>(boxes_xywh) % 16 == 0, "nms: boxes must be 16-byte aligned");
   if (workspace_bytes < mscnn_nms_workspace_bytes(n)) {
     set_error("nms: workspace too small");
     return MSCNN_ERR_WORKSPACE;
   }
   hipStream_t st = as_stream(stream);
+  if (n > kMaxK) {     // tiled greedy NMS (nms_large.h): the boxes are taken in the order given
+    const NmsBigLayout B = nms_big_layout(n);
+    char* ws = static_cast<char*>(workspace);
+    u64* bmask = reinterpret_cast<u64*>(ws + B.mask);
+    int* state = reinterpret_cast<int*>(ws + B.state);
+    int* kidx = reinterpret_cast<int*>(ws + B.kidx);
+    MSCNN_HIP_TRY(hipMemsetAsync(state, 0, BIG_STATE_WORDS * sizeof(int), st));
+    MSCNN_HIP_TRY(hipMemsetAsync(keep_out, 0, (size_t)n, st));
+    auto launch_mask = [&](const float4* tile, const int* tile_n) {
+      nms_mask_kernel<<<dim3(kTileWords, kTileWords), 64, 0, st>>>(tile, tile_n, 0, iou_thr, nms_mode, bmask, kTileWords);
+    };
+    MSCNN_HIP_TRY((big_nms_tiles<RoiTr>(reinterpret_cast<const float4*>(boxes_xywh), nullptr, n, n, RoiTr::Params{iou_thr, nms_mode},
+                                        bmask, reinterpret_cast<u64*>(ws + B.rinit), kidx,
+                                        reinterpret_cast<float4*>(ws + B.kbox), state, launch_mask, st)));
+    big_keep_bytes_kernel<<<cdiv(n, 256), 256, 0, st>>>(kidx, state, keep_out);
+    MSCNN_POST_LAUNCH();
+    return MSCNN_OK;
+  }
   const int wpr = (n + 63) / 64;
   u64* mask = static_cast<u64*>(workspace);
   nms_mask_kernel<<<dim3(wpr, wpr), 64, 0, st>>>(reinterpret_cast<const float4*>(boxes_xywh), nullptr, n, iou_thr, nms_mode,

@@ -589,14 +589,11 @@ void BoxOutputLayer<Dtype>::LayerSetUp(const vector<Blob<Dtype>*>& bottom, const
   output_proposal_with_score_ = (top.size() == 2);
   cap_ = 0;
   last_rows_ = 1;
-  // Limit of this build, reported at set-up rather than at the first Forward: the sorted top-K and its NMS bit matrix live
-  // in LDS-sized buffers of 4032 boxes.  max_nms_num: 0 (caffe.proto default = no cap) or > 4032 is accepted only while the
-  // heads have no more anchors than that; every deploy file of the reference sets 2000.
+  // Parameter errors are reported at set-up rather than at the first Forward.  max_nms_num 0 (the caffe.proto default: no cap)
+  // or above the 4032 boxes the LDS-resident sort / NMS holds is served by the tiled path of csrc/nms_large.h.
   mscnn_boxoutput_desc d;
   FillBoxOutputDesc(this->layer_param_, bottom, fg_thr_, iou_thr_, nms_type_, &d);
-  CHECK_GT(mscnn_boxoutput_workspace_bytes(&d), 0u)
-      << "BoxOutput layer '" << this->layer_param_.name() << "': " << mscnn_last_error()
-      << " -- set box_output_param.max_nms_num to a value in [1, 4032] (the reference's deploy nets use 2000)";
+  CHECK_GT(mscnn_boxoutput_workspace_bytes(&d), 0u) << "BoxOutput layer '" << this->layer_param_.name() << "': " << mscnn_last_error();
 }
 template <typename Dtype>
 void BoxOutputLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {

@@ -864,6 +864,67 @@ def test_boxoutput_full_size_properties(hip):
     assert len(set(aids.cpu().tolist())) == R
 
 
+# ---- more than 4032 boxes into NMS: the tiled path (csrc/nms_large.h) -- global bitonic sort + per-tile bit matrix + cross-tile
+# suppression.  Same bar as the LDS-resident path: the reference's keep set / rows exactly.
+@pytest.mark.parametrize("n,mode", [(4033, "IOU"), (4096, "IOMU"), (8064, "IOU"), (9001, "IOFU")])
+def test_nms_keep_set_bitexact_tiled(hip, orc, n, mode):
+    boxes = _clustered_boxes(np.random.default_rng(n), n)
+    boxes[7, 2] = 0.0                                         # degenerate box: IoU 0 with everything
+    k = hip.nms_greedy(dev(boxes), 0.65, mode).cpu().numpy()
+    assert np.array_equal(k, orc.nms_greedy(boxes, 0.65, mode))
+    assert k.sum() > 200 and k[4032:].any() and (n < 8000 or (~k[4032:]).any())      # kept / suppressed boxes beyond the first tile
+
+
+BIG_HEADS = dict(shapes=[(36, 120), (36, 120), (18, 60)], field=[60, 84, 120], ds=[8, 8, 16])      # 9,720 anchors
+
+
+@pytest.mark.parametrize("name,bg_bias,kw", [
+    ("uncapped_dense", -8.0, dict(max_nms_num=0)),             # caffe.proto default: every candidate enters NMS
+    ("uncapped_sparse", 9.0, dict(max_nms_num=0)),             # large path chosen by the anchor count, few candidates
+    ("cap_6000", -8.0, dict(max_nms_num=6000)),                # top-K above 4032: cut after the global sort
+    ("uncapped_post_500", -8.0, dict(max_nms_num=0, max_post_nms_num=500)),
+    ("uncapped_iomu", -8.0, dict(max_nms_num=0, nms_type="IOMU")),
+])
+def test_boxoutput_more_than_4032_candidates_bitexact(hip, orc, name, bg_bias, kw):
+    rng = np.random.default_rng(77)
+    heads = _heads(rng, BIG_HEADS["shapes"], bg_bias=bg_bias)
+    kw = dict(fg_thr=-5.0, iou_thr=0.65, min_size=15.0, **kw)
+    ref = orc.boxoutput(heads, BIG_HEADS["field"], BIG_HEADS["field"], BIG_HEADS["ds"], with_anchor_ids=True, **kw)
+    d = hip.make_boxoutput_desc(BIG_HEADS["shapes"], 1, 9, BIG_HEADS["field"], BIG_HEADS["field"], BIG_HEADS["ds"], **kw)
+    rois, props, aids, nreal = hip.BoxOutput(d).forward([dev(h) for h in heads])
+    assert nreal == ref[3] and rois.shape[0] == ref[0].shape[0]
+    assert np.array_equal(aids.cpu().numpy(), ref[4])
+    assert np.array_equal(rois.cpu().numpy(), ref[0]) and np.array_equal(props.cpu().numpy(), ref[1])
+    if name == "uncapped_dense":
+        assert rois.shape[0] > 4032                            # more rows out than one tile holds
+
+
+def test_boxoutput_uncapped_batch2(hip, orc):
+    rng = np.random.default_rng(78)
+    heads = _heads(rng, BIG_HEADS["shapes"], num=2, bg_bias=-8.0)
+    heads[1][1, 0] += 9.0                                      # image 1: a sparse head
+    kw = dict(fg_thr=-5.0, iou_thr=0.65, max_nms_num=0, min_size=15.0)
+    ref = orc.boxoutput(heads, BIG_HEADS["field"], BIG_HEADS["field"], BIG_HEADS["ds"], with_anchor_ids=True, **kw)
+    d = hip.make_boxoutput_desc(BIG_HEADS["shapes"], 2, 9, BIG_HEADS["field"], BIG_HEADS["field"], BIG_HEADS["ds"], **kw)
+    layer = hip.BoxOutput(d)
+    for _ in range(2):                                         # second forward: counters / kept list start clean
+        rois, props, aids, nreal = layer.forward([dev(h) for h in heads])
+        assert nreal == ref[3] and np.array_equal(aids.cpu().numpy(), ref[4]) and np.array_equal(rois.cpu().numpy(), ref[0])
+
+
+def test_boxoutput_uncapped_full_size(hip, orc):
+    """BASELINE config-2 head sizes (45,630 anchors), max_nms_num 0, about a third of the anchors pass fg_thr."""
+    shapes = [(72, 240), (72, 240), (36, 120), (36, 120), (18, 60), (18, 60), (9, 30)]
+    rng = np.random.default_rng(5)
+    heads = _heads(rng, shapes, bg_bias=-1.5)
+    kw = dict(fg_thr=-5.0, iou_thr=0.65, max_nms_num=0, min_size=15.0)
+    ref = orc.boxoutput(heads, KITTI_HEADS["field"], KITTI_HEADS["field"], KITTI_HEADS["ds"], with_anchor_ids=True, **kw)
+    d = hip.make_boxoutput_desc(shapes, 1, 9, KITTI_HEADS["field"], KITTI_HEADS["field"], KITTI_HEADS["ds"], **kw)
+    rois, props, aids, nreal = hip.BoxOutput(d).forward([dev(h) for h in heads])
+    assert nreal == ref[3] and np.array_equal(aids.cpu().numpy(), ref[4])
+    assert np.array_equal(props.cpu().numpy(), ref[1])
+
+
 # ------------------------------------------------------------------ DecodeBBox / final detections
 def test_decode_bbox(hip, orc):
     rng = np.random.default_rng(12)
@@ -887,6 +948,40 @@ def test_detections_stage(hip, orc, R):
     dets, ids = hip.detections(dev(bbox_pred), dev(cls_pred), dev(props), **kw)
     dref, iref = orc.detections(bbox_pred, cls_pred, props, **kw)
     assert np.array_equal(ids.cpu().numpy(), iref)               # selection + order: exact
+    close(dets.cpu().numpy(), dref)
+
+
+@pytest.mark.parametrize("R", [4033, 9000])
+def test_detections_stage_more_than_4032_rows(hip, orc, R):
+    """Final stage over more ROIs than the LDS-resident path holds: sort in HBM + tiled NMS, same rows and order."""
+    rng = np.random.default_rng(R)
+    b = _clustered_boxes(rng, R)
+    props = np.concatenate([np.zeros((R, 1), np.float32), b[:, :2], b[:, :2] + b[:, 2:], rng.normal(0, 4, (R, 1)).astype(np.float32)], 1)
+    props[::17, 5] = -11.0
+    props[5::29, 3] = props[5::29, 1]
+    bbox_pred = rng.standard_normal((R, 20)).astype(np.float32)
+    cls_pred = (rng.standard_normal((R, 5)) * 2).astype(np.float32)
+    cls_pred[3::7] = cls_pred[2::7][: len(cls_pred[3::7])]        # exact prob ties -> stable order (lower row first)
+    kw = dict(cls_id=2, ratios=(576 / 375, 1920 / 1242), org_hw=(375, 1242))
+    dets, ids = hip.detections(dev(bbox_pred), dev(cls_pred), dev(props), **kw)
+    dref, iref = orc.detections(bbox_pred, cls_pred, props, **kw)
+    assert np.array_equal(ids.cpu().numpy(), iref)
+    close(dets.cpu().numpy(), dref)
+
+
+def test_detections_cascade_stage_more_than_4032_rows(hip, orc):
+    R = 6000
+    rng = np.random.default_rng(6000)
+    b = _clustered_boxes(rng, R)
+    boxes = np.concatenate([np.zeros((R, 1), np.float32), b[:, :2] - 30, b[:, :2] + b[:, 2:] + 25], 1).astype(np.float32)
+    props = np.concatenate([np.zeros((R, 1), np.float32), b[:, :2], b[:, :2] + b[:, 2:]], 1).astype(np.float32)
+    props[3::31, 3] = props[3::31, 1] - 1
+    prob = rng.uniform(0, 1, (R, 3)).astype(np.float32)
+    prob[3::7] = prob[2::7][: len(prob[3::7])]
+    kw = dict(cls_id=2, det_thr=0.2, ratios=(576 / 375, 1920 / 1242), org_hw=(375, 1242))
+    dets, ids = hip.detections_cascade(dev(boxes), dev(prob), dev(props), **kw)
+    dref, iref = orc.detections_cascade(boxes, prob, props, **kw)
+    assert np.array_equal(ids.cpu().numpy(), iref)
     close(dets.cpu().numpy(), dref)
 
 

@@ -146,6 +146,15 @@ def test_all_reference_deploys_build():
                      "Softmax", "Eltwise", "ROIPooling", "ROIAlign", "BoxOutput", "DecodeBBox"}
 
 
+def test_boxoutput_default_max_nms_num_builds():
+    """box_output_param.max_nms_num 0 is the caffe.proto default ("no cap", box_output_layer.cpp:172-173).  The full-size nets
+    have 45,630 / 81,600 anchors: more than the LDS-resident sort holds, served by the tiled path -- the layer must set up."""
+    for model, anchors in (("kitti_car/mscnn-7s-576", 45630), ("kitti_car/mscnn-8s-768-trainval", 81600)):
+        n = Net(prototxt_text=zoo.prototxt(model, max_nms_num=0))
+        i = n.layer_names.index("proposals")
+        assert "max_nms_num: 0" in n.layer_param_text(i).replace("  ", " ")
+
+
 # ---- .caffemodel (binary NetParameter) reader: Net::CopyTrainedLayersFrom, net.cpp:750-803 / blob.cpp:448-482 ----
 def _varint(v):
     out = bytearray()
