@@ -35,8 +35,10 @@ class Net {
   Dtype ForwardFromTo(int start, int end);
   void Reshape();
 
-  // Loads weights by layer name from a binary NetParameter (.caffemodel), net.cpp:750-803.
+  // Loads weights by layer name from a binary NetParameter (.caffemodel), net.cpp:750-803; a name ending in ".h5" is read as
+  // an HDF5 snapshot like the reference does (net.cpp:788-795, 806-848).
   void CopyTrainedLayersFrom(const string& trained_filename);
+  void CopyTrainedLayersFromHDF5(const string& trained_filename);
   // Must be called after parameter blobs were written through mutable_cpu_data()/mutable_gpu_data().
   void MarkWeightsChanged();
 

@@ -2,6 +2,7 @@
 // Reference behaviour restated from src/caffe/net.cpp:49-284 (Init), :544-575 (ForwardFromTo / Forward), :743-747
 // (Reshape), src/caffe/util/upgrade_proto.cpp:966-1003 (legacy input upgrade) and
 // src/caffe/util/insert_splits.cpp:14-126 (automatic Split layers, identical blob/layer naming).
+#include "caffe/util/hdf5_lite.hpp"
 #include <hip/hip_runtime_api.h>
 
 #include <cstdlib>
@@ -508,9 +509,10 @@ bool ShapeMatches(const ParsedBlob& pb, const vector<int>& target) {
 
 template <typename Dtype>
 void Net<Dtype>::CopyTrainedLayersFrom(const string& trained_filename) {
-  if (trained_filename.size() >= 3 && trained_filename.compare(trained_filename.size() - 3, 3, ".h5") == 0)
-    LOG(FATAL) << "HDF5 weight files (net.cpp:805-848) are not read by this build: convert " << trained_filename
-               << " to a binary .caffemodel";
+  if (trained_filename.size() >= 3 && trained_filename.compare(trained_filename.size() - 3, 3, ".h5") == 0) {   // net.cpp:788-795
+    CopyTrainedLayersFromHDF5(trained_filename);
+    return;
+  }
   string bytes;
   CHECK(ReadFileToString(trained_filename, &bytes)) << "cannot read " << trained_filename;
   Reader net{(const unsigned char*)bytes.data(), (const unsigned char*)bytes.data() + bytes.size()};
@@ -569,6 +571,57 @@ void Net<Dtype>::CopyTrainedLayersFrom(const string& trained_filename) {
           << "Cannot copy param " << j << " weights from layer '" << lname << "'; shape mismatch (target " << target[j]->shape_string()
           << ", source holds " << pblobs[j].data.size() << " values)";
       memcpy(target[j]->mutable_cpu_data(), pblobs[j].data.data(), sizeof(float) * pblobs[j].data.size());   // blob.cpp:448-482
+    }
+    layer->OnWeightsChanged();
+    ++copied;
+  }
+  LOG(INFO) << "Copied weights of " << copied << " layers from " << trained_filename;
+}
+
+// Net::CopyTrainedLayersFromHDF5, net.cpp:806-848: group "data" / <layer name> / "<blob index>" datasets.  The file is parsed by
+// caffe/util/hdf5_lite.hpp (no libhdf5 in the deployment image); the calls below map one to one onto the reference's H5Gopen2 /
+// hdf5_get_num_links / H5Lexists / hdf5_load_nd_dataset sequence.
+template <typename Dtype>
+void Net<Dtype>::CopyTrainedLayersFromHDF5(const string& trained_filename) {
+  string bytes;
+  CHECK(ReadFileToString(trained_filename, &bytes)) << "Couldn't open " << trained_filename;
+  h5lite::File f(bytes);
+  CHECK(f.ok()) << f.error() << " (" << trained_filename << ")";
+  uint64_t data_group = 0;
+  bool found = false;
+  CHECK(f.Find(f.root(), "data", &data_group, &found)) << f.error() << " (" << trained_filename << ")";
+  CHECK(found) << "Error reading weights from " << trained_filename << ": no group \"data\"";
+  vector<std::pair<string, uint64_t> > layers;
+  CHECK(f.ListGroup(data_group, &layers)) << f.error() << " (" << trained_filename << ")";
+  int copied = 0;
+  for (size_t i = 0; i < layers.size(); ++i) {
+    const string& source_layer_name = layers[i].first;
+    if (!has_layer(source_layer_name)) { LOG(INFO) << "Ignoring source layer " << source_layer_name; continue; }   // :815-818
+    shared_ptr<Layer<Dtype> > layer = layer_by_name(source_layer_name);
+    vector<shared_ptr<Blob<Dtype> > >& target_blobs = layer->blobs();
+    vector<std::pair<string, uint64_t> > params;
+    CHECK(f.ListGroup(layers[i].second, &params)) << "Error reading weights from " << trained_filename << ": " << f.error();
+    // :827-830 the source must not hold more params than the target layer
+    CHECK_LE(params.size(), target_blobs.size()) << "Incompatible number of blobs for layer " << source_layer_name;
+    for (size_t j = 0; j < target_blobs.size(); ++j) {
+      std::ostringstream oss;
+      oss << j;
+      size_t k = 0;
+      while (k < params.size() && params[k].first != oss.str()) ++k;
+      // :836-845 a missing dataset is only tolerated for weight-shared params; this Net has no param sharing
+      CHECK_LT(k, params.size()) << "Incompatible number of blobs for layer " << source_layer_name;
+      h5lite::Dataset ds;
+      CHECK(f.ReadDatasetInfo(params[k].second, &ds))
+          << "Failed to read dataset " << oss.str() << " of layer " << source_layer_name << ": " << f.error();
+      CHECK_LE((int)ds.dims.size(), kMaxBlobAxes);                                  // hdf5_load_nd_dataset(.., 0, kMaxBlobAxes, ..)
+      // hdf5_load_nd_dataset_helper reshapes the target blob to the dataset's dims (util/hdf5.cpp:61-65).  The layers here keep
+      // device-side packed copies sized at set-up, so a different element count is refused instead of silently re-shaping.
+      CHECK_EQ((long long)target_blobs[j]->count(), ds.count())
+          << "Cannot copy param " << j << " weights from layer '" << source_layer_name << "'; shape mismatch (target "
+          << target_blobs[j]->shape_string() << ", source holds " << ds.count() << " values)";
+      vector<int> dims(ds.dims.begin(), ds.dims.end());
+      if (dims != target_blobs[j]->shape()) target_blobs[j]->Reshape(dims);
+      CHECK(f.ReadFloats(ds, target_blobs[j]->mutable_cpu_data())) << f.error();   // H5LTread_dataset_float
     }
     layer->OnWeightsChanged();
     ++copied;

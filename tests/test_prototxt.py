@@ -260,3 +260,83 @@ def test_caffemodel_written_by_protobuf_python(tmp_path):
         n.load_caffemodel(bad)
     with pytest.raises(mnet.NetError, match="HDF5"):
         n.load_caffemodel(tmp_path / "weights.caffemodel.h5")
+
+
+# ---- HDF5 weight snapshots (".h5"): Net::CopyTrainedLayersFromHDF5, net.cpp:788-795, 806-848 / util/hdf5.cpp:9-74 ----
+# The product parses the file itself (mscnn_amd/host/src/hdf5_lite.cpp: superblock v0, symbol-table groups, v1 object headers,
+# contiguous datasets); the fixtures are written by the real libhdf5 (tests/golden/make_hdf5_weights.py).
+def test_hdf5_weights_committed_fixture(tmp_path):
+    import numpy as np
+    from tests.golden import make_hdf5_weights as mk
+    n = Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=64, width=128))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "weights_small.h5")
+    n.load_caffemodel(path)                                    # the reference dispatches on the ".h5" suffix too
+    want = dict(mk.small_fixture()[:3])
+    for name, arrs in want.items():
+        for j, a in enumerate(arrs):                           # double / int datasets arrive converted (H5LTread_dataset_float)
+            assert np.array_equal(n.get_param(name, j), a.astype(np.float32)), (name, j)
+    assert not np.any(n.get_param("conv2_1", 0))               # layers absent from the file keep their values
+    # a truncated copy and a file that is not HDF5 at all: errors, never reads past the buffer
+    raw = open(path, "rb").read()
+    for cut in (len(raw) // 2, 5000, 700, 90):
+        bad = tmp_path / f"cut{cut}.h5"
+        bad.write_bytes(raw[:cut])
+        with pytest.raises(mnet.NetError, match="HDF5"):
+            n.load_caffemodel(bad)
+    junk = tmp_path / "junk.h5"
+    junk.write_bytes(_caffemodel([("conv1_1", "Convolution", [np.zeros(3, np.float32)])]) * 40)
+    with pytest.raises(mnet.NetError, match="not an HDF5 file"):
+        n.load_caffemodel(junk)
+    missing = tmp_path / "missing.h5"
+    with pytest.raises(mnet.NetError, match="Couldn't open"):
+        n.load_caffemodel(missing)
+
+
+def test_hdf5_weights_written_by_libhdf5(tmp_path):
+    """Every parameter layer of the net through a snapshot libhdf5 writes here (group B-tree with internal nodes: 40 layers),
+    plus the reference's failure modes."""
+    import numpy as np
+    from tests.golden import make_hdf5_weights as mk
+    if not mk.available():
+        pytest.skip("libhdf5 is not installed on this machine (the committed fixture covers the reader)")
+    n = Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=64, width=128))
+    rng = np.random.default_rng(9)
+    layers, want = [], {}
+    for i, name in enumerate(n.layer_names):
+        shapes = n.param_shapes(i)
+        if not shapes:
+            continue
+        arrs = [rng.standard_normal(s).astype(np.float32 if i % 3 else np.float64) for s in shapes]
+        layers.append((name, arrs)); want[name] = arrs
+    assert len(layers) >= 25
+    path = tmp_path / "all.h5"
+    # + 300 groups the net does not know: more than one B-tree node can index (32 leaves x 8 links) -> a two-level B-tree
+    extra = [(f"zzz_extra_{k:03d}", [np.full((2, 2), k, np.float32)]) for k in range(300)]
+    mk.write(path, layers[:20] + extra + layers[20:])
+    n.load_caffemodel(path)
+    for name, arrs in want.items():
+        for j, a in enumerate(arrs):
+            assert np.array_equal(n.get_param(name, j), a.astype(np.float32)), (name, j)
+    w, b = want["conv1_1"]
+    # element count differs: refused with both shapes in the message
+    p1 = tmp_path / "count.h5"; mk.write(p1, [("conv1_1", [w[:32].astype(np.float32), b.astype(np.float32)])])
+    with pytest.raises(mnet.NetError, match="shape mismatch"):
+        n.load_caffemodel(p1)
+    # more datasets than the layer has blobs (net.cpp:827-830) / a blob without its dataset (:836-845)
+    p2 = tmp_path / "more.h5"; mk.write(p2, [("conv1_1", [w.astype(np.float32), b.astype(np.float32), b.astype(np.float32)])])
+    with pytest.raises(mnet.NetError, match="Incompatible number of blobs"):
+        n.load_caffemodel(p2)
+    p3 = tmp_path / "fewer.h5"; mk.write(p3, [("conv1_1", [w.astype(np.float32)])])
+    with pytest.raises(mnet.NetError, match="Incompatible number of blobs"):
+        n.load_caffemodel(p3)
+    # same count, other dims (a legacy 1x1x1xN bias): the reference reshapes the blob to the file's dims and reads it
+    p4 = tmp_path / "legacy.h5"; mk.write(p4, [("conv1_1", [w.astype(np.float32), b.astype(np.float32).reshape(1, 1, 1, -1)])])
+    n.load_caffemodel(p4)
+    assert np.array_equal(n.get_param("conv1_1", 1).reshape(-1), b.astype(np.float32))
+    # no "data" group
+    import ctypes as C
+    h5 = mk.libs()[0]
+    p5 = tmp_path / "nodata.h5"
+    f = h5.H5Fcreate(os.fsencode(str(p5)), 2, 0, 0); g = h5.H5Gcreate2(f, b"weights", 0, 0, 0); h5.H5Gclose(g); h5.H5Fclose(f)
+    with pytest.raises(mnet.NetError, match='no group "data"'):
+        n.load_caffemodel(p5)
