@@ -37,7 +37,8 @@ MSCNN_NET_API int mscnn_net_create_from_string(const char* prototxt_text, int de
 #define MSCNN_NET_NO_FUSION 1
 MSCNN_NET_API int mscnn_net_create_from_string_ex(const char* prototxt_text, int device, unsigned flags, mscnn_net** out);
 MSCNN_NET_API void mscnn_net_destroy(mscnn_net* net);
-/* net.copy_from(caffemodel) -- Net::CopyTrainedLayersFrom, net.cpp:750-803 (binary NetParameter). */
+/* net.copy_from(weights) -- Net::CopyTrainedLayersFrom, net.cpp:750-803: a binary NetParameter (.caffemodel), or -- for a path
+ * ending in ".h5", like the reference (net.cpp:788-795) -- an HDF5 snapshot (Net::CopyTrainedLayersFromHDF5, net.cpp:806-848). */
 MSCNN_NET_API int mscnn_net_load_caffemodel(mscnn_net* net, const char* path);
 /* HIP stream (hipStream_t as void*) for every subsequent call on this thread; NULL = default stream. */
 MSCNN_NET_API int mscnn_net_set_stream(void* stream);

@@ -60,7 +60,7 @@ class File {
   bool ok_;
   std::string err_;
   int so_, sl_;                 // size of offsets / lengths
-  uint64_t base_, root_header_;
+  uint64_t base_, root_header_, budget_;
 };
 
 }  // namespace h5lite

@@ -47,7 +47,7 @@ bool File::Addr(uint64_t off, uint64_t* a, const char* what) {
 
 File::File(const std::string& bytes)
     : p_(reinterpret_cast<const unsigned char*>(bytes.data())), n_(bytes.size()), ok_(true), so_(8), sl_(8), base_(0),
-      root_header_(0) {
+      root_header_(0), budget_(0) {
   // the superblock sits at 0 or at 512 << k (a user block may precede it)
   uint64_t sb = ~0ull;
   for (uint64_t off = 0; off + 8 <= n_; off = off ? off * 2 : 512)
@@ -129,6 +129,8 @@ bool File::SymbolTable(uint64_t group_header, uint64_t* btree, uint64_t* heap) {
 bool File::WalkBtree(uint64_t node, uint64_t heap_data, uint64_t heap_size, int depth,
                      std::vector<std::pair<std::string, uint64_t> >* links) {
   if (depth > kMaxDepth) return Fail("group B-tree too deep");
+  if (budget_ == 0) return Fail("group B-tree visits more nodes than a file of this size can hold (cycle?)");
+  --budget_;
   const uint64_t hdr = 8 + 2ull * so_;
   if (!Need(node, hdr, "B-tree node")) return false;
   if (std::memcmp(p_ + node, "TREE", 4) != 0) return Fail("bad B-tree node signature");
@@ -145,6 +147,8 @@ bool File::WalkBtree(uint64_t node, uint64_t heap_data, uint64_t heap_size, int 
       continue;
     }
     // symbol table node
+    if (budget_ == 0) return Fail("group B-tree visits more nodes than a file of this size can hold (cycle?)");
+    --budget_;
     if (!Need(child, 8, "symbol table node")) return false;
     if (std::memcmp(p_ + child, "SNOD", 4) != 0) return Fail("bad symbol table node signature");
     const unsigned nsym = (unsigned)U(child + 6, 2);
@@ -177,6 +181,7 @@ bool File::ListGroup(uint64_t group_header, std::vector<std::pair<std::string, u
   uint64_t heap_data;
   if (!Addr(heap + 8 + 2ull * sl_, &heap_data, "local heap data")) return false;
   if (heap_data == ~0ull || !Need(heap_data, heap_size, "local heap data")) return Fail("local heap data out of range");
+  budget_ = n_ / 32 + 16;                // every node occupies more than 32 bytes: a walk that needs more has a cycle
   return WalkBtree(btree, heap_data, heap_size, 0, links);
 }
 

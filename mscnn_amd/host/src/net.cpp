@@ -463,7 +463,7 @@ const shared_ptr<Layer<Dtype> > Net<Dtype>::layer_by_name(const string& layer_na
 }
 
 // ---- .caffemodel (binary NetParameter) reader: varint / length-delimited / packed float only ------------------
-// caffe.proto: NetParameter{ layer = 100 } ; LayerParameter{ name = 1, blobs = 7 } ;
+// caffe.proto: NetParameter{ layer = 100, layers = 2 (V1) } ; LayerParameter{ name = 1, blobs = 7 } ; V1LayerParameter{ name = 4, blobs = 6 } ;
 // BlobProto{ num=1 channels=2 height=3 width=4 data=5 (packed float) shape=7 } ; BlobShape{ dim=1 (packed int64) }
 namespace {
 // Every advance is bounds-checked: a truncated or corrupt file is a CHECK failure, never a read past the buffer.
@@ -520,15 +520,22 @@ void Net<Dtype>::CopyTrainedLayersFrom(const string& trained_filename) {
   while (net.ok()) {
     const unsigned long long key = net.varint();
     const int field = (int)(key >> 3), wire = (int)(key & 7);
-    if (!(field == 100 && wire == 2)) { CHECK(!(field == 2 && wire == 2)) << "V1 caffemodel (layers = 2) is not supported"; net.skip(wire); continue; }
+    // `layer` = 100 (LayerParameter: name = 1, blobs = 7) or the deprecated `layers` = 2 (V1LayerParameter: name = 4, blobs = 6;
+    // caffe.proto:95, 1358-1361, 1405) -- the reference upgrades V1 nets on load (upgrade_proto.cpp UpgradeV1Net: name and
+    // blobs carried over unchanged), and weights are matched by layer name only, so both feed the same copy below.
+    const bool v1 = field == 2 && wire == 2;
+    if (!(field == 100 && wire == 2) && !v1) { net.skip(wire); continue; }
+    const int f_name = v1 ? 4 : 1, f_blobs = v1 ? 6 : 7;
     Reader lr = net.sub();
     string lname;
     vector<ParsedBlob> pblobs;
     while (lr.ok()) {
       const unsigned long long k = lr.varint();
       const int f = (int)(k >> 3), w = (int)(k & 7);
-      if (f == 1 && w == 2) { Reader s = lr.sub(); lname.assign((const char*)s.p, s.left()); }
-      else if (f == 7 && w == 2) {
+      CHECK(!(v1 && f == 1 && w == 2)) << "V0 caffemodel (V1LayerParameter.layer = 1, 2013-era format) is not supported: upgrade it "
+                                          "with the reference's upgrade_net_proto_binary";
+      if (f == f_name && w == 2) { Reader s = lr.sub(); lname.assign((const char*)s.p, s.left()); }
+      else if (f == f_blobs && w == 2) {
         Reader br = lr.sub();
         ParsedBlob pb;
         while (br.ok()) {

@@ -45,25 +45,38 @@ def classes():
     _field(layer, "phase", 10, _F.TYPE_INT32)                # enum Phase in caffe.proto: same wire type
     _field(layer, "loss_weight", 5, _F.TYPE_FLOAT, _F.LABEL_REPEATED)      # NOT packed in caffe.proto: fixed32 per element
     _field(layer, "blobs", 7, _F.TYPE_MESSAGE, _F.LABEL_REPEATED, ".caffe.BlobProto")
+    v1 = fd.message_type.add(); v1.name = "V1LayerParameter"        # caffe.proto:1358-1361, 1405, 1441 (deprecated, still loadable)
+    _field(v1, "bottom", 2, _F.TYPE_STRING, _F.LABEL_REPEATED)
+    _field(v1, "top", 3, _F.TYPE_STRING, _F.LABEL_REPEATED)
+    _field(v1, "name", 4, _F.TYPE_STRING)
+    _field(v1, "type", 5, _F.TYPE_INT32)                     # enum LayerType: same wire type
+    _field(v1, "blobs", 6, _F.TYPE_MESSAGE, _F.LABEL_REPEATED, ".caffe.BlobProto")
+    _field(v1, "blobs_lr", 7, _F.TYPE_FLOAT, _F.LABEL_REPEATED)
     net = fd.message_type.add(); net.name = "NetParameter"
     _field(net, "name", 1, _F.TYPE_STRING)
+    _field(net, "layers", 2, _F.TYPE_MESSAGE, _F.LABEL_REPEATED, ".caffe.V1LayerParameter")
     _field(net, "layer", 100, _F.TYPE_MESSAGE, _F.LABEL_REPEATED, ".caffe.LayerParameter")
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
     _classes = {n: message_factory.GetMessageClass(pool.FindMessageTypeByName("caffe." + n))
-                for n in ("BlobShape", "BlobProto", "LayerParameter", "NetParameter")}
+                for n in ("BlobShape", "BlobProto", "LayerParameter", "V1LayerParameter", "NetParameter")}
     return _classes
 
 
-def serialize(layers, name="from_protobuf_python"):
-    """layers: [(name, type, [(array, mode)])] with mode in {"shape", "legacy", "double"} -> bytes (NetParameter)."""
+def serialize(layers, name="from_protobuf_python", v1=False):
+    """layers: [(name, type, [(array, mode)])] with mode in {"shape", "legacy", "double"} -> bytes (NetParameter).
+    v1: the deprecated `layers = 2` / V1LayerParameter form (the published VGG-16 weights MS-CNN starts from use it)."""
     import numpy as np
     C = classes()
     net = C["NetParameter"](); net.name = name
     for lname, ltype, blobs in layers:
-        lp = net.layer.add(); lp.name, lp.type, lp.phase = lname, ltype, 1
+        if v1:
+            lp = net.layers.add(); lp.name, lp.type = lname, 4          # CONVOLUTION = 4
+            lp.blobs_lr.extend([1.0, 2.0])
+        else:
+            lp = net.layer.add(); lp.name, lp.type, lp.phase = lname, ltype, 1
+            lp.loss_weight.append(1.0)
         lp.bottom.append("x"); lp.top.append(lname)
-        lp.loss_weight.append(1.0)
         for arr, mode in blobs:
             a = np.ascontiguousarray(arr, np.float32)
             bp = lp.blobs.add()

@@ -262,6 +262,26 @@ def test_caffemodel_written_by_protobuf_python(tmp_path):
         n.load_caffemodel(tmp_path / "weights.caffemodel.h5")
 
 
+def test_caffemodel_v1_layers(tmp_path):
+    """The deprecated V1 form (NetParameter.layers = 2, V1LayerParameter name = 4 / blobs = 6): the reference upgrades it on load
+    (upgrade_proto.cpp UpgradeV1Net) and copies by name; legacy 4-D blobs, as every V1-era file has them."""
+    import numpy as np
+    from tests import caffemodel_pb
+    n = Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=64, width=128))
+    rng = np.random.default_rng(4)
+    want, layers = {}, []
+    for name in ("conv1_1", "conv2_2", "cls_pred"):
+        arrs = [rng.standard_normal(sh).astype(np.float32) for sh in n.param_shapes(n.layer_names.index(name))]
+        want[name] = arrs
+        layers.append((name, "Convolution", [(a, "legacy") for a in arrs]))
+    path = tmp_path / "v1.caffemodel"
+    path.write_bytes(caffemodel_pb.serialize(layers + [("fc8_not_here", "InnerProduct", [])], v1=True))
+    n.load_caffemodel(path)
+    for name, arrs in want.items():
+        for j, a in enumerate(arrs):
+            assert np.array_equal(n.get_param(name, j), a), (name, j)
+
+
 # ---- HDF5 weight snapshots (".h5"): Net::CopyTrainedLayersFromHDF5, net.cpp:788-795, 806-848 / util/hdf5.cpp:9-74 ----
 # The product parses the file itself (mscnn_amd/host/src/hdf5_lite.cpp: superblock v0, symbol-table groups, v1 object headers,
 # contiguous datasets); the fixtures are written by the real libhdf5 (tests/golden/make_hdf5_weights.py).
