@@ -52,3 +52,28 @@ def test_reference_style_cpp_compiles_against_the_mirror_headers():
            os.path.join(ROOT, "tests/boundary/user_layers.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def build_boundary_binary(out_dir):
+    """tests/boundary/run_boundary.cpp (the user layers of user_layers.cpp in a live Net + the reference's SyncedMemory / Blob
+    test cases) compiled as plain C++ against the mirror headers and linked with the product libraries."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = os.path.join(str(out_dir), "run_boundary")
+    libdir = os.path.join(ROOT, "mscnn_amd")
+    cmd = [hipcc, "-std=c++17", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-x", "c++", "-I/opt/rocm/include",
+           "-I" + os.path.join(ROOT, "mscnn_amd/host/include"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests/boundary/run_boundary.cpp"), "-L" + libdir, "-lmscnn_caffe", "-lmscnn_hip",
+           "-Wl,-rpath," + libdir, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_user_registered_layers_build_a_net_without_a_device(tmp_path):
+    """REGISTER_LAYER_CLASS from user code reaches the product's registry, the prototxt naming the user types parses, the
+    automatic Split is inserted, LayerSetUp / Reshape of the user layers run -- everything short of Forward (GPU test)."""
+    exe = build_boundary_binary(tmp_path)
+    r = subprocess.run([exe, str(tmp_path / "boundary.prototxt"), "construct-only"], capture_output=True, text=True)
+    assert r.returncode == 0 and "CONSTRUCTION OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])

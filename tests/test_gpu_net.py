@@ -481,3 +481,15 @@ def test_set_image_preprocessing():
     assert np.array_equal(n.get_blob("data"), ref)
     n.set_image("data", torch.from_numpy(img[::-1].copy()).cuda(), mean_bgr=(100.0, 110.0, 120.0))
     assert np.array_equal(n.get_blob("data"), orc.preprocess(img[::-1].copy(), 192, 640, mean_bgr=(100.0, 110.0, 120.0)))
+
+
+def test_reference_style_user_code_runs_on_the_gpu(tmp_path):
+    """The drop-in boundary, executed: tests/boundary/run_boundary.cpp -- the reference's SyncedMemory test cases
+    (test_syncedmem.cpp:13-120), Blob semantics, and a Net whose prototxt names two user-registered layer types (one binds
+    the C ABI inside Forward_gpu the way INTEGRATION.md section 1 shows, one uses only the Layer / Blob interface) beside the
+    stock ROIPooling: the user layer must produce the stock layer's bytes."""
+    import subprocess
+    from tests.test_cabi import build_boundary_binary
+    exe = build_boundary_binary(tmp_path)
+    r = subprocess.run([exe, str(tmp_path / "boundary.prototxt")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("BOUNDARY OK"), (r.stdout[-1000:], r.stderr[-2000:])
