@@ -344,6 +344,22 @@ CASCADES = [   # model, reduced input, cls_id, original image size
 @pytest.mark.parametrize("model,size,cls_id,org_hw,precision",
                          [c + (None,) for c in CASCADES] + [CASCADES[0] + ("f16x3",), CASCADES[3] + ("f16x3",)])
 def test_cascade_deploys_whole_net(model, size, cls_id, org_hw, precision):
+    _check_cascade(model, size, cls_id, org_hw, precision)
+
+
+@pytest.mark.slow
+def test_cascade_full_size_vs_reference():
+    """kitti_car/cascade-mscnn-7s-576-2x at the deploy file's own size (1x3x576x1920, 2x up-sampled conv4_3, three detection
+    stages, max_nms_num 2000) against the reference's own CPU layers (oracle/_ref): the assertions of the reduced-size test."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a MI355X")
+    from oracle import pyref
+    if not pyref.available():
+        pytest.fail("oracle/_ref/libmscnn_ref.so did not travel to this box")
+    _check_cascade("kitti_car/cascade-mscnn-7s-576-2x", {}, 2, (375, 1242), None, backend=pyref)
+
+
+def _check_cascade(model, size, cls_id, org_hw, precision, backend=None):
     """The reference's cascade / CityPersons / WiderFace deploy nets (the generated prototxts are checked against the shipped
     files in tests/test_prototxt.py) forwarded on the GPU: trunk + heads end to end within 1e-4 of the oracle, then EVERY layer
     from BoxOutput on with the device's own bottoms (DecodeBBox chains, stage-wise re-pooling, ROIAlign + AVE pooling, the
@@ -362,7 +378,7 @@ def test_cascade_deploys_whole_net(model, size, cls_id, org_hw, precision):
     layers = layer_list(n)
     names = [l[0] for l in layers]
     ip = names.index("proposals")
-    ref = pynet.forward(layers[:ip], ws, {"data": x})
+    ref = pynet.forward(layers[:ip], ws, {"data": x}, backend=backend)
     for l in layers[:ip]:
         if l[0].startswith("LFCN_") or l[0] in ("conv4_3", "conv5_3", "pool6"):
             assert rel_err(n.get_blob(l[3][0]), ref[l[3][0]]) < 1e-4, l[0]
@@ -375,7 +391,7 @@ def test_cascade_deploys_whole_net(model, size, cls_id, org_hw, precision):
         if l[1] in ("Split", "ReLU", "Dropout"):
             continue
         feeds = {b: n.get_blob(b) for b in l[2]}
-        out = pynet.forward([l], ws, feeds)
+        out = pynet.forward([l], ws, feeds, backend=backend)
         for t in l[3]:
             a, b = n.get_blob(t), out[t].reshape(n.blob_shape(t))
             if t in relu_inplace:
