@@ -355,9 +355,29 @@ def test_hdf5_weights_written_by_libhdf5(tmp_path):
     p4 = tmp_path / "legacy.h5"; mk.write(p4, [("conv1_1", [w.astype(np.float32), b.astype(np.float32).reshape(1, 1, 1, -1)])])
     n.load_caffemodel(p4)
     assert np.array_equal(n.get_param("conv1_1", 1).reshape(-1), b.astype(np.float32))
-    # no "data" group
+    # attributes on the groups and datasets (h5py / pycaffe tooling adds them): object-header continuation blocks and
+    # attribute messages the reader has to walk past
     import ctypes as C
-    h5 = mk.libs()[0]
+    h5, h5l = mk.libs()[0], mk.libs()[1]
+    hid = C.c_int64
+    h5.H5Fopen.restype = hid; h5.H5Fopen.argtypes = [C.c_char_p, C.c_uint, hid]
+    h5.H5Gopen2.restype = hid; h5.H5Gopen2.argtypes = [hid, C.c_char_p, hid]
+    h5l.H5LTset_attribute_string.argtypes = [hid, C.c_char_p, C.c_char_p, C.c_char_p]
+    h5l.H5LTset_attribute_float.argtypes = [hid, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    p6 = tmp_path / "attrs.h5"
+    w2 = (w * 0.5).astype(np.float32)
+    mk.write(p6, [("conv1_1", [w2, b.astype(np.float32)])])
+    f = h5.H5Fopen(os.fsencode(str(p6)), 1, 0)                # H5F_ACC_RDWR
+    g = h5.H5Gopen2(f, b"data", 0)
+    stat = (C.c_float * 16)(*range(16))
+    for k in range(12):
+        assert h5l.H5LTset_attribute_string(g, b"conv1_1", f"note{k}".encode(), b"x" * 120) >= 0
+        assert h5l.H5LTset_attribute_float(g, b"conv1_1/0", f"stat{k}".encode(), stat, 16) >= 0
+    assert h5l.H5LTset_attribute_string(f, b"data", b"origin", b"caffe snapshot") >= 0
+    h5.H5Gclose(g); h5.H5Fclose(f)
+    n.load_caffemodel(p6)
+    assert np.array_equal(n.get_param("conv1_1", 0), w2)
+    # no "data" group
     p5 = tmp_path / "nodata.h5"
     f = h5.H5Fcreate(os.fsencode(str(p5)), 2, 0, 0); g = h5.H5Gcreate2(f, b"weights", 0, 0, 0); h5.H5Gclose(g); h5.H5Fclose(f)
     with pytest.raises(mnet.NetError, match='no group "data"'):
