@@ -83,7 +83,8 @@ typedef struct {
    * fp32 rounding.  tune_variant: igemm tile variant (value + 1, so that 0 keeps the default); tune_grid: workgroups of the
    * persistent igemm / head kernels; tune_flags: bit 0 = no XCD-aware workgroup map, bit 1 = proposal heads on the 32-row
    * igemm tile instead of the M = 4 head kernel, bit 2 = MSCNN_CONV_ALGO_WINO_F3_X3 wherever it is legal (default: only where
-   * the AUTO heuristic picks F(3x3,3x3)); tune_variant with WINO_F3_X3: 1 = 128-row, 2 = 256-row GEMM tiles. */
+   * the AUTO heuristic picks F(3x3,3x3)), bit 4 = fp32 proposal heads as one GEMM over the taps + shift-and-add (measured equal or
+   * slower than the head kernel: opt-in), bit 5 = never that form; tune_variant with WINO_F3_X3: 1 = 128-row, 2 = 256-row GEMM tiles. */
   int tune_variant, tune_grid, tune_flags;
 } mscnn_conv_desc;
 

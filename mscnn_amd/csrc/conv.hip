@@ -819,6 +819,19 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const float* __restric
   }
 }
 
+// proposal heads as GEMM + shift-and-add (head_gemm_plan): w [Cout][Cin][taps] -> W' [tap * Cout + co][Cin]
+constexpr bool kHeadGemmDefault = false;      // A/B pending: opt-in through tune_flags bit 4
+constexpr long kHeadGemmMinPixels = 4096;
+__global__ __launch_bounds__(256) void head_gemm_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                                               int taps) {
+  const long total = (long)taps * Cout * Cin;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Cin), row = (int)(i / Cin);
+    const int tap = row / Cout, co = row % Cout;
+    wp[i] = w[((long)co * Cin + c) * taps + tap];
+  }
+}
+
 // ---- kernel table -------------------------------------------------------------------------------------
 typedef void (*IgemmFn)(IgemmArgs);
 struct KernelEntry {
@@ -928,6 +941,12 @@ struct mscnn_conv_plan {
   // Workspace layout: [4 KB: max |x| slots, used when nobody hands the bound over][V16][M: 25 x Cout x T_pad floats]
   mscnn::X3Plan x3;
   mscnn::X3HeadPlan x3h;       // x3h.rows > 0: proposal head as one split-fp16 GEMM + shift-and-add (wino_x3.hip); per image
+  // fp32 form of the same idea (hg != nullptr): T[tap * Cout + co][pixel] = W'[tap * Cout + co][c] x[c][pixel] on the nested 1x1
+  // igemm plan (one image: the map viewed as HW / 128 rows of 128 pixels where that divides -- the vectorised Winograd GEMM kernel --
+  // else as one row of HW pixels), then the shift-and-add.  Packed buffer: [nested pack][W': rows x Cin floats]; workspace: [T][nested]
+  mscnn_conv_plan* hg = nullptr;
+  int hg_rows = 0;
+  size_t hg_t_bytes = 0;
   size_t x3d_hdr_off = 0, x3d_slots_off = 0;   // X3 direct kernel: header behind the packed weights, own-amax slots behind the slabs
   const unsigned* amax_in = nullptr;   // mscnn_conv2d_plan_set_amax_io (kept across re-planning)
   unsigned* amax_out = nullptr;
@@ -936,6 +955,7 @@ struct mscnn_conv_plan {
   mutable hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   mutable bool ev_valid = false;
   ~mscnn_conv_plan() {
+    delete hg;
     delete wino;
     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
   }
@@ -944,6 +964,40 @@ struct mscnn_conv_plan {
 using namespace mscnn;
 
 static void plan_shape(mscnn_conv_plan* p);
+
+// Proposal heads (Cout <= 12, K x K over 512 channels) on the fp32 MFMA as ONE dense GEMM over the taps + a shift-and-add: the form
+// wino_x3.hip introduced for the split-fp16 mode (M = taps * Cout = 225 / 441 rows instead of 9), here on the nested 1x1 igemm plan.
+// The M = 4 head kernel is bound by a per-chunk latency chain (47-65 TFLOP/s on the conv4_3-sized heads and 25 % slower on a box with
+// slower clocks); the GEMM runs at the Winograd GEMM's rate and the shift-and-add streams T once.  tune_flags bit 4 forces the form
+// wherever it is legal (tests, A/B), bit 5 disables it.
+static bool head_gemm_plan(mscnn_conv_plan* p) {
+  const mscnn_conv_desc& d = p->d;
+  const int flags = tune_env("MSCNN_TUNE_FLAGS", d.tune_flags);
+  const long HW = (long)d.H * d.W;
+  if (tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_WINO_F3_X3 || (flags & 32) || (flags & 2)) return false;
+  if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.Cout > 12 || d.Kh * d.Kw < 2 || d.Kh * d.Kw > 64 || d.N < 1) return false;
+  if (d.Cin % 32 != 0 || d.Cin < 32 || p->Ho < 1 || p->Wo < 1) return false;
+  if (!(flags & 16) && !kHeadGemmDefault) return false;
+  if (!(flags & 16) && HW < kHeadGemmMinPixels) return false;    // small maps: the GEMM has too few tiles, the M = 4 kernel is as fast
+  const int rows = d.Kh * d.Kw * d.Cout;
+  if ((double)rows * HW * 4.0 >= 2.0e9) return false;
+  mscnn_conv_plan* g = new (std::nothrow) mscnn_conv_plan();
+  if (!g) return false;
+  g->d = d;
+  g->d.N = 1; g->d.Cout = rows; g->d.Kh = g->d.Kw = 1; g->d.pad_h = g->d.pad_w = 0; g->d.relu = 0;
+  g->d.algo = MSCNN_CONV_ALGO_DIRECT;
+  g->d.tune_variant = 0; g->d.tune_grid = 0; g->d.tune_flags = flags & 1;
+  if (HW % 128 == 0) { g->d.H = (int)(HW / 128); g->d.W = 128; }   // rows of exactly 128 pixels: the vectorised 1x1 kernel
+  else { g->d.H = 1; g->d.W = (int)HW; }
+  plan_shape(g);
+  if (g->entry < 0 || g->wino || g->hg || g->head.entry >= 0 || g->Ho * (long)g->Wo != HW) { delete g; return false; }
+  p->hg = g;
+  p->hg_rows = rows;
+  p->hg_t_bytes = ((size_t)rows * HW * sizeof(float) + 255) / 256 * 256;
+  p->packed_bytes = g->packed_bytes + (size_t)rows * d.Cin * sizeof(float);
+  p->ws_bytes = p->hg_t_bytes + g->ws_bytes;
+  return true;
+}
 
 // Winograd is chosen where the cut in multiplies (2.25x for F(2x2,3x3), 3.24x for F(3x3,3x3)) outweighs the extra HBM traffic
 // of the transforms (V and M are 4x / 2.78x the input / output and are written and read once each): GEMM FLOPs per transform
@@ -1018,6 +1072,10 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->ws_bytes = 0;
   p->head.entry = -1;
   p->x3h = mscnn::X3HeadPlan();
+  delete p->hg;
+  p->hg = nullptr;
+  p->hg_rows = 0;
+  p->hg_t_bytes = 0;
   // split-fp16 mode: a small-Cout K x K head is ONE dense GEMM over the taps + a shift-and-add (M = taps * Cout instead of Cout)
   if (tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_WINO_F3_X3 && d.stride_h == 1 && d.stride_w == 1 && d.group == 1 &&
       d.Cout <= 12 && d.Kh * d.Kw > 1 && d.N > 0 && !(d.tune_flags & 2) &&
@@ -1026,6 +1084,7 @@ static void plan_shape(mscnn_conv_plan* p) {
     p->ws_bytes = 4096 + p->x3h.t_bytes;
     return;
   }
+  if (head_gemm_plan(p)) return;
   if (head_plan(d, p->Ho, p->Wo, &p->head)) {
     p->packed_bytes = p->head.packed_bytes;
     p->ws_bytes = p->head.ws_bytes;
@@ -1158,6 +1217,7 @@ extern "C" size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* p) { retur
 extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (!p) return "";
   if (p->x3h.rows) return "head_gemm_shiftadd_x3f16";
+  if (p->hg) return "head_gemm_shiftadd_f32";
   if (p->head.entry >= 0) return head_kernel_name(p->head);
   if (p->x3.BM) return p->x3.BM == 256 ? "winograd_f3x3_3x3_x3f16_256" : "winograd_f3x3_3x3_x3f16_128";
   if (p->wino) return p->wino_m == 3 ? "winograd_f3x3_3x3" : "winograd_f2x2_3x3";
@@ -1167,6 +1227,7 @@ extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_p
   if (!p) return 0;
   unsigned long long kind, e, mt, ki;
   if (p->x3h.rows) { kind = 7; e = (unsigned)p->x3h.rows_pad; mt = 0; ki = (unsigned)p->x3h.KG; }
+  else if (p->hg) { kind = 8; e = (unsigned)p->hg->entry; mt = (unsigned)p->hg->MT; ki = (unsigned)p->hg->KI; }
   else if (p->head.entry >= 0) { kind = 2; e = (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
   else if (p->x3.BM) { kind = 6; e = (unsigned)p->x3.BM; mt = (unsigned)p->x3.MT; ki = (unsigned)p->x3.KG; }
   else if (p->wino) { kind = 2 + (unsigned)p->wino_m; e = (unsigned)p->wino->entry; mt = (unsigned)p->wino->MT; ki = (unsigned)p->wino->KI; }
@@ -1237,6 +1298,15 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   if (p->x3h.rows) {
     MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
     return x3_head_pack(p->x3h, w, packed, as_stream(stream));
+  }
+  if (p->hg) {
+    MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
+    float* wprime = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(packed) + p->hg->packed_bytes);
+    const long total = (long)p->hg_rows * p->d.Cin;
+    head_gemm_weight_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, as_stream(stream)>>>(
+        w, wprime, p->d.Cout, p->d.Cin, p->d.Kh * p->d.Kw);
+    MSCNN_POST_LAUNCH();
+    return mscnn_conv2d_pack_weights(p->hg, wprime, packed, stream);
   }
   if (p->head.entry >= 0) {
     MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
@@ -1326,7 +1396,7 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
 }
 
 extern "C" int mscnn_conv2d_plan_can_pool(const mscnn_conv_plan* p) {
-  if (!p || p->head.entry >= 0 || p->x3h.rows) return 0;
+  if (!p || p->head.entry >= 0 || p->x3h.rows || p->hg) return 0;
   if (p->wino || p->x3.BM) return p->wino_m == 2 || (p->tiles_h % 2 == 0 && p->tiles_w % 2 == 0 && p->d.H > 8);
   return p->entry >= 0 && kTable[p->entry].fix_pool_fn != nullptr;
 }
@@ -1424,6 +1494,24 @@ static int conv_forward_single(const mscnn_conv_plan* p, const float* x, const f
     for (int n = 0; n < d.N; ++n) {      // (the deploy nets run batch 1; images share the workspace one after the other)
       const int rc = x3_head_forward(p->x3h, x + (size_t)n * d.Cin * d.H * d.W, packed, bias, y + (size_t)n * d.Cout * p->Ho * p->Wo, d.H,
                                      d.W, p->Ho, p->Wo, d.pad_h, d.pad_w, d.relu, d.N == 1 ? p->amax_in : nullptr, workspace, st);
+      if (rc != MSCNN_OK) return rc;
+    }
+    return MSCNN_OK;
+  }
+  if (p->hg) {
+    MSCNN_REQUIRE(packed, "conv: head kernel needs packed weights (mscnn_conv2d_pack_weights)");
+    if (!workspace || workspace_bytes < p->ws_bytes) {
+      set_error("conv(head gemm): workspace %zu < %zu", workspace_bytes, p->ws_bytes);
+      return MSCNN_ERR_WORKSPACE;
+    }
+    float* T = static_cast<float*>(workspace);
+    void* nested_ws = static_cast<unsigned char*>(workspace) + p->hg_t_bytes;
+    for (int n = 0; n < d.N; ++n) {      // (the deploy nets run batch 1; images share T one after the other)
+      // (tile order: the M tiles of one pixel tile together -- they share the B tile)
+      int rc = launch_igemm(p->hg, x + (size_t)n * d.Cin * d.H * d.W, packed, nullptr, T, nullptr, nested_ws, p->hg->ws_bytes, st, 0u, 1);
+      if (rc != MSCNN_OK) return rc;
+      rc = head_shift_add(T, bias, y + (size_t)n * d.Cout * p->Ho * p->Wo, d.Cout, d.H, d.W, p->Ho, p->Wo, d.Kh, d.Kw, d.pad_h, d.pad_w,
+                          (unsigned)((long)d.H * d.W), d.relu, st);
       if (rc != MSCNN_OK) return rc;
     }
     return MSCNN_OK;

@@ -25,6 +25,9 @@ bool x3_head_plan(int Cin, int Cout, int KH, int KW, long HW, X3HeadPlan* out);
 int x3_head_pack(const X3HeadPlan& p, const float* w, void* packed, hipStream_t st);
 int x3_head_forward(const X3HeadPlan& p, const float* x, const void* packed, const float* bias, float* y, int H, int W, int Ho, int Wo,
                     int pad_h, int pad_w, int relu, const unsigned* in_bound, void* ws, hipStream_t st);
+// y[co] = bias[co] + sum over the taps of T[tap * Cout + co] shifted by the tap's offset (zero padding), rows of T_pad floats
+int head_shift_add(const float* T, const float* bias, float* y, int Cout, int H, int W, int Ho, int Wo, int KH, int KW, int pad_h,
+                   int pad_w, unsigned T_pad, int relu, hipStream_t st);
 
 // false when the shape is not covered (Cin not a multiple of 32, planes beyond the 32-bit buffer window)
 bool x3_plan(int Cin, int Cout, long T_pad, int tune_variant, X3Plan* out);

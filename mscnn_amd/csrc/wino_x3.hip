@@ -593,8 +593,13 @@ int x3_head_forward(const X3HeadPlan& p, const float* x, const void* packed, con
   a.planes = 1; a.ks = 0; a.slabs = nullptr; a.bound_mult = 1.f;
   x3_gemm_kernel<128, true><<<a.tiles, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
-  x3_head_shift_add_kernel<<<dim3(cdiv(Ho * Wo, 256), p.Cout), 256, 0, st>>>(T, bias, y, p.Cout, H, W, Ho, Wo, p.KH, p.KW, pad_h, pad_w,
-                                                                             (unsigned)p.T_pad, relu);
+  return head_shift_add(T, bias, y, p.Cout, H, W, Ho, Wo, p.KH, p.KW, pad_h, pad_w, (unsigned)p.T_pad, relu, st);
+}
+
+// the shift-and-add of the GEMM-over-taps form, shared with the fp32 variant (conv.hip head_gemm_plan): T rows of T_pad floats
+int head_shift_add(const float* T, const float* bias, float* y, int Cout, int H, int W, int Ho, int Wo, int KH, int KW, int pad_h,
+                   int pad_w, unsigned T_pad, int relu, hipStream_t st) {
+  x3_head_shift_add_kernel<<<dim3(cdiv(Ho * Wo, 256), Cout), 256, 0, st>>>(T, bias, y, Cout, H, W, Ho, Wo, KH, KW, pad_h, pad_w, T_pad, relu);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

@@ -156,6 +156,40 @@ def test_conv_head_x3_gemm_shiftadd(hip, orc, case):
     close(pr.forward(dev(x), dev(b)).cpu().numpy(), np.maximum(ref, 0))
 
 
+@pytest.mark.parametrize("case", [(1, 64, 36, 120, 9, (5, 5)), (1, 128, 18, 60, 9, (7, 7)), (2, 64, 12, 20, 7, (5, 3)), (1, 96, 13, 21, 6, (7, 5)),
+                                  (1, 512, 9, 30, 9, (5, 5)), (1, 32, 7, 9, 12, (3, 3)), (1, 512, 72, 240, 9, (7, 7)), (1, 512, 36, 120, 9, (5, 5))])
+def test_conv_head_gemm_shiftadd_f32(hip, orc, case):
+    """Proposal heads on the fp32 MFMA as ONE dense GEMM over the taps (the nested 1x1 igemm plan: the vectorised Winograd GEMM
+    kernel where H * W is a multiple of 128, the generic one else) + the shift-and-add: against the oracle's direct convolution
+    (1e-4) and no worse than 3x the M = 4 head kernel + 2e-6 against float64; borders smaller than the kernel, batch 2, ReLU; the
+    last two cases are LFCN_1_7x7 / LFCN_2_5x5 of mscnn-7s-576 at full size."""
+    N, Cin, H, W, Cout, (kh, kw) = case
+    rng = np.random.default_rng(44)
+    x = np.maximum(rng.standard_normal((N, Cin, H, W)), 0).astype(np.float32) * 2
+    w = (rng.standard_normal((Cout, Cin, kh, kw)) * np.sqrt(2.0 / (Cin * kh * kw))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    plan = hip.ConvPlan(N, Cin, H, W, Cout, kh, kw, (kh // 2, kw // 2), tune_flags=16)
+    assert plan.kernel == "head_gemm_shiftadd_f32" and plan.dtype == "f32" and not plan.can_pool and not plan.publishes_amax
+    plan.pack(dev(w))
+    y = plan.forward(dev(x), dev(b)).cpu().numpy()
+    ref = orc.conv2d(x, w, b, (kh // 2, kw // 2))
+    close(y, ref)
+    p32 = hip.ConvPlan(N, Cin, H, W, Cout, kh, kw, (kh // 2, kw // 2), tune_flags=32)
+    assert not p32.kernel.startswith("head_gemm")                # the M = 4 head kernel (3x3: the igemm tile)
+    p32.pack(dev(w))
+    y32 = p32.forward(dev(x), dev(b)).cpu().numpy()
+    truth = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                       padding=(kh // 2, kw // 2)).numpy()
+    m = lambda a: float((np.abs(a - truth) / np.maximum(1, np.abs(truth))).max())      # noqa: E731
+    print(f"head gemm err {m(y):.2e}  M = 4 head kernel err {m(y32):.2e}")
+    assert m(y) <= 3 * m(y32) + 2e-6
+    pr = hip.ConvPlan(N, Cin, H, W, Cout, kh, kw, (kh // 2, kw // 2), relu=True, tune_flags=16)
+    pr.pack(dev(w))
+    yr = pr.forward(dev(x), dev(b))
+    close(yr.cpu().numpy(), np.maximum(ref, 0))
+    assert np.array_equal(pr.forward(dev(x), dev(b)).cpu().numpy(), yr.cpu().numpy())      # deterministic (k-ordered fix-up, no atomics)
+
+
 WINO_CASES = [   # N, Cin, H, W, Cout, pad
     (1, 16, 8, 12, 24, 1),        # exact 2x2 tiles
     (1, 40, 13, 21, 130, 1),      # odd H and W: partial tiles at the bottom / right edge, Cout ragged

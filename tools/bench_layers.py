@@ -20,7 +20,8 @@ LAYERS = [  # name, N, Cin, H, W, Cout, k, pad
     ("conv4_1", 1, 256, 72, 240, 512, 3, 1), ("conv4_2", 1, 512, 72, 240, 512, 3, 1),
     ("conv5_1", 1, 512, 36, 120, 512, 3, 1), ("conv6_1", 1, 512, 18, 60, 512, 3, 1),
     ("LFCN_1_5x5", 1, 512, 72, 240, 9, 5, 2), ("LFCN_1_7x7", 1, 512, 72, 240, 9, 7, 3),
-    ("LFCN_2_7x7", 1, 512, 36, 120, 9, 7, 3), ("roi_c1", 700, 1024, 7, 7, 512, 3, 0),
+    ("LFCN_2_5x5", 1, 512, 36, 120, 9, 5, 2), ("LFCN_2_7x7", 1, 512, 36, 120, 9, 7, 3),
+    ("LFCN_3_5x5", 1, 512, 18, 60, 9, 5, 2), ("LFCN_3_7x7", 1, 512, 18, 60, 9, 7, 3), ("roi_c1", 700, 1024, 7, 7, 512, 3, 0),
 ]
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=20)
