@@ -229,6 +229,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed loop in the f16x3 mode (reported as alt_precision)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer tables (caffe time format) to stderr")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
+                    help="multi-GPU exchange: libmscnn_dist's direct ncclAllGather (default), or torch.distributed's all_gather of the "
+                         "same device bytes -- the route taken by itself when the direct communicator cannot be set up")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -266,6 +269,8 @@ def main():
             dist.broadcast_object_list(box, src=0)
             return box[0]
         try:
+            if args.gather == "torch":
+                raise RuntimeError("--gather torch")
             gather = mdist.RcclGather(rank, world, local_rank, cap, exchange)
             gather_kind = "libmscnn_dist: ncclAllGather of the device pack"
         except Exception as e:      # a second route to the same bytes, so that the scaling run is never lost
@@ -319,6 +324,7 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
+    main_stats, stats = stats, {"R": [], "D": []}      # the headline loop's ROI / detection counts (later loops append to their own)
 
     # ---- second timed loop, same contract, in the split-fp16 mode (fp32-grade: held to the fp32 parity gates below).  The
     # headline `value` stays the true-fp32-MFMA path; this is reported beside it as `alt_precision`.
@@ -444,7 +450,7 @@ def main():
                     tf = xflops[i] / (lay_ms[i] * 1e-3) / 1e12 if xflops[i] else 0
                     st = f" [in {stage[i, 0]*1e3:6.1f} gemm {stage[i, 1]*1e3:6.1f} out {stage[i, 2]*1e3:6.1f}]" if stage[i].sum() > 0 and kern[i].startswith("wino") else ""
                     print(f"{nm:28s} {net.layer_types[i]:14s} {kern[i]:30s} {lay_ms[i]*1e3:9.1f} us {tf:7.1f} TF executed{st}", file=sys.stderr)
-        Rm = float(np.mean(stats["R"]))
+        Rm = float(np.mean(main_stats["R"]))
         ss = np.sort(np.array(step_s)) * 1e3
         result = {"metric": f"images/sec {args.model.split('/')[-1]} {args.model.split('/')[0].replace('_', '-')} inference", "value": round(value, 3),
                   "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -454,7 +460,7 @@ def main():
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                   "config": {"workload": f"{args.model} {'fp16 MFMA operands / fp32 accumulate' if args.dtype == 'f16' else 'fp32 (Winograd GEMMs as 3 x fp16 MFMA on split operands)' if args.dtype == 'f16x3' else 'fp32'}, batch=1 per GPU, 1x3x{H}x{W} frame resident in HBM -> detections on host "
                                          "(trunk + heads + BoxOutput + ROI pool + det sub-net + final NMS)",
-                             "regime": args.regime, "mean_rois": round(Rm, 1), "mean_detections": round(float(np.mean(stats["D"])), 1),
+                             "regime": args.regime, "mean_rois": round(Rm, 1), "mean_detections": round(float(np.mean(main_stats["D"])), 1),
                              "parallelism": f"image-parallel x{world}", "gather": gather_kind},
                   "numerics": numerics, "roofline": roofline}
         if args.model == DEFAULT_MODEL:

@@ -54,7 +54,15 @@ def test_bench_under_the_launcher_takes_the_distributed_path(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 50 and d["config"]["gather"].startswith("libmscnn_dist"), d["config"]
-    # the second route to the same bytes (kept for the case the direct communicator cannot be set up)
+    # the second route to the same bytes (taken by itself when the direct communicator cannot be set up), end to end
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29673", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--model", "caltech/mscnn-7s-480", "--no-cpu-baseline", "--no-alt", "--gather", "torch"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["config"]["gather"].startswith("torch.distributed") and d2["value"] > 50, d2["config"]
+    assert abs(d2["config"]["mean_detections"] - d["config"]["mean_detections"]) < 1e-9      # the same packs came back
     from bench import _CudaPtr
     t = torch.arange(64, dtype=torch.uint8, device="cuda")
     v = torch.as_tensor(_CudaPtr(t.data_ptr(), 64), device="cuda")
