@@ -99,7 +99,8 @@ def main(argv=None):
             img = load_rgb_u8(path)
         orgH, orgW = img.shape[:2]
         ratios = (imgH / float(orgH), imgW / float(orgW))                      # :63
-        net.set_image("data", torch.from_numpy(img).cuda(a.device))          # :64-69 on the device
+        dev_img = torch.from_numpy(img).cuda(a.device)                       # (kept referenced until the pre-processing has run)
+        net.set_image("data", dev_img)                                       # :64-69 on the device
         torch.cuda.synchronize(a.device)
         t0 = time.perf_counter()
         net.forward()
