@@ -70,7 +70,11 @@ typedef enum {
    * per pair, fp32 accumulators: 22-bit significands -- fp32-grade results (same 1e-4 parity bar as the fp32 kernels) at 16/3
    * of the fp32 MFMA rate.  Opt-in; it replaces the plane GEMMs of the layers the AUTO heuristic runs as F(3x3,3x3); every other
    * layer (and Cin not a multiple of 32) keeps its fp32 kernel.  mscnn_conv2d_plan_dtype() reports "f16x3". */
-  MSCNN_CONV_ALGO_WINO_F3_X3 = 5
+  MSCNN_CONV_ALGO_WINO_F3_X3 = 5,
+  /* F(4x4,3x3) with the interpolation points {0, 1, -1, 2, -1/2, inf} wherever it is legal (whole planes; ROI maps keep
+   * F(3x3,3x3)): 36 multiplies per 16 outputs, fp32 error of the F(3x3,3x3) form (profiles/r02_study_winograd_f4_numerics.txt).
+   * EXPERIMENTAL: transform arithmetic checked on the host, kernels not yet run on hardware; no default path selects it. */
+  MSCNN_CONV_ALGO_WINO_F4 = 6
 } mscnn_conv_algo;
 
 typedef struct {

@@ -1014,7 +1014,8 @@ static bool wino_plan(mscnn_conv_plan* p) {
   if (want_x3 && (d.tune_flags & 8)) return false;        // A/B: the split-fp16 direct kernel instead
   // WINO_F3_X3 follows the AUTO heuristic (it replaces the GEMM of the layers that run F(3x3,3x3) anyway); tune_flags bit 2
   // forces the form wherever it is legal, like WINO_F3 (tests)
-  const bool force = algo == MSCNN_CONV_ALGO_WINO_F2 || algo == MSCNN_CONV_ALGO_WINO_F3 || (want_x3 && (d.tune_flags & 4));
+  const bool force = algo == MSCNN_CONV_ALGO_WINO_F2 || algo == MSCNN_CONV_ALGO_WINO_F3 || algo == MSCNN_CONV_ALGO_WINO_F4 ||
+                     (want_x3 && (d.tune_flags & 4));
   const double intensity = (double)d.Cin * d.Cout / (d.Cin + d.Cout);
   // small maps (the ROI-pooled 7x7 / 7x5 / 8x4 inputs of roi_c1): F(3x3,3x3) -- a 5x5 output is 2x2 tiles x 25 multiplies
   // instead of 225 (measured 1293 -> see DESIGN.md); larger planes: F(2x2,3x3)
@@ -1023,7 +1024,9 @@ static bool wino_plan(mscnn_conv_plan* p) {
   // 481 us with F(2x2,3x3), conv4_2 304 vs 389, conv5_1 107 vs 125, and the same end-to-end error, 3e-5).
   // Threshold for F(3x3,3x3): conv2_2 (intensity 64) 523 vs 642 us direct, conv2_1 (43) 375 vs 383 (tie -> direct), conv1_2
   // (32) 1175 vs 762.  WINO_F2 selects F(2x2,3x3) on planes for A/B runs and tests.
-  const int m = (roi_map || algo != MSCNN_CONV_ALGO_WINO_F2) ? 3 : 2, planes = m == 3 ? 25 : 16;
+  // WINO_F4: F(4x4,3x3) on whole planes (36 planes; wino_f4_math.h) -- opt-in until it has been measured on the GPU
+  const int m = roi_map ? 3 : (algo == MSCNN_CONV_ALGO_WINO_F2 ? 2 : algo == MSCNN_CONV_ALGO_WINO_F4 ? 4 : 3);
+  const int planes = (m + 2) * (m + 2);
   // (split-fp16: the direct kernel runs at ~800 TFLOP/s executed, so Winograd -- HBM-bound on its V / M planes -- only pays from
   // conv3_1 up: measured conv2_2 (64) 415 vs 311 us direct, conv3_1 (85) 159 vs 175, conv3_2 (128) 225 vs 269)
   const double wino_min = want_x3 && d.Cin % 16 == 0 ? 80.0 : (m == 3 ? 60.0 : 100.0);
@@ -1220,7 +1223,7 @@ extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (p->hg) return "head_gemm_shiftadd_f32";
   if (p->head.entry >= 0) return head_kernel_name(p->head);
   if (p->x3.BM) return p->x3.BM == 256 ? "winograd_f3x3_3x3_x3f16_256" : "winograd_f3x3_3x3_x3f16_128";
-  if (p->wino) return p->wino_m == 3 ? "winograd_f3x3_3x3" : "winograd_f2x2_3x3";
+  if (p->wino) return p->wino_m == 4 ? "winograd_f4x4_3x3" : p->wino_m == 3 ? "winograd_f3x3_3x3" : "winograd_f2x2_3x3";
   return p->entry < 0 ? "direct_f32" : kTable[p->entry].name;
 }
 extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_plan* p) {
@@ -1230,7 +1233,7 @@ extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_p
   else if (p->hg) { kind = 8; e = (unsigned)p->hg->entry; mt = (unsigned)p->hg->MT; ki = (unsigned)p->hg->KI; }
   else if (p->head.entry >= 0) { kind = 2; e = (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
   else if (p->x3.BM) { kind = 6; e = (unsigned)p->x3.BM; mt = (unsigned)p->x3.MT; ki = (unsigned)p->x3.KG; }
-  else if (p->wino) { kind = 2 + (unsigned)p->wino_m; e = (unsigned)p->wino->entry; mt = (unsigned)p->wino->MT; ki = (unsigned)p->wino->KI; }
+  else if (p->wino) { kind = p->wino_m == 4 ? 9u : 2 + (unsigned)p->wino_m; e = (unsigned)p->wino->entry; mt = (unsigned)p->wino->MT; ki = (unsigned)p->wino->KI; }
   else if (p->entry >= 0) { kind = 1; e = (unsigned)p->entry; mt = (unsigned)p->MT; ki = (unsigned)p->KI; }   // (entry distinguishes fp16 packs)
   else return 0;   // direct kernel: reads the Caffe layout
   return kind | (e << 8) | (mt << 24) | (ki << 44);
@@ -1251,7 +1254,7 @@ extern "C" double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* p) {
   if (!p->wino && !p->x3.BM)
     return mscnn_conv2d_plan_flops(p) * ((p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant == 210) ? 3.0 : 1.0);
   const mscnn_conv_desc& d = p->d;
-  const double planes = (p->wino_m == 3 ? 25.0 : 16.0) * (p->x3.BM ? 3.0 : 1.0);    // x3: three fp16 MFMA products per pair
+  const double planes = (double)((p->wino_m + 2) * (p->wino_m + 2)) * (p->x3.BM ? 3.0 : 1.0);    // x3: three fp16 MFMA products per pair
   return 2.0 * planes * d.Cout * d.Cin * ((double)d.N * p->tiles_h * p->tiles_w);
 }
 extern "C" int mscnn_conv2d_plan_set_profiling(mscnn_conv_plan* p, int on) {
@@ -1273,7 +1276,7 @@ extern "C" int mscnn_conv2d_plan_stage_ms(const mscnn_conv_plan* p, float ms_out
 }
 extern "C" int mscnn_conv2d_plan_publishes_amax(const mscnn_conv_plan* p) {
   // the F(3x3,3x3) output transforms and every kernel of the implicit-GEMM family (main + fix-up) publish
-  return p && !p->x3h.rows && (p->x3.BM || (p->wino && p->wino_m == 3) ||
+  return p && !p->x3h.rows && (p->x3.BM || (p->wino && p->wino_m >= 3) ||
                (!p->wino && p->head.entry < 0 && p->entry >= 0 && !(kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202))) ? 1 : 0;
 }
 extern "C" int mscnn_conv2d_plan_set_amax_io(mscnn_conv_plan* p, const uint32_t* in_bound, uint32_t* out_amax) {
@@ -1397,7 +1400,7 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
 
 extern "C" int mscnn_conv2d_plan_can_pool(const mscnn_conv_plan* p) {
   if (!p || p->head.entry >= 0 || p->x3h.rows || p->hg) return 0;
-  if (p->wino || p->x3.BM) return p->wino_m == 2 || (p->tiles_h % 2 == 0 && p->tiles_w % 2 == 0 && p->d.H > 8);
+  if (p->wino || p->x3.BM) return p->wino_m == 2 || p->wino_m == 4 || (p->tiles_h % 2 == 0 && p->tiles_w % 2 == 0 && p->d.H > 8);
   return p->entry >= 0 && kTable[p->entry].fix_pool_fn != nullptr;
 }
 
@@ -1460,7 +1463,7 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
       return MSCNN_ERR_WORKSPACE;
     }
     const mscnn_conv_plan* g = p->wino;
-    const size_t planes = p->wino_m == 3 ? 25 : 16;
+    const size_t planes = (size_t)(p->wino_m + 2) * (p->wino_m + 2);
     float* V = static_cast<float*>(workspace);
     float* M = V + planes * d.Cin * p->T_pad;
     float* gws = M + planes * d.Cout * p->T_pad;
@@ -1472,7 +1475,7 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
     if (rc != MSCNN_OK) return rc;
     MSCNN_STAGE_EVENT(2);
     rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st,
-                               p->wino_m == 3 ? p->amax_out : nullptr);
+                               p->wino_m >= 3 ? p->amax_out : nullptr);
     if (rc != MSCNN_OK) return rc;
     MSCNN_STAGE_EVENT(3);
     p->ev_valid = p->profiling;

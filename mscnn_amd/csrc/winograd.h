@@ -1,5 +1,6 @@
 // Internal interface of winograd.hip: the three data transforms of the Winograd convolution paths.
-// m = output tile edge: 2 -> F(2x2, 3x3) (4x4 input tiles, 16 transform planes), 3 -> F(3x3, 3x3) (5x5 tiles, 25 planes).
+// m = output tile edge: 2 -> F(2x2, 3x3) (4x4 input tiles, 16 transform planes), 3 -> F(3x3, 3x3) (5x5 tiles, 25 planes),
+// 4 -> F(4x4, 3x3) (6x6 tiles, 36 planes; wino_f4_math.h).
 #pragma once
 #include "common.h"
 
@@ -18,7 +19,7 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
 // y_pool != nullptr: also write max over the tile's (in-plane) outputs to y_pool[n][co][ty][tx] (fused 2x2/2 max pooling).
 int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
                           int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st, unsigned* amax = nullptr);
-// amax != nullptr (m == 3 only): max |y| is published as bit patterns into amax[0 .. kAmaxSlots) (atomicMax, one slot per
+// amax != nullptr (m >= 3 only): max |y| is published as bit patterns into amax[0 .. kAmaxSlots) (atomicMax, one slot per
 // workgroup; the caller zeroes the slots before the forward and takes the maximum over them)
 
 }  // namespace mscnn

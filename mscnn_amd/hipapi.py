@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
 
 # mscnn_conv_algo
 AMAX_SLOTS = 1024
-ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_F2, ALGO_WINO_F3, ALGO_F16, ALGO_WINO_F3_X3 = 0, 1, 2, 3, 4, 5
+ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_F2, ALGO_WINO_F3, ALGO_F16, ALGO_WINO_F3_X3, ALGO_WINO_F4 = 0, 1, 2, 3, 4, 5, 6
 
 
 MAX_HEADS = 16

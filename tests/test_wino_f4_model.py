@@ -40,3 +40,55 @@ def test_f4x4_with_asymmetric_points_has_the_error_of_todays_f3x3():
         assert err[good] <= 1.5 * f3, (good, err[good], f3)
     for textbook in ("F(4x4,3x3) {0,1,-1,2,-2}", "F(4x4,3x3) {0,1,-1,1/2,-1/2}"):
         assert err[textbook] >= 1.3 * min(err["F(4x4,3x3) {0,1,-1,2,-1/2}"], err["F(4x4,3x3) {0,1,-1,1/2,-2}"]), (textbook, err)
+
+
+def test_device_transform_functions_match_the_exact_matrices(tmp_path):
+    """csrc/wino_f4_math.h (bt6 / g6 / at6: the straight-line code the F(4x4,3x3) kernels of csrc/winograd.hip call) compiled
+    for the host and probed with unit vectors: it must apply exactly 2 B^T, G / 2 and A^T of the generator, and a full 2-D tile
+    through the three functions must equal the direct 3x3 correlation."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "probe.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "wino_f4_math.h"
+int main() {
+  using namespace wino_f4;
+  for (int k = 0; k < 6; ++k) { float d[6] = {0, 0, 0, 0, 0, 0}, r[6]; d[k] = 1.f; bt6(d, r); for (int i = 0; i < 6; ++i) printf("%.9g ", r[i]); printf("\n"); }
+  for (int k = 0; k < 3; ++k) { float g[3] = {0, 0, 0}, u[6]; g[k] = 1.f; g6(g, u); for (int i = 0; i < 6; ++i) printf("%.9g ", u[i]); printf("\n"); }
+  for (int k = 0; k < 6; ++k) { float m[6] = {0, 0, 0, 0, 0, 0}, y[4]; m[k] = 1.f; at6(m, y); for (int i = 0; i < 4; ++i) printf("%.9g ", y[i]); printf("\n"); }
+  // one 2-D tile: d 6x6, g 3x3 -> y 4x4
+  float d[6][6], g[3][3], U[6][6], V[6][6], M[6][6], y[4][4], t[6][6];
+  unsigned s = 7u;
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { s = s * 1664525u + 1013904223u; d[i][j] = (float)((int)(s >> 10) % 201 - 100) / 32.f; }
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { s = s * 1664525u + 1013904223u; g[i][j] = (float)((int)(s >> 10) % 201 - 100) / 64.f; }
+  for (int j = 0; j < 6; ++j) { float c[6], r[6]; for (int i = 0; i < 6; ++i) c[i] = d[i][j]; bt6(c, r); for (int i = 0; i < 6; ++i) t[i][j] = r[i]; }
+  for (int i = 0; i < 6; ++i) bt6(t[i], V[i]);
+  float tg[6][3];
+  for (int j = 0; j < 3; ++j) { float c[3] = {g[0][j], g[1][j], g[2][j]}, u[6]; g6(c, u); for (int i = 0; i < 6; ++i) tg[i][j] = u[i]; }
+  for (int i = 0; i < 6; ++i) g6(tg[i], U[i]);
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) M[i][j] = U[i][j] * V[i][j];
+  float ta[4][6];
+  for (int j = 0; j < 6; ++j) { float c[6], o[4]; for (int i = 0; i < 6; ++i) c[i] = M[i][j]; at6(c, o); for (int i = 0; i < 4; ++i) ta[i][j] = o[i]; }
+  for (int i = 0; i < 4; ++i) at6(ta[i], y[i]);
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+    double ref = 0; for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) ref += (double)d[i + a][j + b] * g[a][b];
+    printf("%.9g %.9g\n", y[i][j], ref);
+  }
+  return 0;
+}
+''')
+    exe = tmp_path / "probe"
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "mscnn_amd", "csrc"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [[float(v) for v in line.split()] for line in subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip().split("\n")]
+    AT, G, BT = (wm.as_float(M) for M in wm.matrices(4, [0, 1, -1, 2, Fr(-1, 2)]))
+    assert np.allclose(np.array(rows[0:6]).T, 2 * BT, rtol=0, atol=1e-7)          # probe row k = column k of the matrix
+    assert np.allclose(np.array(rows[6:9]).T, G / 2, rtol=1e-6, atol=1e-8)
+    assert np.allclose(np.array(rows[9:15]).T, AT, rtol=0, atol=1e-7)
+    tile = np.array(rows[15:])
+    assert tile.shape == (16, 2) and np.abs(tile[:, 0] - tile[:, 1]).max() < 2e-5 * max(1.0, np.abs(tile[:, 1]).max())
