@@ -475,151 +475,32 @@ __global__ __launch_bounds__(256) void wino33_output_pool_kernel(const float* __
 // 36 multiplies per 4x4 output tile and channel pair instead of 144: 4x fewer MFMA FLOPs than the direct form, 19 % fewer than
 // F(3x3,3x3), and 36 / 16 = 2.25 plane elements per output instead of 25 / 9 = 2.78.  Interpolation points {0, 1, -1, 2, -1/2, inf}:
 // with them the fp32 error is that of the F(3x3,3x3) form above (profiles/r02_study_winograd_f4_numerics.txt; the textbook points
-// {0, +-1, +-2} treble it).  The 1-D transforms live in wino_f4_math.h (checked on the host against the exact matrices).  Same
-// kernel shape as the other forms: one thread per (channel, tile), tiles fastest.  MSCNN_CONV_ALGO_WINO_F4 selects it.
+// {0, +-1, +-2} treble it).  The per-thread bodies live in wino_f4_math.h as host + device functions, so the host can run exactly what a
+// GPU thread runs (tests/test_wino_f4_model.py: 1-D transforms against the exact matrices, whole layers against the direct convolution).
+// Same kernel shape as the other forms: one thread per (channel, tile), tiles fastest.  MSCNN_CONV_ALGO_WINO_F4 selects it.
 // STATUS (end of round 2): written and CPU-checked (transform arithmetic, tests/test_wino_f4_model.py), NOT yet run on the GPU --
 // no default path selects it; tests/test_gpu_ops.py::test_conv_winograd_f4x4 is skipped unless MSCNN_TEST_WINO_F4=1.
 __global__ __launch_bounds__(256) void wino44_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
                                                             int BM, int CK, int MT, int KI) {
-  const long img_stride = (long)MT * KI * CK * BM;
   const long total = (long)MT * BM * KI * CK;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int m = (int)(i % BM);
-    long r = i / BM;
-    const int ck = (int)(r % CK); r /= CK;
-    const int kc = (int)(r % KI);
-    const int mt = (int)(r / KI);
-    const int co = mt * BM + m, ci = kc * CK + ck;
-    const bool live = co < Cout && ci < Cin;
-    float t[6][3];   // G g (columns of g)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      float col[3], u[6];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) col[a] = live ? w[((long)co * Cin + ci) * 9 + a * 3 + b] : 0.f;
-      wino_f4::g6(col, u);
-#pragma unroll
-      for (int a = 0; a < 6; ++a) t[a][b] = u[a];
-    }
-    float* dst = wp + (((long)mt * KI + kc) * CK + ck) * BM + m;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      float u[6];
-      wino_f4::g6(t[a], u);     // (G g) G^T
-#pragma unroll
-      for (int b = 0; b < 6; ++b) dst[(a * 6 + b) * img_stride] = u[b];
-    }
-  }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) wino_f4::weight_pair(w, wp, i, Cout, Cin, BM, CK, MT, KI);
 }
 
 __global__ __launch_bounds__(256) void wino44_input_plane_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int Cin,
                                                                  int H, int W, int pad_h, int pad_w, int tiles_h, int tiles_w,
                                                                  int T, int T_pad) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  const int ci = blockIdx.y;
   if (t >= T_pad) return;
-  const long plane_stride = (long)Cin * T_pad;
-  float* dst = V + (long)ci * T_pad + t;
-  float d[6][6];
-  if (t < T) {
-    const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
-    const float* src = x + ((long)n * Cin + ci) * H * W;
-    const int h0 = 4 * ty - pad_h, w0 = 4 * tx - pad_w;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int h = h0 + i;
-      const bool hok = h >= 0 && h < H;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int wv = w0 + j;
-        d[i][j] = (hok && wv >= 0 && wv < W) ? src[h * W + wv] : 0.f;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) d[i][j] = 0.f;
-  }
-  float r[6][6];   // B^T d (columns of d)
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
-    float o[6];
-    wino_f4::bt6(col, o);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) r[i][j] = o[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float o[6];
-    wino_f4::bt6(r[i], o);     // (B^T d) B
-#pragma unroll
-    for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * plane_stride] = o[j];
-  }
+  wino_f4::input_tile(x, V, t, blockIdx.y, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
 }
 
-// Output transform, optional fused MAX 2x2 / stride 2 pooling: a 4x4 tile holds exactly 2x2 pooling windows (ceil mode: windows
-// cut by the bottom / right edge take the maximum over what is inside, pooling_layer.cpp:87-101).
 __global__ __launch_bounds__(256) void wino44_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                             float* __restrict__ y, float* __restrict__ yp, int N, int Cout, int Ho,
                                                             int Wo, int tiles_h, int tiles_w, int T, int T_pad, int relu,
                                                             unsigned* __restrict__ amax) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  const int co = blockIdx.y;
   unsigned am = 0;
-  if (t < T) {
-    const long plane_stride = (long)Cout * T_pad;
-    const float* src = M + (long)co * T_pad + t;
-    float r[4][6];   // A^T m (columns of m)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      float col[6], o[4];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) col[i] = src[(i * 6 + j) * plane_stride];
-      wino_f4::at6(col, o);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) r[i][j] = o[i];
-    }
-    const float b = bias ? bias[co] : 0.f;
-    const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
-    float* dst = y + ((long)n * Cout + co) * Ho * Wo;
-    float out[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float o[4];
-      wino_f4::at6(r[i], o);     // (A^T m) A
-      const int oh = 4 * ty + i;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ow = 4 * tx + j;
-        float u = o[j] + b;
-        if (relu) u = u > 0.f ? u : 0.f;
-        const bool in = oh < Ho && ow < Wo;
-        if (in) {
-          dst[oh * Wo + ow] = u;
-          am = max(am, __float_as_uint(u) & 0x7fffffffu);
-        }
-        out[i][j] = in ? u : -3.402823466e+38f;
-      }
-    }
-    if (yp) {
-      const int Hp = (Ho + 1) / 2, Wp = (Wo + 1) / 2;
-      float* pd = yp + ((long)n * Cout + co) * Hp * Wp;
-#pragma unroll
-      for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-        for (int pj = 0; pj < 2; ++pj) {
-          const int ph = 2 * ty + pi, pw = 2 * tx + pj;
-          if (ph >= Hp || pw >= Wp) continue;
-          float m = out[2 * pi][2 * pj];
-          if (out[2 * pi][2 * pj + 1] > m) m = out[2 * pi][2 * pj + 1];
-          if (out[2 * pi + 1][2 * pj] > m) m = out[2 * pi + 1][2 * pj];
-          if (out[2 * pi + 1][2 * pj + 1] > m) m = out[2 * pi + 1][2 * pj + 1];
-          pd[ph * Wp + pw] = m;
-        }
-    }
-  }
+  if (t < T) am = wino_f4::output_tile(M, bias, y, yp, t, blockIdx.y, Cout, Ho, Wo, tiles_h, tiles_w, T_pad, relu);
   if (amax) mscnn::publish_amax(am, amax, blockIdx.y * gridDim.x + blockIdx.x);
 }
 

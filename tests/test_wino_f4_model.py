@@ -92,3 +92,119 @@ int main() {
     assert np.allclose(np.array(rows[9:15]).T, AT, rtol=0, atol=1e-7)
     tile = np.array(rows[15:])
     assert tile.shape == (16, 2) and np.abs(tile[:, 0] - tile[:, 1]).max() < 2e-5 * max(1.0, np.abs(tile[:, 1]).max())
+
+
+_LAYER_HARNESS = r'''
+// Runs a whole 3x3 / stride 1 layer through the per-thread bodies of the F(4x4,3x3) kernels (wino_f4_math.h) on the host: the loops
+// below stand in for the grid, the plane GEMMs read the packed weight layout the way the 1x1 igemm kernel addresses it.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "wino_f4_math.h"
+int main(int argc, char** argv) {
+  const int N = atoi(argv[1]), Cin = atoi(argv[2]), H = atoi(argv[3]), W = atoi(argv[4]), Cout = atoi(argv[5]), pad = atoi(argv[6]), relu = atoi(argv[7]);
+  const int BM = 128, CK = 32, MT = (Cout + BM - 1) / BM, KI = (Cin + CK - 1) / CK;
+  const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2, th = (Ho + 3) / 4, tw = (Wo + 3) / 4, T = N * th * tw, T_pad = (T + 127) / 128 * 128;
+  std::vector<float> x((size_t)N * Cin * H * W), w((size_t)Cout * Cin * 9), bias(Cout);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((int)(s >> 9) % 2001 - 1000) / 500.f; };
+  for (auto& v : x) { v = rnd(); if (v < 0) v = 0; }
+  const float ws = std::sqrt(2.f / (Cin * 9));
+  for (auto& v : w) v = rnd() * ws;
+  for (auto& v : bias) v = rnd();
+  const long img_stride = (long)MT * KI * CK * BM;
+  std::vector<float> wp((size_t)36 * img_stride, 1e30f), V((size_t)36 * Cin * T_pad, 1e30f), M((size_t)36 * Cout * T_pad, 0.f);
+  for (long i = 0; i < (long)MT * BM * KI * CK; ++i) wino_f4::weight_pair(w.data(), wp.data(), i, Cout, Cin, BM, CK, MT, KI);
+  for (int ci = 0; ci < Cin; ++ci) for (int t = 0; t < T_pad; ++t) wino_f4::input_tile(x.data(), V.data(), t, ci, Cin, H, W, pad, pad, th, tw, T, T_pad);
+  for (int p = 0; p < 36; ++p)
+    for (int co = 0; co < Cout; ++co) {
+      const int mt = co / BM, m = co % BM;
+      for (int t = 0; t < T_pad; ++t) {
+        float acc = 0.f;
+        for (int ci = 0; ci < KI * CK; ++ci) {      // padded K: the packed weights must be zero there
+          const float u = wp[p * img_stride + (((long)mt * KI + ci / CK) * CK + ci % CK) * BM + m];
+          const float v = ci < Cin ? V[((long)p * Cin + ci) * T_pad + t] : 0.f;
+          acc += u * v;
+        }
+        M[((long)p * Cout + co) * T_pad + t] = acc;
+      }
+    }
+  const int Hp = (Ho + 1) / 2, Wp = (Wo + 1) / 2;
+  std::vector<float> y((size_t)N * Cout * Ho * Wo, -7.f), yp((size_t)N * Cout * Hp * Wp, -7.f);
+  unsigned am = 0;
+  for (int co = 0; co < Cout; ++co) for (int t = 0; t < T; ++t) {
+    const unsigned a = wino_f4::output_tile(M.data(), bias.data(), y.data(), yp.data(), t, co, Cout, Ho, Wo, th, tw, T_pad, relu);
+    am = a > am ? a : am;
+  }
+  double err = 0, ymax = 0; int pool_bad = 0, pad_bad = 0;
+  for (int n = 0; n < N; ++n) for (int co = 0; co < Cout; ++co) for (int oh = 0; oh < Ho; ++oh) for (int ow = 0; ow < Wo; ++ow) {
+    double ref = bias[co];
+    for (int ci = 0; ci < Cin; ++ci) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+      const int h = oh + a - pad, ww = ow + b - pad;
+      if (h >= 0 && h < H && ww >= 0 && ww < W) ref += (double)x[(((size_t)n * Cin + ci) * H + h) * W + ww] * w[(((size_t)co * Cin + ci) * 3 + a) * 3 + b];
+    }
+    if (relu && ref < 0) ref = 0;
+    const double got = y[(((size_t)n * Cout + co) * Ho + oh) * Wo + ow];
+    const double e = std::fabs(got - ref) / std::fmax(1.0, std::fabs(ref));
+    if (e > err) err = e;
+    if (std::fabs(got) > ymax) ymax = std::fabs(got);
+  }
+  for (int n = 0; n < N; ++n) for (int co = 0; co < Cout; ++co) for (int ph = 0; ph < Hp; ++ph) for (int pw = 0; pw < Wp; ++pw) {
+    float m = -3.402823466e+38f;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+      const int oh = 2 * ph + a, ow = 2 * pw + b;
+      if (oh < Ho && ow < Wo) { const float v = y[(((size_t)n * Cout + co) * Ho + oh) * Wo + ow]; if (v > m) m = v; }
+    }
+    if (yp[(((size_t)n * Cout + co) * Hp + ph) * Wp + pw] != m) ++pool_bad;
+  }
+  for (int p = 0; p < 36; ++p) for (int ci = 0; ci < Cin; ++ci) for (int t = T; t < T_pad; ++t) if (V[((long)p * Cin + ci) * T_pad + t] != 0.f) ++pad_bad;
+  union { float f; unsigned u; } c; c.f = (float)ymax;
+  printf("%.6g %d %d %d\n", err, pool_bad, pad_bad, (int)(am == c.u));
+  return 0;
+}
+'''
+
+
+@pytest.mark.parametrize("case", [(1, 16, 8, 12, 24, 1, 0), (1, 20, 13, 21, 130, 1, 1), (2, 24, 10, 14, 32, 1, 1), (1, 8, 9, 16, 16, 0, 0),
+                                  (1, 40, 7, 30, 12, 0, 1), (1, 64, 16, 16, 64, 1, 1)])
+def test_kernel_bodies_run_whole_layers_on_the_host(tmp_path, case):
+    """The code a GPU thread of wino44_{weight,input_plane,output}_kernel executes (wino_f4::weight_pair / input_tile /
+    output_tile), driven over whole layers by host loops: packed-weight layout, tile decode, zero padding of the image border and
+    of the GEMM's padding tiles, ragged last tiles, the fused 2x2 pooling (ceil mode, odd sizes) and the published max |y|.
+    Odd sizes, pad 0 / 1, batch 2, Cout beyond one 128-row tile, Cin not a multiple of the 32-channel chunk."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "layer"
+    src = tmp_path / "layer.cpp"
+    src.write_text(_LAYER_HARNESS)
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "mscnn_amd", "csrc"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([str(exe)] + [str(v) for v in case], capture_output=True, text=True, timeout=300).stdout.split()
+    err, pool_bad, pad_bad, amax_ok = float(out[0]), int(out[1]), int(out[2]), int(out[3])
+    assert err < 2e-5, err                 # fp32 Winograd against the float64 direct sum at these channel counts
+    assert pool_bad == 0 and pad_bad == 0 and amax_ok == 1
+
+
+def test_f4_plan_plumbing_without_a_device():
+    """MSCNN_CONV_ALGO_WINO_F4 through the plan API (host-only calls): 36 planes in the packed weights and the workspace,
+    executed FLOPs 36 / 16 per output against F(3x3,3x3)'s 25 / 9, pooling supported, ROI maps stay on F(3x3,3x3)."""
+    torch = pytest.importorskip("torch")  # noqa: F841  (ConvPlan holds its buffers as torch tensors)
+    from mscnn_amd import hipapi as hip
+    L = hip.lib()
+    p3 = hip.ConvPlan(1, 512, 72, 240, 512, 3, 3, (1, 1), relu=True, algo=hip.ALGO_WINO_F3, device="cpu")
+    p4 = hip.ConvPlan(1, 512, 72, 240, 512, 3, 3, (1, 1), relu=True, algo=hip.ALGO_WINO_F4, device="cpu")
+    assert (p3.kernel, p4.kernel) == ("winograd_f3x3_3x3", "winograd_f4x4_3x3") and p4.dtype == "f32" and p4.can_pool
+    assert L.mscnn_conv2d_packed_weight_bytes(p4._p) * 25 == L.mscnn_conv2d_packed_weight_bytes(p3._p) * 36
+    tiles3, tiles4 = 24 * 80, 18 * 60
+    assert p3.executed_flops == 2.0 * 25 * 512 * 512 * tiles3 and p4.executed_flops == 2.0 * 36 * 512 * 512 * tiles4
+    assert p4.flops == p3.flops and p4.executed_flops < 0.82 * p3.executed_flops
+    pad4 = (tiles4 + 127) // 128 * 128
+    assert L.mscnn_conv2d_workspace_bytes(p4._p) >= 36 * (512 + 512) * pad4 * 4
+    roi = hip.ConvPlan(64, 1024, 7, 7, 512, 3, 3, (0, 0), relu=True, algo=hip.ALGO_WINO_F4, device="cpu")
+    assert roi.kernel == "winograd_f3x3_3x3"
+    assert hip.ConvPlan(1, 512, 72, 240, 512, 3, 3, (1, 1), device="cpu").kernel == "winograd_f3x3_3x3"      # the default is unchanged
