@@ -389,7 +389,7 @@ def main():
         flops = np.array([net.layer_flops(i) for i in range(L)])
         xflops = np.array([net.layer_executed_flops(i) for i in range(L)])
         kern = [net.layer_kernel(i) for i in range(L)]
-        wino = [i for i in range(L) if kern[i].startswith("winograd_f3x3")]
+        wino = [i for i in range(L) if kern[i].startswith("winograd_f")]      # F(3x3,3x3) and F(4x4,3x3) layers: the same GEMM kernel
         idx = [net.layer_names.index(nm) for nm in ROOFLINE_LAYERS]
         dtypes = [net.layer_dtype(i) for i in range(L)]
         conv16 = [i for i in range(L) if dtypes[i] == "f16" and net.layer_types[i] == "Convolution"]

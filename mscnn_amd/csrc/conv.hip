@@ -55,7 +55,18 @@ struct IgemmArgs {
   // split-fp16 (X3) kernels: kAmaxSlots partial maxima bounding |x| (scale of the activations), 1 / s_w of the packed weights
   const unsigned* amax_in; const float* w_inv;
   unsigned* amax_out;  // != nullptr: every kernel of the family publishes max |y| into these slots (x3_device.h)
+#ifdef MSCNN_WG_TRACE
+  unsigned long long* trace;   // debug builds only (make EXTRA=-DMSCNN_WG_TRACE): 16 words per workgroup, see tools/wg_trace.py
+#endif
 };
+#ifdef MSCNN_WG_TRACE
+static unsigned long long* g_wg_trace = nullptr;
+extern "C" __attribute__((visibility("default"))) void mscnn_debug_set_wg_trace(void* p) { g_wg_trace = static_cast<unsigned long long*>(p); }
+#define MSCNN_TRACE_STAMP(slot)                                                                                  \
+  if (a.trace && tid == 0 && (slot) < 16) a.trace[(long)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define MSCNN_TRACE_STAMP(slot)
+#endif
 constexpr int kSlabsPerWg = 2;   // stream-K tail partial, stream-K head partial
 
 // Tile configuration.  Two geometries share one kernel:
@@ -288,6 +299,17 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int wm = wave / C::WGN, wn = wave % C::WGN;
+#ifdef MSCNN_WG_TRACE
+  int trace_slot = 2;
+  if (a.trace && tid == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.trace[(long)blockIdx.x * 16 + 0] = ((unsigned long long)xcc << 32) | hw;
+    a.trace[(long)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();     // shader clock at entry / exit: the effective clock
+  }
+  MSCNN_TRACE_STAMP(1);
+#endif
 
   // Hybrid schedule: first full_q whole tiles per workgroup (no partial sums at all), then the remaining tiles are
   // cut stream-K style into G equal (tile, chunk) ranges so that every CU finishes at the same time.
@@ -434,6 +456,9 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
     const TileGeo<C> geo_e = geo;
     const int t_e = t, k0_e = k0, k1_e = k1, mt_e = mt;
     more = false;
+#ifdef MSCNN_WG_TRACE
+    MSCNN_TRACE_STAMP(trace_slot); ++trace_slot;          // segment start (accumulators zeroed)
+#endif
     for (int kc = k0_e; kc < k1_e; ++kc) {
       __syncthreads();                 // everyone finished reading the previous chunk
 #pragma unroll
@@ -558,6 +583,9 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
       }
     }
 
+#ifdef MSCNN_WG_TRACE
+    MSCNN_TRACE_STAMP(trace_slot); ++trace_slot;          // K loop done
+#endif
     if constexpr (C::X3) {      // un-scale (exact: a power of two) before the epilogue / the partial-sum slab
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
@@ -641,8 +669,14 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
     }
     }
     __syncthreads();   // LDS is re-used by the next segment's first stores
+#ifdef MSCNN_WG_TRACE
+    MSCNN_TRACE_STAMP(trace_slot); ++trace_slot;          // epilogue done
+#endif
   }
 #undef MSCNN_LOAD_CHUNK
+#ifdef MSCNN_WG_TRACE
+  if (a.trace && tid == 0) a.trace[(long)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
+#endif
   if constexpr (C::PUBLISH) { if (a.amax_out) mscnn::publish_amax(am, a.amax_out, blockIdx.x); }
 }
 
@@ -1024,12 +1058,21 @@ static bool wino_plan(mscnn_conv_plan* p) {
   // 481 us with F(2x2,3x3), conv4_2 304 vs 389, conv5_1 107 vs 125, and the same end-to-end error, 3e-5).
   // Threshold for F(3x3,3x3): conv2_2 (intensity 64) 523 vs 642 us direct, conv2_1 (43) 375 vs 383 (tie -> direct), conv1_2
   // (32) 1175 vs 762.  WINO_F2 selects F(2x2,3x3) on planes for A/B runs and tests.
-  // WINO_F4: F(4x4,3x3) on whole planes (36 planes; wino_f4_math.h) -- opt-in until it has been measured on the GPU
-  const int m = roi_map ? 3 : (algo == MSCNN_CONV_ALGO_WINO_F2 ? 2 : algo == MSCNN_CONV_ALGO_WINO_F4 ? 4 : 3);
+  // F(4x4,3x3) on whole planes (36 planes; wino_f4_math.h; points {0, 1, -1, 2, -1/2, inf}: the fp32 error of the F(3x3,3x3) form):
+  // 19 % fewer GEMM FLOPs and plane bytes.  First run on hardware in round 3 (profiles/r03_ab_wino_f4.txt, 7s-576 layers, us,
+  // AUTO of round 2 / F(3x3,3x3) / F(4x4,3x3)): conv2_1 435 (direct) / 330 / 310, conv2_2 469 / 469 / 436, conv3_2 336 / 336 / 329,
+  // conv4_2 287 / 286 / 279 -- but conv3_1 226 / 226 / 233, conv4_1 178 / 177 / 180, conv5_1 110 / 110 / 119: with 36 planes the
+  // tile count of the batched GEMM no longer divides its grid on the Cout = 2 Cin layers, and below 1000 tiles the 128-tile
+  // padding eats the gain.  AUTO therefore takes F(4x4,3x3) where the 4x4 tiles number >= 1000 and the layer is not one of the
+  // (Cin >= 128, Cout = 2 Cin) shapes; intensity threshold 40 (conv2_1: 43) instead of 60.
+  const long T4 = (long)d.N * cdiv(p->Ho, 4) * cdiv(p->Wo, 4);
+  const bool auto_f4 = algo == MSCNN_CONV_ALGO_AUTO && !roi_map && T4 >= 1000 && !(d.Cin >= 128 && d.Cout == 2 * d.Cin) &&
+                       !(d.tune_flags & 64);         // (tune_flags bit 6: A/B runs keep the round-2 choice)
+  const int m = roi_map ? 3 : (algo == MSCNN_CONV_ALGO_WINO_F2 ? 2 : (algo == MSCNN_CONV_ALGO_WINO_F4 || auto_f4) ? 4 : 3);
   const int planes = (m + 2) * (m + 2);
   // (split-fp16: the direct kernel runs at ~800 TFLOP/s executed, so Winograd -- HBM-bound on its V / M planes -- only pays from
   // conv3_1 up: measured conv2_2 (64) 415 vs 311 us direct, conv3_1 (85) 159 vs 175, conv3_2 (128) 225 vs 269)
-  const double wino_min = want_x3 && d.Cin % 16 == 0 ? 80.0 : (m == 3 ? 60.0 : 100.0);
+  const double wino_min = want_x3 && d.Cin % 16 == 0 ? 80.0 : (m == 4 ? 40.0 : m == 3 ? 60.0 : 100.0);
   if (!force && (intensity < wino_min || (!roi_map && d.H * d.W < 256))) return false;
   if (roi_map && d.N < 8) return false;
   const int th = cdiv(p->Ho, m), tw = cdiv(p->Wo, m);
@@ -1373,6 +1416,9 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
     return MSCNN_ERR_BAD_ARG;
   }
   a.xcd_map = (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 1) ? 0 : 1;
+#ifdef MSCNN_WG_TRACE
+  a.trace = g_wg_trace;
+#endif
   a.amax_in = nullptr; a.w_inv = nullptr;
   a.amax_out = nt_major ? nullptr : p->amax_out;          // (nt_major: the nested Winograd GEMM -- its output transform publishes)
   if (k.variant == 210) {

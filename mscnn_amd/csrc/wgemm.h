@@ -1,0 +1,29 @@
+// Internal interface of wgemm.hip: the batched transform-domain GEMM of the Winograd convolution paths,
+//   M[p][Cout][T_pad] = U[p][Cout][Cin] x V[p][Cin][T_pad]     for the P = (m+2)^2 transform planes of F(m x m, 3x3).
+// It replaces the 1x1 igemm kernel that ran these GEMMs in rounds 1-2 (conv.hip) -- see the header of wgemm.hip for why.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+namespace mscnn {
+
+struct WgemmPlan {
+  int P, Cout, Cin, T, T_pad;       // T_pad: row stride of V and M (multiple of the N tile)
+  int BM, BN, CK, MT, NT, KI;       // tile shape, tiles per plane, K chunks
+  int G;                            // persistent grid (workgroups)
+  int full_q;                       // whole tiles per workgroup; the remaining tiles are split stream-K style
+  int variant;
+  const char* name;
+  size_t packed_bytes;              // U in the packed layout Up[p][mt][kc][ck][BM]
+  size_t ws_bytes;                  // partial-tile slabs of the stream-K phase
+};
+
+// variant 0: pick per shape.  Returns false when no kernel covers the shape (the caller keeps the igemm path).
+bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* out);
+
+// abl: development ablations (0 in the product): bit 0 no loads after the prologue, bit 1 no stores, bit 2 no MFMAs, bit 3 no
+// LDS operand reads, bit 4 no barriers; dbg: per-workgroup {shader cycles, 100 MHz ticks} (tools/micro/wgemm_bench.hip)
+int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, float* ws, hipStream_t st, int abl = 0,
+                 unsigned long long* dbg = nullptr);
+
+}  // namespace mscnn

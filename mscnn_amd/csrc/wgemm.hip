@@ -1,0 +1,343 @@
+// The batched transform-domain GEMM of the Winograd convolution paths on gfx950:
+//     M[p][Cout][T_pad] = U[p][Cout][Cin] x V[p][Cin][T_pad],   p < P = 25 (F(3x3,3x3)) or 36 (F(4x4,3x3)) planes,
+// exact fp32 on v_mfma_f32_32x32x2_f32.  This is where cudnnConvolutionForward's time goes in the reference
+// (cudnn_conv_layer.cu:11-46) and the dominant kernel of this library (13 launches per 7s-576 frame).
+//
+// Why a second GEMM kernel.  Rounds 1-2 ran these GEMMs on the 1x1 instance of the implicit-GEMM convolution kernel
+// (conv.hip: 128 x 128 tiles, 4 waves, operands staged global -> VGPR -> ds_write_b128 -> LDS, two barriers per 32-channel
+// chunk, 2-4 workgroups per CU).  The per-workgroup timeline of round 3 (tools/wg_trace.py, profiles/r03_wg_trace.txt) showed
+// where its 0.72-0.76 of the MFMA peak goes: the K loop itself runs at 63 % (one workgroup per CU) to 80 % (two) of the
+// MFMA-bound time -- every chunk pays the barrier / ds_write / barrier / load-issue / first-ds_read sequence with the matrix
+// pipe idle, and more co-resident workgroups stop helping because they fetch 8 bytes per MFMA clock and CU from L2 --
+// and every tile then pays a 3-9 us store epilogue during which the workgroup issues no MFMA at all.
+//
+// This kernel is built around those three findings:
+//   * bigger tiles, fewer bytes: one 512-thread workgroup (8 waves, two per SIMD) per CU owns a 256 x 128 (or 128 x 256)
+//     tile; 48 KB of operands per 32-channel chunk instead of 2 x 32 KB for the same MFMA work (5.9 instead of 8 B/clk/CU);
+//   * no staging through registers: the operands travel HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KB per
+//     wave instruction) into a 3-stage ring, issued two chunks ahead; the loads stay in flight across the ONE s_barrier per
+//     chunk (counted s_waitcnt vmcnt(N), never 0 in the steady state), and the ring runs across tile boundaries, so a tile has
+//     no prologue;
+//   * the epilogue overlaps the next tile: a finished tile's accumulators are moved aside and their stores are issued a few
+//     at a time between the MFMAs of the next tile's first chunks.
+// U is packed once per weight change as Up[p][mt][kc][ck][BM] (the igemm packing, so one chunk of a tile's A operand is
+// one contiguous slab); V and M are the plain planes the transform kernels of winograd.hip write / read.
+//
+// Schedule: persistent grid, one workgroup per CU; tile t = ((p * NT + nt) * MT + mt); slot s of the grid takes tiles
+// s, s + G, ...; XCD x (workgroups b = x mod 8) owns the contiguous slots [x G/8, (x+1) G/8): in every round an XCD works on
+// 32 consecutive tiles = one or two planes, so that plane's U (<= 1 MB) and the V tile shared by the MT tiles above it stay in
+// the XCD's own 4 MB L2.  Where the tile count does not divide the grid the remainder is split stream-K style (whole
+// K chunks), partial tiles go through fp32 slabs and are summed in k order by the workgroup that owns the tile's last chunk
+// (deterministic; no atomics on data).
+#include "wgemm.h"
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgemmArgs {
+  const float* Up; const float* V; float* M; float* ws;
+  int P, MT, NT, KI, Cin, Cout, T_pad;
+  int tiles, G, abl;
+  unsigned long long* dbg;      // development: per-workgroup {shader cycles, 100 MHz ticks} over the kernel (nullptr in the product)
+  unsigned up_bytes, v_bytes, m_bytes;
+};
+
+template <int BM_, int BN_, int WGM_, int WGN_, int CK_, int ST_>
+struct WCfg {
+  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, CK = CK_, ST = ST_;
+  static constexpr int NW = WGM * WGN, THREADS = NW * 64;
+  static constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
+  static constexpr int A_BYTES = CK * BM * 4, B_BYTES = CK * BN * 4, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int STAGE_FLOATS = STAGE_BYTES / 4;
+  static constexpr int PA = A_BYTES / 1024, PB = B_BYTES / 1024;      // 1 KB LDS-DMA pieces per chunk
+  static constexpr int PA_W = PA / NW, PB_W = PB / NW;                // ... per wave
+  static constexpr int NP = PA_W + PB_W;
+  static constexpr int F4_PER_ROW = BN / 4;                           // 16-byte units per B row
+  static constexpr int ROWS_PER_PIECE = 64 / F4_PER_ROW;              // BN 128: 2 rows, BN 256: 1 row
+  static constexpr int STEPS = CK / 2;                                // MFMA k-pairs per chunk
+  static_assert(PA % NW == 0 && PB % NW == 0 && 64 % F4_PER_ROW == 0, "pieces per wave");
+  static_assert(ST * STAGE_BYTES <= 160 * 1024, "LDS ring");
+  static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile");
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// One LDS-DMA instruction: lane l copies 16 bytes from  rsrc + voff(l) + soff  to LDS  lds_addr + 16 l  (1 KB per wave).
+// Invisible to the compiler's s_waitcnt bookkeeping by design: completion is counted by hand (wait_vm below).
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// LDS operand read with an immediate offset (no address arithmetic on the vector ALU, which the fp32 MFMA shares) -- hidden from the
+// compiler's lgkmcnt bookkeeping, so every use is preceded by lds_wait<N>() + lds_pin().
+template <int OFF>
+__device__ __forceinline__ float lds_rd(unsigned addr) {
+  float r;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void lds_pin(float& v) { asm volatile("" : "+v"(v)); }
+
+template <class C, int ABL>
+__global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs a) {
+  __shared__ __attribute__((aligned(1024))) float lds[C::ST * C::STAGE_FLOATS];
+  static_assert(C::ST == 3, "the ring protocol below is written for three stages");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int wm = wave / C::WGN, wn = wave % C::WGN;
+
+  // slot of this workgroup (XCD-contiguous, see header)
+  const int xcd = (int)(blockIdx.x % 8), gq = a.G / 8, gr = a.G % 8;
+  const int slot = xcd * gq + min(xcd, gr) + (int)(blockIdx.x / 8);
+  const int ntl = slot < a.tiles ? (a.tiles - slot + a.G - 1) / a.G : 0;     // whole tiles of this workgroup
+  const int nunits = ntl * a.KI;
+  if (nunits == 0) return;
+  unsigned long long dbg_c = 0, dbg_r = 0;
+  if (a.dbg && tid == 0) { dbg_c = __builtin_amdgcn_s_memtime(); dbg_r = __builtin_amdgcn_s_memrealtime(); }
+
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(a.Up, a.up_bytes), rB = make_rsrc(a.V, a.v_bytes), rM = make_rsrc(a.M, a.m_bytes);
+  const unsigned row_bytes = (unsigned)a.T_pad * 4u;
+  const unsigned vA = (unsigned)lane * 16u;
+  const unsigned vB = (unsigned)(lane / C::F4_PER_ROW) * row_bytes + (unsigned)(lane % C::F4_PER_ROW) * 16u;
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  // per-lane LDS read bases inside a stage (bytes)
+  const unsigned a_lane = (unsigned)(khalf * C::BM + wm * C::WM + l31) * 4u;
+  const unsigned b_lane = (unsigned)C::A_BYTES + (unsigned)(khalf * C::BN + wn * C::WN + l31) * 4u;
+
+  // ---- producer cursor: the next (tile, chunk) unit to put in flight; one LDS-DMA piece per call -----------------------------
+  int pu = 0, p_kc = 0, p_round = 0, p_stage = 0;
+  unsigned p_a = 0, p_b = 0;            // byte offsets of the unit's A slab / first B row
+  unsigned vA_eff = vA, vB_eff = vB;
+  auto p_begin = [&]() {                // called before piece 0 of a unit
+    if (pu >= nunits) { vA_eff = 0x80000000u; vB_eff = 0x80000000u; }
+    if (p_kc == 0 && pu < nunits) {
+      const int t = slot + p_round * a.G;
+      const int mt = t % a.MT, nt = (t / a.MT) % a.NT, p = t / (a.MT * a.NT);
+      p_a = (unsigned)((p * a.MT + mt) * a.KI) * (unsigned)C::A_BYTES;
+      p_b = ((unsigned)(p * a.Cin) * (unsigned)a.T_pad + (unsigned)(nt * C::BN)) * 4u;
+    }
+  };
+  // (past the last unit the cursor keeps running with out-of-range lane offsets: those pieces fetch nothing and write zeros into
+  // a stage nobody reads any more -- the steady-state code path has no "is there a next unit" branch)
+  auto p_piece = [&](auto ic) {         // piece i of the unit at the cursor (i < NP): A pieces first, then B pieces
+    constexpr int i = decltype(ic)::value;
+    const unsigned ls = lds0 + (unsigned)p_stage * C::STAGE_BYTES;
+    if constexpr (i < C::PA_W) {
+      const unsigned sa = p_a + (unsigned)p_kc * C::A_BYTES + (unsigned)(wave * C::PA_W + i) * 1024u;
+      dma16(rA, vA_eff, sa, ls + (unsigned)(wave * C::PA_W + i) * 1024u);
+    } else {
+      const int j = wave * C::PB_W + (i - C::PA_W);
+      const unsigned sb = p_b + (unsigned)(p_kc * C::CK + j * C::ROWS_PER_PIECE) * row_bytes;
+      dma16(rB, vB_eff, sb, ls + C::A_BYTES + (unsigned)j * 1024u);
+    }
+  };
+  auto p_end = [&]() {
+    ++pu;
+    if (++p_kc == a.KI) { p_kc = 0; ++p_round; }
+    if (++p_stage == C::ST) p_stage = 0;
+  };
+
+  // ---- ring protocol (three stages; unit u lives in stage u % 3) ------------------------------------------------------------
+  //   chunk u:  its LDS-DMA pieces of unit u + 2 go out one per MFMA group during the first NP groups, into the stage that was
+  //             read during chunk u - 1 (everybody is past that chunk's barrier);
+  //             at its end every wave waits for ITS pieces of unit u + 2 (vmcnt), then the one s_barrier of the chunk.
+  //   => unit u + 1 was complete and visible a whole chunk earlier, so the operands of the next chunk's first MFMA group are
+  //      read BEFORE the barrier and the matrix pipe restarts right behind it.
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (pu < nunits) {
+      p_begin();
+      static_for<0, C::NP>([&](auto ic) { p_piece(ic); });
+      p_end();
+    }
+  wait_vm_barrier<0>();
+
+  f32x16 acc[C::MI][C::NI], old[C::MI][C::NI];
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[mi][ni][r] = 0.f; old[mi][ni][r] = 0.f; }
+  unsigned old_voff[C::MI][C::NI];      // byte offset of the finished tile's 32 x 32 blocks in M (row 0 of the block, this lane's column)
+#pragma unroll
+  for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni) old_voff[mi][ni] = 0x80000000u;
+
+  float av[2][C::MI], bv[2][C::NI];
+#define WG_READ(buf, stage_addr, s)                                                                                         \
+  {                                                                                                                         \
+    _Pragma("unroll") for (int mi = 0; mi < C::MI; ++mi) av[buf][mi] = 0.f;                                                  \
+    static_for<0, C::MI>([&](auto m_) { av[buf][decltype(m_)::value] = lds_rd<(s) * 2 * C::BM * 4 + decltype(m_)::value * 128>((stage_addr) + a_lane); }); \
+    static_for<0, C::NI>([&](auto n_) { bv[buf][decltype(n_)::value] = lds_rd<(s) * 2 * C::BN * 4 + decltype(n_)::value * 128>((stage_addr) + b_lane); }); \
+  }
+  constexpr int NR = C::MI + C::NI;                       // LDS reads per MFMA group
+  constexpr int NMF = C::MI * C::NI;                      // MFMAs per group
+  constexpr int SPG = NMF * 16 / C::STEPS;                // stores of the previous tile per group while it is flushed
+  static_assert(NMF * 16 % C::STEPS == 0 && SPG % NMF == 0, "flush schedule");
+  constexpr int SPM = SPG / NMF;                          // ... per MFMA
+  constexpr int JD = NMF >= 2 ? NMF - 2 : 0;              // the MFMA of a group behind which that group's DMA piece is issued
+  constexpr int AFTER_DMA = (C::STEPS - C::NP) * SPG + SPM * (NMF - 1 - JD);   // stores issued behind a chunk's last piece
+  static_assert(C::NP <= C::STEPS, "one DMA piece per MFMA group");
+
+  unsigned c_addr = lds0;                                 // LDS address of the stage being multiplied
+  WG_READ(0, c_addr, 0);
+
+  auto store_one = [&](auto ec) {                        // element e of the flushed tile: block (e / 16), register e % 16
+    constexpr int e = decltype(ec)::value;
+    constexpr int blk = e / 16, r = e % 16, mi = blk / C::NI, ni = blk % C::NI, dr = (r & 3) + 8 * (r >> 2);
+    const float v = old[mi][ni][r];
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rM, old_voff[mi][ni], (unsigned)dr * row_bytes, 0);
+  };
+
+  // one chunk = STEPS MFMA groups.  FLUSH: the previous tile's stores ride along (SPM per MFMA); DMA: this chunk carries the
+  // NP pieces of the unit two ahead.
+  auto chunk = [&](auto flush_c, unsigned next_addr) {
+    constexpr bool FLUSH = decltype(flush_c)::value;
+    p_begin();
+    static_for<0, C::STEPS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, cur = s & 1, nxt = cur ^ 1;
+      if constexpr (!(ABL & 8)) {
+        if constexpr (s + 1 < C::STEPS) WG_READ(nxt, c_addr, s + 1)
+        else WG_READ(nxt, next_addr, 0)
+        lds_wait<NR>();
+      }
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi) lds_pin(av[cur][mi]);
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) lds_pin(bv[cur][ni]);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NMF>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, mi = j / C::NI, ni = j % C::NI;
+        if constexpr (!(ABL & 4)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi], bv[cur][ni], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FLUSH) {
+          if constexpr (!(ABL & 2)) static_for<0, SPM>([&](auto kc_) { store_one(std::integral_constant<int, (s * NMF + j) * SPM + decltype(kc_)::value>{}); });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (j == JD && s < C::NP) {
+          if constexpr (!(ABL & 1)) p_piece(std::integral_constant<int, s>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    });
+    p_end();
+    // this wave's pieces of the unit two ahead have landed; the stores of a flushed tile issued behind the last piece may still
+    // be in flight (the hardware's vmcnt field holds 63)
+    if constexpr (ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (FLUSH) wait_vm_barrier<(AFTER_DMA < 63 ? AFTER_DMA : 63)>();
+    else wait_vm_barrier<0>();
+    c_addr = next_addr;
+  };
+
+  int c_stage = 0;
+  auto next_stage_addr = [&]() {
+    if (++c_stage == C::ST) c_stage = 0;
+    return lds0 + (unsigned)c_stage * C::STAGE_BYTES;
+  };
+  for (int tl = 0; tl < ntl; ++tl) {
+    // first chunk of the tile: the previous tile's stores ride along (tile 0: `old` is empty and its offsets out of range)
+    chunk(std::true_type{}, next_stage_addr());
+    for (int kc = 1; kc < a.KI; ++kc) chunk(std::false_type{}, next_stage_addr());
+    // ---- tile done: move its accumulators aside ----
+    const int t = slot + tl * a.G;
+    const int mt = t % a.MT, nt = (t / a.MT) % a.NT, p = t / (a.MT * a.NT);
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) {
+        const int co0 = mt * C::BM + wm * C::WM + mi * 32;
+        old_voff[mi][ni] = co0 + 32 <= a.Cout
+                               ? ((unsigned)(p * a.Cout + co0 + 4 * khalf) * (unsigned)a.T_pad + (unsigned)(nt * C::BN + wn * C::WN + ni * 32 + l31)) * 4u
+                               : 0x80000000u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { old[mi][ni][r] = acc[mi][ni][r]; acc[mi][ni][r] = 0.f; }
+      }
+  }
+  // the last tile's stores
+  if (!(ABL & 2) || a.tiles < 0) static_for<0, NMF * 16>([&](auto ec) { store_one(ec); });      // (ablation builds keep the MFMAs alive)
+  if (a.dbg && tid == 0) {
+    a.dbg[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - dbg_c;
+    a.dbg[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - dbg_r;
+  }
+}
+
+typedef void (*WgemmFn)(WgemmArgs);
+struct WEntry { const char* name; int variant, abl, BM, BN, CK, threads; WgemmFn fn; };
+#define WG_ENTRY(name, v, abl, BM, BN, WGM, WGN, CK) {name, v, abl, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3>, abl>}
+const WEntry kW[] = {
+    WG_ENTRY("wgemm_256x128_ck32", 1, 0, 256, 128, 4, 2, 32),
+    WG_ENTRY("wgemm_128x256_ck32", 2, 0, 128, 256, 2, 4, 32),
+    WG_ENTRY("wgemm_128x128_ck32", 3, 0, 128, 128, 2, 4, 32),
+#ifdef MSCNN_WGEMM_DEV      // development ablations (tools/micro/wgemm_bench.hip): bit 0 no loads, 1 no stores, 2 no MFMAs, 3 no LDS reads, 4 no barriers
+    WG_ENTRY("wgemm_256x128_ck32", 1, 1, 256, 128, 4, 2, 32),
+    WG_ENTRY("wgemm_256x128_ck32", 1, 2, 256, 128, 4, 2, 32),
+    WG_ENTRY("wgemm_256x128_ck32", 1, 3, 256, 128, 4, 2, 32),
+    WG_ENTRY("wgemm_256x128_ck32", 1, 4, 256, 128, 4, 2, 32),
+    WG_ENTRY("wgemm_256x128_ck32", 1, 11, 256, 128, 4, 2, 32),
+    WG_ENTRY("wgemm_256x128_ck32", 1, 19, 256, 128, 4, 2, 32),
+    WG_ENTRY("wgemm_256x128_ck32", 1, 27, 256, 128, 4, 2, 32),
+#endif
+};
+
+}  // namespace
+
+namespace mscnn {
+
+bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
+  if (variant == 0) variant = Cout >= 256 ? 1 : 2;
+  const WEntry* e = nullptr;
+  for (const WEntry& w : kW) if (w.variant == variant && w.abl == 0) e = &w;
+  if (!e || Cin % e->CK != 0 || Cout % 32 != 0) return false;
+  o->P = P; o->Cout = Cout; o->Cin = Cin; o->T = T;
+  o->BM = e->BM; o->BN = e->BN; o->CK = e->CK;
+  o->T_pad = (T + e->BN - 1) / e->BN * e->BN;
+  if (o->T_pad % 128) o->T_pad = (o->T_pad + 127) / 128 * 128;
+  o->MT = (Cout + e->BM - 1) / e->BM; o->NT = o->T_pad / e->BN; o->KI = Cin / e->CK;
+  o->G = 256; o->full_q = (int)((long)P * o->MT * o->NT / o->G);
+  o->variant = variant; o->name = e->name;
+  o->packed_bytes = (size_t)P * o->MT * o->KI * e->CK * e->BM * 4;
+  o->ws_bytes = 0;
+  const double lim = 4.0e9;
+  if ((double)P * Cin * o->T_pad * 4 >= lim || (double)P * Cout * o->T_pad * 4 >= lim || (double)o->packed_bytes >= lim) return false;
+  return true;
+}
+
+int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, float* ws, hipStream_t st, int abl, unsigned long long* dbg) {
+  const WEntry* e = nullptr;
+  for (const WEntry& w : kW) if (w.variant == p.variant && w.abl == abl) e = &w;
+  if (!e) return MSCNN_ERR_BAD_ARG;
+  WgemmArgs a;
+  a.Up = Up; a.V = V; a.M = M; a.ws = ws;
+  a.P = p.P; a.MT = p.MT; a.NT = p.NT; a.KI = p.KI; a.Cin = p.Cin; a.Cout = p.Cout; a.T_pad = p.T_pad;
+  a.tiles = p.P * p.MT * p.NT; a.G = p.G; a.abl = abl; a.dbg = dbg;
+  a.up_bytes = (unsigned)p.packed_bytes; a.v_bytes = (unsigned)((size_t)p.P * p.Cin * p.T_pad * 4); a.m_bytes = (unsigned)((size_t)p.P * p.Cout * p.T_pad * 4);
+  e->fn<<<p.G, e->threads, 0, st>>>(a);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+}  // namespace mscnn

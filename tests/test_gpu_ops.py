@@ -226,14 +226,8 @@ def test_conv_winograd(hip, orc, case, relu, m):
     assert not hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (pad, pad), algo=hip.ALGO_DIRECT).kernel.startswith("winograd")
 
 
-# F(4x4,3x3) (MSCNN_CONV_ALGO_WINO_F4): written at the end of round 2 with its transform arithmetic checked on the host
-# (tests/test_wino_f4_model.py) but not yet run on hardware, and selected by no default path -- so these tests are opt-in
-# (MSCNN_TEST_WINO_F4=1) until the first GPU session has seen them pass; then drop the gate.
-wino_f4 = pytest.mark.skipif(os.environ.get("MSCNN_TEST_WINO_F4") != "1",
-                             reason="F(4x4,3x3) kernels have not been run on hardware yet: set MSCNN_TEST_WINO_F4=1")
-
-
-@wino_f4
+# F(4x4,3x3) (MSCNN_CONV_ALGO_WINO_F4): first run on hardware in round 3 (all 23 cases green on the first run); the plan's AUTO choice
+# takes it for the large layers (conv.hip: wino_plan).
 @pytest.mark.parametrize("case", WINO_CASES + [(1, 256, 36, 60, 256, 1), (1, 512, 24, 40, 512, 1)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_conv_winograd_f4x4(hip, orc, case, relu):
@@ -263,7 +257,6 @@ def test_conv_winograd_f4x4(hip, orc, case, relu):
     assert m(y) <= 1.5 * m(y3) + 2e-6
 
 
-@wino_f4
 @pytest.mark.parametrize("case", [(1, 32, 16, 24, 48, 1), (1, 24, 13, 21, 32, 1), (2, 16, 10, 14, 24, 1)])
 def test_conv_winograd_f4x4_fused_pool(hip, orc, case):
     """The 4x4 tile holds 2x2 pooling windows: fused MAX 2x2 / stride 2 (ceil mode, odd sizes) bit-identical to pooling the
@@ -621,9 +614,11 @@ def test_conv_fused_pool(hip, orc, case):
     assert np.array_equal(yp.cpu().numpy(), orc.pool2d(y0.cpu().numpy(), (2, 2), (0, 0), (2, 2), "MAX"))
     close(y0.cpu().numpy(), orc.relu(orc.conv2d(x, w, b, (1, 1))))
     assert not hip.ConvPlan(1, 512, 72, 240, 9, 5, 5, (2, 2)).can_pool       # proposal-head kernel: no pooling epilogue
-    p3 = hip.ConvPlan(1, 512, 72, 240, 512, 3, 3, (1, 1))
-    assert p3.kernel == "winograd_f3x3_3x3" and p3.can_pool                    # 24 x 80 tiles: even -> fused pooling
-    assert not hip.ConvPlan(1, 512, 75, 240, 512, 3, 3, (1, 1)).can_pool       # 25 tile rows: the caller pools separately
+    p4 = hip.ConvPlan(1, 512, 72, 240, 512, 3, 3, (1, 1))
+    assert p4.kernel == "winograd_f4x4_3x3" and p4.can_pool                    # AUTO: 18 x 60 tiles of 4x4 -> F(4x4,3x3), pooling inside a tile
+    p3 = hip.ConvPlan(1, 512, 36, 120, 512, 3, 3, (1, 1))
+    assert p3.kernel == "winograd_f3x3_3x3" and p3.can_pool                    # 12 x 40 tiles: even -> fused pooling
+    assert not hip.ConvPlan(1, 512, 39, 120, 512, 3, 3, (1, 1)).can_pool       # 13 tile rows: the caller pools separately
 
 
 def test_conv_no_bias_and_kernel_selection(hip, orc):

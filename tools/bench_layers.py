@@ -13,16 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mscnn_amd import hipapi as hip
 
-LAYERS = [  # name, N, Cin, H, W, Cout, k, pad
-    ("conv1_1", 1, 3, 576, 1920, 64, 3, 1), ("conv1_2", 1, 64, 576, 1920, 64, 3, 1),
-    ("conv2_1", 1, 64, 288, 960, 128, 3, 1), ("conv2_2", 1, 128, 288, 960, 128, 3, 1),
-    ("conv3_1", 1, 128, 144, 480, 256, 3, 1), ("conv3_2", 1, 256, 144, 480, 256, 3, 1),
-    ("conv4_1", 1, 256, 72, 240, 512, 3, 1), ("conv4_2", 1, 512, 72, 240, 512, 3, 1),
-    ("conv5_1", 1, 512, 36, 120, 512, 3, 1), ("conv6_1", 1, 512, 18, 60, 512, 3, 1),
-    ("LFCN_1_5x5", 1, 512, 72, 240, 9, 5, 2), ("LFCN_1_7x7", 1, 512, 72, 240, 9, 7, 3),
-    ("LFCN_2_5x5", 1, 512, 36, 120, 9, 5, 2), ("LFCN_2_7x7", 1, 512, 36, 120, 9, 7, 3),
-    ("LFCN_3_5x5", 1, 512, 18, 60, 9, 5, 2), ("LFCN_3_7x7", 1, 512, 18, 60, 9, 7, 3), ("roi_c1", 700, 1024, 7, 7, 512, 3, 0),
-]
+from tools_layers import LAYERS
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
