@@ -34,6 +34,12 @@ typedef struct mscnn_dist mscnn_dist;
 
 MSCNN_DIST_API const char* mscnn_dist_last_error(void);
 
+/* Optional, before the first other call of the process: resolve the collective library from this path instead of the default
+ * search (librccl.so.1, librccl.so, /opt/rocm/lib/librccl.so.1) -- an RCCL build in a non-standard place, or the transport stub
+ * of the CPU tests (tests/stub/fake_rccl.c).  It must export ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllGather,
+ * ncclAllReduce and ncclGetErrorString with RCCL's signatures. */
+MSCNN_DIST_API int mscnn_dist_use_transport(const char* library_path);
+
 /* Rank 0 creates the rendezvous id and hands the 128 bytes to every other rank by any out-of-band channel (the launcher's
  * store, a file, a socket); every rank then calls mscnn_dist_init with the same id. */
 MSCNN_DIST_API int mscnn_dist_unique_id(unsigned char id_out[MSCNN_DIST_ID_BYTES]);

@@ -32,6 +32,7 @@
 #include "headconv.h"
 #include "winograd.h"
 #include "wino_x3.h"
+#include "wgemm.h"
 #include "x3_device.h"
 #include <new>
 #include <type_traits>
@@ -969,6 +970,10 @@ struct mscnn_conv_plan {
   // Winograd F(2x2, 3x3) path (wino != nullptr): input transform -> 16 batched 1x1 GEMMs (the nested igemm plan) ->
   // output transform.  Workspace layout: [V: 16 x Cin x T_pad][M: 16 x Cout x T_pad][nested plan's stream-K slabs].
   mscnn_conv_plan* wino = nullptr;
+  // use_wg: the plane GEMMs run on the LDS-DMA ring kernel of wgemm.hip instead of the nested igemm plan (which stays as the
+  // description of the fall-back; tune_flags bit 7 selects it for A/B runs).  Workspace: [V][M][wgemm's stream-K slabs]
+  bool use_wg = false;
+  mscnn::WgemmPlan wg;
   int wino_m = 2;        // output tile edge: 2 = F(2x2,3x3) (16 planes), 3 = F(3x3,3x3) (25 planes; small ROI maps)
   int tiles_h = 0, tiles_w = 0, T_pad = 0;
   // split-fp16 form of the F(3x3,3x3) path (MSCNN_CONV_ALGO_WINO_F3_X3, wino_x3.hip): x3.BM > 0, wino == nullptr.
@@ -1106,6 +1111,14 @@ static bool wino_plan(mscnn_conv_plan* p) {
   p->tiles_h = th; p->tiles_w = tw; p->T_pad = (int)T_pad;
   p->packed_bytes = (size_t)planes * g->packed_bytes;
   p->ws_bytes = (size_t)planes * ((size_t)d.Cin + d.Cout) * T_pad * sizeof(float) + g->ws_bytes;
+  // the plane GEMMs on wgemm.hip's kernel where it covers the shape (F(3x3,3x3) / F(4x4,3x3); Cin % 32 == 0, Cout % 32 == 0)
+  p->use_wg = false;
+  if (m >= 3 && !(d.tune_flags & 128) && mscnn::wgemm_plan(planes, d.Cout, d.Cin, (int)T, (d.tune_variant >= 300 && d.tune_variant < 1100) ? d.tune_variant - 300 : 0, &p->wg)) {
+    p->use_wg = true;
+    p->T_pad = p->wg.T_pad;
+    p->packed_bytes = p->wg.packed_bytes;
+    p->ws_bytes = (size_t)planes * ((size_t)d.Cin + d.Cout) * p->wg.T_pad * sizeof(float) + p->wg.ws_bytes;
+  }
   return true;
 }
 
@@ -1276,6 +1289,7 @@ extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_p
   else if (p->hg) { kind = 8; e = (unsigned)p->hg->entry; mt = (unsigned)p->hg->MT; ki = (unsigned)p->hg->KI; }
   else if (p->head.entry >= 0) { kind = 2; e = (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
   else if (p->x3.BM) { kind = 6; e = (unsigned)p->x3.BM; mt = (unsigned)p->x3.MT; ki = (unsigned)p->x3.KG; }
+  else if (p->wino && p->use_wg) { kind = p->wino_m == 4 ? 9u : 2 + (unsigned)p->wino_m; e = 200u + (unsigned)p->wg.variant; mt = (unsigned)p->wg.MT; ki = (unsigned)p->wg.KI; }
   else if (p->wino) { kind = p->wino_m == 4 ? 9u : 2 + (unsigned)p->wino_m; e = (unsigned)p->wino->entry; mt = (unsigned)p->wino->MT; ki = (unsigned)p->wino->KI; }
   else if (p->entry >= 0) { kind = 1; e = (unsigned)p->entry; mt = (unsigned)p->MT; ki = (unsigned)p->KI; }   // (entry distinguishes fp16 packs)
   else return 0;   // direct kernel: reads the Caffe layout
@@ -1364,6 +1378,7 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   }
   if (p->wino) {
     MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
+    if (p->use_wg) return wino_pack_weights(p->wino_m, w, packed, p->d.Cout, p->d.Cin, p->wg.BM, p->wg.CK, p->wg.MT, p->wg.KI, as_stream(stream));
     const KernelEntry& k = kTable[p->wino->entry];
     return wino_pack_weights(p->wino_m, w, packed, p->d.Cout, p->d.Cin, k.BM, k.CK, p->wino->MT, p->wino->KI, as_stream(stream));
   }
@@ -1517,7 +1532,8 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
     int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st);
     if (rc != MSCNN_OK) return rc;
     MSCNN_STAGE_EVENT(1);
-    rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
+    if (p->use_wg) rc = mscnn::wgemm_launch(p->wg, packed, V, M, gws, st);
+    else rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
     if (rc != MSCNN_OK) return rc;
     MSCNN_STAGE_EVENT(2);
     rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st,

@@ -378,10 +378,30 @@ __global__ __launch_bounds__(256) void ip_generic_kernel(const float* __restrict
 
 using namespace mscnn;
 
-// Workspace for the stream-K slabs is owned by the library (grown on demand, per device) because the Caffe
-// layer interface has no workspace argument for InnerProduct.
-static float* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
+// Workspace for the stream-K slabs is owned by the library because the Caffe layer interface has no workspace argument for
+// InnerProduct: one buffer per (host thread, device), grown on demand.  Per thread because the reference's execution model is one
+// thread per GPU with a thread-local Caffe singleton (common.cpp:13-20; host/tools/detect_multi_gpu.cpp runs one replica per
+// thread), per device because a thread may switch devices; a buffer shared across threads would have concurrent replicas
+// writing their partial sums into each other's slabs.
+namespace {
+constexpr int kMaxDevices = 64;
+struct SlabWs { float* p = nullptr; size_t bytes = 0; };
+int reserve_slabs(size_t need, float** out) {
+  static thread_local SlabWs ws[kMaxDevices];
+  int dev = 0;
+  MSCNN_HIP_TRY(hipGetDevice(&dev));
+  MSCNN_REQUIRE(dev >= 0 && dev < kMaxDevices, "inner_product: device index %d out of range", dev);
+  SlabWs& w = ws[dev];
+  if (need > w.bytes) {
+    if (w.p) MSCNN_HIP_TRY(hipFree(w.p));      // (synchronises the device: kernels still reading the old buffer have finished)
+    w.p = nullptr; w.bytes = 0;
+    MSCNN_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.p), need));
+    w.bytes = need;
+  }
+  *out = w.p;
+  return MSCNN_OK;
+}
+}  // namespace
 
 extern "C" int mscnn_inner_product_f16_supported(int N, int K) { return N >= 64 && K % 8 == 0; }
 
@@ -442,13 +462,10 @@ static int inner_product_gemm(const float* x, const void* w, bool w_is_f16, cons
   if (G < 1) G = 1;
   a.G = (int)G;
   const size_t need = (size_t)a.G * 2 * BM * BN * sizeof(float);
-  if (need > g_ws_bytes) {
-    if (g_ws) MSCNN_HIP_TRY(hipFree(g_ws));
-    g_ws = nullptr; g_ws_bytes = 0;
-    MSCNN_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_ws), need));
-    g_ws_bytes = need;
+  {
+    const int rc = reserve_slabs(need, &a.ws);
+    if (rc != MSCNN_OK) return rc;
   }
-  a.ws = g_ws;
   if (w_is_f16) {
     if (m64) gemm16_tn_kernel<64, 256><<<a.G, 256, 0, st>>>(a);
     else gemm16_tn_kernel<128, 128><<<a.G, 256, 0, st>>>(a);

@@ -18,7 +18,8 @@ struct WgemmPlan {
   size_t ws_bytes;                  // partial-tile slabs of the stream-K phase
 };
 
-// variant 0: pick per shape.  Returns false when no kernel covers the shape (the caller keeps the igemm path).
+// variant 0: pick per shape (bits 8 / 9 of variant: development -- force the stream-K split / whole tiles).  Returns false when no
+// kernel covers the shape (the caller keeps the igemm path).
 bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* out);
 
 // abl: development ablations (0 in the product): bit 0 no loads after the prologue, bit 1 no stores, bit 2 no MFMAs, bit 3 no

@@ -40,6 +40,8 @@ struct WgemmArgs {
   const float* Up; const float* V; float* M; float* ws;
   int P, MT, NT, KI, Cin, Cout, T_pad;
   int tiles, G, abl;
+  int full_q;                   // whole tiles per workgroup (tile slot + r G, r < full_q); the other tiles are split stream-K style
+  unsigned ws_bytes;
   unsigned long long* dbg;      // development: per-workgroup {shader cycles, 100 MHz ticks} over the kernel (nullptr in the product)
   unsigned up_bytes, v_bytes, m_bytes;
 };
@@ -77,7 +79,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 // One LDS-DMA instruction: lane l copies 16 bytes from  rsrc + voff(l) + soff  to LDS  lds_addr + 16 l  (1 KB per wave).
 // Invisible to the compiler's s_waitcnt bookkeeping by design: completion is counted by hand (wait_vm below).
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
+  soff = __builtin_amdgcn_readfirstlane(soff);            // wave-uniform by construction; makes it provably so for the "s" constraints
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  // (s_nop 4: an SGPR written by v_readfirstlane needs 5 wait states before a VMEM instruction reads it -- the compiler does not pad
+  // inline asm; s_nop 0: M0 write -> LDS-DMA)
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
 }
 
 template <int N>
@@ -98,6 +104,39 @@ template <int N>
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void lds_pin(float& v) { asm volatile("" : "+v"(v)); }
 
+// (tile, chunk) units of the stream-K remainder [0, total) owned by workgroup g: total < 2^31 / G is checked by the plan
+__device__ __host__ __forceinline__ void wg_range(int total, int G, int g, int& b, int& e) {
+  b = (int)((unsigned)total * (unsigned)g / (unsigned)G);
+  e = (int)((unsigned)total * (unsigned)(g + 1) / (unsigned)G);
+}
+
+// A workgroup's work as a list of segments (tile, chunks [k0, k1)): first its full_q whole tiles, then its share of the remainder
+// tiles' (tile, chunk) space.  part: -1 = the segment is a whole tile (stored to M), 0 / 1 = partial (stored to that slab).
+struct SegCursor {
+  int slot, G, KI, full_q, rem_tile0, r;
+  int it, re;
+  int nparts;
+  __device__ __forceinline__ void init(const WgemmArgs& a, int slot_) {
+    slot = slot_; G = a.G; KI = a.KI; rem_tile0 = a.full_q * a.G; r = 0; nparts = 0;
+    // whole tiles of this slot: rounds r < full_q whose tile exists (with whole-tile scheduling the last round is not full)
+    full_q = slot_ < a.tiles ? min(a.full_q, (a.tiles - slot_ + a.G - 1) / a.G) : 0;
+    if (a.tiles > rem_tile0) wg_range((a.tiles - rem_tile0) * a.KI, a.G, slot_, it, re);
+    else it = re = 0;
+  }
+  __device__ __forceinline__ int units() const { return full_q * KI + (re - it); }
+  __device__ __forceinline__ bool next(int& t, int& k0, int& k1, int& part) {
+    if (r < full_q) { t = slot + r * G; k0 = 0; k1 = KI; part = -1; ++r; return true; }
+    if (it >= re) return false;
+    t = rem_tile0 + it / KI;
+    k0 = it % KI;
+    const int left = re - it;
+    k1 = left < KI - k0 ? k0 + left : KI;
+    it += k1 - k0;
+    part = (k0 == 0 && k1 == KI) ? -1 : nparts++;
+    return true;
+  }
+};
+
 template <class C, int ABL>
 __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs a) {
   __shared__ __attribute__((aligned(1024))) float lds[C::ST * C::STAGE_FLOATS];
@@ -111,13 +150,15 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   // slot of this workgroup (XCD-contiguous, see header)
   const int xcd = (int)(blockIdx.x % 8), gq = a.G / 8, gr = a.G % 8;
   const int slot = xcd * gq + min(xcd, gr) + (int)(blockIdx.x / 8);
-  const int ntl = slot < a.tiles ? (a.tiles - slot + a.G - 1) / a.G : 0;     // whole tiles of this workgroup
-  const int nunits = ntl * a.KI;
+  SegCursor pcur, ccur;                      // producer (LDS-DMA) and consumer (MFMA) walk the same segment list
+  pcur.init(a, slot); ccur.init(a, slot);
+  const int nunits = pcur.units();
   if (nunits == 0) return;
   unsigned long long dbg_c = 0, dbg_r = 0;
   if (a.dbg && tid == 0) { dbg_c = __builtin_amdgcn_s_memtime(); dbg_r = __builtin_amdgcn_s_memrealtime(); }
 
-  const __amdgpu_buffer_rsrc_t rA = make_rsrc(a.Up, a.up_bytes), rB = make_rsrc(a.V, a.v_bytes), rM = make_rsrc(a.M, a.m_bytes);
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(a.Up, a.up_bytes), rB = make_rsrc(a.V, a.v_bytes), rM = make_rsrc(a.M, a.m_bytes),
+                               rW = make_rsrc(a.ws, a.ws_bytes);
   const unsigned row_bytes = (unsigned)a.T_pad * 4u;
   const unsigned vA = (unsigned)lane * 16u;
   const unsigned vB = (unsigned)(lane / C::F4_PER_ROW) * row_bytes + (unsigned)(lane % C::F4_PER_ROW) * 16u;
@@ -127,16 +168,19 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   const unsigned b_lane = (unsigned)C::A_BYTES + (unsigned)(khalf * C::BN + wn * C::WN + l31) * 4u;
 
   // ---- producer cursor: the next (tile, chunk) unit to put in flight; one LDS-DMA piece per call -----------------------------
-  int pu = 0, p_kc = 0, p_round = 0, p_stage = 0;
+  int pu = 0, p_kc = 0, p_k1 = 0, p_stage = 0;
   unsigned p_a = 0, p_b = 0;            // byte offsets of the unit's A slab / first B row
   unsigned vA_eff = vA, vB_eff = vB;
   auto p_begin = [&]() {                // called before piece 0 of a unit
     if (pu >= nunits) { vA_eff = 0x80000000u; vB_eff = 0x80000000u; }
-    if (p_kc == 0 && pu < nunits) {
-      const int t = slot + p_round * a.G;
+    if (p_kc == p_k1 && pu < nunits) {  // next segment
+      int t, part;
+      pcur.next(t, p_kc, p_k1, part);
       const int mt = t % a.MT, nt = (t / a.MT) % a.NT, p = t / (a.MT * a.NT);
-      p_a = (unsigned)((p * a.MT + mt) * a.KI) * (unsigned)C::A_BYTES;
-      p_b = ((unsigned)(p * a.Cin) * (unsigned)a.T_pad + (unsigned)(nt * C::BN)) * 4u;
+      // (the compiler does the divisions on the vector ALU: pin the results back to scalars -- the LDS-DMA statement needs SGPR operands)
+      p_kc = __builtin_amdgcn_readfirstlane(p_kc); p_k1 = __builtin_amdgcn_readfirstlane(p_k1);
+      p_a = __builtin_amdgcn_readfirstlane((unsigned)((p * a.MT + mt) * a.KI) * (unsigned)C::A_BYTES);
+      p_b = __builtin_amdgcn_readfirstlane(((unsigned)(p * a.Cin) * (unsigned)a.T_pad + (unsigned)(nt * C::BN)) * 4u);
     }
   };
   // (past the last unit the cursor keeps running with out-of-range lane offsets: those pieces fetch nothing and write zeros into
@@ -155,7 +199,7 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   };
   auto p_end = [&]() {
     ++pu;
-    if (++p_kc == a.KI) { p_kc = 0; ++p_round; }
+    ++p_kc;
     if (++p_stage == C::ST) p_stage = 0;
   };
 
@@ -203,6 +247,8 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   constexpr int AFTER_DMA = (C::STEPS - C::NP) * SPG + SPM * (NMF - 1 - JD);   // stores issued behind a chunk's last piece
   static_assert(C::NP <= C::STEPS, "one DMA piece per MFMA group");
 
+  __amdgpu_buffer_rsrc_t old_rsrc = rM;                  // where the finished segment goes: M (whole tile) or a partial-sum slab
+  unsigned old_rowb = row_bytes;                          // ... and its row stride in bytes
   unsigned c_addr = lds0;                                 // LDS address of the stage being multiplied
   WG_READ(0, c_addr, 0);
 
@@ -210,7 +256,7 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     constexpr int e = decltype(ec)::value;
     constexpr int blk = e / 16, r = e % 16, mi = blk / C::NI, ni = blk % C::NI, dr = (r & 3) + 8 * (r >> 2);
     const float v = old[mi][ni][r];
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rM, old_voff[mi][ni], (unsigned)dr * row_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 0);
   };
 
   // one chunk = STEPS MFMA groups.  FLUSH: the previous tile's stores ride along (SPM per MFMA); DMA: this chunk carries the
@@ -258,21 +304,25 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     if (++c_stage == C::ST) c_stage = 0;
     return lds0 + (unsigned)c_stage * C::STAGE_BYTES;
   };
-  for (int tl = 0; tl < ntl; ++tl) {
-    // first chunk of the tile: the previous tile's stores ride along (tile 0: `old` is empty and its offsets out of range)
+  int t, k0, k1, part;
+  while (ccur.next(t, k0, k1, part)) {
+    // first chunk of the segment: the previous segment's stores ride along (segment 0: `old` is empty, its offsets out of range)
     chunk(std::true_type{}, next_stage_addr());
-    for (int kc = 1; kc < a.KI; ++kc) chunk(std::false_type{}, next_stage_addr());
-    // ---- tile done: move its accumulators aside ----
-    const int t = slot + tl * a.G;
+    for (int kc = k0 + 1; kc < k1; ++kc) chunk(std::false_type{}, next_stage_addr());
+    // ---- segment done: move its accumulators aside ----
     const int mt = t % a.MT, nt = (t / a.MT) % a.NT, p = t / (a.MT * a.NT);
+    if (part < 0) { old_rsrc = rM; old_rowb = row_bytes; }
+    else { old_rsrc = rW; old_rowb = (unsigned)C::BN * 4u; }
+    const unsigned slab = (unsigned)(slot * 2 + (part < 0 ? 0 : part)) * (unsigned)(C::BM * C::BN * 4);
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < C::NI; ++ni) {
-        const int co0 = mt * C::BM + wm * C::WM + mi * 32;
-        old_voff[mi][ni] = co0 + 32 <= a.Cout
-                               ? ((unsigned)(p * a.Cout + co0 + 4 * khalf) * (unsigned)a.T_pad + (unsigned)(nt * C::BN + wn * C::WN + ni * 32 + l31)) * 4u
-                               : 0x80000000u;
+        const int row = wm * C::WM + mi * 32, col = wn * C::WN + ni * 32 + l31;
+        const int co0 = mt * C::BM + row;
+        const unsigned to_m = co0 + 32 <= a.Cout ? ((unsigned)(p * a.Cout + co0 + 4 * khalf) * (unsigned)a.T_pad + (unsigned)(nt * C::BN + col)) * 4u : 0x80000000u;
+        const unsigned to_ws = slab + (unsigned)((row + 4 * khalf) * C::BN + col) * 4u;
+        old_voff[mi][ni] = part < 0 ? to_m : to_ws;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { old[mi][ni][r] = acc[mi][ni][r]; acc[mi][ni][r] = 0.f; }
       }
@@ -285,9 +335,59 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   }
 }
 
+// Sums the partial slabs of the remainder tiles in k order (deterministic) into M.  BM * BN / 4096 workgroups per tile, each owning
+// 4096 consecutive slab elements (four float4 per thread).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void wgemm_fixup_kernel(WgemmArgs a) {
+  constexpr int SPLIT = BM * BN / 4096;
+  __shared__ const float* s_slab[64];
+  __shared__ int s_n;
+  const int j = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;      // j: index among the remainder tiles
+  const int rem_tile0 = a.full_q * a.G;
+  const int RU = (a.tiles - rem_tile0) * a.KI;
+  if (threadIdx.x == 0) {
+    const int its = j * a.KI, ite = its + a.KI;
+    int gf = (int)((long)its * a.G / RU), gl = (int)((long)(ite - 1) * a.G / RU);
+    int b, e;
+    wg_range(RU, a.G, gf, b, e);
+    while (e <= its) { ++gf; wg_range(RU, a.G, gf, b, e); }
+    while (b > its) { --gf; wg_range(RU, a.G, gf, b, e); }
+    wg_range(RU, a.G, gl, b, e);
+    while (e <= ite - 1) { ++gl; wg_range(RU, a.G, gl, b, e); }
+    while (b > ite - 1) { --gl; wg_range(RU, a.G, gl, b, e); }
+    int n = 0;
+    if (gf != gl) {               // gf == gl: one workgroup computed the whole tile and stored it to M itself
+      for (int g = gf; g <= gl && n < 64; ++g) {
+        wg_range(RU, a.G, g, b, e);
+        if (e <= b) continue;
+        // the tile holding a workgroup's first remainder unit is its slab 0, the next one its slab 1
+        s_slab[n++] = a.ws + ((long)g * 2 + (b / a.KI == j ? 0 : 1)) * (BM * BN);
+      }
+    }
+    s_n = n;
+  }
+  __syncthreads();
+  const int n = s_n;
+  if (n == 0) return;
+  const int t = rem_tile0 + j;
+  const int mt = t % a.MT, nt = (t / a.MT) % a.NT, p = t / (a.MT * a.NT);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = part * 4096 + (q * 256 + threadIdx.x) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sidx = 0; sidx < n; ++sidx) {
+      const float4 u = *reinterpret_cast<const float4*>(s_slab[sidx] + i);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int row = i / BN, col = i % BN, co = mt * BM + row;
+    if (co >= a.Cout) continue;
+    *reinterpret_cast<float4*>(a.M + ((long)p * a.Cout + co) * a.T_pad + nt * BN + col) = v;
+  }
+}
+
 typedef void (*WgemmFn)(WgemmArgs);
-struct WEntry { const char* name; int variant, abl, BM, BN, CK, threads; WgemmFn fn; };
-#define WG_ENTRY(name, v, abl, BM, BN, WGM, WGN, CK) {name, v, abl, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3>, abl>}
+struct WEntry { const char* name; int variant, abl, BM, BN, CK, threads; WgemmFn fn, fix; };
+#define WG_ENTRY(name, v, abl, BM, BN, WGM, WGN, CK) {name, v, abl, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3>, abl>, wgemm_fixup_kernel<BM, BN>}
 const WEntry kW[] = {
     WG_ENTRY("wgemm_256x128_ck32", 1, 0, 256, 128, 4, 2, 32),
     WG_ENTRY("wgemm_128x256_ck32", 2, 0, 128, 256, 2, 4, 32),
@@ -308,6 +408,8 @@ const WEntry kW[] = {
 namespace mscnn {
 
 bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
+  const int variant_flags = variant >> 8;
+  variant &= 255;
   if (variant == 0) variant = Cout >= 256 ? 1 : 2;
   const WEntry* e = nullptr;
   for (const WEntry& w : kW) if (w.variant == variant && w.abl == 0) e = &w;
@@ -317,11 +419,24 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   o->T_pad = (T + e->BN - 1) / e->BN * e->BN;
   if (o->T_pad % 128) o->T_pad = (o->T_pad + 127) / 128 * 128;
   o->MT = (Cout + e->BM - 1) / e->BM; o->NT = o->T_pad / e->BN; o->KI = Cin / e->CK;
-  o->G = 256; o->full_q = (int)((long)P * o->MT * o->NT / o->G);
+  o->G = 256;                   // one 512-thread workgroup per CU
+  const long tiles = (long)P * o->MT * o->NT;
+  // Whole tiles (ceil(tiles / G) rounds) or the hybrid stream-K split of the last partial round?  The split costs a fix-up launch
+  // that moves three slabs per remainder tile (measured ~3 TB/s + ~5 us, profiles/r03_wgemm.txt): it pays for the small layers
+  // (conv6_1: 50 tiles on 256 CUs) and not where the last round is nearly full (conv4_2: 750 tiles = 2.93 rounds).
+  const long rem = tiles % o->G;
+  const double chunk_us = (double)e->BM * e->BN * e->CK / 128.0 / 2300.0;                       // MFMA-bound time of one K chunk
+  const double whole = (double)((tiles + o->G - 1) / o->G) * o->KI;
+  const double split = (double)tiles * o->KI / o->G + (5.0 + (double)rem * 3.0 * e->BM * e->BN * 4.0 / 3.0e6) / chunk_us;
+  o->full_q = (int)(tiles / o->G);
+  if (rem > 0 && !(split < 0.93 * whole)) o->full_q += 1;       // whole tiles: the last round is simply not full
+  if (variant_flags & 1) o->full_q = (int)(tiles / o->G);       // development: force the split
+  if (variant_flags & 2) o->full_q = (int)((tiles + o->G - 1) / o->G);   // ... or whole tiles
   o->variant = variant; o->name = e->name;
   o->packed_bytes = (size_t)P * o->MT * o->KI * e->CK * e->BM * 4;
-  o->ws_bytes = 0;
+  o->ws_bytes = tiles > (long)o->full_q * o->G ? (size_t)o->G * 2 * e->BM * e->BN * 4 : 0;
   const double lim = 4.0e9;
+  if ((double)tiles * o->KI * o->G >= 2.0e9 || o->KI < 1) return false;      // wg_range's 32-bit product
   if ((double)P * Cin * o->T_pad * 4 >= lim || (double)P * Cout * o->T_pad * 4 >= lim || (double)o->packed_bytes >= lim) return false;
   return true;
 }
@@ -334,9 +449,16 @@ int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, 
   a.Up = Up; a.V = V; a.M = M; a.ws = ws;
   a.P = p.P; a.MT = p.MT; a.NT = p.NT; a.KI = p.KI; a.Cin = p.Cin; a.Cout = p.Cout; a.T_pad = p.T_pad;
   a.tiles = p.P * p.MT * p.NT; a.G = p.G; a.abl = abl; a.dbg = dbg;
+  a.full_q = p.full_q; a.ws_bytes = (unsigned)p.ws_bytes;
+  const int rem = a.tiles - p.full_q * p.G;
+  if (rem > 0 && !ws) { set_error("wgemm: workspace missing"); return MSCNN_ERR_WORKSPACE; }
   a.up_bytes = (unsigned)p.packed_bytes; a.v_bytes = (unsigned)((size_t)p.P * p.Cin * p.T_pad * 4); a.m_bytes = (unsigned)((size_t)p.P * p.Cout * p.T_pad * 4);
   e->fn<<<p.G, e->threads, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
+  if (rem > 0) {
+    e->fix<<<rem * (e->BM * e->BN / 4096), 256, 0, st>>>(a);
+    MSCNN_POST_LAUNCH();
+  }
   return MSCNN_OK;
 }
 

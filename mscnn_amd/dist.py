@@ -35,6 +35,7 @@ def dist_lib():
         L = C.CDLL(DIST_LIB_PATH)
         L.mscnn_dist_last_error.restype = C.c_char_p
         L.mscnn_dist_unique_id.argtypes = [C.c_void_p]
+        L.mscnn_dist_use_transport.argtypes = [C.c_char_p]
         L.mscnn_dist_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
         L.mscnn_dist_destroy.argtypes = [C.c_void_p]
         L.mscnn_dist_destroy.restype = None
@@ -66,6 +67,8 @@ def split_packs(gathered, world, cap, copy=True):
     for r in range(world):
         p = buf[r * pb:(r + 1) * pb]
         D, R, c, _ = (int(v) for v in p[:16].view(np.int32))
+        if c == cap and D == -1:      # the writer's overflow mark (mscnn_net_detect_device): raised on EVERY rank after the exchange
+            raise DistError(f"rank {r}: {R} ROIs exceed the detection pack capacity {cap} (size it by BoxOutput's max_nms_num)")
         if c != cap or not (0 <= D <= R <= cap):
             raise DistError(f"rank {r}: corrupt detection pack ({D} detections, {R} ROIs, written for capacity {c}, read with {cap})")
         dets = p[16:16 + 40 * D].view(np.float64).reshape(D, 5)

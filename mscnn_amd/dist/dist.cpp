@@ -32,15 +32,19 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+char g_transport[1024] = "";      // mscnn_dist_use_transport: an explicit library path instead of the default search
+
 Rccl* rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-      r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-      if (r.handle) break;
-    }
+    if (g_transport[0]) r.handle = dlopen(g_transport, RTLD_NOW | RTLD_LOCAL);
+    else
+      for (const char* n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+      }
     if (!r.handle) return;
 #define LOAD(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym))
     LOAD(GetUniqueId, "ncclGetUniqueId");
@@ -76,6 +80,12 @@ struct mscnn_dist {
 extern "C" {
 
 const char* mscnn_dist_last_error(void) { return g_err; }
+
+int mscnn_dist_use_transport(const char* library_path) {
+  DIST_REQUIRE(library_path && library_path[0] && std::strlen(library_path) < sizeof(g_transport), "use_transport: bad path");
+  std::snprintf(g_transport, sizeof(g_transport), "%s", library_path);
+  return 0;
+}
 
 int mscnn_dist_unique_id(unsigned char id_out[MSCNN_DIST_ID_BYTES]) {
   static_assert(sizeof(ncclUniqueId) == MSCNN_DIST_ID_BYTES, "ncclUniqueId size");

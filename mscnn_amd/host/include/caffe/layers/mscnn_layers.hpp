@@ -82,6 +82,10 @@ class ConvolutionLayer : public Layer<Dtype> {
   // Net::CalibrateNumerics sets 1 on layers whose Winograd result strays from the direct sum on representative data.
   void set_algo(int algo);
   int algo() const { return algo_; }
+  // Net::CalibrateNumerics found this layer's Winograd form off the direct sum on the user's data: it stays on the direct fp32
+  // kernel across precision switches (mscnn_net_set_precision) until an explicit mscnn_net_set_conv_algo clears the mark.
+  void set_calibrated_direct(bool on) { calibrated_direct_ = on; }
+  bool calibrated_direct() const { return calibrated_direct_; }
   void set_tuning(int variant, int grid, int flags);      // A/B measurement knobs (mscnn_conv_desc::tune_*)
   // FLOPs the MFMA pipe executes (Winograd forms: fewer than ForwardFlops) and per-stage HIP-event times of the last
   // Forward {input transform, MFMA GEMM, output transform} -- roofline accounting (bench.py).
@@ -111,6 +115,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   Blob<Dtype>* pooled_top_ = nullptr;     // fused Pooling layer's top (FusePool2x2)
   DeviceBuffer packed_, workspace_;
   int algo_, tune_[3];
+  bool calibrated_direct_ = false;
   bool profiling_;
   const ConvolutionLayer* amax_src_ = nullptr;
   const unsigned* amax_in_ = nullptr;

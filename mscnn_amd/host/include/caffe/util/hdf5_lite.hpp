@@ -25,7 +25,19 @@ struct Dataset {
   bool big_endian = false, is_signed = false;
   uint64_t data_offset = 0;     // file offset of the raw data (contiguous or compact)
   uint64_t data_bytes = 0;
-  long long count() const { long long c = 1; for (size_t i = 0; i < dims.size(); ++i) c *= dims[i]; return c; }
+  // element count, saturated at kMaxCount + 1 (a crafted dataspace must not wrap the product: ReadDatasetInfo refuses anything above
+  // kMaxCount = INT_MAX, the limit of Blob's int shapes)
+  static constexpr long long kMaxCount = 2147483647LL;
+  long long count() const {
+    long long c = 1;
+    for (size_t i = 0; i < dims.size(); ++i) {
+      if (dims[i] < 0) return kMaxCount + 1;
+      if (dims[i] == 0) return 0;
+      if (c > kMaxCount / dims[i]) return kMaxCount + 1;
+      c *= dims[i];
+    }
+    return c;
+  }
 };
 
 class File {

@@ -146,7 +146,7 @@ int mscnn_net_set_conv_algo(mscnn_net* n, int layer, int algo) {
   return guarded([&] {
     CHECK_LT(layer, (int)n->net->layers().size());
     for (int l = (layer < 0 ? 0 : layer); l < (layer < 0 ? (int)n->net->layers().size() : layer + 1); ++l)
-      if (auto* c = conv_of(n, l)) c->set_algo(algo);
+      if (auto* c = conv_of(n, l)) { c->set_algo(algo); c->set_calibrated_direct(false); }
       else CHECK_LT(layer, 0) << "layer " << n->net->layer_names()[l] << " is not a Convolution";
   });
 }
@@ -162,7 +162,9 @@ int mscnn_net_set_precision(mscnn_net* n, const char* dtype) {
     const std::string d = dtype ? dtype : "";
     CHECK(d == "f32" || d == "f16" || d == "f16x3") << "precision must be f32, f16 or f16x3, not '" << d << "'";
     for (size_t l = 0; l < n->net->layers().size(); ++l) {
-      if (auto* c = conv_of(n, (int)l)) c->set_algo(d == "f16" ? 4 : d == "f16x3" ? 5 : 0);
+      // (a layer the numerical calibration sent to the direct fp32 kernel stays there in the fp32-grade modes: the calibration is about
+      // the data, not about the mode that happened to be active; the reduced-precision f16 mode has its own tolerance policy)
+      if (auto* c = conv_of(n, (int)l)) c->set_algo(d == "f16" ? 4 : c->calibrated_direct() ? 1 : d == "f16x3" ? 5 : 0);
       if (auto* ip = dynamic_cast<caffe::InnerProductLayer<float>*>(n->net->layers()[l].get())) { ip->set_f16(d == "f16"); ip->set_x3(d == "f16x3"); }
     }
   });
@@ -289,6 +291,19 @@ static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap
   const int R = props->num();
   CHECK_EQ(bbox->num(), R);
   CHECK_EQ(cls->num(), R);
+  if (with_header && R > cap) {
+    // Multi-GPU pack: a rank that fails here alone would leave the others blocked in the all_gather.  Mark the overflow in the header
+    // {-1, R, cap, 0} and take part in the exchange: mscnn_net_unpack_detections then fails on EVERY rank, naming the numbers.
+    char* pk = static_cast<char*>(n->det_pack.Reserve(mscnn_net_detect_pack_bytes(cap)));
+    hipStream_t s0 = (hipStream_t)Caffe::stream();
+    int* h = reinterpret_cast<int*>(pk);
+    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h), -1, 1, s0));
+    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h + 1), R, 1, s0));
+    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h + 2), cap, 1, s0));
+    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h + 3), 0, 1, s0));
+    if (R_out) *R_out = R;
+    return;
+  }
   CHECK_LE(R, cap) << "detection pack capacity " << cap << " < " << R << " ROIs (size it by BoxOutput's max_nms_num)";
   mscnn_detections_desc d;
   d.ncls = R > 0 ? cls->count() / R : 1;
@@ -330,6 +345,7 @@ int mscnn_net_unpack_detections(const void* pack_host, int cap, double* dets_hos
     const int* hdr = reinterpret_cast<const int*>(hp);
     const int D = hdr[0], R = hdr[1];
     CHECK_EQ(hdr[2], cap) << "detection pack was written for another capacity";
+    CHECK(D != -1) << "detection pack capacity " << cap << " < " << R << " ROIs on the rank that wrote this pack (size it by BoxOutput's max_nms_num)";
     CHECK(D >= 0 && D <= R && R <= cap) << "corrupt detection pack: " << D << " detections, " << R << " ROIs, capacity " << cap;
     const size_t rows = (size_t)(cap > 0 ? cap : 1);
     if (D > 0 && dets_host) std::memcpy(dets_host, hp + 16, sizeof(double) * 5 * D);

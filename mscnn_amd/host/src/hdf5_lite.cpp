@@ -269,6 +269,7 @@ bool File::ReadDatasetInfo(uint64_t object_header, Dataset* ds) {
     }
   }
   if (!have_space || !have_type || !have_layout) return Fail("object at offset " + Str(object_header) + " is not a dataset");
+  if (ds->count() > Dataset::kMaxCount) return Fail("dataset has more than INT_MAX elements (or a dimension product that overflows)");
   const uint64_t want = (uint64_t)ds->count() * (uint64_t)ds->type_size;
   if (ds->data_bytes == ~0ull) ds->data_bytes = want;
   if (want == 0) return true;

@@ -164,7 +164,7 @@ void ConvolutionLayer<Dtype>::Plan(int n, int h, int w) {
 
 template <typename Dtype>
 void ConvolutionLayer<Dtype>::set_algo(int algo) {
-  CHECK(algo >= 0 && algo <= 5) << "unknown mscnn_conv_algo " << algo;
+  CHECK(algo >= 0 && algo <= 6) << "unknown mscnn_conv_algo " << algo;
   if (algo == algo_) return;
   algo_ = algo;
   if (plan_) { mscnn_conv2d_plan_destroy(plan_); plan_ = nullptr; }

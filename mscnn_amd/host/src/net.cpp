@@ -343,6 +343,7 @@ vector<int> Net<Dtype>::CalibrateNumerics(double tol) {
       LOG(WARNING) << "layer " << layer_names_[i] << ": Winograd result off the direct sum by " << calib_err_[i] << " > " << tol
                    << " on the calibration input: using the direct kernel";
       c->set_algo(1);
+      c->set_calibrated_direct(true);
       switched.push_back((int)i);
     }
   }
@@ -417,6 +418,13 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
     }
   }
   if (timing_) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+  // The max |x| slots a split-fp16 layer takes from its producer are only valid inside this call: a later Layer::Forward called
+  // directly on a layer (caffe time, user code, the boundary tests) must measure its bottom itself instead of trusting the slots of
+  // the frame that went through here.
+  for (size_t i = 0; i < layers_.size(); ++i) {
+    if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) c->set_amax_trusted(false);
+    else if (InnerProductLayer<Dtype>* ip = dynamic_cast<InnerProductLayer<Dtype>*>(layers_[i].get())) ip->set_amax_trusted(false);
+  }
   return 0;
 }
 

@@ -91,3 +91,99 @@ def test_pack_capacity_is_enforced():
     bad[:16].view(np.int32)[:] = [CAP + 1, CAP + 1, CAP, 0]                      # more rows than the pack can hold
     with pytest.raises(mnet.NetError, match="corrupt detection pack"):
         mnet.unpack_detections(bad, CAP)
+
+
+# ---- the product's own exchange code at world size 2 -------------------------------------------------------------------------------
+# libmscnn_dist.so (mscnn_dist_unique_id / _init / _all_gather / _barrier) and mscnn_amd.dist.RcclGather, unchanged, in two
+# processes: the collective library is the shared-memory stand-in tests/stub/fake_rccl.c (mscnn_dist_use_transport) and the HIP
+# runtime calls land in tests/stub/fake_hip.c (LD_PRELOAD: "device" memory is host memory).  What this pins without a second GPU:
+# the rendezvous-id hand-over, rank / world bookkeeping, buffer sizing and offsets of the gathered packs, the pinned-buffer views,
+# the barrier, and that an over-capacity rank fails on EVERY rank after the exchange instead of hanging the others.
+_RCCL_WORKER = r'''
+import os, sys, time
+import numpy as np
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import ctypes as C
+from mscnn_amd import dist as mdist
+from test_dist_cpu import _fake_dets, _host_pack, CAP
+rank, world, tmp, overflow = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4] == "1"
+assert mdist.dist_lib().mscnn_dist_use_transport({stub!r}.encode()) == 0
+idfile = os.path.join(tmp, "id.bin")
+def exchange(mine):                      # rank 0's bytes to every rank, through a file (any out-of-band channel does)
+    if rank == 0:
+        open(idfile + ".tmp", "wb").write(mine); os.rename(idfile + ".tmp", idfile)
+        return mine
+    for _ in range(600):
+        if os.path.exists(idfile):
+            return open(idfile, "rb").read()
+        time.sleep(0.05)
+    raise SystemExit("no id")
+g = mdist.RcclGather(rank, world, 0, CAP, exchange)
+g.barrier()
+seen = []
+for step in range(3):
+    img = step * world + rank
+    dets, ids = _fake_dets(img, 2 + 3 * img)
+    pack = _host_pack(dets, ids, len(dets) + 1, CAP)
+    if overflow and step == 2 and rank == 1:
+        pack[:16].view(np.int32)[:] = [-1, CAP + 7, CAP, 0]      # what mscnn_net_detect_device writes for R > cap
+    try:
+        per_rank = g(pack.ctypes.data)
+    except mdist.DistError as e:
+        print("DISTERROR", step, str(e)); sys.stdout.flush()
+        break
+    seen.append([(d.copy(), i.copy(), R) for d, i, R in per_rank])
+g.barrier()
+g.close()
+np.save(os.path.join(tmp, "seen%d.npy" % rank), np.array(seen, dtype=object), allow_pickle=True)
+'''
+
+
+def _build_stubs(tmp_path):
+    import subprocess
+    src = os.path.join(ROOT, "tests", "stub")
+    out = {}
+    for name in ("fake_hip", "fake_rccl"):
+        so = str(tmp_path / f"lib{name}.so")
+        subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(src, name + ".c")])
+        out[name] = so
+    return out
+
+
+def _run_rccl_workers(tmp_path, overflow):
+    import subprocess
+    stubs = _build_stubs(tmp_path)
+    code = _RCCL_WORKER.format(root=ROOT, stub=stubs["fake_rccl"])
+    env = dict(os.environ, LD_PRELOAD=stubs["fake_hip"])
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", str(tmp_path), "1" if overflow else "0"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    return [so for so, _ in outs]
+
+
+def test_rccl_gather_code_path_world2_bit_identical(tmp_path):
+    _run_rccl_workers(tmp_path, overflow=False)
+    for rank in range(2):
+        seen = np.load(str(tmp_path / f"seen{rank}.npy"), allow_pickle=True)
+        assert len(seen) == 3
+        for step, per_rank in enumerate(seen):
+            assert len(per_rank) == 2
+            for r, (dets, ids, R) in enumerate(per_rank):
+                img = step * 2 + r
+                ref_d, ref_i = _fake_dets(img, 2 + 3 * img)
+                assert dets.dtype == np.float64 and dets.tobytes() == ref_d.tobytes()      # float64 bit patterns, both ranks
+                assert np.array_equal(ids, ref_i) and R == len(ref_d) + 1
+
+
+def test_rccl_gather_overflow_fails_on_every_rank(tmp_path):
+    """One rank's image has more ROIs than the agreed capacity: it marks its pack and still takes part in the all-gather, so
+    both ranks raise the same error after the exchange (round 2: only the overflowing rank failed, the other hung in the
+    collective)."""
+    outs = _run_rccl_workers(tmp_path, overflow=True)
+    for so in outs:
+        assert "DISTERROR 2 rank 1:" in so and "exceed the detection pack capacity" in so, so
+    for rank in range(2):
+        assert len(np.load(str(tmp_path / f"seen{rank}.npy"), allow_pickle=True)) == 2
