@@ -13,9 +13,12 @@ device-resident detection pack of every rank (libmscnn_dist.so calls RCCL direct
 
 Rank 0 prints ONE JSON line:
   value / ms_per_step   whole-job images/sec over the K timed steps (max over ranks); step_ms = median / p10 / p90 per step
-  roofline              the DOMINANT kernel (the 25-plane Winograd GEMM igemm_kernel<128x128,k1x1,ck32,vec>): FLOPs its MFMAs
+  roofline              the DOMINANT kernel (wgemm_kernel: the 25 / 36 plane GEMMs of the Winograd layers): FLOPs its MFMAs
                         EXECUTE / its HIP-event time / 157.3 TFLOP/s (never above 1); the conv3_1..conv5_3 block the north star
                         names is reported beside it, executed and as algorithmic-equivalent rate
+  robustness            the same step with "vgg_like" weights (tap sums not zero, log-normal gains, dead filters, hot activations):
+                        which Winograd layers the calibration sends to the direct kernel, the resulting images/sec, and the
+                        floor with EVERY Winograd layer on the direct kernel (value_all_direct)
   cpu_baseline          oracle/_ref (the reference's own CPU layers, MKL sgemm) on one full frame, all host cores, plus a
                         1-thread row on a bounded sample; the same frame goes through the HIP path: parity_ok asserts it
 """
@@ -42,8 +45,9 @@ MODELS = {
 }
 DEFAULT_MODEL = "kitti_car/mscnn-7s-576"
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
-FP32_MFMA_MEASURED_TFLOPS = 141.7      # MFMA-only loop on this part (tools/micro/mfma_valu_overlap.hip, profiles/r02_micro_mfma_valu_overlap.txt):
-                                        # what the pipe sustains at the clock it holds under fp32 MFMA load (SURVEY 8d asks for this reference too)
+FP32_MFMA_MEASURED_TFLOPS = 154.5      # MFMA-only loop on this part (tools/micro/mfma_clock.hip, profiles/r03_micro_mfma_clock.txt): 64.00 cycles per
+                                        # v_mfma_f32_32x32x2_f32 and SIMD at 2.39 GHz once the clock has ramped (tens of ms of load); the 141.7 of
+                                        # round 2 was a 1 ms run on a clock still ramping (SURVEY 8d asks for this reference too)
 FP16_MFMA_PEAK_TFLOPS = 2500.0         # dense fp16 / bf16 MFMA (cdna_hip_programming.md: ~2.5 PF; 16x the fp32 MFMA rate)
 # fp16 mode (BASELINE config 5; no reference counterpart): per-blob error relative to the blob's rms, detection matching
 # (a) blobs: max error / rms(blob) < 1e-2 against the reference's CPU path; (b) detections: fp16 noise (1e-3 .. 1e-2 of a score)
@@ -149,7 +153,7 @@ def cpu_baseline(model, regime, R_gpu, net=None, kw=None, layer_table=None, dtyp
         sample = {}
         prev = pyref.set_threads(1)
         try:
-            for nt in sorted({1, 8, 32, min(cores, 128), cores}):
+            for nt in (1, 8, 32):      # (round 2 also timed 128 / all threads: always slower here, and the sweep outweighed the GPU loop)
                 if nt > cores:
                     continue
                 pyref.set_threads(nt)
@@ -228,6 +232,7 @@ def main():
     ap.add_argument("--regime", default="mid", choices=["dense", "mid", "sparse"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed loop in the f16x3 mode (reported as alt_precision)")
+    ap.add_argument("--no-robust", action="store_true", help="skip the robustness leg (vgg_like weights: calibration fall-backs, all-direct floor)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer tables (caffe time format) to stderr")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
                     help="multi-GPU exchange: libmscnn_dist's direct ncclAllGather (default), or torch.distributed's all_gather of the "
@@ -365,6 +370,50 @@ def main():
                        "conv2_2 as a direct 3x3 implicit GEMM, conv3_1 .. conv6_1 and roi_c1 as Winograd F(3x3,3x3) plane GEMMs, fc6 as a "
                        "k-split GEMM.  22-bit operands: held to the fp32 parity gates (parity_ok in this object)"}
 
+    # ---- robustness leg (untimed for the headline; N = 1 only): the same step with "vgg_like" weights -- tap sums not zero, log-normal
+    # per-filter gains, dead filters, biases, activations ~4x hotter (mscnn_amd/synth.py).  The Winograd forms carry ~10x the rounding
+    # error of the direct sum; the calibration step decides per layer on THIS data which ones stay.  Reported: the layers that fell
+    # back, the images/sec that results, and the floor with every Winograd layer on the direct kernel.
+    robust = None
+    if args.dtype == "f32" and world == 1 and not args.no_robust:
+        rs = max(5, min(args.steps, 20))
+
+        def timed(nsteps):
+            for i in range(3):
+                step(i)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(nsteps):
+                step(i)
+            sync()
+            return nsteps / (time.perf_counter() - t0)
+        he_fallbacks = list((numerics or {}).get("fallback_layers", []))
+        synth.load_into(net, args.regime, style="vgg_like")
+        net.set_conv_algo(-1, 0)                              # every convolution back to AUTO (clears calibration marks)
+        step(0)
+        r_errs, r_sw = net.calibrate_numerics(CALIBRATION_TOL)
+        v_cal = timed(rs)
+        r_rois = float(np.mean(stats["R"][-rs:]))
+        wino_layers = [net.layer_names[i] for i in range(len(net.layer_names)) if net.layer_kernel(i).startswith("winograd")]
+        for l in wino_layers:
+            net.set_conv_algo(l, 1)
+        v_dir = timed(rs)
+        robust = {"weights": "vgg_like (mscnn_amd/synth.py: centre-weighted taps + a low-pass part, log-normal filter gains, 3 % dead filters, "
+                             "biases, conv1_1 scaled for activations of rms ~4 instead of ~1), same frames (BGR - mean, [-123, 151])",
+                  "value": round(v_cal, 3), "unit": "images/sec", "steps": rs, "mean_rois": round(r_rois, 1),
+                  "winograd_layers_checked": len(r_errs), "max_err_vs_direct_kernel": float(f"{max(r_errs.values(), default=0.0):.3g}"),
+                  "tol": CALIBRATION_TOL, "fallback_layers": r_sw,
+                  "value_all_direct": round(v_dir, 3), "all_direct_layers": wino_layers + r_sw,
+                  "note": "value = after Net::CalibrateNumerics on this data; value_all_direct = every Winograd layer forced onto the direct "
+                          "implicit-GEMM kernel (the floor of the fp32 path, whatever the data)"}
+        synth.load_into(net, args.regime)                     # back to the headline configuration for the roofline passes
+        net.set_conv_algo(-1, 0)
+        for l in he_fallbacks:
+            net.set_conv_algo(l, 1)
+        step(0)
+        sync()
+        stats = {"R": [], "D": []}
+
     result = None
     rc = 0
     if rank == 0:
@@ -373,7 +422,7 @@ def main():
         # plans (their extra event records would inflate the small layers of the first table)
         net.set_layer_timing(True)
         L = len(net.layer_names)
-        acc = np.zeros(L); stage = np.zeros((L, 3)); reps = 5
+        acc = np.zeros(L); stage = np.zeros((L, 3)); reps = 5; stage_reps = []
         for i in range(reps):
             net.set_blob("data", frames[i % len(frames)])
             net.forward()
@@ -382,7 +431,8 @@ def main():
         for i in range(reps):
             net.set_blob("data", frames[i % len(frames)])
             net.forward()
-            stage += np.array([net.layer_stage_ms(j) for j in range(L)])
+            stage_reps.append(np.array([net.layer_stage_ms(j) for j in range(L)]))
+            stage += stage_reps[-1]
         net.set_layer_timing(False)
         net.set_conv_profiling(False)
         lay_ms, stage = acc / reps, stage / reps
@@ -405,16 +455,11 @@ def main():
         blk_exec = float(xflops[idx].sum()) / (blk_ms * 1e-3) / 1e12
         blk_alg = float(flops[idx].sum()) / (blk_ms * 1e-3) / 1e12
         conv_idx = [i for i, t in enumerate(net.layer_types) if t == "Convolution"]
-        traffic, tsrc = None, None
-        for tp in ("r02_traffic_gemm.json", "r01_traffic_conv4_2_v5.json"):
-            tpath = os.path.join(ROOT, "profiles", tp)
-            if os.path.exists(tpath):     # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
-                traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
-                tsrc = f"static: profiles/{tp} (rocprofv3 PMC passes of an earlier run of this command, not measured in this run)"
-                break
+        # HBM bytes of the dominant kernel are a PMC measurement (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): not
+        # something this process can take of itself, so the line carries null and names the file of the latest such run
+        traffic = None
+        tsrc = "not measured in this run; PMC passes of this kernel: profiles/r03_traffic_wgemm.json (tools/pmc_traffic.py)"
         peak = FP16_MFMA_PEAK_TFLOPS if args.dtype in ("f16", "f16x3") else FP32_MFMA_PEAK_TFLOPS
-        if args.dtype != "f32":
-            traffic, tsrc = None, None
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc,
@@ -425,14 +470,16 @@ def main():
                       ("x3_gemm_kernel<128|256> -- the 25 plane GEMMs of the Winograd F(3x3,3x3) layers on v_mfma_f32_32x32x16_f16 with "
                        "every fp32 operand split exactly into fp16 hi + lo: three MFMAs per product pair (all three counted as "
                        "executed FLOPs), fp32 accumulate") if args.dtype == "f16x3" else
-                      "igemm_kernel<Cfg<128,128,2,2,1,1,32,128,...,vec>> -- the 25 batched [Cout x Cin] x [Cin x tiles] GEMMs of the "
-                      "Winograd F(3x3,3x3) layers (two builds of the same kernel: 3 workgroups / CU, and 4 / CU for the >= 3000-tile "
-                      "layers; + its stream-K fix-up where a grid does not divide the tiles)",
-            "flops_note": "achieved = FLOPs the kernel's MFMAs execute for the real problem (2 * 25 * Cout * Cin * tiles per launch) / "
+                      "wgemm_kernel<256x128 | 128x256, ck32> (mscnn_amd/csrc/wgemm.hip) -- the batched [Cout x Cin] x [Cin x tiles] GEMMs of the "
+                      "Winograd layers (25 planes F(3x3,3x3), 36 planes F(4x4,3x3)) on v_mfma_f32_32x32x2_f32: 8 waves per CU, operands by "
+                      "LDS-DMA into a 3-stage ring (+ its fix-up launch where the tile count is split stream-K style)",
+            "flops_note": "achieved = FLOPs the kernel's MFMAs execute for the real problem (2 * planes * Cout * Cin * tiles per launch) / "
                           "its HIP-event time on the net's stream, summed over its launches of one image",
             **({"fp32_equivalent_tflops": round(achieved / 3, 2),
                 "fp32_equivalent_vs_fp32_mfma_peak": round(achieved / 3 / FP32_MFMA_PEAK_TFLOPS, 4)} if args.dtype == "f16x3" else {}),
             "launches_per_image": len(wino), "avg_launch_us": round(1e3 * g_ms / max(len(wino), 1), 1),
+            "gemm_ms_over_passes": {"min": round(float(min(r[wino, 1].sum() for r in stage_reps)), 4),
+                                    "max": round(float(max(r[wino, 1].sum() for r in stage_reps)), 4), "passes": reps},
             "executed_gflop_per_image": round(g_flops / 1e9, 2),
             "layers": [net.layer_names[i] for i in wino],
             "conv3_5_block": {"layers": ROOFLINE_LAYERS, "ms_per_image": round(blk_ms, 4),
@@ -484,6 +531,8 @@ def main():
         if alt:
             alt.setdefault("parity_ok", None)
             result["alt_precision"] = alt
+        if robust:
+            result["robustness"] = robust
         stage_ms = {}
         for i, nm in enumerate(net.layer_names):
             t = net.layer_types[i]

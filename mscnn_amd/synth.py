@@ -36,8 +36,14 @@ def frame(height, width, seed=1701, org_hw=(375, 1242)):
     return np.ascontiguousarray(bgr.transpose(2, 0, 1)[None], dtype=np.float32)
 
 
-def weights(layer_names, layer_types, param_shapes, regime="dense", cls_num=None):
-    """Returns {layer_name: [w, b]} for every Convolution / InnerProduct layer (Deconvolution keeps its bilinear filler)."""
+def weights(layer_names, layer_types, param_shapes, regime="dense", cls_num=None, style="he"):
+    """Returns {layer_name: [w, b]} for every Convolution / InnerProduct layer (Deconvolution keeps its bilinear filler).
+
+    style "vgg_like": the statistics a trained VGG-16 shows and He-normal noise does not -- smooth centre-weighted 3x3 taps that do
+    NOT sum to zero (so the input's DC survives into every layer), a log-normal gain per filter, a few dead filters, non-zero
+    biases, and activations that are not renormalised to unit scale after conv1_1 (the mean-subtracted frame spans [-123, 151]).
+    Used by bench.py's robustness leg and the full-size parity test: the Winograd forms carry ~10x the rounding error of the
+    direct sum, and whether that fits the 1e-4 bound depends on exactly these statistics (Net::CalibrateNumerics decides per layer)."""
     out = {}
     for idx, (name, typ, shapes) in enumerate(zip(layer_names, layer_types, param_shapes)):
         if typ not in ("Convolution", "InnerProduct") or not shapes:
@@ -47,8 +53,19 @@ def weights(layer_names, layer_types, param_shapes, regime="dense", cls_num=None
         fan_in = int(np.prod(wshape[1:]))
         w = (rng.standard_normal(wshape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
         b = np.zeros(shapes[1], np.float32) if len(shapes) > 1 else None
+        if style == "vgg_like" and typ == "Convolution" and len(wshape) == 4 and wshape[2] == 3 and wshape[3] == 3 and not name.startswith("LFCN_"):
+            tap = np.array([[0.5, 1.0, 0.5], [1.0, 2.0, 1.0], [0.5, 1.0, 0.5]]) / 2.0
+            gain = np.exp(0.5 * rng.standard_normal((wshape[0], 1, 1, 1)))
+            # low-pass part: tap sums are not zero.  (0.15 sigma: at 0.5 sigma the per-channel means compound through the ReLUs and the
+            # activations grow 3x per layer -- 2e4 at conv6_1 -- where fp32 itself no longer holds 1e-4 against another summation order)
+            dc = 0.15 * np.sqrt(2.0 / fan_in) * rng.standard_normal((wshape[0], wshape[1], 1, 1))
+            w = ((w * tap / np.sqrt((tap ** 2).mean()) + dc) * gain / np.sqrt(1.0225 * np.exp(0.25))).astype(np.float32)   # same expected output variance
+            w[rng.uniform(size=wshape[0]) < 0.03] = 0
+            if b is not None:
+                b = (0.1 * rng.standard_normal(b.shape)).astype(np.float32)
         if name == "conv1_1":
-            w *= 1.0 / 57.0          # the mean-subtracted frame has std ~57: bring activations to rms ~1
+            # the mean-subtracted frame has std ~57: bring activations to rms ~1 ("vgg_like": only to rms ~4, trained nets run hot)
+            w *= (1.0 / 28.0) if style == "vgg_like" else (1.0 / 57.0)
         if name.startswith("LFCN_"):
             # inputs to the heads are post-ReLU features with rms ~ 1: He-normal gives output sigma ~ sqrt(2) * rms / sqrt(2)
             ncls = wshape[0] - 4
@@ -57,16 +74,18 @@ def weights(layer_names, layer_types, param_shapes, regime="dense", cls_num=None
             w[:ncls] *= 1.14
             w[ncls:] *= 0.13
             b[0] = {"dense": -6.0, "mid": 8.2, "sparse": 11.5}[regime]
+            if style == "vgg_like":      # the features feeding the heads are ~20x hotter in this regime: keep scores / deltas in range
+                w *= {"LFCN_1": 0.05, "LFCN_2": 0.025, "LFCN_3": 0.015, "LFCN_4": 0.015}.get(name[:6], 0.02)
         elif name in ("cls_pred", "bbox_pred"):
-            w *= 0.7
+            w *= 0.7 * (0.04 if style == "vgg_like" else 1.0)
         out[name] = [w] + ([b] if b is not None else [])
     return out
 
 
-def load_into(net, regime="dense"):
+def load_into(net, regime="dense", style="he"):
     """Generates the weights for `net` (mscnn_amd.net.Net) and injects them through layer->blobs()."""
     shapes = [net.param_shapes(i) for i in range(len(net.layer_names))]
-    ws = weights(net.layer_names, net.layer_types, shapes, regime)
+    ws = weights(net.layer_names, net.layer_types, shapes, regime, style=style)
     for name, blobs in ws.items():
         for p, arr in enumerate(blobs):
             net.set_param(name, p, arr)

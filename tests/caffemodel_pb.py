@@ -86,7 +86,7 @@ def serialize(layers, name="from_protobuf_python", v1=False):
             else:
                 bp.shape.dim.extend(a.shape)
             if mode == "double":
-                bp.double_data.extend(float(v) for v in a.reshape(-1))
+                bp.double_data.extend(a.reshape(-1).astype(np.float64).tolist())
             else:
-                bp.data.extend(float(v) for v in a.reshape(-1))
+                bp.data.extend(a.reshape(-1).tolist())
     return net.SerializeToString()
