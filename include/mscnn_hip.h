@@ -194,6 +194,8 @@ MSCNN_API int mscnn_deconv2d_fwd_f32(const float* x, const float* w, const float
 /* out_dev[0] = max_i |a[i] - ref[i]| / max(floor, |ref[i]|) (+inf if any NaN): the parity metric of the test-suite on the
  * device; used by the host runtime's per-layer numerical calibration (Winograd against the direct sum). */
 MSCNN_API int mscnn_max_rel_diff_f32(const float* a, const float* ref, size_t count, float floor, float* out_dev, void* stream);
+/* out_dev[0] = sum_i x[i]^2 in double: the scale (rms) of a blob, the floor of the calibration metric on hot activations. */
+MSCNN_API int mscnn_sum_squares_f32(const float* x, size_t count, double* out_dev, void* stream);
 
 /* Softmax over axis 1 of x[outer][C][inner] -- SoftmaxLayer::Forward_gpu (softmax_layer.cu:83-120). */
 MSCNN_API int mscnn_softmax_fwd_f32(const float* x, float* y, int outer, int C, int inner, void* stream);

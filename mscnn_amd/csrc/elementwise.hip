@@ -267,9 +267,26 @@ __global__ __launch_bounds__(kThreads) void max_rel_diff_kernel(const float* __r
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// sum of squares in double (the scale of a blob for the calibration metric): per-wave partial sums, one f64 atomicAdd per wave
+__global__ __launch_bounds__(kThreads) void sum_squares_kernel(const float* __restrict__ x, long n, double* __restrict__ out) {
+  double s = 0.0;
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) s += (double)x[i] * (double)x[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
 }  // namespace
 
 using namespace mscnn;
+
+extern "C" int mscnn_sum_squares_f32(const float* x, size_t count, double* out_dev, void* stream) {
+  MSCNN_REQUIRE(out_dev && (count == 0 || x), "sum_squares: bad argument");
+  MSCNN_HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(double), as_stream(stream)));
+  if (count == 0) return MSCNN_OK;
+  sum_squares_kernel<<<grid_for((long)count), kThreads, 0, as_stream(stream)>>>(x, (long)count, out_dev);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
 
 extern "C" int mscnn_max_rel_diff_f32(const float* a, const float* ref, size_t count, float floor_, float* out_dev, void* stream) {
   MSCNN_REQUIRE(out_dev && (count == 0 || (a && ref)) && floor_ > 0.f, "max_rel_diff: bad argument");

@@ -27,10 +27,13 @@
 // s, s + G, ...; XCD x (workgroups b = x mod 8) owns the contiguous slots [x G/8, (x+1) G/8): in every round an XCD works on
 // 32 consecutive tiles = one or two planes, so that plane's U (<= 1 MB) and the V tile shared by the MT tiles above it stay in
 // the XCD's own 4 MB L2.  Where the tile count does not divide the grid the remainder is split stream-K style (whole
-// K chunks), partial tiles go through fp32 slabs and are summed in k order by the workgroup that owns the tile's last chunk
-// (deterministic; no atomics on data).
+// K chunks): a workgroup that holds later chunks of a split tile publishes its partial sum as a write-through fp32 slab + flag,
+// the workgroup that holds the tile's FIRST chunks (it gets to them last in time) adds the slabs in k order and stores the tile
+// (deterministic: fixed order, no atomics on data; hand-off = the release / acquire recipe of the CDNA programming guide, G16).
 #include "wgemm.h"
 #include "common.h"
+#include <atomic>
+#include <chrono>
 
 namespace {
 
@@ -42,6 +45,7 @@ struct WgemmArgs {
   int tiles, G, abl;
   int full_q;                   // whole tiles per workgroup (tile slot + r G, r < full_q); the other tiles are split stream-K style
   unsigned ws_bytes;
+  unsigned epoch;               // this launch's tag for the partial-sum hand-off flags (never 0, unique per launch in the process)
   unsigned long long* dbg;      // development: per-workgroup {shader cycles, 100 MHz ticks} over the kernel (nullptr in the product)
   unsigned up_bytes, v_bytes, m_bytes;
 };
@@ -248,7 +252,8 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   static_assert(C::NP <= C::STEPS, "one DMA piece per MFMA group");
 
   __amdgpu_buffer_rsrc_t old_rsrc = rM;                  // where the finished segment goes: M (whole tile) or a partial-sum slab
-  unsigned old_rowb = row_bytes;                          // ... and its row stride in bytes
+  unsigned old_rowb = row_bytes;                          // ... its row stride in bytes
+  bool old_pub = false;                                   // ... and whether it is a partial sum to publish (flag after its stores)
   unsigned c_addr = lds0;                                 // LDS address of the stage being multiplied
   WG_READ(0, c_addr, 0);
 
@@ -256,7 +261,10 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     constexpr int e = decltype(ec)::value;
     constexpr int blk = e / 16, r = e % 16, mi = blk / C::NI, ni = blk % C::NI, dr = (r & 3) + 8 * (r >> 2);
     const float v = old[mi][ni][r];
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 0);
+    // (a partial sum bound for another workgroup is stored write-through -- sc1 -- so that the flag that follows needs no L2
+    // write-back; the branch is wave-uniform)
+    if (old_pub) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 16);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 0);
   };
 
   // one chunk = STEPS MFMA groups.  FLUSH: the previous tile's stores ride along (SPM per MFMA); DMA: this chunk carries the
@@ -305,15 +313,29 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     return lds0 + (unsigned)c_stage * C::STAGE_BYTES;
   };
   int t, k0, k1, part;
+  int fin_tile = -1;
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  gu64* flags = (gu64*)(a.ws + (size_t)a.G * (C::BM * C::BN));      // [G] hand-off flags + 1 status word, behind the G slabs
+  const unsigned long long want_flag = ((unsigned long long)a.epoch << 32) | (unsigned)~a.epoch;
+  auto publish_flag = [&]() {      // R1 of the guide's hand-off recipe: every storing wave drains, one barrier, ONE lane sets the flag
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid == 0) __hip_atomic_store(flags + slot, want_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   while (ccur.next(t, k0, k1, part)) {
     // first chunk of the segment: the previous segment's stores ride along (segment 0: `old` is empty, its offsets out of range)
     chunk(std::true_type{}, next_stage_addr());
+    if (old_pub) { publish_flag(); old_pub = false; }
     for (int kc = k0 + 1; kc < k1; ++kc) chunk(std::false_type{}, next_stage_addr());
-    // ---- segment done: move its accumulators aside ----
+    // ---- segment done: move its accumulators aside.  Whole tile -> M.  Partial without the tile's first chunk -> this
+    // workgroup's slab, published for the workgroup that has it.  Partial WITH the first chunk (always the last segment) -> M,
+    // after the other contributors' slabs have been added (below). ----
     const int mt = t % a.MT, nt = (t / a.MT) % a.NT, p = t / (a.MT * a.NT);
-    if (part < 0) { old_rsrc = rM; old_rowb = row_bytes; }
-    else { old_rsrc = rW; old_rowb = (unsigned)C::BN * 4u; }
-    const unsigned slab = (unsigned)(slot * 2 + (part < 0 ? 0 : part)) * (unsigned)(C::BM * C::BN * 4);
+    const bool pub = part >= 0 && k0 > 0;
+    if (part >= 0 && k0 == 0) fin_tile = t;
+    old_pub = pub;
+    if (pub) { old_rsrc = rW; old_rowb = (unsigned)C::BN * 4u; }
+    else { old_rsrc = rM; old_rowb = row_bytes; }
+    const unsigned slab = (unsigned)slot * (unsigned)(C::BM * C::BN * 4);
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
@@ -322,72 +344,53 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
         const int co0 = mt * C::BM + row;
         const unsigned to_m = co0 + 32 <= a.Cout ? ((unsigned)(p * a.Cout + co0 + 4 * khalf) * (unsigned)a.T_pad + (unsigned)(nt * C::BN + col)) * 4u : 0x80000000u;
         const unsigned to_ws = slab + (unsigned)((row + 4 * khalf) * C::BN + col) * 4u;
-        old_voff[mi][ni] = part < 0 ? to_m : to_ws;
+        old_voff[mi][ni] = pub ? to_ws : to_m;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { old[mi][ni][r] = acc[mi][ni][r]; acc[mi][ni][r] = 0.f; }
       }
   }
+  if (fin_tile >= 0) {
+    // ---- finish the split tile whose first chunks this workgroup computed: add the other contributors' slabs in k order (the
+    // workgroups slot + 1, slot + 2, ... until the tile's chunks are covered; each published its part as ITS first remainder
+    // segment, i.e. earlier in time).  Deterministic: the order of the additions is fixed. ----
+    const int rem_tile0 = a.full_q * a.G, RU = (a.tiles - rem_tile0) * a.KI;
+    const int tile_end = (fin_tile - rem_tile0 + 1) * a.KI;
+    for (int s2 = slot + 1; s2 < a.G; ++s2) {
+      int b, e;
+      wg_range(RU, a.G, s2, b, e);
+      if (b >= tile_end) break;
+      if (e <= b) continue;
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flags + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_flag && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
+        if (spins >= (1u << 22)) __hip_atomic_store(flags + a.G, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // status word: hand-off timed out
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      asm volatile("s_barrier" ::: "memory");
+      const unsigned sl2 = (unsigned)s2 * (unsigned)(C::BM * C::BN * 4);
+#pragma unroll
+      for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni) {
+          const unsigned vo = sl2 + (unsigned)((wm * C::WM + mi * 32 + 4 * khalf) * C::BN + wn * C::WN + ni * 32 + l31) * 4u;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            old[mi][ni][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)(C::BN * 4), 0));
+        }
+    }
+  }
   // the last tile's stores
   if (!(ABL & 2) || a.tiles < 0) static_for<0, NMF * 16>([&](auto ec) { store_one(ec); });      // (ablation builds keep the MFMAs alive)
+  if (old_pub) publish_flag();
   if (a.dbg && tid == 0) {
     a.dbg[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - dbg_c;
     a.dbg[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - dbg_r;
   }
 }
 
-// Sums the partial slabs of the remainder tiles in k order (deterministic) into M.  BM * BN / 4096 workgroups per tile, each owning
-// 4096 consecutive slab elements (four float4 per thread).
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void wgemm_fixup_kernel(WgemmArgs a) {
-  constexpr int SPLIT = BM * BN / 4096;
-  __shared__ const float* s_slab[64];
-  __shared__ int s_n;
-  const int j = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;      // j: index among the remainder tiles
-  const int rem_tile0 = a.full_q * a.G;
-  const int RU = (a.tiles - rem_tile0) * a.KI;
-  if (threadIdx.x == 0) {
-    const int its = j * a.KI, ite = its + a.KI;
-    int gf = (int)((long)its * a.G / RU), gl = (int)((long)(ite - 1) * a.G / RU);
-    int b, e;
-    wg_range(RU, a.G, gf, b, e);
-    while (e <= its) { ++gf; wg_range(RU, a.G, gf, b, e); }
-    while (b > its) { --gf; wg_range(RU, a.G, gf, b, e); }
-    wg_range(RU, a.G, gl, b, e);
-    while (e <= ite - 1) { ++gl; wg_range(RU, a.G, gl, b, e); }
-    while (b > ite - 1) { --gl; wg_range(RU, a.G, gl, b, e); }
-    int n = 0;
-    if (gf != gl) {               // gf == gl: one workgroup computed the whole tile and stored it to M itself
-      for (int g = gf; g <= gl && n < 64; ++g) {
-        wg_range(RU, a.G, g, b, e);
-        if (e <= b) continue;
-        // the tile holding a workgroup's first remainder unit is its slab 0, the next one its slab 1
-        s_slab[n++] = a.ws + ((long)g * 2 + (b / a.KI == j ? 0 : 1)) * (BM * BN);
-      }
-    }
-    s_n = n;
-  }
-  __syncthreads();
-  const int n = s_n;
-  if (n == 0) return;
-  const int t = rem_tile0 + j;
-  const int mt = t % a.MT, nt = (t / a.MT) % a.NT, p = t / (a.MT * a.NT);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = part * 4096 + (q * 256 + threadIdx.x) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int sidx = 0; sidx < n; ++sidx) {
-      const float4 u = *reinterpret_cast<const float4*>(s_slab[sidx] + i);
-      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-    }
-    const int row = i / BN, col = i % BN, co = mt * BM + row;
-    if (co >= a.Cout) continue;
-    *reinterpret_cast<float4*>(a.M + ((long)p * a.Cout + co) * a.T_pad + nt * BN + col) = v;
-  }
-}
-
 typedef void (*WgemmFn)(WgemmArgs);
-struct WEntry { const char* name; int variant, abl, BM, BN, CK, threads; WgemmFn fn, fix; };
-#define WG_ENTRY(name, v, abl, BM, BN, WGM, WGN, CK) {name, v, abl, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3>, abl>, wgemm_fixup_kernel<BM, BN>}
+struct WEntry { const char* name; int variant, abl, BM, BN, CK, threads; WgemmFn fn; };
+#define WG_ENTRY(name, v, abl, BM, BN, WGM, WGN, CK) {name, v, abl, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3>, abl>}
 const WEntry kW[] = {
     WG_ENTRY("wgemm_256x128_ck32", 1, 0, 256, 128, 4, 2, 32),
     WG_ENTRY("wgemm_128x256_ck32", 2, 0, 128, 256, 2, 4, 32),
@@ -400,6 +403,9 @@ const WEntry kW[] = {
     WG_ENTRY("wgemm_256x128_ck32", 1, 11, 256, 128, 4, 2, 32),
     WG_ENTRY("wgemm_256x128_ck32", 1, 19, 256, 128, 4, 2, 32),
     WG_ENTRY("wgemm_256x128_ck32", 1, 27, 256, 128, 4, 2, 32),
+    WG_ENTRY("wgemm_128x256_ck32", 2, 1, 128, 256, 2, 4, 32),
+    WG_ENTRY("wgemm_128x256_ck32", 2, 2, 128, 256, 2, 4, 32),
+    WG_ENTRY("wgemm_128x256_ck32", 2, 3, 128, 256, 2, 4, 32),
 #endif
 };
 
@@ -421,20 +427,22 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   o->MT = (Cout + e->BM - 1) / e->BM; o->NT = o->T_pad / e->BN; o->KI = Cin / e->CK;
   o->G = 256;                   // one 512-thread workgroup per CU
   const long tiles = (long)P * o->MT * o->NT;
-  // Whole tiles (ceil(tiles / G) rounds) or the hybrid stream-K split of the last partial round?  The split costs a fix-up launch
-  // that moves three slabs per remainder tile (measured ~3 TB/s + ~5 us, profiles/r03_wgemm.txt): it pays for the small layers
-  // (conv6_1: 50 tiles on 256 CUs) and not where the last round is nearly full (conv4_2: 750 tiles = 2.93 rounds).
+  // Whole tiles (ceil(tiles / G) rounds) or the hybrid stream-K split of the last partial round?  Fitted to the measurements of
+  // profiles/r03_wgemm.txt (256 x 128 x 32 chunks: 3.7 us each at the sustained clock, ~6 us per tile for its ride-along stores,
+  // ~18 us for a workgroup's slab hand-off): the split wins for conv4_2 / conv4_3 / loss1 in the F(4x4,3x3) form (648 tiles = 2.53
+  // rounds: 173 vs 187 us), roi_c1 (1100 tiles: 548 vs 605) and conv6_1 (50 tiles: 38 vs 71); whole tiles win where the last round is
+  // nearly full (conv4_2 F(3x3,3x3): 750 tiles = 2.93 rounds, 192 vs 196) -- the model reproduces each of those choices.
   const long rem = tiles % o->G;
-  const double chunk_us = (double)e->BM * e->BN * e->CK / 128.0 / 2300.0;                       // MFMA-bound time of one K chunk
-  const double whole = (double)((tiles + o->G - 1) / o->G) * o->KI;
-  const double split = (double)tiles * o->KI / o->G + (5.0 + (double)rem * 3.0 * e->BM * e->BN * 4.0 / 3.0e6) / chunk_us;
+  const double chunk_us = (double)e->BM * e->BN * e->CK / 128.0 / 2214.0;                       // MFMA-bound time of one K chunk
+  const double whole = (double)((tiles + o->G - 1) / o->G) * (o->KI * chunk_us + 6.0);
+  const double split = (double)tiles * o->KI / o->G * chunk_us + (double)tiles / o->G * 6.0 + 18.0;
   o->full_q = (int)(tiles / o->G);
-  if (rem > 0 && !(split < 0.93 * whole)) o->full_q += 1;       // whole tiles: the last round is simply not full
+  if (rem > 0 && !(split < 0.97 * whole)) o->full_q += 1;       // whole tiles: the last round is simply not full
   if (variant_flags & 1) o->full_q = (int)(tiles / o->G);       // development: force the split
   if (variant_flags & 2) o->full_q = (int)((tiles + o->G - 1) / o->G);   // ... or whole tiles
   o->variant = variant; o->name = e->name;
   o->packed_bytes = (size_t)P * o->MT * o->KI * e->CK * e->BM * 4;
-  o->ws_bytes = tiles > (long)o->full_q * o->G ? (size_t)o->G * 2 * e->BM * e->BN * 4 : 0;
+  o->ws_bytes = tiles > (long)o->full_q * o->G ? (size_t)o->G * e->BM * e->BN * 4 + ((size_t)o->G + 1) * 8 : 0;     // slabs, flags, status
   const double lim = 4.0e9;
   if ((double)tiles * o->KI * o->G >= 2.0e9 || o->KI < 1) return false;      // wg_range's 32-bit product
   if ((double)P * Cin * o->T_pad * 4 >= lim || (double)P * Cout * o->T_pad * 4 >= lim || (double)o->packed_bytes >= lim) return false;
@@ -453,12 +461,14 @@ int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, 
   const int rem = a.tiles - p.full_q * p.G;
   if (rem > 0 && !ws) { set_error("wgemm: workspace missing"); return MSCNN_ERR_WORKSPACE; }
   a.up_bytes = (unsigned)p.packed_bytes; a.v_bytes = (unsigned)((size_t)p.P * p.Cin * p.T_pad * 4); a.m_bytes = (unsigned)((size_t)p.P * p.Cout * p.T_pad * 4);
+  // hand-off tag of this launch: unique within the process (monotonic), seeded per process so that flags a previous process left
+  // in recycled device memory cannot match either; the workspace needs no clearing between launches
+  static std::atomic<unsigned> g_epoch{(unsigned)std::chrono::steady_clock::now().time_since_epoch().count() * 2654435761u};
+  unsigned ep = ++g_epoch;
+  if (ep == 0) ep = ++g_epoch;
+  a.epoch = ep;
   e->fn<<<p.G, e->threads, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
-  if (rem > 0) {
-    e->fix<<<rem * (e->BM * e->BN / 4096), 256, 0, st>>>(a);
-    MSCNN_POST_LAUNCH();
-  }
   return MSCNN_OK;
 }
 

@@ -209,10 +209,19 @@ double ConvolutionLayer<Dtype>::ErrorAgainstDirect(const vector<Blob<Dtype>*>& b
   const float* w = this->blobs_[0]->gpu_data();
   MSCNN_CHECK(mscnn_conv2d_pack_weights(dp, w, pk, S()));
   float* yd = static_cast<float*>(y.Reserve(sizeof(float) * top[0]->count()));
-  float* ed = static_cast<float*>(err.Reserve(sizeof(float)));
+  float* ed = static_cast<float*>(err.Reserve(sizeof(double) * 2));
+  double* sd = reinterpret_cast<double*>(ed) + 1;
   MSCNN_CHECK(mscnn_conv2d_fwd_f32(dp, bottom[0]->gpu_data(), w, pk, bias_term_ ? this->blobs_[1]->gpu_data() : nullptr, yd,
                                    wb ? ws.Reserve(wb) : nullptr, wb, S()));
-  MSCNN_CHECK(mscnn_max_rel_diff_f32(top[0]->gpu_data(), yd, (size_t)top[0]->count(), 1.0f, ed, S()));
+  // The metric: max |dy| / max(1, |y|, rms(y)).  On unit-scale activations this is the parity metric of the tests (rms ~ 1 .. 3); on
+  // hot ones (rms 10 .. 100, trained nets) an element near zero is the difference of partial sums far larger than itself, where
+  // two fp32 summation orders of the DIRECT form already differ by more than 1e-4 of 1 -- the floor follows the blob's scale.
+  MSCNN_CHECK(mscnn_sum_squares_f32(yd, (size_t)top[0]->count(), sd, S()));
+  double ss = 0.0;
+  HIP_CHECK(hipMemcpyAsync(&ss, sd, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)S()));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)S()));
+  const float rms = (float)std::sqrt(ss / (double)top[0]->count());
+  MSCNN_CHECK(mscnn_max_rel_diff_f32(top[0]->gpu_data(), yd, (size_t)top[0]->count(), rms > 1.0f ? rms : 1.0f, ed, S()));
   float e = 0.f;
   HIP_CHECK(hipMemcpyAsync(&e, ed, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)S()));
   HIP_CHECK(hipStreamSynchronize((hipStream_t)S()));
