@@ -1529,7 +1529,8 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
     float* M = V + planes * d.Cin * p->T_pad;
     float* gws = M + planes * d.Cout * p->T_pad;
     MSCNN_STAGE_EVENT(0);
-    int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st);
+    int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st,
+                                  (d.tune_flags & 256) != 0);
     if (rc != MSCNN_OK) return rc;
     MSCNN_STAGE_EVENT(1);
     if (p->use_wg) rc = mscnn::wgemm_launch(p->wg, packed, V, M, gws, st);
@@ -1537,7 +1538,7 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
     if (rc != MSCNN_OK) return rc;
     MSCNN_STAGE_EVENT(2);
     rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st,
-                               p->wino_m >= 3 ? p->amax_out : nullptr);
+                               p->wino_m >= 3 ? p->amax_out : nullptr, (d.tune_flags & 256) != 0);
     if (rc != MSCNN_OK) return rc;
     MSCNN_STAGE_EVENT(3);
     p->ev_valid = p->profiling;

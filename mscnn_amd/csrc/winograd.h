@@ -13,12 +13,14 @@ int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, i
 // V[xinu][ci][t] = (B^T d B)[xi][nu],  d = the 4x4 input patch of output tile t = (n, ty, tx) (zero outside the image);
 // t < T real tiles, row stride T_pad (columns T..T_pad are written as zeros).
 int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
-                         int tiles_w, int T_pad, hipStream_t st);
+                         int tiles_w, int T_pad, hipStream_t st, bool scalar_f4 = false);
+// scalar_f4: F(4x4,3x3) only -- run the scalar kernels (the bodies of wino_f4_math.h, checked on the host) instead of the vectorised
+// ones; mscnn_conv_desc::tune_flags bit 8, used by the bit-identity test and for A/B runs
 
 // y[n][co][2ty + i][2tx + j] = (A^T m A)[i][j] + bias[co], optional ReLU;  m[xi][nu] = M[xinu][co][t].
 // y_pool != nullptr: also write max over the tile's (in-plane) outputs to y_pool[n][co][ty][tx] (fused 2x2/2 max pooling).
 int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
-                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st, unsigned* amax = nullptr);
+                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st, unsigned* amax = nullptr, bool scalar_f4 = false);
 // amax != nullptr (m >= 3 only): max |y| is published as bit patterns into amax[0 .. kAmaxSlots) (atomicMax, one slot per
 // workgroup; the caller zeroes the slots before the forward and takes the maximum over them)
 

@@ -20,6 +20,7 @@
 #include "winograd.h"
 #include "x3_device.h"
 #include "wino_f4_math.h"
+#include <cstdint>
 
 namespace {
 
@@ -504,6 +505,131 @@ __global__ __launch_bounds__(256) void wino44_output_kernel(const float* __restr
   if (amax) mscnn::publish_amax(am, amax, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
+
+// Vectorised forms of the two F(4x4,3x3) data transforms for the common geometry (pad 1, W a multiple of 4, 16-byte aligned planes):
+// a 4x4 tile's columns are one aligned float4 per input row, so a lane loads SIX float4 (its 4 new columns of the 6 patch rows)
+// instead of 36 scalars at a 16-byte lane stride (every cache line fetched six times through the L1), and takes the patch's
+// left / right column from its neighbour lanes (tiles of one tile row sit in consecutive lanes).  One wave = up to 64 consecutive
+// tiles of ONE tile row; the arithmetic is wino_f4::bt6 / at6 in the scalar kernels' order, so the planes are bit-identical
+// (tests/test_gpu_ops.py::test_wino_f4_vector_transforms_bit_identical).  Measured: profiles/r03_ab_f4_transforms.txt.
+__global__ __launch_bounds__(256) void wino44_input_vec_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int Cin, int H, int W,
+                                                               int pad_h, int tiles_h, int tiles_w, int segs, int T_pad) {
+  const int lane = threadIdx.x & 63;
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);            // wave -> (n, ty, segment of the tile row)
+  const int ci = blockIdx.y;
+  const int seg = wv % segs, row = wv / segs;                    // row = n * tiles_h + ty
+  if (row >= N * tiles_h) return;
+  const int ty = row % tiles_h, n = row / tiles_h;
+  const int tx = seg * 64 + lane;
+  const bool live = tx < tiles_w;
+  const float* src = x + ((long)n * Cin + ci) * H * W;
+  float d[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int h = 4 * ty - pad_h + i;
+    const bool ok = live && h >= 0 && h < H;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) v = *reinterpret_cast<const float4*>(src + (long)h * W + 4 * tx);
+    float left = __shfl_up(v.w, 1), right = __shfl_down(v.x, 1);
+    // wave borders: the neighbour tile lives in another wave (or outside the image: zero padding)
+    if (lane == 0) left = (ok && tx > 0) ? src[(long)h * W + 4 * tx - 1] : 0.f;
+    if (lane == 63 || tx == tiles_w - 1) right = (ok && tx + 1 < tiles_w) ? src[(long)h * W + 4 * tx + 4] : 0.f;
+    d[i][0] = left; d[i][1] = v.x; d[i][2] = v.y; d[i][3] = v.z; d[i][4] = v.w; d[i][5] = right;
+  }
+  if (!live) return;
+  const long plane_stride = (long)Cin * T_pad;
+  float* dst = V + (long)ci * T_pad + (long)row * tiles_w + tx;
+  float r[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+    float o[6];
+    wino_f4::bt6(col, o);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r[i][j] = o[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float o[6];
+    wino_f4::bt6(r[i], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * plane_stride] = o[j];
+  }
+}
+
+// columns T .. T_pad of every plane (the GEMM's padding tiles) are zeros
+__global__ __launch_bounds__(256) void wino_zero_tail_kernel(float* __restrict__ V, int planes, int C, int T, int T_pad) {
+  const int tail = T_pad - T;
+  const long total = (long)planes * C * tail;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) V[(i / tail) * T_pad + T + i % tail] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void wino44_output_vec_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y,
+                                                                float* __restrict__ yp, int N, int Cout, int Ho, int Wo, int tiles_h,
+                                                                int tiles_w, int T, int T_pad, int relu, unsigned* __restrict__ amax) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int co = blockIdx.y;
+  unsigned am = 0;
+  if (t < T) {
+    const long plane_stride = (long)Cout * T_pad;
+    const float* src = M + (long)co * T_pad + t;
+    float r[4][6];   // A^T m (columns of m)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float col[6], o[4];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) col[i] = src[(i * 6 + j) * plane_stride];
+      wino_f4::at6(col, o);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i][j] = o[i];
+    }
+    const float b = bias ? bias[co] : 0.f;
+    const int tx = t % tiles_w, ty = (t / tiles_w) % tiles_h, n = t / (tiles_w * tiles_h);
+    float* dst = y + ((long)n * Cout + co) * Ho * Wo;
+    float out[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float o[4];
+      wino_f4::at6(r[i], o);     // (A^T m) A
+      const int oh = 4 * ty + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float u = o[j] + b;
+        if (relu) u = u > 0.f ? u : 0.f;
+        out[i][j] = u;
+      }
+      if (oh < Ho) {             // (Wo is a multiple of 4 here: every column of the tile is inside the plane)
+        *reinterpret_cast<float4*>(dst + (long)oh * Wo + 4 * tx) = make_float4(out[i][0], out[i][1], out[i][2], out[i][3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const unsigned a = wino_f4::abs_bits(out[i][j]); am = a > am ? a : am; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[i][j] = -3.402823466e+38f;
+      }
+    }
+    if (yp) {
+      const int Hp = (Ho + 1) / 2, Wp = Wo / 2;
+      float* pd = yp + ((long)n * Cout + co) * Hp * Wp;
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const int ph = 2 * ty + pi;
+        if (ph >= Hp) continue;
+        float m2[2];
+#pragma unroll
+        for (int pj = 0; pj < 2; ++pj) {
+          float m = out[2 * pi][2 * pj];
+          if (out[2 * pi][2 * pj + 1] > m) m = out[2 * pi][2 * pj + 1];
+          if (out[2 * pi + 1][2 * pj] > m) m = out[2 * pi + 1][2 * pj];
+          if (out[2 * pi + 1][2 * pj + 1] > m) m = out[2 * pi + 1][2 * pj + 1];
+          m2[pj] = m;
+        }
+        *reinterpret_cast<float2*>(pd + (long)ph * Wp + 2 * tx) = make_float2(m2[0], m2[1]);
+      }
+    }
+  }
+  if (amax) mscnn::publish_amax(am, amax, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
 }  // namespace
 
 namespace mscnn {
@@ -520,10 +646,18 @@ int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, i
 }
 
 int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
-                         int tiles_w, int T_pad, hipStream_t st) {
+                         int tiles_w, int T_pad, hipStream_t st, bool scalar_f4) {
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T_pad, 256), Cin);
-  if (m == 4) {
+  if (m == 4 && pad_w == 1 && W % 4 == 0 && tiles_w * 4 == W && reinterpret_cast<uintptr_t>(x) % 16 == 0 && !scalar_f4) {
+    const int segs = cdiv(tiles_w, 64);
+    wino44_input_vec_kernel<<<dim3(cdiv((long)N * tiles_h * segs, 4), Cin), 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, tiles_h, tiles_w, segs, T_pad);
+    MSCNN_POST_LAUNCH();
+    if (T_pad > T) {
+      const long total = 36L * Cin * (T_pad - T);
+      wino_zero_tail_kernel<<<(int)(total + 255 < 256L * 2048 ? (total + 255) / 256 : 2048), 256, 0, st>>>(V, 36, Cin, T, T_pad);
+    }
+  } else if (m == 4) {
     wino44_input_plane_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
   } else if (m == 3 && H * W <= kW33MaxHW) {
     dim3 g3(cdiv(N, kW33Rois), cdiv(Cin, kW33Ch));
@@ -536,11 +670,14 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
 }
 
 int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
-                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st, unsigned* amax) {
+                          int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st, unsigned* amax, bool scalar_f4) {
   MSCNN_REQUIRE(!amax || m >= 3, "winograd: max |y| is published by the F(3x3,3x3) / F(4x4,3x3) output transforms only");
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T, 256), Cout);
-  if (m == 4) {
+  if (m == 4 && Wo % 4 == 0 && tiles_w * 4 == Wo && reinterpret_cast<uintptr_t>(y) % 16 == 0 && (!y_pool || reinterpret_cast<uintptr_t>(y_pool) % 8 == 0) &&
+      !scalar_f4) {
+    wino44_output_vec_kernel<<<grid, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu, amax);
+  } else if (m == 4) {
     wino44_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu, amax);
   } else if (m == 3 && y_pool) {
     MSCNN_REQUIRE(tiles_h % 2 == 0 && tiles_w % 2 == 0, "winograd F(3x3,3x3): fused pooling needs even tile counts");

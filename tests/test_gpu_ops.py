@@ -274,6 +274,27 @@ def test_conv_winograd_f4x4_fused_pool(hip, orc, case):
     assert np.array_equal(yp.cpu().numpy(), orc.pool2d(y))
 
 
+@pytest.mark.parametrize("case", [(1, 32, 24, 64, 48), (2, 16, 36, 260, 32), (1, 64, 72, 240, 64), (1, 8, 10, 512, 16), (1, 24, 13, 28, 40)])
+def test_wino_f4_vector_transforms_bit_identical(hip, case):
+    """The vectorised F(4x4,3x3) transforms (float4 rows + neighbour-lane halo, float4 / float2 stores) against the scalar kernels
+    whose per-thread bodies the host model checks (tune_flags bit 8): same arithmetic, same order -- y and the fused pooled output
+    must be bit-identical, over tile rows shorter / longer than a wave, several segments per row, odd tile-row counts and batch 2."""
+    N, Cin, H, W, Cout = case
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((N, Cin, H, W), device="cuda", generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn((Cout,), device="cuda", generator=g)
+    outs = []
+    for flags in (0, 256):
+        plan = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True, algo=hip.ALGO_WINO_F4, tune_flags=flags)
+        plan.pack(w)
+        yp = torch.full((N, Cout, (H + 1) // 2, (W + 1) // 2), float("nan"), device="cuda")
+        y = plan.forward(x, b, pool_out=yp).clone()
+        outs.append((y, yp))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][1], hip.pool2d(outs[0][0], (2, 2), (0, 0), (2, 2)))
+
+
 WINO33_CASES = [   # R, Cin, H, W, Cout, pad  (ROI-pooled maps -> roi_c1)
     (20, 64, 7, 7, 48, 0),        # kitti_car: 7x7 -> 5x5 (2x2 tiles of 3x3, last row / column dropped)
     (33, 40, 7, 5, 130, 0),       # ped/cyc: 7x5 -> 5x3
