@@ -1063,16 +1063,15 @@ static bool wino_plan(mscnn_conv_plan* p) {
   // 481 us with F(2x2,3x3), conv4_2 304 vs 389, conv5_1 107 vs 125, and the same end-to-end error, 3e-5).
   // Threshold for F(3x3,3x3): conv2_2 (intensity 64) 523 vs 642 us direct, conv2_1 (43) 375 vs 383 (tie -> direct), conv1_2
   // (32) 1175 vs 762.  WINO_F2 selects F(2x2,3x3) on planes for A/B runs and tests.
-  // F(4x4,3x3) on whole planes (36 planes; wino_f4_math.h; points {0, 1, -1, 2, -1/2, inf}: the fp32 error of the F(3x3,3x3) form):
-  // 19 % fewer GEMM FLOPs and plane bytes.  First run on hardware in round 3 (profiles/r03_ab_wino_f4.txt, 7s-576 layers, us,
-  // AUTO of round 2 / F(3x3,3x3) / F(4x4,3x3)): conv2_1 435 (direct) / 330 / 310, conv2_2 469 / 469 / 436, conv3_2 336 / 336 / 329,
-  // conv4_2 287 / 286 / 279 -- but conv3_1 226 / 226 / 233, conv4_1 178 / 177 / 180, conv5_1 110 / 110 / 119: with 36 planes the
-  // tile count of the batched GEMM no longer divides its grid on the Cout = 2 Cin layers, and below 1000 tiles the 128-tile
-  // padding eats the gain.  AUTO therefore takes F(4x4,3x3) where the 4x4 tiles number >= 1000 and the layer is not one of the
-  // (Cin >= 128, Cout = 2 Cin) shapes; intensity threshold 40 (conv2_1: 43) instead of 60.
+  // F(4x4,3x3) on whole planes (36 planes; wino_f4_math.h; points {0, 1, -1, 2, -1/2, inf}: the fp32 error of the F(3x3,3x3) form within
+  // 0.8 .. 3.2x, profiles/r03_robustness.txt): 19 % fewer GEMM FLOPs and plane bytes.  First run on hardware in round 3.  With the
+  // round-2 GEMM kernel it only paid where the tile count happened to divide the grid (profiles/r03_ab_wino_f4.txt); with the
+  // wgemm kernel's stream-K schedule and the vectorised transforms (profiles/r03_ab_f4_more.txt, 7s-576 layers, us, F(3x3,3x3) /
+  // F(4x4,3x3)): conv3_1 214 / 175, conv4_1 161 / 152, conv2_1 330 / 268 (direct: 435), conv2_2 469 / 374, conv3_2 336 / 273,
+  // conv4_2 286 / 243 -- but conv5_1 103 / 105 (270 tiles of 4x4 pad to 384: the 128-tile padding eats the gain).  AUTO therefore
+  // takes F(4x4,3x3) where the 4x4 tiles number >= 1000; intensity threshold 40 (conv2_1: 43) instead of 60.
   const long T4 = (long)d.N * cdiv(p->Ho, 4) * cdiv(p->Wo, 4);
-  const bool auto_f4 = algo == MSCNN_CONV_ALGO_AUTO && !roi_map && T4 >= 1000 && !(d.Cin >= 128 && d.Cout == 2 * d.Cin) &&
-                       !(d.tune_flags & 64);         // (tune_flags bit 6: A/B runs keep the round-2 choice)
+  const bool auto_f4 = algo == MSCNN_CONV_ALGO_AUTO && !roi_map && T4 >= 1000 && !(d.tune_flags & 64);   // (bit 6: A/B runs keep F(3x3,3x3))
   const int m = roi_map ? 3 : (algo == MSCNN_CONV_ALGO_WINO_F2 ? 2 : (algo == MSCNN_CONV_ALGO_WINO_F4 || auto_f4) ? 4 : 3);
   const int planes = (m + 2) * (m + 2);
   // (split-fp16: the direct kernel runs at ~800 TFLOP/s executed, so Winograd -- HBM-bound on its V / M planes -- only pays from

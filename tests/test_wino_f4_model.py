@@ -207,11 +207,11 @@ def test_f4_plan_plumbing_without_a_device():
     assert L.mscnn_conv2d_workspace_bytes(p4._p) >= 36 * (512 + 512) * pad4 * 4
     roi = hip.ConvPlan(64, 1024, 7, 7, 512, 3, 3, (0, 0), relu=True, algo=hip.ALGO_WINO_F4, device="cpu")
     assert roi.kernel == "winograd_f3x3_3x3"
-    # AUTO (round 3, after the first hardware runs): F(4x4,3x3) where the 4x4 tiles number >= 1000 and the shape is not Cout = 2 Cin >= 256
+    # AUTO (round 3, after the first hardware runs): F(4x4,3x3) where the 4x4 tiles number >= 1000
     auto = lambda cin, h, w, cout, **kw: hip.ConvPlan(1, cin, h, w, cout, 3, 3, (1, 1), device="cpu", **kw).kernel      # noqa: E731
     assert auto(512, 72, 240, 512) == "winograd_f4x4_3x3" and auto(256, 144, 480, 256) == "winograd_f4x4_3x3"
     assert auto(128, 288, 960, 128) == "winograd_f4x4_3x3" and auto(64, 288, 960, 128) == "winograd_f4x4_3x3"        # conv2_2, conv2_1
-    assert auto(128, 144, 480, 256) == "winograd_f3x3_3x3" and auto(256, 72, 240, 512) == "winograd_f3x3_3x3"        # conv3_1, conv4_1
+    assert auto(128, 144, 480, 256) == "winograd_f4x4_3x3" and auto(256, 72, 240, 512) == "winograd_f4x4_3x3"        # conv3_1, conv4_1
     assert auto(512, 36, 120, 512) == "winograd_f3x3_3x3" and auto(512, 18, 60, 512) == "winograd_f3x3_3x3"          # conv5_x, conv6_1
     assert auto(64, 576, 1920, 64).startswith("igemm_")                                                              # conv1_2 stays direct
     assert auto(512, 72, 240, 512, tune_flags=64) == "winograd_f3x3_3x3"                                             # A/B knob: the round-2 choice

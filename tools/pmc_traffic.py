@@ -12,8 +12,9 @@ def per_kernel(path, counter):
             if r["Counter_Name"] != counter:
                 continue
             n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-            key = "gemm" if "igemm_kernel" in n else "gemm_fixup" if "igemm_fixup" in n else "input_transform" if "wino33_input" in n else \
-                "output_transform" if "wino33_output" in n else None
+            key = "gemm" if ("wgemm_kernel" in n or "igemm_kernel" in n) else "gemm_fixup" if "igemm_fixup" in n else \
+                "input_transform" if ("wino33_input" in n or "wino44_input" in n) else \
+                "output_transform" if ("wino33_output" in n or "wino44_output" in n) else "zero_tail" if "wino_zero_tail" in n else None
             if key:
                 acc[key].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
@@ -21,15 +22,18 @@ def per_kernel(path, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 kb = {k: 2.0 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in set(fetch) | set(write)}
+planes, T_pad = (36, 1152) if len(sys.argv) <= 4 or sys.argv[4] == "f4" else (25, 1920)
 out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
-                  "python tools/bench_layers.py --iters 6 --only conv4_2   (conv4_2: 1x512x72x240 -> 512, Winograd F(3x3,3x3))",
+                  "python tools/bench_layers.py --iters 6 --only conv4_2   (conv4_2: 1x512x72x240 -> 512, Winograd "
+                  + ("F(4x4,3x3), 36 planes of 512 x 512 x 1152)" if planes == 36 else "F(3x3,3x3), 25 planes of 512 x 512 x 1920)"),
        "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
        "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE = 64 B per 128-B request on gfx950 -> x2; WRITE_SIZE taken as is",
-       "kernel": "igemm_kernel<Cfg<128,128,2,2,1,1,32,128,...,vec>> on conv4_2's 25 planes (512 x 512 x 1920 each)",
+       "kernel": "wgemm_kernel<256x128, ck32> on conv4_2's plane GEMMs",
        "traffic_bytes_per_launch": int(1024 * kb.get("gemm", 0.0)),
-       "algorithmic_bytes_per_launch": int(25 * (512 * 512 + 512 * 1920 + 512 * 1920) * 4),
+       "algorithmic_bytes_per_launch": int(planes * (512 * 512 + 512 * T_pad + 512 * T_pad) * 4),
        "layer_traffic_bytes": {k: int(1024 * v) for k, v in kb.items()},
-       "note": "fabric-side (L2 miss) bytes of ONE launch of the dominant kernel: it reads U (26 MB) and V (98 MB) and writes M (98 MB) = "
-               "222 MB algorithmic; re-reads beyond that are L2 misses of operand tiles shared between workgroups on different XCDs"}
+       "note": "fabric-side (L2 miss) bytes of ONE launch of the dominant kernel: it reads U and V and writes M once (algorithmic); "
+               "re-reads beyond that are L2 misses of operand tiles shared between workgroups on different XCDs; the stream-K slabs "
+               "(128 KB per workgroup, written through and read once) are part of the measured figure"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
