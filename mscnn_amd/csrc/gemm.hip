@@ -305,6 +305,10 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(GemmArgs a) {
 // (K / 256 values per thread), every output n is a register dot product + wave reduction, the 4 wave partials of all N
 // outputs are combined after ONE barrier.  W (N x K) is re-read by every workgroup out of L2.
 constexpr int kRowMaxN = 64, kRowMaxKPerThread = 16, kRowsPerBlock = 4;
+// NB = outputs handled per pass, a compile-time bound: the NB dot products and their wave reductions are unrolled, so the 6-step
+// shuffle chains of different outputs interleave instead of running one after the other (bbox_pred, N = 20: 42 -> see
+// profiles/r03_layers_*.txt); the order of the additions inside one output is unchanged (bit-identical results).
+template <int NB>
 __global__ __launch_bounds__(256) void ip_rowwise_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int M, int N,
                                                          int K, int relu) {
@@ -319,23 +323,35 @@ __global__ __launch_bounds__(256) void ip_rowwise_kernel(const float* __restrict
       const int k = tid + i * 256;
       xv[r][i] = (k < K && m0 + r < M) ? x[(long)(m0 + r) * K + k] : 0.f;
     }
-  for (int n = 0; n < N; ++n) {
-    const float* wr = w + (long)n * K;
-    float acc[kRowsPerBlock];
+  for (int n0 = 0; n0 < N; n0 += NB) {
+    float acc[NB][kRowsPerBlock];
 #pragma unroll
-    for (int r = 0; r < kRowsPerBlock; ++r) acc[r] = 0.f;
+    for (int j = 0; j < NB; ++j) {
+      const int n = min(n0 + j, N - 1);                 // (surplus outputs of the last pass recompute the last one; not stored)
+      const float* wr = w + (long)n * K;
 #pragma unroll
-    for (int i = 0; i < kRowMaxKPerThread; ++i) {
-      const int k = tid + i * 256;
-      const float wv = k < K ? wr[k] : 0.f;
+      for (int r = 0; r < kRowsPerBlock; ++r) acc[j][r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < kRowsPerBlock; ++r) acc[r] += xv[r][i] * wv;
+      for (int i = 0; i < kRowMaxKPerThread; ++i) {
+        const int k = tid + i * 256;
+        const float wv = k < K ? wr[k] : 0.f;
+#pragma unroll
+        for (int r = 0; r < kRowsPerBlock; ++r) acc[j][r] += xv[r][i] * wv;
+      }
     }
 #pragma unroll
-    for (int r = 0; r < kRowsPerBlock; ++r) {
-      float a = acc[r];
-      for (int d = 32; d > 0; d >>= 1) a += __shfl_down(a, d, 64);
-      if (lane == 0) red[r][wave][n] = a;
+    for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < kRowsPerBlock; ++r) acc[j][r] += __shfl_down(acc[j][r], d, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        if (n0 + j < N) {
+#pragma unroll
+          for (int r = 0; r < kRowsPerBlock; ++r) red[r][wave][n0 + j] = acc[j][r];
+        }
     }
   }
   __syncthreads();
@@ -437,7 +453,8 @@ extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const
   const bool aligned = (K % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(w) % 16 == 0);
   if (N < 64 || !aligned) {
     if (N <= kRowMaxN && K <= 256 * kRowMaxKPerThread) {
-      ip_rowwise_kernel<<<cdiv(M, kRowsPerBlock), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+      if (N <= 5) ip_rowwise_kernel<5><<<cdiv(M, kRowsPerBlock), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+      else ip_rowwise_kernel<4><<<cdiv(M, kRowsPerBlock), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
     } else {
       ip_generic_kernel<<<dim3(M, N < 64 ? N : 64), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
     }

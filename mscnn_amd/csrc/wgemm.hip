@@ -50,9 +50,11 @@ struct WgemmArgs {
   unsigned up_bytes, v_bytes, m_bytes;
 };
 
-template <int BM_, int BN_, int WGM_, int WGN_, int CK_, int ST_>
+template <int BM_, int BN_, int WGM_, int WGN_, int CK_, int ST_, int DPG_ = 1, int SK_ = 0>
 struct WCfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, CK = CK_, ST = ST_;
+  // schedule knobs: LDS-DMA pieces issued per MFMA group (from group 0 on), first group that carries ride-along stores
+  static constexpr int DPG = DPG_, SK = SK_;
   static constexpr int NW = WGM * WGN, THREADS = NW * 64;
   static constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
   static constexpr int A_BYTES = CK * BM * 4, B_BYTES = CK * BN * 4, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -244,12 +246,26 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   }
   constexpr int NR = C::MI + C::NI;                       // LDS reads per MFMA group
   constexpr int NMF = C::MI * C::NI;                      // MFMAs per group
-  constexpr int SPG = NMF * 16 / C::STEPS;                // stores of the previous tile per group while it is flushed
-  static_assert(NMF * 16 % C::STEPS == 0 && SPG % NMF == 0, "flush schedule");
-  constexpr int SPM = SPG / NMF;                          // ... per MFMA
-  constexpr int JD = NMF >= 2 ? NMF - 2 : 0;              // the MFMA of a group behind which that group's DMA piece is issued
-  constexpr int AFTER_DMA = (C::STEPS - C::NP) * SPG + SPM * (NMF - 1 - JD);   // stores issued behind a chunk's last piece
-  static_assert(C::NP <= C::STEPS, "one DMA piece per MFMA group");
+  // ride-along stores of a finished tile: TOTAL of them over the groups SK .. STEPS-1, spread over a group's MFMAs
+  constexpr int TOTAL = NMF * 16;
+  constexpr int SPG = (TOTAL + (C::STEPS - C::SK) - 1) / (C::STEPS - C::SK);     // per group
+  constexpr int SPM = (SPG + NMF - 1) / NMF;                                     // per MFMA
+  constexpr int DMA_GROUPS = (C::NP + C::DPG - 1) / C::DPG;                      // groups 0 .. DMA_GROUPS-1 carry the unit's pieces
+  static_assert(C::DPG <= NMF && DMA_GROUPS <= C::STEPS && C::SK < C::STEPS, "schedule");
+  // stores issued behind a chunk's last piece (piece NP-1 sits behind MFMA (NP-1) % DPG of group DMA_GROUPS-1, after that slot's stores)
+  constexpr int AFTER_DMA = [] {
+    int n = 0;
+    for (int g = 0; g < C::STEPS; ++g)
+      for (int j = 0; j < NMF; ++j) {
+        if (g < C::SK) continue;
+        const int lo = (g - C::SK) * SPG + j * SPM, hi_g = (g - C::SK + 1) * SPG;
+        int cnt = 0;
+        for (int k = lo; k < lo + SPM && k < hi_g && k < TOTAL; ++k) ++cnt;
+        const bool after = g > DMA_GROUPS - 1 || (g == DMA_GROUPS - 1 && j > (C::NP - 1) % C::DPG);
+        if (after) n += cnt;
+      }
+    return n;
+  }();
 
   __amdgpu_buffer_rsrc_t old_rsrc = rM;                  // where the finished segment goes: M (whole tile) or a partial-sum slab
   unsigned old_rowb = row_bytes;                          // ... its row stride in bytes
@@ -288,12 +304,16 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
         constexpr int j = decltype(jc)::value, mi = j / C::NI, ni = j % C::NI;
         if constexpr (!(ABL & 4)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi], bv[cur][ni], acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (FLUSH) {
-          if constexpr (!(ABL & 2)) static_for<0, SPM>([&](auto kc_) { store_one(std::integral_constant<int, (s * NMF + j) * SPM + decltype(kc_)::value>{}); });
+        if constexpr (FLUSH && s >= C::SK) {
+          if constexpr (!(ABL & 2))
+            static_for<0, SPM>([&](auto kc_) {
+              constexpr int e = (s - C::SK) * SPG + j * SPM + decltype(kc_)::value;
+              if constexpr (e < (s - C::SK + 1) * SPG && e < TOTAL) store_one(std::integral_constant<int, e>{});
+            });
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (j == JD && s < C::NP) {
-          if constexpr (!(ABL & 1)) p_piece(std::integral_constant<int, s>{});
+        if constexpr (j < C::DPG && s * C::DPG + j < C::NP) {
+          if constexpr (!(ABL & 1)) p_piece(std::integral_constant<int, s * C::DPG + j>{});
           __builtin_amdgcn_sched_barrier(0);
         }
       });
@@ -391,10 +411,17 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
 typedef void (*WgemmFn)(WgemmArgs);
 struct WEntry { const char* name; int variant, abl, BM, BN, CK, threads; WgemmFn fn; };
 #define WG_ENTRY(name, v, abl, BM, BN, WGM, WGN, CK) {name, v, abl, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3>, abl>}
+#define WG_ENTRY_S(name, v, BM, BN, WGM, WGN, CK, DPG, SK) {name, v, 0, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3, DPG, SK>, 0>}
 const WEntry kW[] = {
     WG_ENTRY("wgemm_256x128_ck32", 1, 0, 256, 128, 4, 2, 32),
     WG_ENTRY("wgemm_128x256_ck32", 2, 0, 128, 256, 2, 4, 32),
     WG_ENTRY("wgemm_128x128_ck32", 3, 0, 128, 128, 2, 4, 32),
+#ifdef MSCNN_WGEMM_DEV      // schedule A/B (pieces per group, first store group)
+    WG_ENTRY_S("wgemm_256x128_ck32_d2", 5, 256, 128, 4, 2, 32, 2, 0),
+    WG_ENTRY_S("wgemm_256x128_ck32_d2_s3", 6, 256, 128, 4, 2, 32, 2, 3),
+    WG_ENTRY_S("wgemm_256x128_ck32_d3_s2", 7, 256, 128, 4, 2, 32, 3, 2),
+    WG_ENTRY_S("wgemm_256x128_ck32_d1_s6", 8, 256, 128, 4, 2, 32, 1, 6),
+#endif
 #ifdef MSCNN_WGEMM_DEV      // development ablations (tools/micro/wgemm_bench.hip): bit 0 no loads, 1 no stores, 2 no MFMAs, 3 no LDS reads, 4 no barriers
     WG_ENTRY("wgemm_256x128_ck32", 1, 1, 256, 128, 4, 2, 32),
     WG_ENTRY("wgemm_256x128_ck32", 1, 2, 256, 128, 4, 2, 32),

@@ -557,13 +557,6 @@ __global__ __launch_bounds__(256) void wino44_input_vec_kernel(const float* __re
   }
 }
 
-// columns T .. T_pad of every plane (the GEMM's padding tiles) are zeros
-__global__ __launch_bounds__(256) void wino_zero_tail_kernel(float* __restrict__ V, int planes, int C, int T, int T_pad) {
-  const int tail = T_pad - T;
-  const long total = (long)planes * C * tail;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) V[(i / tail) * T_pad + T + i % tail] = 0.f;
-}
-
 __global__ __launch_bounds__(256) void wino44_output_vec_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y,
                                                                 float* __restrict__ yp, int N, int Cout, int Ho, int Wo, int tiles_h,
                                                                 int tiles_w, int T, int T_pad, int relu, unsigned* __restrict__ amax) {
@@ -652,11 +645,8 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
   if (m == 4 && pad_w == 1 && W % 4 == 0 && tiles_w * 4 == W && reinterpret_cast<uintptr_t>(x) % 16 == 0 && !scalar_f4) {
     const int segs = cdiv(tiles_w, 64);
     wino44_input_vec_kernel<<<dim3(cdiv((long)N * tiles_h * segs, 4), Cin), 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, tiles_h, tiles_w, segs, T_pad);
-    MSCNN_POST_LAUNCH();
-    if (T_pad > T) {
-      const long total = 36L * Cin * (T_pad - T);
-      wino_zero_tail_kernel<<<(int)(total + 255 < 256L * 2048 ? (total + 255) / 256 : 2048), 256, 0, st>>>(V, 36, Cin, T, T_pad);
-    }
+    // (the GEMM's padding columns T .. T_pad of V are NOT written: every column of M depends on its own column of V only, and the
+    // output transform never reads a padding column -- whatever the workspace holds there stays in padding columns)
   } else if (m == 4) {
     wino44_input_plane_kernel<<<grid, 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, pad_w, tiles_h, tiles_w, T, T_pad);
   } else if (m == 3 && H * W <= kW33MaxHW) {
