@@ -867,6 +867,19 @@ __global__ __launch_bounds__(256) void head_gemm_weight_kernel(const float* __re
   }
 }
 
+// "kw" form: w [Cout][Cin][KH][KW] -> w' [kw * Cout + co][Cin][KH][1]  (a KH x 1 convolution with KW * Cout output channels)
+__global__ __launch_bounds__(256) void head_kw_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                                             int KH, int KW) {
+  const long total = (long)KW * Cout * Cin * KH;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int kh = (int)(i % KH);
+    long r = i / KH;
+    const int c = (int)(r % Cin); r /= Cin;
+    const int co = (int)(r % Cout), kw = (int)(r / Cout);
+    wp[i] = w[(((long)co * Cin + c) * KH + kh) * KW + kw];
+  }
+}
+
 // ---- kernel table -------------------------------------------------------------------------------------
 typedef void (*IgemmFn)(IgemmArgs);
 struct KernelEntry {
@@ -950,6 +963,9 @@ const KernelEntry kTable[] = {
     ENTRY(32, 128, 1, 4, 7, 7, 8, 16),
     ENTRY(32, 128, 1, 4, 5, 3, 8, 16),   // "3x5" heads are kernel_w 3 x kernel_h 5
     ENTRY(32, 128, 1, 4, 7, 5, 8, 16),   // "5x7": kernel_w 5 x kernel_h 7
+    // proposal heads with the kernel's columns folded into M (head_gemm_plan, "kw" form): KH x 1 taps, Cout' = KW * Cout <= 64 rows
+    ENTRY(64, 256, 1, 4, 5, 1, 8, 32),
+    ENTRY(64, 256, 1, 4, 7, 1, 8, 32),
     // detection sub-net roi_c1 (3x3 over the ROI-pooled maps): kitti_car 7x7 pad 0, ped/cyc 7x5 pad 0, caltech 8x4 pad 1
     ROI_ENTRY(128, 128, 2, 2, 3, 3, 8, 7, 7, 0),
     ROI_ENTRY(128, 128, 2, 2, 3, 3, 8, 7, 5, 0),
@@ -985,6 +1001,7 @@ struct mscnn_conv_plan {
   // else as one row of HW pixels), then the shift-and-add.  Packed buffer: [nested pack][W': rows x Cin floats]; workspace: [T][nested]
   mscnn_conv_plan* hg = nullptr;
   int hg_rows = 0;
+  int hg_kw = 0;           // > 0: the "kw" form (nested plan = KH x 1 convolution with hg_kw * Cout channels; T = [rows][H][W])
   size_t hg_t_bytes = 0;
   size_t x3d_hdr_off = 0, x3d_slots_off = 0;   // X3 direct kernel: header behind the packed weights, own-amax slots behind the slabs
   const unsigned* amax_in = nullptr;   // mscnn_conv2d_plan_set_amax_io (kept across re-planning)
@@ -1016,6 +1033,36 @@ static bool head_gemm_plan(mscnn_conv_plan* p) {
   if (tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_WINO_F3_X3 || (flags & 32) || (flags & 2)) return false;
   if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.Cout > 12 || d.Kh * d.Kw < 2 || d.Kh * d.Kw > 64 || d.N < 1) return false;
   if (d.Cin % 32 != 0 || d.Cin < 32 || p->Ho < 1 || p->Wo < 1) return false;
+  // (r3) "kw" form: fold the kernel's COLUMNS into M instead of all its taps.  T[(kw, co)][y][x'] = sum_{c, kh} w[co][c][kh][kw]
+  // x[c][y + kh - pad_h][x'] is a KH x 1 convolution with KW * Cout = 45 / 63 output channels -- one 64-row MFMA tile at 70 / 98 %
+  // row utilisation, the patch staged once in LDS and reused by the KH taps, K = Cin * KH inside the accumulators -- and
+  // y[co][y][x] = bias + sum_kw T[(kw, co)][y][x + kw - pad_w] is a shift-and-add over KW rows of a T that is only 3 - 4 MB (the
+  // taps form's T has KH * KW * Cout rows).  Measured against the M = 4 head kernel (profiles/r03_ab_heads_kwfold.txt, us): LFCN_1_7x7
+  // (63 rows, 17,280 pixels) 108 vs 130; LFCN_1_5x5 (45 rows) 92 vs 90; on the smaller maps every form sits on the same ~50 us of
+  // launch + K-chain latency (LFCN_2_7x7 72 vs 72, LFCN_3_5x5 52 vs 46) -> taken for >= 56 rows on maps of >= 8192 pixels.
+  // tune_flags bit 9 disables it, bit 10 forces it wherever it is legal (tests, A/B).
+  const bool kw_legal = d.Kw * d.Cout >= 40 && d.Kw * d.Cout <= 64 && d.pad_w * 2 + 1 == d.Kw && p->Ho == d.H && p->Wo == d.W &&
+                        (d.Kh == 5 || d.Kh == 7) && HW >= 1024;
+  if (!(flags & 16) && !(flags & 512) && kw_legal && ((flags & 1024) || (d.Kw * d.Cout >= 56 && HW >= 8192))) {
+    mscnn_conv_plan* g = new (std::nothrow) mscnn_conv_plan();
+    if (!g) return false;
+    g->d = d;
+    g->d.N = 1; g->d.Cout = d.Kw * d.Cout; g->d.Kw = 1; g->d.pad_w = 0; g->d.relu = 0;
+    g->d.algo = MSCNN_CONV_ALGO_DIRECT;
+    g->d.tune_variant = 0; g->d.tune_grid = 0; g->d.tune_flags = (flags & 1) | 32 | 2;      // (no nested head forms)
+    plan_shape(g);
+    if (g->entry >= 0 && !g->wino && !g->hg && g->head.entry < 0 && g->Ho == d.H && g->Wo == d.W && kTable[g->entry].KW == 1 &&
+        kTable[g->entry].BM == 64) {
+      p->hg = g;
+      p->hg_kw = d.Kw;
+      p->hg_rows = d.Kw * d.Cout;
+      p->hg_t_bytes = ((size_t)p->hg_rows * HW * sizeof(float) + 255) / 256 * 256;
+      p->packed_bytes = g->packed_bytes + (size_t)p->hg_rows * d.Cin * d.Kh * sizeof(float);
+      p->ws_bytes = p->hg_t_bytes + g->ws_bytes;
+      return true;
+    }
+    delete g;
+  }
   if (!(flags & 16) && !kHeadGemmDefault) return false;
   if (!(flags & 16) && HW < kHeadGemmMinPixels) return false;    // small maps: the GEMM has too few tiles, the M = 4 kernel is as fast
   const int rows = d.Kh * d.Kw * d.Cout;
@@ -1031,6 +1078,7 @@ static bool head_gemm_plan(mscnn_conv_plan* p) {
   plan_shape(g);
   if (g->entry < 0 || g->wino || g->hg || g->head.entry >= 0 || g->Ho * (long)g->Wo != HW) { delete g; return false; }
   p->hg = g;
+  p->hg_kw = 0;
   p->hg_rows = rows;
   p->hg_t_bytes = ((size_t)rows * HW * sizeof(float) + 255) / 256 * 256;
   p->packed_bytes = g->packed_bytes + (size_t)rows * d.Cin * sizeof(float);
@@ -1133,6 +1181,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   delete p->hg;
   p->hg = nullptr;
   p->hg_rows = 0;
+  p->hg_kw = 0;
   p->hg_t_bytes = 0;
   // split-fp16 mode: a small-Cout K x K head is ONE dense GEMM over the taps + a shift-and-add (M = taps * Cout instead of Cout)
   if (tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_WINO_F3_X3 && d.stride_h == 1 && d.stride_w == 1 && d.group == 1 &&
@@ -1275,7 +1324,7 @@ extern "C" size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* p) { retur
 extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (!p) return "";
   if (p->x3h.rows) return "head_gemm_shiftadd_x3f16";
-  if (p->hg) return "head_gemm_shiftadd_f32";
+  if (p->hg) return p->hg_kw ? "head_kwfold_shiftadd_f32" : "head_gemm_shiftadd_f32";
   if (p->head.entry >= 0) return head_kernel_name(p->head);
   if (p->x3.BM) return p->x3.BM == 256 ? "winograd_f3x3_3x3_x3f16_256" : "winograd_f3x3_3x3_x3f16_128";
   if (p->wino) return p->wino_m == 4 ? "winograd_f4x4_3x3" : p->wino_m == 3 ? "winograd_f3x3_3x3" : "winograd_f2x2_3x3";
@@ -1285,7 +1334,7 @@ extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_p
   if (!p) return 0;
   unsigned long long kind, e, mt, ki;
   if (p->x3h.rows) { kind = 7; e = (unsigned)p->x3h.rows_pad; mt = 0; ki = (unsigned)p->x3h.KG; }
-  else if (p->hg) { kind = 8; e = (unsigned)p->hg->entry; mt = (unsigned)p->hg->MT; ki = (unsigned)p->hg->KI; }
+  else if (p->hg) { kind = p->hg_kw ? 10 : 8; e = (unsigned)p->hg->entry; mt = (unsigned)p->hg->MT; ki = (unsigned)p->hg->KI; }
   else if (p->head.entry >= 0) { kind = 2; e = (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
   else if (p->x3.BM) { kind = 6; e = (unsigned)p->x3.BM; mt = (unsigned)p->x3.MT; ki = (unsigned)p->x3.KG; }
   else if (p->wino && p->use_wg) { kind = p->wino_m == 4 ? 9u : 2 + (unsigned)p->wino_m; e = 200u + (unsigned)p->wg.variant; mt = (unsigned)p->wg.MT; ki = (unsigned)p->wg.KI; }
@@ -1361,6 +1410,13 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   if (p->hg) {
     MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
     float* wprime = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(packed) + p->hg->packed_bytes);
+    if (p->hg_kw) {
+      const long tot = (long)p->hg_rows * p->d.Cin * p->d.Kh;
+      head_kw_weight_kernel<<<(int)((tot + 255) / 256 > 4096 ? 4096 : (tot + 255) / 256), 256, 0, as_stream(stream)>>>(
+          w, wprime, p->d.Cout, p->d.Cin, p->d.Kh, p->d.Kw);
+      MSCNN_POST_LAUNCH();
+      return mscnn_conv2d_pack_weights(p->hg, wprime, packed, stream);
+    }
     const long total = (long)p->hg_rows * p->d.Cin;
     head_gemm_weight_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, as_stream(stream)>>>(
         w, wprime, p->d.Cout, p->d.Cin, p->d.Kh * p->d.Kw);
@@ -1573,10 +1629,15 @@ static int conv_forward_single(const mscnn_conv_plan* p, const float* x, const f
     void* nested_ws = static_cast<unsigned char*>(workspace) + p->hg_t_bytes;
     for (int n = 0; n < d.N; ++n) {      // (the deploy nets run batch 1; images share T one after the other)
       // (tile order: the M tiles of one pixel tile together -- they share the B tile)
-      int rc = launch_igemm(p->hg, x + (size_t)n * d.Cin * d.H * d.W, packed, nullptr, T, nullptr, nested_ws, p->hg->ws_bytes, st, 0u, 1);
+      int rc = launch_igemm(p->hg, x + (size_t)n * d.Cin * d.H * d.W, packed, nullptr, T, nullptr, nested_ws, p->hg->ws_bytes, st, 0u,
+                            p->hg_kw ? 0 : 1);
       if (rc != MSCNN_OK) return rc;
-      rc = head_shift_add(T, bias, y + (size_t)n * d.Cout * p->Ho * p->Wo, d.Cout, d.H, d.W, p->Ho, p->Wo, d.Kh, d.Kw, d.pad_h, d.pad_w,
-                          (unsigned)((long)d.H * d.W), d.relu, st);
+      if (p->hg_kw)      // the rows already hold the sums over kh: shift-and-add over the kernel's columns only
+        rc = head_shift_add(T, bias, y + (size_t)n * d.Cout * p->Ho * p->Wo, d.Cout, d.H, d.W, p->Ho, p->Wo, 1, d.Kw, 0, d.pad_w,
+                            (unsigned)((long)d.H * d.W), d.relu, st);
+      else
+        rc = head_shift_add(T, bias, y + (size_t)n * d.Cout * p->Ho * p->Wo, d.Cout, d.H, d.W, p->Ho, p->Wo, d.Kh, d.Kw, d.pad_h, d.pad_w,
+                            (unsigned)((long)d.H * d.W), d.relu, st);
       if (rc != MSCNN_OK) return rc;
     }
     return MSCNN_OK;

@@ -33,10 +33,13 @@ def test_rccl_gather_world1_is_bit_identical_to_single_gpu_detect():
         assert gR == R and len(gd) == len(dets) > 0
         assert gd.tobytes() == dets.tobytes() and np.array_equal(gi, ids)
     gather.barrier()
-    # capacity below the ROI count is an error, not a truncation
-    with pytest.raises(mnet.NetError, match="capacity"):
-        n.detect_device(R - 1, **kw)
     gather.close()
+    # capacity below the ROI count is an error, not a truncation -- and (round 3) not an error on the overflowing rank ALONE, which
+    # would leave the other ranks blocked in the collective: the pack is marked {-1, R, cap}, travels, and every rank's unpack raises
+    small = mdist.RcclGather(0, 1, 0, R - 1, exchange_id=lambda b: b)
+    with pytest.raises(mdist.DistError, match="exceed the detection pack capacity"):
+        small(n.detect_device(R - 1, **kw))
+    small.close()
 
 
 def test_bench_under_the_launcher_takes_the_distributed_path(tmp_path):

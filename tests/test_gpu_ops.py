@@ -190,6 +190,40 @@ def test_conv_head_gemm_shiftadd_f32(hip, orc, case):
     assert np.array_equal(pr.forward(dev(x), dev(b)).cpu().numpy(), yr.cpu().numpy())      # deterministic (k-ordered fix-up, no atomics)
 
 
+@pytest.mark.parametrize("case", [(1, 64, 36, 120, 9, (5, 5)), (1, 128, 34, 61, 9, (7, 7)), (2, 64, 33, 40, 9, (7, 7)), (1, 96, 40, 37, 8, (7, 5)),
+                                  (1, 512, 72, 240, 9, (7, 7)), (1, 512, 72, 240, 9, (5, 5))])
+def test_conv_head_kwfold(hip, orc, case):
+    """Proposal heads with the kernel's COLUMNS folded into M (round 3): a KH x 1 implicit-GEMM convolution with KW * Cout <= 64 output
+    channels on the 64-row MFMA tile + a shift-and-add over KW rows, against the oracle's direct convolution (1e-4) and no worse than
+    3x the M = 4 head kernel + 2e-6 against float64; ragged widths, batch 2, ReLU, determinism; the last two cases are LFCN_1_7x7 (the
+    shape AUTO takes it for) and LFCN_1_5x5 of mscnn-7s-576 at full size."""
+    N, Cin, H, W, Cout, (kh, kw) = case
+    rng = np.random.default_rng(45)
+    x = np.maximum(rng.standard_normal((N, Cin, H, W)), 0).astype(np.float32) * 2
+    w = (rng.standard_normal((Cout, Cin, kh, kw)) * np.sqrt(2.0 / (Cin * kh * kw))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    plan = hip.ConvPlan(N, Cin, H, W, Cout, kh, kw, (kh // 2, kw // 2), tune_flags=1024)
+    assert plan.kernel == "head_kwfold_shiftadd_f32" and plan.dtype == "f32" and not plan.can_pool
+    plan.pack(dev(w))
+    y = plan.forward(dev(x), dev(b)).cpu().numpy()
+    ref = orc.conv2d(x, w, b, (kh // 2, kw // 2))
+    close(y, ref)
+    p32 = hip.ConvPlan(N, Cin, H, W, Cout, kh, kw, (kh // 2, kw // 2), tune_flags=512 | 32)
+    assert p32.kernel.startswith("head4x4")
+    p32.pack(dev(w))
+    y32 = p32.forward(dev(x), dev(b)).cpu().numpy()
+    truth = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                       padding=(kh // 2, kw // 2)).numpy()
+    m = lambda a: float((np.abs(a - truth) / np.maximum(1, np.abs(truth))).max())      # noqa: E731
+    print(f"kw-fold err {m(y):.2e}  M = 4 head kernel err {m(y32):.2e}")
+    assert m(y) <= 3 * m(y32) + 2e-6
+    pr = hip.ConvPlan(N, Cin, H, W, Cout, kh, kw, (kh // 2, kw // 2), relu=True, tune_flags=1024)
+    pr.pack(dev(w))
+    yr = pr.forward(dev(x), dev(b))
+    close(yr.cpu().numpy(), np.maximum(ref, 0))
+    assert np.array_equal(pr.forward(dev(x), dev(b)).cpu().numpy(), yr.cpu().numpy())      # deterministic (k-ordered fix-up, no atomics)
+
+
 WINO_CASES = [   # N, Cin, H, W, Cout, pad
     (1, 16, 8, 12, 24, 1),        # exact 2x2 tiles
     (1, 40, 13, 21, 130, 1),      # odd H and W: partial tiles at the bottom / right edge, Cout ragged
@@ -665,7 +699,9 @@ def test_conv_no_bias_and_kernel_selection(hip, orc):
     assert hip.ConvPlan(1, 8, 8, 16, 32, 3, 3, (1, 1), stride=(2, 2)).kernel == "direct_f32"
     assert hip.ConvPlan(50, 1024, 7, 7, 512, 3, 3).kernel == "winograd_f3x3_3x3"             # roi_c1: F(3x3,3x3)
     assert "roi7x7p0" in hip.ConvPlan(50, 1024, 7, 7, 512, 3, 3, algo=hip.ALGO_DIRECT).kernel   # direct ROI-mode igemm
-    assert hip.ConvPlan(1, 512, 72, 240, 9, 7, 7, (3, 3)).kernel == "head4x4_k7x7_m3x4"     # proposal heads: M = 4 MFMA
+    assert hip.ConvPlan(1, 512, 72, 240, 9, 7, 7, (3, 3)).kernel == "head_kwfold_shiftadd_f32"     # 63 rows x 17,280 pixels: columns folded into M
+    assert hip.ConvPlan(1, 512, 36, 120, 9, 7, 7, (3, 3)).kernel == "head4x4_k7x7_m3x4"     # smaller maps / 5x5: M = 4 MFMA head kernel
+    assert hip.ConvPlan(1, 512, 72, 240, 9, 5, 5, (2, 2)).kernel == "head4x4_k5x5_m3x4"
     assert hip.ConvPlan(1, 512, 72, 240, 6, 5, 3, (2, 1)).kernel == "head4x4_k5x3_m2x4"
     assert plan.flops == 2.0 * 32 * 8 * 16 * 8 * 9
 
