@@ -1142,6 +1142,7 @@ static bool wino_plan(mscnn_conv_plan* p) {
   mscnn_conv_plan* g = new (std::nothrow) mscnn_conv_plan();
   if (!g) return false;
   g->d = d;
+  if (g->d.tune_variant >= 300) g->d.tune_variant = 0;      // (300 + v addresses the wgemm kernel, not the nested igemm plan)
   g->d.N = planes; g->d.H = (int)(T_pad / 128); g->d.W = 128; g->d.Kh = g->d.Kw = 1; g->d.pad_h = g->d.pad_w = 0; g->d.relu = 0;
   g->d.algo = MSCNN_CONV_ALGO_DIRECT;
   plan_shape(g);

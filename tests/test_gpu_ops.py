@@ -308,6 +308,40 @@ def test_conv_winograd_f4x4_fused_pool(hip, orc, case):
     assert np.array_equal(yp.cpu().numpy(), orc.pool2d(y))
 
 
+@pytest.mark.parametrize("case", [(1, 64, 24, 40, 256, 3), (1, 96, 36, 60, 288, 4), (2, 32, 20, 28, 128, 4), (1, 512, 36, 120, 512, 3), (1, 128, 72, 240, 128, 4)])
+def test_wgemm_plane_gemm_against_the_igemm_kernel(hip, case):
+    """The plane GEMM of the Winograd layers (wgemm.hip, round 3) against the round-2 igemm kernel on the same planes.  With whole
+    tiles both are k-ordered fmaf chains over the same operands, so the layer outputs must be BIT-IDENTICAL (tune_variant 300 + v +
+    512 forces whole tiles, tune_flags bit 7 selects the igemm kernel).  With the stream-K split forced (+ 256) a tile's chunks are
+    summed in two or three parts: equal within 1e-5, and bit-identical from run to run (fixed order, no atomics on data)."""
+    N, Cin, H, W, Cout, m = case
+    algo = hip.ALGO_WINO_F4 if m == 4 else hip.ALGO_WINO_F3
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.relu(torch.randn((N, Cin, H, W), device="cuda", generator=g))
+    w = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn((Cout,), device="cuda", generator=g)
+
+    def run(tune_variant, tune_flags):
+        p = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True, algo=algo, tune_variant=tune_variant, tune_flags=tune_flags)
+        assert p.kernel.startswith(f"winograd_f{m}x{m}")
+        p.pack(w)
+        return p.forward(x, b).clone(), p
+    y_ig, _ = run(0, 128)
+    y_whole, _ = run(300 + 512, 0)
+    rel = lambda a, r: ((a - r).abs() / torch.clamp(r.abs(), min=1.0)).max().item()      # noqa: E731
+    if Cin >= 128:      # (shapes on which the igemm plan runs whole tiles too; on the small ones it splits K itself)
+        assert torch.equal(y_whole, y_ig)
+    else:
+        assert rel(y_whole, y_ig) < 1e-5
+    y_split, p = run(300 + 256, 0)
+    err = ((y_split - y_whole).abs() / torch.clamp(y_whole.abs(), min=1.0)).max().item()
+    assert err < 1e-5, err
+    for _ in range(3):
+        assert torch.equal(p.forward(x, b), y_split)
+    y_auto, _ = run(0, 0)
+    assert torch.equal(y_auto, y_whole) or ((y_auto - y_whole).abs() / torch.clamp(y_whole.abs(), min=1.0)).max().item() < 1e-5
+
+
 @pytest.mark.parametrize("case", [(1, 32, 24, 64, 48), (2, 16, 36, 260, 32), (1, 64, 72, 240, 64), (1, 8, 10, 512, 16), (1, 24, 13, 28, 40)])
 def test_wino_f4_vector_transforms_bit_identical(hip, case):
     """The vectorised F(4x4,3x3) transforms (float4 rows + neighbour-lane halo, float4 / float2 stores) against the scalar kernels
