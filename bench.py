@@ -237,6 +237,10 @@ def main():
     ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
                     help="multi-GPU exchange: libmscnn_dist's direct ncclAllGather (default), or torch.distributed's all_gather of the "
                          "same device bytes -- the route taken by itself when the direct communicator cannot be set up")
+    ap.add_argument("--gather-mode", default="pipelined", choices=["pipelined", "sync"],
+                    help="multi-GPU exchange inside the timed loops: pipelined = mscnn_dist_all_gather_begin/_end (the collective and "
+                         "the D2H copy of image i on the communicator's own stream under image i + 1's trunk; all K images' packs are on "
+                         "the host before the closing barrier), sync = one blocking exchange per image")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -289,17 +293,34 @@ def main():
         dist.all_gather_object(allf, flags[0])
         assert all(f == allf[0] for f in allf), "ranks disagree on the gather route"
     stats = {"R": [], "D": []}
+    pipe = {"on": False, "inflight": 0}
+    can_pipeline = hasattr(gather, "begin") and args.gather_mode == "pipelined"
+    if gather is not None:
+        gather_kind += " (pipelined, two in flight)" if can_pipeline else " (blocking)"
+
+    def take(per_rank):
+        dets, ids, R = per_rank[rank]
+        stats["R"].append(R); stats["D"].append(len(dets))
+        return dets
 
     def step(i):
         net.set_blob("data", frames[i % len(frames)])        # D2D: the frame is already in HBM
         net.forward()
         if gather is None:
-            dets, ids, R = net.detect(**kw)                   # final stage on device; detections land on the host
-        else:                                                 # final stage into the device pack, one all_gather, packs on the host
-            per_rank = gather(net.detect_device(cap, **kw))
-            dets, ids, R = per_rank[rank]
-        stats["R"].append(R); stats["D"].append(len(dets))
-        return dets
+            return take([net.detect(**kw)])                   # final stage on device; detections land on the host
+        if pipe["on"]:                                        # final stage into the device pack; exchange i runs under image i + 1
+            gather.begin(net.detect_device(cap, **kw))
+            pipe["inflight"] += 1
+            if pipe["inflight"] == 2:
+                pipe["inflight"] -= 1
+                return take(gather.end())
+            return None
+        return take(gather(net.detect_device(cap, **kw)))     # one blocking all_gather, packs on the host
+
+    def drain():                                              # the last image's packs (inside the timed region, before the barrier)
+        while pipe["inflight"]:
+            pipe["inflight"] -= 1
+            take(gather.end())
 
     def sync():
         if dist is not None:
@@ -316,11 +337,14 @@ def main():
     stats = {"R": [], "D": []}
     sync()
     step_s = []
+    pipe["on"] = can_pipeline
     t0 = time.perf_counter()
     for i in range(args.steps):
         ts = time.perf_counter()
         step(i)                                               # ends with the detections on the host (stream-synchronised)
         step_s.append(time.perf_counter() - ts)
+    drain()
+    pipe["on"] = False
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -345,11 +369,14 @@ def main():
                          "tol": CALIBRATION_TOL, "fallback_layers": sw}
         sync()
         a_s = []
+        pipe["on"] = can_pipeline
         t0 = time.perf_counter()
         for i in range(args.steps):
             ts = time.perf_counter()
             step(i)
             a_s.append(time.perf_counter() - ts)
+        drain()
+        pipe["on"] = False
         sync()
         a_el = time.perf_counter() - t0
         if dist is not None:

@@ -41,6 +41,8 @@ def dist_lib():
         L.mscnn_dist_destroy.restype = None
         L.mscnn_dist_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mscnn_dist_barrier.argtypes = [C.c_void_p, C.c_void_p]
+        L.mscnn_dist_all_gather_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mscnn_dist_all_gather_end.argtypes = [C.c_void_p, C.c_void_p]
         _dlib = L
     return _dlib
 
@@ -104,6 +106,17 @@ class RcclGather:
         _dcheck(dist_lib().mscnn_dist_all_gather(self._h, C.c_void_p(pack_dev_ptr), C.c_void_p(stream or 0), C.byref(out)))
         host = (C.c_ubyte * (self.world * self.pack_bytes)).from_address(out.value)
         return split_packs(np.frombuffer(host, np.uint8), self.world, self.cap, copy=False)      # views of the pinned buffer
+
+    def begin(self, pack_dev_ptr, stream=None):
+        """Pipelined form: enqueue this step's exchange on the communicator's own stream and return at once."""
+        _dcheck(dist_lib().mscnn_dist_all_gather_begin(self._h, C.c_void_p(pack_dev_ptr), C.c_void_p(stream or 0)))
+
+    def end(self):
+        """Wait for the oldest exchange in flight; returns its per-rank list of (dets, ids, R) (views: valid for two more begins)."""
+        out = C.c_void_p()
+        _dcheck(dist_lib().mscnn_dist_all_gather_end(self._h, C.byref(out)))
+        host = (C.c_ubyte * (self.world * self.pack_bytes)).from_address(out.value)
+        return split_packs(np.frombuffer(host, np.uint8), self.world, self.cap, copy=False)
 
     def barrier(self, stream=None):
         _dcheck(dist_lib().mscnn_dist_barrier(self._h, C.c_void_p(stream or 0)))

@@ -75,6 +75,11 @@ struct mscnn_dist {
   void* recv_dev = nullptr;       // world * pack_bytes
   void* recv_host = nullptr;      // pinned, same size
   int* flag_dev = nullptr;        // barrier payload
+  // pipelined exchange (mscnn_dist_all_gather_begin / _end): two slots on the communicator's own stream
+  hipStream_t xstream = nullptr;
+  hipEvent_t ready = nullptr;     // compute stream -> exchange stream: the pack copy of this step has been enqueued
+  struct Slot { void* send_dev = nullptr; void* recv_dev = nullptr; void* recv_host = nullptr; hipEvent_t done = nullptr; bool busy = false; } slot[2];
+  int head = 0, tail = 0, inflight = 0;
 };
 
 extern "C" {
@@ -133,6 +138,15 @@ void mscnn_dist_destroy(mscnn_dist* d) {
   if (!d) return;
   Rccl* R = rccl();
   (void)hipSetDevice(d->device);
+  if (d->xstream) (void)hipStreamSynchronize(d->xstream);
+  for (auto& sl : d->slot) {
+    if (sl.send_dev) (void)hipFree(sl.send_dev);
+    if (sl.recv_dev) (void)hipFree(sl.recv_dev);
+    if (sl.recv_host) (void)hipHostFree(sl.recv_host);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
+  if (d->ready) (void)hipEventDestroy(d->ready);
+  if (d->xstream) (void)hipStreamDestroy(d->xstream);
   if (d->comm && R) (void)R->CommDestroy(d->comm);
   if (d->recv_dev) (void)hipFree(d->recv_dev);
   if (d->recv_host) (void)hipHostFree(d->recv_host);
@@ -158,6 +172,56 @@ int mscnn_dist_all_gather(mscnn_dist* d, const void* send_dev, void* stream, con
   DIST_HIP(hipMemcpyAsync(d->recv_host, d->recv_dev, d->pack_bytes * d->world, hipMemcpyDeviceToHost, st));
   DIST_HIP(hipStreamSynchronize(st));
   if (gathered_host) *gathered_host = d->recv_host;
+  return 0;
+}
+
+// ---- pipelined form: the collective and the D2H copy of step i run on the communicator's own stream while the compute stream goes
+// on with step i + 1; the host takes step i's packs one step later.  begin() copies the pack (device to device, on the compute
+// stream: it may be overwritten by the next frame's final stage right after) and returns at once; end() waits for the OLDEST
+// exchange in flight.  At most two may be in flight.
+static int ensure_pipeline(mscnn_dist* d) {
+  if (d->xstream) return 0;
+  DIST_HIP(hipSetDevice(d->device));
+  DIST_HIP(hipStreamCreateWithFlags(&d->xstream, hipStreamNonBlocking));
+  DIST_HIP(hipEventCreateWithFlags(&d->ready, hipEventDisableTiming));
+  for (auto& sl : d->slot) {
+    DIST_HIP(hipMalloc(&sl.send_dev, d->pack_bytes));
+    DIST_HIP(hipMalloc(&sl.recv_dev, d->pack_bytes * d->world));
+    DIST_HIP(hipHostMalloc(&sl.recv_host, d->pack_bytes * d->world, hipHostMallocDefault));
+    DIST_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  }
+  return 0;
+}
+
+int mscnn_dist_all_gather_begin(mscnn_dist* d, const void* send_dev, void* stream) {
+  Rccl* R = rccl();
+  DIST_REQUIRE(R && d && send_dev, "dist all_gather_begin: bad argument");
+  DIST_REQUIRE(d->inflight < 2, "dist all_gather_begin: two exchanges already in flight (call mscnn_dist_all_gather_end)");
+  const int rc = ensure_pipeline(d);
+  if (rc) return rc;
+  mscnn_dist::Slot& sl = d->slot[d->head];
+  hipStream_t cs = reinterpret_cast<hipStream_t>(stream);
+  DIST_HIP(hipMemcpyAsync(sl.send_dev, send_dev, d->pack_bytes, hipMemcpyDeviceToDevice, cs));
+  DIST_HIP(hipEventRecord(d->ready, cs));
+  DIST_HIP(hipStreamWaitEvent(d->xstream, d->ready, 0));
+  DIST_NCCL(R->AllGather(sl.send_dev, sl.recv_dev, d->pack_bytes, ncclChar, d->comm, d->xstream));
+  DIST_HIP(hipMemcpyAsync(sl.recv_host, sl.recv_dev, d->pack_bytes * d->world, hipMemcpyDeviceToHost, d->xstream));
+  DIST_HIP(hipEventRecord(sl.done, d->xstream));
+  sl.busy = true;
+  d->head ^= 1;
+  ++d->inflight;
+  return 0;
+}
+
+int mscnn_dist_all_gather_end(mscnn_dist* d, const void** gathered_host) {
+  DIST_REQUIRE(d && gathered_host, "dist all_gather_end: bad argument");
+  DIST_REQUIRE(d->inflight > 0, "dist all_gather_end: nothing in flight");
+  mscnn_dist::Slot& sl = d->slot[d->tail];
+  DIST_HIP(hipEventSynchronize(sl.done));
+  sl.busy = false;
+  d->tail ^= 1;
+  --d->inflight;
+  *gathered_host = sl.recv_host;      // valid until this slot's next begin (two begins from now)
   return 0;
 }
 

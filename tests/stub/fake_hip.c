@@ -14,4 +14,12 @@ hipError_t hipHostFree(void* p) { free(p); return 0; }
 hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int kind, hipStream_t st) { (void)kind; (void)st; memcpy(d, s, n); return 0; }
 hipError_t hipStreamSynchronize(hipStream_t st) { (void)st; return 0; }
+typedef void* hipEvent_t;
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned f) { (void)f; *s = (void*)1; return 0; }
+hipError_t hipStreamDestroy(hipStream_t s) { (void)s; return 0; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned f) { (void)f; *e = (void*)1; return 0; }
+hipError_t hipEventDestroy(hipEvent_t e) { (void)e; return 0; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { (void)e; (void)s; return 0; }
+hipError_t hipEventSynchronize(hipEvent_t e) { (void)e; return 0; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned f) { (void)s; (void)e; (void)f; return 0; }
 const char* hipGetErrorString(hipError_t e) { return e ? "fake hip error" : "no error"; }

@@ -107,7 +107,7 @@ sys.path.insert(0, os.path.join({root!r}, "tests"))
 import ctypes as C
 from mscnn_amd import dist as mdist
 from test_dist_cpu import _fake_dets, _host_pack, CAP
-rank, world, tmp, overflow = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4] == "1"
+rank, world, tmp, overflow, pipelined = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4] == "1", sys.argv[4] == "2"
 assert mdist.dist_lib().mscnn_dist_use_transport({stub!r}.encode()) == 0
 idfile = os.path.join(tmp, "id.bin")
 def exchange(mine):                      # rank 0's bytes to every rank, through a file (any out-of-band channel does)
@@ -122,7 +122,28 @@ def exchange(mine):                      # rank 0's bytes to every rank, through
 g = mdist.RcclGather(rank, world, 0, CAP, exchange)
 g.barrier()
 seen = []
-for step in range(3):
+if pipelined:        # begin(i) ... begin(i + 1) ... end() -> step i: the product's double-buffered exchange on its own stream
+    packs = []
+    for step in range(5):
+        img = step * world + rank
+        dets, ids = _fake_dets(img, 2 + 3 * img)
+        packs.append(_host_pack(dets, ids, len(dets) + 1, CAP))
+        g.begin(packs[-1].ctypes.data)
+        packs[-1][16:] = 0xAB                  # the caller may overwrite its pack right after begin(): begin() took a copy
+        if step >= 1:
+            seen.append([(d.copy(), i.copy(), R) for d, i, R in g.end()])
+    seen.append([(d.copy(), i.copy(), R) for d, i, R in g.end()])
+    try:
+        g.end()
+    except mdist.DistError as e:
+        print("DISTERROR", str(e)); sys.stdout.flush()
+    g.begin(packs[0].ctypes.data); g.begin(packs[1].ctypes.data)
+    try:
+        g.begin(packs[2].ctypes.data)
+    except mdist.DistError as e:
+        print("DISTERROR", str(e)); sys.stdout.flush()
+    g.end(); g.end()
+for step in range(0 if pipelined else 3):
     img = step * world + rank
     dets, ids = _fake_dets(img, 2 + 3 * img)
     pack = _host_pack(dets, ids, len(dets) + 1, CAP)
@@ -151,12 +172,12 @@ def _build_stubs(tmp_path):
     return out
 
 
-def _run_rccl_workers(tmp_path, overflow):
+def _run_rccl_workers(tmp_path, overflow, mode=None):
     import subprocess
     stubs = _build_stubs(tmp_path)
     code = _RCCL_WORKER.format(root=ROOT, stub=stubs["fake_rccl"])
     env = dict(os.environ, LD_PRELOAD=stubs["fake_hip"])
-    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", str(tmp_path), "1" if overflow else "0"], env=env,
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", str(tmp_path), mode or ("1" if overflow else "0")], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (so, se) in zip(procs, outs):
@@ -176,6 +197,22 @@ def test_rccl_gather_code_path_world2_bit_identical(tmp_path):
                 ref_d, ref_i = _fake_dets(img, 2 + 3 * img)
                 assert dets.dtype == np.float64 and dets.tobytes() == ref_d.tobytes()      # float64 bit patterns, both ranks
                 assert np.array_equal(ids, ref_i) and R == len(ref_d) + 1
+
+
+def test_rccl_gather_pipelined_world2_bit_identical(tmp_path):
+    """mscnn_dist_all_gather_begin / _end: five steps with two exchanges in flight arrive in order and bit-identical on both
+    ranks; end() with nothing in flight and a third begin() are refused."""
+    outs = _run_rccl_workers(tmp_path, overflow=False, mode="2")
+    for so in outs:
+        assert "nothing in flight" in so and "two exchanges already in flight" in so, so
+    for rank in range(2):
+        seen = np.load(str(tmp_path / f"seen{rank}.npy"), allow_pickle=True)
+        assert len(seen) == 5
+        for step, per_rank in enumerate(seen):
+            for r, (dets, ids, R) in enumerate(per_rank):
+                img = step * 2 + r
+                ref_d, ref_i = _fake_dets(img, 2 + 3 * img)
+                assert dets.tobytes() == ref_d.tobytes() and np.array_equal(ids, ref_i) and R == len(ref_d) + 1
 
 
 def test_rccl_gather_overflow_fails_on_every_rank(tmp_path):

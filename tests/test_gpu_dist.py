@@ -32,6 +32,21 @@ def test_rccl_gather_world1_is_bit_identical_to_single_gpu_detect():
         (gd, gi, gR), = gather(n.detect_device(cap, **kw))
         assert gR == R and len(gd) == len(dets) > 0
         assert gd.tobytes() == dets.tobytes() and np.array_equal(gi, ids)
+    # the pipelined form (exchange i on the communicator's own stream under image i + 1): same bytes, in order
+    want = []
+    for seed in (4, 5, 6, 7):
+        n.set_blob("data", synth.frame(192, 640, seed=seed))
+        n.forward()
+        d_, i_, _ = n.detect(**kw)
+        want.append((d_.copy(), i_.copy()))
+        gather.begin(n.detect_device(cap, **kw))
+        if len(want) >= 2:
+            (gd, gi, _), = gather.end()
+            assert gd.tobytes() == want[-2][0].tobytes() and np.array_equal(gi, want[-2][1])
+    (gd, gi, _), = gather.end()
+    assert gd.tobytes() == want[-1][0].tobytes() and np.array_equal(gi, want[-1][1])
+    with pytest.raises(mdist.DistError, match="nothing in flight"):
+        gather.end()
     gather.barrier()
     gather.close()
     # capacity below the ROI count is an error, not a truncation -- and (round 3) not an error on the overflowing rank ALONE, which
@@ -57,6 +72,7 @@ def test_bench_under_the_launcher_takes_the_distributed_path(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 50 and d["config"]["gather"].startswith("libmscnn_dist"), d["config"]
+    assert "pipelined" in d["config"]["gather"], d["config"]
     # the second route to the same bytes (taken by itself when the direct communicator cannot be set up), end to end
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29673", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
