@@ -51,6 +51,7 @@ def test_rccl_gather_world1_is_bit_identical_to_single_gpu_detect():
     gather.close()
     # capacity below the ROI count is an error, not a truncation -- and (round 3) not an error on the overflowing rank ALONE, which
     # would leave the other ranks blocked in the collective: the pack is marked {-1, R, cap}, travels, and every rank's unpack raises
+    _, _, R = n.detect(**kw)      # the ROI count of the frame the net holds now
     small = mdist.RcclGather(0, 1, 0, R - 1, exchange_id=lambda b: b)
     with pytest.raises(mdist.DistError, match="exceed the detection pack capacity"):
         small(n.detect_device(R - 1, **kw))

@@ -313,8 +313,11 @@ def test_wgemm_plane_gemm_against_the_igemm_kernel(hip, case):
     """The plane GEMM of the Winograd layers (wgemm.hip, round 3) against the round-2 igemm kernel on the same planes.  With whole
     tiles both are k-ordered fmaf chains over the same operands, so the layer outputs must be BIT-IDENTICAL (tune_variant 300 + v +
     512 forces whole tiles, tune_flags bit 7 selects the igemm kernel).  With the stream-K split forced (+ 256) a tile's chunks are
-    summed in two or three parts: equal within 1e-5, and bit-identical from run to run (fixed order, no atomics on data)."""
+    summed in two or three parts: equal within 1e-5 (F(3x3,3x3)) / 4e-5 (F(4x4,3x3), whose output transform multiplies a
+    re-association difference in M by up to 8 x 8; measured 1.5e-5), and bit-identical from run to run (fixed order, no atomics on
+    data)."""
     N, Cin, H, W, Cout, m = case
+    tol = 4e-5 if m == 4 else 1e-5
     algo = hip.ALGO_WINO_F4 if m == 4 else hip.ALGO_WINO_F3
     g = torch.Generator(device="cuda").manual_seed(17)
     x = torch.relu(torch.randn((N, Cin, H, W), device="cuda", generator=g))
@@ -332,14 +335,14 @@ def test_wgemm_plane_gemm_against_the_igemm_kernel(hip, case):
     if Cin >= 128:      # (shapes on which the igemm plan runs whole tiles too; on the small ones it splits K itself)
         assert torch.equal(y_whole, y_ig)
     else:
-        assert rel(y_whole, y_ig) < 1e-5
+        assert rel(y_whole, y_ig) < tol
     y_split, p = run(300 + 256, 0)
     err = ((y_split - y_whole).abs() / torch.clamp(y_whole.abs(), min=1.0)).max().item()
-    assert err < 1e-5, err
+    assert err < tol, err
     for _ in range(3):
         assert torch.equal(p.forward(x, b), y_split)
     y_auto, _ = run(0, 0)
-    assert torch.equal(y_auto, y_whole) or ((y_auto - y_whole).abs() / torch.clamp(y_whole.abs(), min=1.0)).max().item() < 1e-5
+    assert torch.equal(y_auto, y_whole) or ((y_auto - y_whole).abs() / torch.clamp(y_whole.abs(), min=1.0)).max().item() < tol
 
 
 @pytest.mark.parametrize("case", [(1, 32, 24, 64, 48), (2, 16, 36, 260, 32), (1, 64, 72, 240, 64), (1, 8, 10, 512, 16), (1, 24, 13, 28, 40)])
