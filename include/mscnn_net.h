@@ -82,6 +82,12 @@ MSCNN_NET_API const char* mscnn_net_layer_dtype(const mscnn_net* net, int layer)
  * then on.  *num_switched = how many; mscnn_net_layer_calibration_err gives each layer's measured value. */
 MSCNN_NET_API int mscnn_net_calibrate_numerics(mscnn_net* net, double tol, int* num_switched);
 MSCNN_NET_API double mscnn_net_layer_calibration_err(const mscnn_net* net, int layer);
+/* The same check on live frames: every period-th whole forward re-computes ONE Winograd layer (round robin over the layers) with the
+ * direct kernel on the frame just processed; a layer off by more than tol runs the direct kernel from the next frame on.  period 0
+ * switches the watch off (the default).  _state: *checks = layer checks done so far; returns how many layers were switched and
+ * writes up to cap of their indices. */
+MSCNN_NET_API int mscnn_net_set_numerics_watch(mscnn_net* net, int period, double tol);
+MSCNN_NET_API int mscnn_net_numerics_watch_state(const mscnn_net* net, int* checks, int* switched_layers, int cap);
 MSCNN_NET_API int mscnn_net_num_blobs(const mscnn_net* net);
 MSCNN_NET_API const char* mscnn_net_blob_name(const mscnn_net* net, int blob);
 MSCNN_NET_API int mscnn_net_blob_shape(const mscnn_net* net, const char* name, int* dims8, int* ndim);

@@ -75,6 +75,12 @@ class Net {
   // errors (per layer index, 0 for layers not checked) are left in calibration_err().
   vector<int> CalibrateNumerics(double tol);
   const vector<double>& calibration_err() const { return calib_err_; }
+  // The same check while a stream of frames runs: every `period`-th whole Forward re-computes ONE Winograd layer (round robin) with
+  // the direct kernel on the frame just processed and switches it to the direct kernel for good when it is off by more than tol --
+  // the calibration of the first frame is re-examined on live data at the cost of one extra layer per `period` frames (period 0: off).
+  void SetNumericsWatch(int period, double tol) { watch_period_ = period; watch_tol_ = tol; watch_frame_ = 0; }
+  int numerics_watch_checks() const { return watch_checks_; }
+  const vector<int>& numerics_watch_switched() const { return watch_switched_; }
 
  protected:
   void Init(const NetParameter& param);
@@ -108,6 +114,10 @@ class Net {
   std::map<int, Redirect> redirect_;               // blob id -> where its data really lives
   mutable std::map<int, bool> redirect_dirty_;     // producer ran since the last MaterializeBlob
   vector<double> calib_err_;
+  void NumericsWatchStep();
+  int watch_period_ = 0, watch_frame_ = 0, watch_next_ = 0, watch_checks_ = 0;
+  double watch_tol_ = 0.0;
+  vector<int> watch_switched_;
   DISABLE_COPY_AND_ASSIGN(Net);
 };
 

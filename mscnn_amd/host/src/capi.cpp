@@ -181,6 +181,18 @@ int mscnn_net_calibrate_numerics(mscnn_net* n, double tol, int* num_switched) {
   });
 }
 double mscnn_net_layer_calibration_err(const mscnn_net* n, int l) { return n->net->calibration_err()[l]; }
+int mscnn_net_set_numerics_watch(mscnn_net* n, int period, double tol) {
+  return guarded([&] {
+    CHECK_GE(period, 0);
+    n->net->SetNumericsWatch(period, tol);
+  });
+}
+int mscnn_net_numerics_watch_state(const mscnn_net* n, int* checks, int* switched_layers, int cap) {
+  const std::vector<int>& sw = n->net->numerics_watch_switched();
+  if (checks) *checks = n->net->numerics_watch_checks();
+  for (int i = 0; switched_layers && i < cap && i < (int)sw.size(); ++i) switched_layers[i] = sw[i];
+  return (int)sw.size();
+}
 int mscnn_net_num_blobs(const mscnn_net* n) { return (int)n->net->blobs().size(); }
 const char* mscnn_net_blob_name(const mscnn_net* n, int b) { return n->net->blob_names()[b].c_str(); }
 int mscnn_net_blob_shape(const mscnn_net* n, const char* name, int* dims8, int* ndim) {

@@ -351,6 +351,27 @@ vector<int> Net<Dtype>::CalibrateNumerics(double tol) {
 }
 
 template <typename Dtype>
+void Net<Dtype>::NumericsWatchStep() {
+  const int L = (int)layers_.size();
+  for (int k = 0; k < L; ++k) {
+    const int i = (watch_next_ + k) % L;
+    ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
+    if (!c || fused_away_[i] || c->algo() == 1 || c->algo() == 4 || std::strncmp(c->kernel_name(), "winograd", 8) != 0) continue;
+    watch_next_ = (i + 1) % L;
+    ++watch_checks_;
+    calib_err_[i] = c->ErrorAgainstDirect(bottom_vecs_[i], top_vecs_[i]);
+    if (!(calib_err_[i] <= watch_tol_)) {
+      LOG(WARNING) << "layer " << layer_names_[i] << ": Winograd result off the direct sum by " << calib_err_[i] << " > " << watch_tol_
+                   << " on a live frame: using the direct kernel from the next frame on";
+      c->set_algo(1);
+      c->set_calibrated_direct(true);
+      watch_switched_.push_back(i);
+    }
+    return;
+  }
+}
+
+template <typename Dtype>
 Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   CHECK_GE(start, 0);
   CHECK_LT(end, (int)layers_.size());
@@ -425,6 +446,7 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
     if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) c->set_amax_trusted(false);
     else if (InnerProductLayer<Dtype>* ip = dynamic_cast<InnerProductLayer<Dtype>*>(layers_[i].get())) ip->set_amax_trusted(false);
   }
+  if (watch_period_ > 0 && start == 0 && end == (int)layers_.size() - 1 && ++watch_frame_ % watch_period_ == 0) NumericsWatchStep();
   return 0;
 }
 

@@ -46,7 +46,8 @@ def lib():
             "mscnn_net_layer_executed_flops": [vp, ci], "mscnn_net_set_conv_profiling": [vp, ci], "mscnn_net_layer_stage_ms": [vp, ci, vp],
             "mscnn_net_set_precision": [vp, cs], "mscnn_net_layer_dtype": [vp, ci],
             "mscnn_net_set_conv_algo": [vp, ci, ci], "mscnn_net_set_conv_tuning": [vp, ci, ci, ci, ci],
-            "mscnn_net_calibrate_numerics": [vp, C.c_double, vp], "mscnn_net_layer_calibration_err": [vp, ci],
+            "mscnn_net_calibrate_numerics": [vp, C.c_double, vp], "mscnn_net_set_numerics_watch": [vp, ci, C.c_double],
+            "mscnn_net_numerics_watch_state": [vp, vp, vp, ci], "mscnn_net_layer_calibration_err": [vp, ci],
             "mscnn_net_load_caffemodel": [vp, cs], "mscnn_net_set_stream": [vp], "mscnn_net_num_layers": [vp],
             "mscnn_net_layer_name": [vp, ci], "mscnn_net_layer_type": [vp, ci], "mscnn_net_layer_index": [vp, cs],
             "mscnn_net_layer_num_bottoms": [vp, ci], "mscnn_net_layer_num_tops": [vp, ci], "mscnn_net_layer_bottom": [vp, ci, ci],
@@ -176,6 +177,16 @@ class Net:
         switched = [nm for nm, e in errs.items() if not e <= tol]
         assert len(switched) == n.value
         return errs, switched
+
+    def set_numerics_watch(self, period, tol=5e-5):
+        """Every period-th forward re-checks one Winograd layer (round robin) against the direct kernel on the live frame."""
+        _check(lib().mscnn_net_set_numerics_watch(self._h, period, tol))
+
+    def numerics_watch_state(self):
+        """(layer checks done, [names of the layers the watch sent to the direct kernel])."""
+        n, sw = C.c_int(), (C.c_int * 64)()
+        k = lib().mscnn_net_numerics_watch_state(self._h, C.byref(n), sw, 64)
+        return n.value, [self.layer_names[sw[i]] for i in range(min(k, 64))]
 
     # ---- weights ----
     def set_param(self, layer, p, arr):

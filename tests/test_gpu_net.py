@@ -353,6 +353,36 @@ def test_numerical_calibration_falls_back_per_layer():
         assert rel_err(n.get_blob(b), v) < 1e-4, b
 
 
+def test_numerics_watch_rechecks_one_layer_per_period_on_live_frames():
+    """mscnn_net_set_numerics_watch: every period-th whole forward re-computes one Winograd layer (round robin) with the direct
+    kernel on the live frame.  Default tolerance: checks happen, nothing is switched, outputs unchanged; impossible tolerance: the
+    layers leave Winograd one per period, in net order."""
+    n = mnet.Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=192, width=384, max_nms_num=100))
+    synth.load_into(n, "mid")
+    wino = lambda: [nm for i, nm in enumerate(n.layer_names) if n.layer_kernel(i).startswith("winograd")]      # noqa: E731
+    n.set_blob("data", synth.frame(192, 384))
+    n.forward()
+    w0 = wino()
+    ref = n.get_blob("fc6")
+    assert n.numerics_watch_state() == (0, [])
+    n.set_numerics_watch(2, 5e-5)
+    for _ in range(2 * len(w0) + 1):
+        n.forward()
+    checks, switched = n.numerics_watch_state()
+    assert checks == len(w0) and switched == [] and wino() == w0
+    assert np.array_equal(n.get_blob("fc6"), ref)
+    n.set_numerics_watch(1, 1e-9)
+    for k in range(3):
+        n.set_blob("data", synth.frame(192, 384, seed=5 + k))
+        n.forward()
+    checks, switched = n.numerics_watch_state()
+    assert checks == len(w0) + 3 and len(switched) == 3 and set(switched) <= set(w0)
+    assert wino() == [nm for nm in w0 if nm not in switched]
+    n.set_numerics_watch(0)
+    n.forward()
+    assert n.numerics_watch_state()[0] == checks
+
+
 def test_dynamic_roi_count_across_forwards():
     """R changes from image to image; Reshape propagation (layer.hpp:451-456) must follow without reallocating downwards."""
     n = mnet.Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=128, width=256))
