@@ -144,9 +144,11 @@ void ConvolutionLayer<Dtype>::Plan(int n, int h, int w) {
   if (plan_ && planned_h_ == h && planned_w_ == w) {
     if (planned_n_ != n) {
       const unsigned long long before = mscnn_conv2d_plan_weight_layout(plan_);
+      const size_t bytes_before = mscnn_conv2d_packed_weight_bytes(plan_);
       MSCNN_CHECK(mscnn_conv2d_plan_set_batch(plan_, n));
       planned_n_ = n;
-      if (mscnn_conv2d_plan_weight_layout(plan_) != before) weights_dirty_ = true;   // another kernel family: re-pack
+      // another kernel family, or a packed buffer of another size (the head kernels keep per-tile counters behind the weights): re-pack
+      if (mscnn_conv2d_plan_weight_layout(plan_) != before || mscnn_conv2d_packed_weight_bytes(plan_) != bytes_before) weights_dirty_ = true;
     }
     return;
   }

@@ -122,6 +122,31 @@ def test_conv(hip, orc, case, relu):
     close(y, ref)
 
 
+@pytest.mark.parametrize("case", [(1, 512, 72, 240, 9, (5, 5), (2, 2)), (1, 512, 36, 120, 9, (7, 7), (3, 3)), (1, 512, 18, 60, 9, (5, 5), (2, 2)),
+                                  (1, 512, 9, 30, 9, (7, 7), (3, 3)), (2, 96, 40, 70, 6, (5, 3), (2, 1)), (3, 64, 20, 33, 12, (5, 5), (2, 2))])
+def test_conv_head_in_kernel_combine(hip, orc, case):
+    """The M = 4 head kernel splits its few tiles stream-K style; since round 3 the LAST workgroup to deliver a tile's partial sums
+    adds the slabs (in k order) inside the same launch -- per-tile arrival counters behind the packed weights, no fix-up launch.
+    Against the oracle (reference tolerance 1e-4), bit-identical over 20 back-to-back launches (the order of the sum is the
+    slabs', not the arrivals'; the counters return to zero), and exactly doubled after re-packing doubled weights."""
+    N, Cin, H, W, Cout, k, pad = case
+    rng = np.random.default_rng(99)
+    x = np.maximum(rng.standard_normal((N, Cin, H, W)), 0).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, *k)) * np.sqrt(2.0 / (Cin * k[0] * k[1]))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    p = hip.ConvPlan(N, Cin, H, W, Cout, k[0], k[1], pad)
+    assert p.kernel.startswith("head4x4")
+    p.pack(dev(w))
+    xd, bd = dev(x), dev(b)
+    y0 = p.forward(xd, bd).clone()
+    close(y0.cpu().numpy(), orc.conv2d(x, w, b, pad))
+    for _ in range(20):
+        assert torch.equal(p.forward(xd, bd), y0)
+    p.pack(dev(w * 2))      # re-packing zeroes the counters again and the next launch sees the new weights
+    y2 = p.forward(xd, dev(b * 2))
+    assert torch.equal(y2, y0 * 2)
+
+
 @pytest.mark.parametrize("case", [(1, 64, 36, 120, 9, (5, 5)), (1, 128, 18, 60, 9, (7, 7)), (2, 64, 12, 20, 7, (5, 3)), (1, 96, 13, 21, 6, (7, 5)),
                                   (1, 512, 9, 30, 9, (5, 5)), (1, 32, 7, 9, 12, (3, 3))])
 def test_conv_head_x3_gemm_shiftadd(hip, orc, case):
