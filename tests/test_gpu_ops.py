@@ -900,6 +900,28 @@ def test_inner_product(hip, orc, M, N, K):
     close(hip.inner_product(dev(x), dev(w), None, relu=True).cpu().numpy(), orc.relu(orc.inner_product(x, w, None)))
 
 
+def test_inner_product_in_kernel_combine_is_deterministic(hip):
+    """The stream-K InnerProduct adds a tile's partial sums inside the launch (last arrival combines, in k order): the same bits from
+    launch to launch, with other shapes (other tile counts and slab sizes, fp16 weights) through the same library-owned slab /
+    counter buffer in between, and the float64 product within the reference's 1e-4."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(540, 4096, 12800), (257, 320, 1024), (700, 4096, 12800), (130, 2048, 4096)]
+    data = []
+    for M, N, K in shapes:
+        x = torch.relu(torch.randn((M, K), device="cuda", generator=g))
+        w = torch.randn((N, K), device="cuda", generator=g) * (2.0 / K) ** 0.5
+        b = torch.randn(N, device="cuda", generator=g)
+        y = hip.inner_product(x, w, b, relu=True).clone()
+        ref = torch.relu(x.double() @ w.double().t() + b.double())
+        assert ((y.double() - ref).abs() / torch.clamp(ref.abs(), min=1.0)).max().item() < 1e-4
+        data.append((x, w, b, y))
+    for rep in range(4):
+        for x, w, b, y in data:
+            assert torch.equal(hip.inner_product(x, w, b, relu=True), y)
+        x, w, b, _ = data[rep % len(data)]
+        hip.inner_product_f16(x.half().float(), w.half().float(), b)      # the fp16 kernel shares the buffer and the protocol
+
+
 # ------------------------------------------------------------------ ROI pooling (bit-exact)
 def _random_rois(rng, R, img_h, img_w, batch=1):
     x1 = rng.uniform(-40, img_w, R); y1 = rng.uniform(-40, img_h, R)
