@@ -381,6 +381,75 @@ __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restr
 }
 
 
+// Output transform of the ROI maps (roi_c1: y is [roi][channel][Ho*Wo] with Ho*Wo <= 64, 5x5 for the KITTI nets).  The generic
+// kernel above lets consecutive lanes (consecutive tiles) store 4-byte pieces 12 .. 60 bytes apart and, from one ROI to the next,
+// Cout * Ho * Wo * 4 bytes apart: 27 MB written as 100-byte fragments, 65 us on the 7s-576 frame (2.1 TB/s over M + y).  Here a
+// workgroup owns 16 ROIs x 8 channels, the mirror image of wino33_input_kernel: thread = (channel, roi, tile) with (roi, tile)
+// fastest, so each of the 25 plane reads of a wave covers 256-byte runs of M; the 3x3 outputs go to LDS in y's own layout and
+// leave as float4 runs of 8 channels x Ho*Wo floats per ROI.  Same expressions in the same order: bit-identical results.
+constexpr int kW33ORois = 16, kW33OCh = 8;
+
+__global__ __launch_bounds__(256) void wino33_output_roi_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                                float* __restrict__ y, int N, int Cout, int Ho, int Wo, int tiles_h,
+                                                                int tiles_w, int T_pad, int relu, unsigned* __restrict__ amax) {
+  __shared__ __attribute__((aligned(16))) float sm[kW33ORois * kW33OCh * kW33MaxHW];
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * kW33ORois, c0 = blockIdx.y * kW33OCh;
+  const int HW = Ho * Wo, tpr = tiles_h * tiles_w;
+  const int nch = min(kW33OCh, Cout - c0), nroi = min(kW33ORois, N - r0);
+  const long plane_stride = (long)Cout * T_pad;
+  const int per_ch = nroi * tpr;
+  unsigned am = 0;
+  for (int it = tid; it < nch * per_ch; it += 256) {
+    const int c = it / per_ch, q = it % per_ch;
+    const int rl = q / tpr, tl = q % tpr;
+    const int ty = tl / tiles_w, tx = tl % tiles_w;
+    const float* src = M + (long)(c0 + c) * T_pad + (long)(r0 + rl) * tpr + tl;
+    float r[3][5];   // A^T m
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const float m0 = src[(0 * 5 + j) * plane_stride], m1 = src[(1 * 5 + j) * plane_stride], m2 = src[(2 * 5 + j) * plane_stride];
+      const float m3 = src[(3 * 5 + j) * plane_stride], m4 = src[(4 * 5 + j) * plane_stride];
+      r[0][j] = m0 + m1 + m2 + m3;
+      r[1][j] = m1 - m2 + 2.f * m3;
+      r[2][j] = m1 + m2 + 4.f * m3 + m4;
+    }
+    const float b = bias ? bias[c0 + c] : 0.f;
+    float* dst = sm + (rl * nch + c) * HW;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int oh = 3 * ty + i;
+      if (oh >= Ho) continue;
+      float v[3];
+      v[0] = r[i][0] + r[i][1] + r[i][2] + r[i][3] + b;
+      v[1] = r[i][1] - r[i][2] + 2.f * r[i][3] + b;
+      v[2] = r[i][1] + r[i][2] + 4.f * r[i][3] + r[i][4] + b;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int ow = 3 * tx + j;
+        if (ow >= Wo) continue;
+        float u = v[j];
+        if (relu) u = u > 0.f ? u : 0.f;
+        dst[oh * Wo + ow] = u;
+        am = max(am, __float_as_uint(u) & 0x7fffffffu);
+      }
+    }
+  }
+  __syncthreads();
+  const int run = nch * HW;                               // contiguous floats of y per ROI
+  for (int rl = 0; rl < nroi; ++rl) {
+    float* dst = y + ((long)(r0 + rl) * Cout + c0) * HW;
+    const float* src = sm + rl * run;
+    if ((run & 3) == 0 && ((((long)(r0 + rl) * Cout + c0) * HW) & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+      for (int i = tid; i < run / 4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+      for (int i = tid; i < run; i += 256) dst[i] = src[i];
+    }
+  }
+  if (amax) mscnn::publish_amax(am, amax, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+
 // F(3x3,3x3) output transform with the fused MAX 2x2 / stride 2 pooling: 3x3 tiles and 2x2 windows meet every 6 pixels, so a
 // thread owns a 2x2 group of tiles (= 6x6 outputs = 3x3 pooling windows).  Tiles t and t+1 are neighbours in a plane, so the
 // 25 x 2 M reads per tile row are float2 loads; the six output rows are written as three float2 each.  Needs an even number
@@ -673,6 +742,9 @@ int wino_output_transform(int m, const float* M, const float* bias, float* y, fl
     MSCNN_REQUIRE(tiles_h % 2 == 0 && tiles_w % 2 == 0, "winograd F(3x3,3x3): fused pooling needs even tile counts");
     dim3 gp(cdiv((long)N * (tiles_h / 2) * (tiles_w / 2), 256), Cout);
     wino33_output_pool_kernel<<<gp, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T_pad, relu, amax);
+  } else if (m == 3 && Ho * Wo <= kW33MaxHW && !scalar_f4) {
+    // (sm rows are packed [roi][nch][HW]: a float4 read of row rl needs rl * run * 4 bytes 16-aligned -- run % 4 == 0 is checked in the kernel)
+    wino33_output_roi_kernel<<<dim3(cdiv(N, kW33ORois), cdiv(Cout, kW33OCh)), 256, 0, st>>>(M, bias, y, N, Cout, Ho, Wo, tiles_h, tiles_w, T_pad, relu, amax);
   } else if (m == 3) {
     wino33_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu, amax);
   } else {

@@ -900,6 +900,26 @@ def test_inner_product(hip, orc, M, N, K):
     close(hip.inner_product(dev(x), dev(w), None, relu=True).cpu().numpy(), orc.relu(orc.inner_product(x, w, None)))
 
 
+@pytest.mark.parametrize("case", [(540, 64, 7, 7, 96, 0), (37, 32, 7, 5, 40, 0), (130, 32, 8, 4, 64, 1), (9, 48, 5, 5, 24, 1), (257, 1024, 7, 7, 512, 0)])
+def test_wino_roi_output_transform_bit_identical(hip, case):
+    """roi_c1's F(3x3,3x3) output transform through LDS (contiguous runs of y per ROI) against the generic per-tile kernel
+    (tune_flags bit 8): the same expressions in the same order -- the same bits; ragged ROI / channel counts, 5x5, 5x3, 8x4 outputs."""
+    R, Cin, H, W, Cout, pad = case
+    g = torch.Generator(device="cuda").manual_seed(R)
+    x = torch.relu(torch.randn((R, Cin, H, W), device="cuda", generator=g))
+    w = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn((Cout,), device="cuda", generator=g)
+    outs = []
+    for flags in (0, 256):
+        p = hip.ConvPlan(R, Cin, H, W, Cout, 3, 3, (pad, pad), relu=True, algo=hip.ALGO_WINO_F3, tune_flags=flags)
+        assert p.kernel.startswith("winograd_f3x3")
+        p.pack(w)
+        outs.append(p.forward(x, b).clone())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=pad))
+    assert ((outs[0].double() - ref).abs() / torch.clamp(ref.abs(), min=1.0)).max().item() < 1e-4
+
+
 def test_inner_product_in_kernel_combine_is_deterministic(hip):
     """The stream-K InnerProduct adds a tile's partial sums inside the launch (last arrival combines, in k order): the same bits from
     launch to launch, with other shapes (other tile counts and slab sizes, fp16 weights) through the same library-owned slab /
