@@ -71,34 +71,41 @@ __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, 
                                            const u64* __restrict__ removed_init = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunks = (n + 63) >> 6;
-  // rows r = r0, r0 + rstep, ... of chunk c -> buffer b; this thread moves word `lane` of each
-  auto fill = [&](int c, int b, int r0, int rstep) {
-    u64* dst = buf + (size_t)b * 64 * W;
-    if (lane >= W) return;
-    const bool need = lane >= c && lane < wpr;           // words left of the diagonal are never read
-    constexpr int kBatch = 22;                           // ceil(64 / 3): every row of a producer wave in one batch
-    for (int rb = r0; rb < 64; rb += rstep * kBatch) {
-      u64 v[kBatch];
+  // rows r = r0, r0 + rstep, ... of chunk c; this thread moves word `lane` of each.  The producers are software-pipelined across
+  // the chunk barrier: the rows of chunk c + 2 are requested while chunk c is scanned and parked in LDS one iteration later, so
+  // the L2 round trip of a chunk's rows overlaps a whole scan step instead of being waited for inside it (round 3: 63 -> see DESIGN.md).
+  constexpr int kBatch = 22;                             // ceil(64 / 3): every row of a producer wave in one batch
+  auto load_rows = [&](int c, int r0, int rstep, u64 (&v)[kBatch]) {
+    const bool need = lane < W && lane >= c && lane < wpr;      // words left of the diagonal are never read
 #pragma unroll
-      for (int j = 0; j < kBatch; ++j) {
-        const int r = rb + j * rstep, row = c * 64 + r;
-        v[j] = (need && r < 64 && row < n) ? mask[(size_t)row * wpr + lane] : 0ull;
-      }
-#pragma unroll
-      for (int j = 0; j < kBatch; ++j) {
-        const int r = rb + j * rstep;
-        if (r < 64) dst[r * W + lane] = v[j];
-      }
+    for (int j = 0; j < kBatch; ++j) {
+      const int r = r0 + j * rstep, row = c * 64 + r;
+      v[j] = (need && r < 64 && row < n) ? mask[(size_t)row * wpr + lane] : 0ull;
     }
   };
-  fill(0, 0, wave, 4);
+  auto store_rows = [&](int b, int r0, int rstep, const u64 (&v)[kBatch]) {
+    if (lane >= W) return;
+    u64* dst = buf + (size_t)b * 64 * W;
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      const int r = r0 + j * rstep;
+      if (r < 64) dst[r * W + lane] = v[j];
+    }
+  };
+  u64 v[kBatch];
+  load_rows(0, wave, 4, v);                              // chunk 0: all four waves, 16 rows each
+  store_rows(0, wave, 4, v);
+  if (wave != 0 && nchunks > 1) load_rows(1, wave - 1, 3, v);      // in flight across the barrier
   __syncthreads();
   u64 removed = 0, mykeep = 0;
   if (removed_init != nullptr && wave == 0 && lane < W) removed = removed_init[lane];
   for (int c = 0; c < nchunks; ++c) {
     const u64* cur_rows = buf + (size_t)(c & 1) * 64 * W;
     if (wave != 0) {
-      if (c + 1 < nchunks) fill(c + 1, (c + 1) & 1, wave - 1, 3);
+      if (c + 1 < nchunks) {
+        store_rows((c + 1) & 1, wave - 1, 3, v);         // requested one step ago
+        if (c + 2 < nchunks) load_rows(c + 2, wave - 1, 3, v);
+      }
     } else {
       const int valid = min(64, n - c * 64);
       const u64 dg = cur_rows[min(lane, 63) * W + c];    // diagonal word of row (c*64 + lane): bits j > lane it suppresses

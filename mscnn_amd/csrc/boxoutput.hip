@@ -129,6 +129,19 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   if (tid == 0) { cnt[CNT_K] = K; s_fill = 0; }
   if (K == 0) return;
 
+  // The candidate keys of a frame (a few thousand .. ~12 k) are read ONCE, kRegKeys per thread with all loads in flight together, and
+  // every pass below works on the registers: the passes used to re-read the list from L2 with one dependent round trip per 1024
+  // keys each (3-4 select passes + the compaction: ~50 round trips, most of the kernel's 70 us).  Longer lists take the loops.
+  constexpr int kRegKeys = 12;
+  const bool inreg = n <= kRegKeys * kSortThreads;
+  u64 rk[kRegKeys];
+  if (inreg) {
+#pragma unroll
+    for (int j = 0; j < kRegKeys; ++j) {
+      const int i = tid + j * kSortThreads;
+      rk[j] = i < n ? keys[i] : 0ull;
+    }
+  }
   u64 thresh = 0;             // keep keys >= thresh
   if (n > K) {
     // radix select, MSB first, 8 bits per pass: find the K-th largest key.  The bucket walk is a 64-lane suffix scan
@@ -142,9 +155,17 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
       __syncthreads();
       const u64 prefix = s_prefix;
       const u64 himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-      for (int i = tid; i < n; i += kSortThreads) {
-        const u64 k = keys[i];
-        if ((k & himask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+      if (inreg) {
+#pragma unroll
+        for (int j = 0; j < kRegKeys; ++j) {
+          const u64 k = rk[j];
+          if (tid + j * kSortThreads < n && (k & himask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+        }
+      } else {
+        for (int i = tid; i < n; i += kSortThreads) {
+          const u64 k = keys[i];
+          if ((k & himask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+        }
       }
       __syncthreads();
       if (tid < 64) {
@@ -182,11 +203,22 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   __syncthreads();
   int P = 1;
   while (P < K) P <<= 1;
-  for (int i = tid; i < n; i += kSortThreads) {
-    const u64 k = keys[i];
-    if (k >= thresh) {
-      const int pos = atomicAdd(&s_fill, 1);
-      if (pos < kMaxK) sk[pos] = k;
+  if (inreg) {
+#pragma unroll
+    for (int j = 0; j < kRegKeys; ++j) {
+      const u64 k = rk[j];
+      if (tid + j * kSortThreads < n && k >= thresh) {
+        const int pos = atomicAdd(&s_fill, 1);
+        if (pos < kMaxK) sk[pos] = k;
+      }
+    }
+  } else {
+    for (int i = tid; i < n; i += kSortThreads) {
+      const u64 k = keys[i];
+      if (k >= thresh) {
+        const int pos = atomicAdd(&s_fill, 1);
+        if (pos < kMaxK) sk[pos] = k;
+      }
     }
   }
   for (int i = K + tid; i < P; i += kSortThreads) sk[i] = 0ull;   // pad sorts last (real keys are never 0)
