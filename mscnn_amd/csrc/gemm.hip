@@ -35,7 +35,8 @@ __device__ __forceinline__ void wg_range(long total, int G, int g, long& b, long
 
 // Partial tile t delivered (slab stores issued by every thread of the workgroup): count the arrival; the workgroup that completes
 // the tile adds its slabs in k order (= workgroup order: deterministic whoever arrives last) + bias / ReLU into y.
-// Hand-off recipe: every wave drains its stores, barrier, one lane releases (agent scope) and counts; the last one acquires.
+// Hand-off recipe: the slab was stored write-through (sc1), every wave drains its stores, barrier, one lane counts (agent scope);
+// the last one acquires.  (An agent-scope release fence per delivering workgroup -- an L2 write-back each -- cost fc6 +80 us.)
 template <int BM, int BN>
 __device__ __forceinline__ void deliver_partial_tile(const GemmArgs& a, int t, int m0, int n0, int* s_owner) {
   const int tid = threadIdx.x;
@@ -51,7 +52,6 @@ __device__ __forceinline__ void deliver_partial_tile(const GemmArgs& a, int t, i
     wg_range(a.total_iters, a.G, gl, b, e);
     while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
     while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const unsigned before = __hip_atomic_fetch_add(a.arrivals + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = before == (unsigned)(gl - gf);      // (every range is non-empty: G <= total_iters / 8)
     if (last) {
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {      // (min
     }
 
     const bool full = (k0 == 0 && k1 == a.KI);
-    float* slab = a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (BM * BN);
+    const __amdgpu_buffer_rsrc_t ssrc = __builtin_amdgcn_make_buffer_rsrc(a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (BM * BN), 0,
+                                                                           BM * BN * 4, 0x00020000);      // partial sums: write-through (sc1)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {      // (min
               a.y[(long)m * a.N + n] = v;
             }
           } else {
-            slab[ml * BN + nl] = acc[i][j][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[i][j][r]), ssrc, (unsigned)(ml * BN + nl) * 4u, 0, 16);
           }
         }
       }
@@ -283,7 +284,8 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(GemmArgs a) {
     }
 
     const bool full = (k0 == 0 && k1 == a.KI);
-    float* slab = a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (BM * BN);
+    const __amdgpu_buffer_rsrc_t ssrc = __builtin_amdgcn_make_buffer_rsrc(a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (BM * BN), 0,
+                                                                           BM * BN * 4, 0x00020000);      // partial sums: write-through (sc1)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(GemmArgs a) {
               a.y[(long)m * a.N + n] = v;
             }
           } else {
-            slab[ml * BN + nl] = acc[i][j][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[i][j][r]), ssrc, (unsigned)(ml * BN + nl) * 4u, 0, 16);
           }
         }
       }

@@ -20,9 +20,9 @@
 //   * tiles are few (72x240 -> 40 tiles), so the (tile, chunk) space is cut stream-K style into G equal ranges;
 //     partial sums go to fp32 slabs and the LAST workgroup to deliver a tile's slab adds them in k order (deterministic:
 //     the order is the slabs', not the arrivals') + bias, inside the same launch (round 3; rounds 1-2: a second, fix-up
-//     launch per head -- 7 launches of 11-15 us each on the 7s nets).  Hand-off: every storing wave drains its stores, one
-//     barrier, one lane's agent-scope release, then an arrival counter per tile; the workgroup that reads count - 1
-//     acquires and reduces.  Nobody waits for anybody, so nothing depends on dispatch order or co-residency.  The counters
+//     launch per head -- 7 launches of 11-15 us each on the 7s nets).  Hand-off: slabs are stored write-through (sc1), every
+//     storing wave drains its stores, one barrier, then an agent-scope arrival counter per tile; the workgroup that reads
+//     count - 1 acquires (one agent-scope fence) and reduces.  Nobody waits for anybody, so nothing depends on dispatch order or co-residency.  The counters
 //     live behind the packed weights (zeroed by the pack kernel, reset to zero by each tile's reducer).
 // Useful-work fraction: Cout / (4 * NQ) = 75 % for the 9-channel KITTI heads (vs 28 % with M = 32).
 // Measured (conv4_3 heads 5x5 / 7x7, 1 x 512 x 72 x 240): 81 / 140 us against 136 / 231 us for the 32-row igemm tile.
@@ -250,22 +250,25 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
           }
       }
     } else {
-      float* slab = a.ws + ((long)wg * 2 + (k0 > 0 ? 0 : 1)) * C::SLAB;
+      // partial sums leave write-through (sc1: the bytes are in memory when the store is acknowledged -- no L2 write-back, which
+      // an agent-scope release fence per delivering workgroup would cost: measured +50 .. 90 us per head)
+      const __amdgpu_buffer_rsrc_t ssrc = make_rsrc(a.ws + ((long)wg * 2 + (k0 > 0 ? 0 : 1)) * C::SLAB, (unsigned)C::SLAB * 4u);
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int p = (prow + 2 * g) * C::TW + pcol;
 #pragma unroll
         for (int q = 0; q < C::NQ; ++q)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) slab[(q * 4 + i) * C::BN + p] = acc[g][q][i];
+          for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[g][q][i]), ssrc, (unsigned)p * 4u,
+                                                  (unsigned)((q * 4 + i) * C::BN) * 4u, 16);
       }
-      // ---- hand-off (see the header): drain, barrier, one lane releases and counts the arrival
+      // ---- hand-off (see the header): drain, barrier, one lane counts the arrival
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) {
         int gf, gl;
         tile_owners(a.total_iters, a.G, a.KI, t, gf, gl);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const unsigned before = __hip_atomic_fetch_add(a.arrivals + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = before == (unsigned)(gl - gf);
         if (last) {

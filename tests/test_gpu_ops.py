@@ -338,11 +338,11 @@ def test_wgemm_plane_gemm_against_the_igemm_kernel(hip, case):
     """The plane GEMM of the Winograd layers (wgemm.hip, round 3) against the round-2 igemm kernel on the same planes.  With whole
     tiles both are k-ordered fmaf chains over the same operands, so the layer outputs must be BIT-IDENTICAL (tune_variant 300 + v +
     512 forces whole tiles, tune_flags bit 7 selects the igemm kernel).  With the stream-K split forced (+ 256) a tile's chunks are
-    summed in two or three parts: equal within 1e-5 (F(3x3,3x3)) / 4e-5 (F(4x4,3x3), whose output transform multiplies a
-    re-association difference in M by up to 8 x 8; measured 1.5e-5), and bit-identical from run to run (fixed order, no atomics on
-    data)."""
+    summed in two or three parts: equal within 4e-5 (the output transforms multiply a re-association difference in M by up to
+    4 x 4 / 8 x 8; measured 1.5e-5 .. 2.9e-5 at Cin = 512; the reference's own tolerance is 1e-4), and bit-identical from run to run
+    (fixed order, no atomics on data)."""
     N, Cin, H, W, Cout, m = case
-    tol = 4e-5 if m == 4 else 1e-5
+    tol = 4e-5
     algo = hip.ALGO_WINO_F4 if m == 4 else hip.ALGO_WINO_F3
     g = torch.Generator(device="cuda").manual_seed(17)
     x = torch.relu(torch.randn((N, Cin, H, W), device="cuda", generator=g))
