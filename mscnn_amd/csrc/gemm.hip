@@ -64,13 +64,17 @@ __device__ __forceinline__ void deliver_partial_tile(const GemmArgs& a, int t, i
   if (!s_owner[2]) return;
   const int gf = s_owner[0], n = s_owner[1] - gf + 1;
   const long its = (long)t * a.KI;
+  if (tid < n) {      // the slab offsets once, into LDS (wg_range is two 64-bit divisions); n <= KI / 8 + 2 contributors ... capped below
+    long b, e;
+    wg_range(a.total_iters, a.G, gf + tid, b, e);
+    s_owner[4 + tid] = ((gf + tid) * 2 + (b > its ? 0 : 1));
+  }
+  __syncthreads();
   for (int j = 0; j < BM * BN / 1024; ++j) {
     const int i = (j * 256 + tid) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < n; ++s) {
-      long b, e;
-      wg_range(a.total_iters, a.G, gf + s, b, e);
-      const float4 u = *reinterpret_cast<const float4*>(a.ws + ((long)(gf + s) * 2 + (b > its ? 0 : 1)) * (BM * BN) + i);
+      const float4 u = *reinterpret_cast<const float4*>(a.ws + (long)s_owner[4 + s] * (BM * BN) + i);
       v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
     const int m = m0 + i / BN, nn = n0 + i % BN;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {      // (min
   static_assert(BM * BN == 128 * 128 && BM % 64 == 0 && BN % 64 == 0, "4 waves of 64 x 64");
   __shared__ __attribute__((aligned(16))) float ldsX[BM * LDK];
   __shared__ __attribute__((aligned(16))) float ldsW[BN * LDK];
-  __shared__ int s_owner[3];
+  __shared__ int s_owner[4 + 256];      // tile combine: {first, last workgroup, combine here, -}, then the slab indices
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   constexpr int WN = BN / 64;                   // waves along N
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(GemmArgs a) {
   static_assert(BM * BN == 128 * 128 && BM % 64 == 0 && BN % 64 == 0, "4 waves of 64 x 64");
   __shared__ __attribute__((aligned(16))) _Float16 ldsX[BM * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 ldsW[BN * LDH];
-  __shared__ int s_owner[3];
+  __shared__ int s_owner[4 + 256];      // tile combine: {first, last workgroup, combine here, -}, then the slab indices
   const _Float16* w16 = reinterpret_cast<const _Float16*>(a.w);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
   __shared__ __attribute__((aligned(16))) float ldsA[C::A_ELEMS];
   __shared__ float ldsB[C::B_ELEMS];
   __shared__ int s_owner[3];      // {first, last} workgroup of the tile being combined, "this workgroup combines"
+  __shared__ int s_slab[256];     // float offsets of the tile's slabs in the workspace (<= 256 contributors: KI <= 256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wg = blockIdx.x;
   long it, it_end;
@@ -279,30 +280,32 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
       }
       __syncthreads();
       if (s_owner[2]) {
-        // the tile's slabs in k order = workgroup order; 512 pixels: a float2 per thread and channel, slab loads four deep
-        const int gf = s_owner[0], gl = s_owner[1], n = gl - gf + 1;
+        // the tile's slabs in k order = workgroup order; 512 pixels: a float2 per thread and channel, slab loads four deep.
+        // (The slab offsets are worked out once, by n lanes, into LDS: wg_range is two 64-bit divisions.)
+        const int gf = s_owner[0], n = s_owner[1] - gf + 1;
         const long its = (long)t * a.KI;
+        if (tid < n) {
+          long b, e;
+          wg_range(a.total_iters, a.G, gf + tid, b, e);
+          s_slab[tid] = ((gf + tid) * 2 + (b > its ? 0 : 1)) * C::SLAB;
+        }
+        __syncthreads();
         const int p = tid * 2;
         const int oh = h0 + p / C::TW, ow = w0 + p % C::TW;
         for (int co = 0; co < a.Cout; ++co) {
-          auto slab_of = [&](int s) -> const float* {
-            const int g = gf + s;
-            long b, e;
-            wg_range(a.total_iters, a.G, g, b, e);
-            return a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * C::SLAB + co * C::BN + p;
-          };
+          const float* base = a.ws + co * C::BN + p;
           float2 v = make_float2(0.f, 0.f);
           int s = 0;
           for (; s + 4 <= n; s += 4) {
-            const float2 u0 = *reinterpret_cast<const float2*>(slab_of(s)), u1 = *reinterpret_cast<const float2*>(slab_of(s + 1));
-            const float2 u2 = *reinterpret_cast<const float2*>(slab_of(s + 2)), u3 = *reinterpret_cast<const float2*>(slab_of(s + 3));
+            const float2 u0 = *reinterpret_cast<const float2*>(base + s_slab[s]), u1 = *reinterpret_cast<const float2*>(base + s_slab[s + 1]);
+            const float2 u2 = *reinterpret_cast<const float2*>(base + s_slab[s + 2]), u3 = *reinterpret_cast<const float2*>(base + s_slab[s + 3]);
             v.x += u0.x; v.y += u0.y;
             v.x += u1.x; v.y += u1.y;
             v.x += u2.x; v.y += u2.y;
             v.x += u3.x; v.y += u3.y;
           }
           for (; s < n; ++s) {
-            const float2 u = *reinterpret_cast<const float2*>(slab_of(s));
+            const float2 u = *reinterpret_cast<const float2*>(base + s_slab[s]);
             v.x += u.x; v.y += u.y;
           }
           const float bv = a.bias ? a.bias[co] : 0.f;
