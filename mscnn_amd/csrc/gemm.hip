@@ -70,16 +70,26 @@ __device__ __forceinline__ void deliver_partial_tile(const GemmArgs& a, int t, i
     s_owner[4 + tid] = ((gf + tid) * 2 + (b > its ? 0 : 1));
   }
   __syncthreads();
-  for (int j = 0; j < BM * BN / 1024; ++j) {
+  // slab-major: all BM * BN / 1024 float4 of the thread in registers, each slab adds to all of them -- one round trip per slab
+  // (16 independent loads in flight), the sum order per output still s = 0, 1, ..
+  constexpr int NJ = BM * BN / 1024;
+  float4 v[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < n; ++s) {
+    const float* slab = a.ws + (long)s_owner[4 + s] * (BM * BN) + tid * 4;
+    float4 u[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) u[j] = *reinterpret_cast<const float4*>(slab + j * 1024);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { v[j].x += u[j].x; v[j].y += u[j].y; v[j].z += u[j].z; v[j].w += u[j].w; }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
     const int i = (j * 256 + tid) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < n; ++s) {
-      const float4 u = *reinterpret_cast<const float4*>(a.ws + (long)s_owner[4 + s] * (BM * BN) + i);
-      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-    }
     const int m = m0 + i / BN, nn = n0 + i % BN;
     if (m >= a.M) continue;
-    const float vals[4] = {v.x, v.y, v.z, v.w};
+    const float vals[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (nn + q >= a.N) continue;

@@ -290,31 +290,33 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
           s_slab[tid] = ((gf + tid) * 2 + (b > its ? 0 : 1)) * C::SLAB;
         }
         __syncthreads();
+        // slab-major: the thread's float2 of EVERY channel is in registers and each slab adds to all of them, so a slab costs one
+        // round trip (4 * NQ independent loads in flight) instead of one per channel; the sum order per output is still s = 0, 1, ..
         const int p = tid * 2;
         const int oh = h0 + p / C::TW, ow = w0 + p % C::TW;
-        for (int co = 0; co < a.Cout; ++co) {
-          const float* base = a.ws + co * C::BN + p;
-          float2 v = make_float2(0.f, 0.f);
-          int s = 0;
-          for (; s + 4 <= n; s += 4) {
-            const float2 u0 = *reinterpret_cast<const float2*>(base + s_slab[s]), u1 = *reinterpret_cast<const float2*>(base + s_slab[s + 1]);
-            const float2 u2 = *reinterpret_cast<const float2*>(base + s_slab[s + 2]), u3 = *reinterpret_cast<const float2*>(base + s_slab[s + 3]);
-            v.x += u0.x; v.y += u0.y;
-            v.x += u1.x; v.y += u1.y;
-            v.x += u2.x; v.y += u2.y;
-            v.x += u3.x; v.y += u3.y;
-          }
-          for (; s < n; ++s) {
-            const float2 u = *reinterpret_cast<const float2*>(base + s_slab[s]);
-            v.x += u.x; v.y += u.y;
-          }
-          const float bv = a.bias ? a.bias[co] : 0.f;
-          float r0 = v.x + bv, r1 = v.y + bv;
-          if (a.relu) { r0 = r0 > 0.f ? r0 : 0.f; r1 = r1 > 0.f ? r1 : 0.f; }
-          if (oh < a.Ho) {
-            float* yrow = a.y + ((long)img * a.Cout + co) * co_stride + oh * a.Wo;
-            if (ow < a.Wo) yrow[ow] = r0;
-            if (ow + 1 < a.Wo) yrow[ow + 1] = r1;
+        constexpr int NC = C::NQ * 4;
+        float2 v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = make_float2(0.f, 0.f);
+        const float* base = a.ws + p;
+        for (int sidx = 0; sidx < n; ++sidx) {
+          const float* b0 = base + s_slab[sidx];
+          float2 u[NC];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) u[c] = *reinterpret_cast<const float2*>(b0 + c * C::BN);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) { v[c].x += u[c].x; v[c].y += u[c].y; }
+        }
+        float* yrow = a.y + (long)img * a.Cout * co_stride + oh * a.Wo;
+        const bool w0ok = oh < a.Ho && ow < a.Wo, w1ok = oh < a.Ho && ow + 1 < a.Wo;
+#pragma unroll
+        for (int co = 0; co < NC; ++co) {
+          if (co < a.Cout) {
+            const float bv = a.bias ? a.bias[co] : 0.f;
+            float r0 = v[co].x + bv, r1 = v[co].y + bv;
+            if (a.relu) { r0 = r0 > 0.f ? r0 : 0.f; r1 = r1 > 0.f ? r1 : 0.f; }
+            if (w0ok) yrow[(long)co * co_stride + ow] = r0;
+            if (w1ok) yrow[(long)co * co_stride + ow + 1] = r1;
           }
         }
       }
