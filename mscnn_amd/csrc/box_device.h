@@ -1,5 +1,6 @@
 // Device helpers shared by boxoutput.hip and detections.hip (gfx950).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 namespace mscnn_dev {
@@ -75,12 +76,19 @@ __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, 
   // the chunk barrier: the rows of chunk c + 2 are requested while chunk c is scanned and parked in LDS one iteration later, so
   // the L2 round trip of a chunk's rows overlaps a whole scan step instead of being waited for inside it (round 3: 63 -> see DESIGN.md).
   constexpr int kBatch = 22;                             // ceil(64 / 3): every row of a producer wave in one batch
+  // (buffer loads: a row past n or a word this lane does not need is an out-of-range offset and reads as 0 -- no branch and no
+  // 64-bit address arithmetic per row; the per-row form with both was 15 instructions x 22 rows per chunk and paced the scan)
+  const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(mask), 0, n * wpr * 8, 0x00020000);
   auto load_rows = [&](int c, int r0, int rstep, u64 (&v)[kBatch]) {
     const bool need = lane < W && lane >= c && lane < wpr;      // words left of the diagonal are never read
+    const unsigned off0 = need ? (unsigned)(((c * 64 + r0) * wpr + lane) * 8) : 0x80000000u;
+    const unsigned step = (unsigned)(rstep * wpr * 8);
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) {
-      const int r = r0 + j * rstep, row = c * 64 + r;
-      v[j] = (need && r < 64 && row < n) ? mask[(size_t)row * wpr + lane] : 0ull;
+      // (rows r >= 64 of the batch belong to the next chunk or lie past n: they are loaded into registers nobody stores)
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(msrc, off0 + (unsigned)j * step, 0, 0);
+      v[j] = ((u64)w[1] << 32) | w[0];
     }
   };
   auto store_rows = [&](int b, int r0, int rstep, const u64 (&v)[kBatch]) {
@@ -136,6 +144,64 @@ __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, 
     __syncthreads();
   }
   return mykeep;
+}
+
+// Bitonic sort (descending) of 1024 * EPT keys held in registers by a 1024-thread workgroup: element i lives in thread i % 1024,
+// register i / 1024.  A compare-exchange at stride s pairs i with i ^ s: s < 64 is a lane exchange inside the wavefront
+// (two 32-bit shuffles, no LDS, no barrier), s >= 1024 another register of the same thread, and only 64 <= s <= 512 goes through
+// LDS with a barrier -- 10 (EPT 1) / 14 (EPT 2) / 18 (EPT 4) such steps instead of the 55 / 66 / 78 of the all-LDS network below,
+// which paced select_sort_kernel (round 3).  Same network, same comparisons: the same order.  `sk` needs 1024 * EPT words.
+template <int EPT>
+__device__ __forceinline__ void bitonic_desc_regs(u64 (&r)[EPT], u64* sk, int tid) {
+  constexpr int P = 1024 * EPT;
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride >= 1024) {
+        // (register pairs named by constants: a run-time register index would send r[] to scratch)
+        auto cx = [&](auto jl_c, auto jh_c) {
+          constexpr int jl = decltype(jl_c)::value, jh = decltype(jh_c)::value;
+          const bool desc = ((tid + (jl << 10)) & size) == 0;
+          const u64 a = r[jl], b = r[jh];                       // a = the lower index of the pair
+          const bool swap = desc ? (a < b) : (a > b);
+          if (swap) { r[jl] = b; r[jh] = a; }
+        };
+        typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+        typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 3> I3;
+        if constexpr (EPT >= 2) {
+          if (stride == 1024) { cx(I0{}, I1{}); if constexpr (EPT == 4) cx(I2{}, I3{}); }
+        }
+        if constexpr (EPT == 4) {
+          if (stride == 2048) { cx(I0{}, I2{}); cx(I1{}, I3{}); }
+        }
+      } else if (stride < 64) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+          const int i = tid + (j << 10);
+          const u64 a = r[j];
+          const unsigned blo = (unsigned)__shfl_xor((int)(unsigned)a, stride, 64), bhi = (unsigned)__shfl_xor((int)(unsigned)(a >> 32), stride, 64);
+          const u64 b = ((u64)bhi << 32) | blo;
+          const bool want_max = (((i & stride) == 0) == ((i & size) == 0));
+          r[j] = want_max ? (a > b ? a : b) : (a < b ? a : b);
+        }
+      } else {
+        __syncthreads();                                        // (the previous LDS round has been read)
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) sk[tid + (j << 10)] = r[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+          const int i = tid + (j << 10);
+          const u64 a = r[j], b = sk[i ^ stride];
+          const bool want_max = (((i & stride) == 0) == ((i & size) == 0));
+          r[j] = want_max ? (a > b ? a : b) : (a < b ? a : b);
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) sk[tid + (j << 10)] = r[j];
+  __syncthreads();
 }
 
 // Bitonic sort (descending) of P (power of two, <= kMaxK) 64-bit keys in LDS by one workgroup.

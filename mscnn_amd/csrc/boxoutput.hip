@@ -221,9 +221,13 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
       }
     }
   }
-  for (int i = K + tid; i < P; i += kSortThreads) sk[i] = 0ull;   // pad sorts last (real keys are never 0)
+  // pad sorts last (real keys are never 0); the network runs on registers (element i in thread i % 1024, register i / 1024)
+  const int P2 = P < 1024 ? 1024 : P;
+  for (int i = K + tid; i < P2; i += kSortThreads) sk[i] = 0ull;
   __syncthreads();
-  bitonic_desc(sk, P, tid, kSortThreads);
+  if (P2 == 1024) { u64 r[1] = {sk[tid]}; bitonic_desc_regs<1>(r, sk, tid); }
+  else if (P2 == 2048) { u64 r[2] = {sk[tid], sk[tid + 1024]}; bitonic_desc_regs<2>(r, sk, tid); }
+  else { u64 r[4] = {sk[tid], sk[tid + 1024], sk[tid + 2048], sk[tid + 3072]}; bitonic_desc_regs<4>(r, sk, tid); }
   for (int i = tid; i < K; i += kSortThreads) {
     const int aid = (int)(unsigned)(sk[i] & 0xffffffffull);
     sorted_box[i] = box_by_anchor[aid];

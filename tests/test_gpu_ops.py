@@ -1063,7 +1063,7 @@ def _heads(rng, shapes, num=1, cls=5, bg_bias=0.0, sigma=2.0):
 
 
 @pytest.mark.parametrize("regime,bg_bias,max_nms", [("dense", -8.0, 2000), ("sparse", 6.0, 2000), ("trunc", -8.0, 300),
-                                                    ("empty", 60.0, 2000)])
+                                                    ("empty", 60.0, 2000), ("k1024", -8.0, 1024), ("k3000", -8.0, 3000), ("k4032", -8.0, 4032)])
 def test_boxoutput_selection_bitexact(hip, orc, regime, bg_bias, max_nms):
     rng = np.random.default_rng(1701)
     heads = _heads(rng, KITTI_HEADS["shapes"], bg_bias=bg_bias)
