@@ -8,8 +8,7 @@
 // The ROI rows are the MFMA "M" side and the output units the "N" side so that each accumulator register
 // is a 128-B run of y[m][n..n+31] (coalesced stores).  Work split is stream-K over (tile, k-chunk), as in
 // conv.hip: M is data dependent (1..2000 ROIs) so tile counts never match the 256 CUs; partial tiles go
-// through fp32 slabs; the last workgroup to deliver a tile's slab adds them in k order + bias/ReLU inside the same launch
-// (arrival counters, as in headconv.hip; rounds 1-2: a fix-up launch).  Tiles are ordered with the ROI-tile
+// through fp32 slabs + a fix-up kernel that also applies bias/ReLU.  Tiles are ordered with the ROI-tile
 // index fastest so that the workgroups sharing a 128-row slice of W run together and share it in L2
 // (W for fc6 is 210 MB: it must stream from HBM once, not once per ROI tile).
 // cls_pred / bbox_pred (N = 5 / 20): one workgroup per row, lanes split K, wave reductions.
@@ -23,7 +22,6 @@ constexpr int BK = 32, LDK = BK + 4;     // tile shapes: 128 x 128 (2 x 2 waves)
 
 struct GemmArgs {
   const float* x; const float* w; const float* bias; float* y; float* ws;
-  unsigned* arrivals;      // [MT * NT], zero between launches
   int M, N, K, MT, NT, KI, G, relu;
   long total_iters;
 };
@@ -33,80 +31,11 @@ __device__ __forceinline__ void wg_range(long total, int G, int g, long& b, long
   e = total * (g + 1) / G;
 }
 
-// Partial tile t delivered (slab stores issued by every thread of the workgroup): count the arrival; the workgroup that completes
-// the tile adds its slabs in k order (= workgroup order: deterministic whoever arrives last) + bias / ReLU into y.
-// Hand-off recipe: the slab was stored write-through (sc1), every wave drains its stores, barrier, one lane counts (agent scope);
-// the last one acquires.  (An agent-scope release fence per delivering workgroup -- an L2 write-back each -- cost fc6 +80 us.)
-template <int BM, int BN>
-__device__ __forceinline__ void deliver_partial_tile(const GemmArgs& a, int t, int m0, int n0, int* s_owner) {
-  const int tid = threadIdx.x;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    const long its = (long)t * a.KI, ite = its + a.KI;
-    int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
-    long b, e;
-    wg_range(a.total_iters, a.G, gf, b, e);
-    while (e <= its) { ++gf; wg_range(a.total_iters, a.G, gf, b, e); }
-    while (b > its) { --gf; wg_range(a.total_iters, a.G, gf, b, e); }
-    wg_range(a.total_iters, a.G, gl, b, e);
-    while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
-    while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
-    const unsigned before = __hip_atomic_fetch_add(a.arrivals + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = before == (unsigned)(gl - gf);      // (every range is non-empty: G <= total_iters / 8)
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(a.arrivals + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    s_owner[0] = gf; s_owner[1] = gl; s_owner[2] = last;
-  }
-  __syncthreads();
-  if (!s_owner[2]) return;
-  const int gf = s_owner[0], n = s_owner[1] - gf + 1;
-  const long its = (long)t * a.KI;
-  if (tid < n) {      // the slab offsets once, into LDS (wg_range is two 64-bit divisions); n <= KI / 8 + 2 contributors ... capped below
-    long b, e;
-    wg_range(a.total_iters, a.G, gf + tid, b, e);
-    s_owner[4 + tid] = ((gf + tid) * 2 + (b > its ? 0 : 1));
-  }
-  __syncthreads();
-  // slab-major: all BM * BN / 1024 float4 of the thread in registers, each slab adds to all of them -- one round trip per slab
-  // (16 independent loads in flight), the sum order per output still s = 0, 1, ..
-  constexpr int NJ = BM * BN / 1024;
-  float4 v[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < n; ++s) {
-    const float* slab = a.ws + (long)s_owner[4 + s] * (BM * BN) + tid * 4;
-    float4 u[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) u[j] = *reinterpret_cast<const float4*>(slab + j * 1024);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) { v[j].x += u[j].x; v[j].y += u[j].y; v[j].z += u[j].z; v[j].w += u[j].w; }
-  }
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int i = (j * 256 + tid) * 4;
-    const int m = m0 + i / BN, nn = n0 + i % BN;
-    if (m >= a.M) continue;
-    const float vals[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (nn + q >= a.N) continue;
-      float r = vals[q];
-      if (a.bias) r += a.bias[nn + q];
-      if (a.relu) r = r > 0.f ? r : 0.f;
-      a.y[(long)m * a.N + nn + q] = r;
-    }
-  }
-}
-
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {      // (min 3 workgroups / CU was tried: 168 VGPRs + 176 B scratch)
   static_assert(BM * BN == 128 * 128 && BM % 64 == 0 && BN % 64 == 0, "4 waves of 64 x 64");
   __shared__ __attribute__((aligned(16))) float ldsX[BM * LDK];
   __shared__ __attribute__((aligned(16))) float ldsW[BN * LDK];
-  __shared__ int s_owner[4 + 256];      // tile combine: {first, last workgroup, combine here, -}, then the slab indices
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   constexpr int WN = BN / 64;                   // waves along N
@@ -176,8 +105,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {      // (min
     }
 
     const bool full = (k0 == 0 && k1 == a.KI);
-    const __amdgpu_buffer_rsrc_t ssrc = __builtin_amdgcn_make_buffer_rsrc(a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (BM * BN), 0,
-                                                                           BM * BN * 4, 0x00020000);      // partial sums: write-through (sc1)
+    float* slab = a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (BM * BN);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -195,13 +123,62 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {      // (min
               a.y[(long)m * a.N + n] = v;
             }
           } else {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[i][j][r]), ssrc, (unsigned)(ml * BN + nl) * 4u, 0, 16);
+            slab[ml * BN + nl] = acc[i][j][r];
           }
         }
       }
-    if (!full) deliver_partial_tile<BM, BN>(a, t, m0, n0, s_owner);
     it += (k1 - k0);
     __syncthreads();
+  }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmArgs a) {
+  __shared__ const float* s_slab[64];
+  __shared__ int s_n;
+  const int t = blockIdx.x >> 2, part = blockIdx.x & 3;    // 4 workgroups per 128x128 tile
+  if (threadIdx.x == 0) {
+    const long its = (long)t * a.KI, ite = its + a.KI;
+    int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
+    long b, e;
+    wg_range(a.total_iters, a.G, gf, b, e);
+    while (e <= its) { ++gf; wg_range(a.total_iters, a.G, gf, b, e); }
+    while (b > its) { --gf; wg_range(a.total_iters, a.G, gf, b, e); }
+    wg_range(a.total_iters, a.G, gl, b, e);
+    while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
+    while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
+    int n = 0;
+    if (gf != gl)
+      for (int g = gf; g <= gl && n < 64; ++g) {
+        wg_range(a.total_iters, a.G, g, b, e);
+        s_slab[n++] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * (BM * BN);
+      }
+    s_n = n;
+  }
+  __syncthreads();
+  const int n = s_n;
+  if (n == 0) return;
+  const int nt = t / a.MT, mt = t % a.MT;
+  const int m0 = mt * BM, n0 = nt * BN;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = part * 4096 + (j * 256 + threadIdx.x) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < n; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(s_slab[s] + i);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int m = m0 + i / BN, nn = n0 + i % BN;
+    if (m >= a.M) continue;
+    const float vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (nn + q >= a.N) continue;
+      float r = vals[q];
+      if (a.bias) r += a.bias[nn + q];
+      if (a.relu) r = r > 0.f ? r : 0.f;
+      a.y[(long)m * a.N + nn + q] = r;
+    }
   }
 }
 
@@ -223,7 +200,6 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(GemmArgs a) {
   static_assert(BM * BN == 128 * 128 && BM % 64 == 0 && BN % 64 == 0, "4 waves of 64 x 64");
   __shared__ __attribute__((aligned(16))) _Float16 ldsX[BM * LDH];
   __shared__ __attribute__((aligned(16))) _Float16 ldsW[BN * LDH];
-  __shared__ int s_owner[4 + 256];      // tile combine: {first, last workgroup, combine here, -}, then the slab indices
   const _Float16* w16 = reinterpret_cast<const _Float16*>(a.w);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -298,8 +274,7 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(GemmArgs a) {
     }
 
     const bool full = (k0 == 0 && k1 == a.KI);
-    const __amdgpu_buffer_rsrc_t ssrc = __builtin_amdgcn_make_buffer_rsrc(a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (BM * BN), 0,
-                                                                           BM * BN * 4, 0x00020000);      // partial sums: write-through (sc1)
+    float* slab = a.ws + ((long)blockIdx.x * 2 + (k0 > 0 ? 0 : 1)) * (BM * BN);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -317,11 +292,10 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(GemmArgs a) {
               a.y[(long)m * a.N + n] = v;
             }
           } else {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[i][j][r]), ssrc, (unsigned)(ml * BN + nl) * 4u, 0, 16);
+            slab[ml * BN + nl] = acc[i][j][r];
           }
         }
       }
-    if (!full) deliver_partial_tile<BM, BN>(a, t, m0, n0, s_owner);
     it += (k1 - k0);
     __syncthreads();
   }
@@ -428,11 +402,7 @@ using namespace mscnn;
 namespace {
 constexpr int kMaxDevices = 64;
 struct SlabWs { float* p = nullptr; size_t bytes = 0; };
-// Layout: [kCounterBytes of per-tile arrival counters][slabs].  The counters are zero between launches (zeroed here when the buffer
-// is (re)allocated, returned to zero by each tile's combining workgroup); only this file's kernels touch the buffer.
-constexpr size_t kCounterBytes = 64 * 1024;      // 16384 tiles (fc6 of a 2000-ROI frame: 32 x 16)
-int reserve_slabs(size_t need, float** out, hipStream_t st) {
-  need += kCounterBytes;
+int reserve_slabs(size_t need, float** out) {
   static thread_local SlabWs ws[kMaxDevices];
   int dev = 0;
   MSCNN_HIP_TRY(hipGetDevice(&dev));
@@ -443,7 +413,6 @@ int reserve_slabs(size_t need, float** out, hipStream_t st) {
     w.p = nullptr; w.bytes = 0;
     MSCNN_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.p), need));
     w.bytes = need;
-    MSCNN_HIP_TRY(hipMemsetAsync(w.p, 0, kCounterBytes, st));
   }
   *out = w.p;
   return MSCNN_OK;
@@ -510,13 +479,9 @@ static int inner_product_gemm(const float* x, const void* w, bool w_is_f16, cons
   if (G < 1) G = 1;
   a.G = (int)G;
   const size_t need = (size_t)a.G * 2 * BM * BN * sizeof(float);
-  MSCNN_REQUIRE((size_t)a.MT * a.NT * sizeof(unsigned) <= kCounterBytes, "inner_product: %d x %d tiles exceed the arrival-counter table", a.MT, a.NT);
   {
-    float* base = nullptr;
-    const int rc = reserve_slabs(need, &base, st);
+    const int rc = reserve_slabs(need, &a.ws);
     if (rc != MSCNN_OK) return rc;
-    a.arrivals = reinterpret_cast<unsigned*>(base);
-    a.ws = base + kCounterBytes / sizeof(float);
   }
   if (w_is_f16) {
     if (m64) gemm16_tn_kernel<64, 256><<<a.G, 256, 0, st>>>(a);
@@ -525,6 +490,9 @@ static int inner_product_gemm(const float* x, const void* w, bool w_is_f16, cons
     if (m64) gemm_tn_kernel<64, 256><<<a.G, 256, 0, st>>>(a);
     else gemm_tn_kernel<128, 128><<<a.G, 256, 0, st>>>(a);
   }
+  MSCNN_POST_LAUNCH();
+  if (m64) gemm_fixup_kernel<64, 256><<<a.MT * a.NT * 4, 256, 0, st>>>(a);
+  else gemm_fixup_kernel<128, 128><<<a.MT * a.NT * 4, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

@@ -8,7 +8,7 @@ struct HeadPlan {
   int entry = -1;          // index into headconv.hip's kernel table; -1: shape not covered
   int NTH = 0, NTW = 0, KI = 0, G = 0, tiles = 0;
   long total_iters = 0;
-  size_t packed_bytes = 0, weight_bytes = 0, ws_bytes = 0;      // packed = weights + per-tile arrival counters
+  size_t packed_bytes = 0, ws_bytes = 0;
 };
 
 bool head_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp);

@@ -18,12 +18,7 @@
 //     the patch [CK][16+KH-1][32+KW-1] and the chunk's packed weights wp[chunk][quad][reg][lane] are staged through
 //     registers into LDS (prefetched one chunk ahead); each wave then copies the weights LDS -> VGPRs once per chunk;
 //   * tiles are few (72x240 -> 40 tiles), so the (tile, chunk) space is cut stream-K style into G equal ranges;
-//     partial sums go to fp32 slabs and the LAST workgroup to deliver a tile's slab adds them in k order (deterministic:
-//     the order is the slabs', not the arrivals') + bias, inside the same launch (round 3; rounds 1-2: a second, fix-up
-//     launch per head -- 7 launches of 11-15 us each on the 7s nets).  Hand-off: slabs are stored write-through (sc1), every
-//     storing wave drains its stores, one barrier, then an agent-scope arrival counter per tile; the workgroup that reads
-//     count - 1 acquires (one agent-scope fence) and reduces.  Nobody waits for anybody, so nothing depends on dispatch order or co-residency.  The counters
-//     live behind the packed weights (zeroed by the pack kernel, reset to zero by each tile's reducer).
+//     partial sums go to fp32 slabs and a fix-up kernel adds them in k order (deterministic) + bias.
 // Useful-work fraction: Cout / (4 * NQ) = 75 % for the 9-channel KITTI heads (vs 28 % with M = 32).
 // Measured (conv4_3 heads 5x5 / 7x7, 1 x 512 x 72 x 240): 81 / 140 us against 136 / 231 us for the 32-row igemm tile.
 // PMC (rocprofv3, 5x5 head): 12.29 M MFMAs, SQ_VALU_MFMA_BUSY_CYCLES = 8 cycles each, 57 % of the kernel's cycles at
@@ -43,7 +38,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct HeadArgs {
   const float* x; const float* wp; const float* bias; float* y; float* ws;
-  unsigned* arrivals;           // [tiles], zero between launches
   int N, Cin, H, W, Cout, Ho, Wo, pad_h, pad_w;
   int NTH, NTW, KI, G, relu;
   long total_iters;
@@ -96,19 +90,6 @@ __global__ __launch_bounds__(256) void head_pack_kernel(const float* __restrict_
   }
 }
 
-// The workgroups gf .. gl whose iteration ranges touch tile t (every range is non-empty: G <= total_iters / 2).
-__device__ __forceinline__ void tile_owners(long total_iters, int G, int KI, int t, int& gf, int& gl) {
-  const long its = (long)t * KI, ite = its + KI;
-  gf = (int)(its * G / total_iters); gl = (int)((ite - 1) * G / total_iters);
-  long b, e;
-  wg_range(total_iters, G, gf, b, e);
-  while (e <= its) { ++gf; wg_range(total_iters, G, gf, b, e); }
-  while (b > its) { --gf; wg_range(total_iters, G, gf, b, e); }
-  wg_range(total_iters, G, gl, b, e);
-  while (e <= ite - 1) { ++gl; wg_range(total_iters, G, gl, b, e); }
-  while (b > ite - 1) { --gl; wg_range(total_iters, G, gl, b, e); }
-}
-
 // B operands of pipeline group G: GK consecutive k, both 64-pixel groups of the wave
 template <class C, int G>
 __device__ __forceinline__ void lds_group(const float* b0, const float* b1, float (&bv)[C::GK][2]) {
@@ -129,8 +110,6 @@ template <class C>
 __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
   __shared__ __attribute__((aligned(16))) float ldsA[C::A_ELEMS];
   __shared__ float ldsB[C::B_ELEMS];
-  __shared__ int s_owner[3];      // {first, last} workgroup of the tile being combined, "this workgroup combines"
-  __shared__ int s_slab[256];     // float offsets of the tile's slabs in the workspace (<= 256 contributors: KI <= 256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wg = blockIdx.x;
   long it, it_end;
@@ -251,89 +230,86 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
           }
       }
     } else {
-      // partial sums leave write-through (sc1: the bytes are in memory when the store is acknowledged -- no L2 write-back, which
-      // an agent-scope release fence per delivering workgroup would cost: measured +50 .. 90 us per head)
-      const __amdgpu_buffer_rsrc_t ssrc = make_rsrc(a.ws + ((long)wg * 2 + (k0 > 0 ? 0 : 1)) * C::SLAB, (unsigned)C::SLAB * 4u);
+      float* slab = a.ws + ((long)wg * 2 + (k0 > 0 ? 0 : 1)) * C::SLAB;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int p = (prow + 2 * g) * C::TW + pcol;
 #pragma unroll
         for (int q = 0; q < C::NQ; ++q)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[g][q][i]), ssrc, (unsigned)p * 4u,
-                                                  (unsigned)((q * 4 + i) * C::BN) * 4u, 16);
-      }
-      // ---- hand-off (see the header): drain, barrier, one lane counts the arrival
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        int gf, gl;
-        tile_owners(a.total_iters, a.G, a.KI, t, gf, gl);
-        const unsigned before = __hip_atomic_fetch_add(a.arrivals + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = before == (unsigned)(gl - gf);
-        if (last) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          __hip_atomic_store(a.arrivals + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (every arrival of this launch is in)
-        }
-        s_owner[0] = gf; s_owner[1] = gl; s_owner[2] = last;
-      }
-      __syncthreads();
-      if (s_owner[2]) {
-        // the tile's slabs in k order = workgroup order; 512 pixels: a float2 per thread and channel, slab loads four deep.
-        // (The slab offsets are worked out once, by n lanes, into LDS: wg_range is two 64-bit divisions.)
-        const int gf = s_owner[0], n = s_owner[1] - gf + 1;
-        const long its = (long)t * a.KI;
-        if (tid < n) {
-          long b, e;
-          wg_range(a.total_iters, a.G, gf + tid, b, e);
-          s_slab[tid] = ((gf + tid) * 2 + (b > its ? 0 : 1)) * C::SLAB;
-        }
-        __syncthreads();
-        // slab-major: the thread's float2 of EVERY channel is in registers and each slab adds to all of them, so a slab costs one
-        // round trip (4 * NQ independent loads in flight) instead of one per channel; the sum order per output is still s = 0, 1, ..
-        const int p = tid * 2;
-        const int oh = h0 + p / C::TW, ow = w0 + p % C::TW;
-        constexpr int NC = C::NQ * 4;
-        float2 v[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = make_float2(0.f, 0.f);
-        const float* base = a.ws + p;
-        for (int sidx = 0; sidx < n; ++sidx) {
-          const float* b0 = base + s_slab[sidx];
-          float2 u[NC];
-#pragma unroll
-          for (int c = 0; c < NC; ++c) u[c] = *reinterpret_cast<const float2*>(b0 + c * C::BN);
-#pragma unroll
-          for (int c = 0; c < NC; ++c) { v[c].x += u[c].x; v[c].y += u[c].y; }
-        }
-        float* yrow = a.y + (long)img * a.Cout * co_stride + oh * a.Wo;
-        const bool w0ok = oh < a.Ho && ow < a.Wo, w1ok = oh < a.Ho && ow + 1 < a.Wo;
-#pragma unroll
-        for (int co = 0; co < NC; ++co) {
-          if (co < a.Cout) {
-            const float bv = a.bias ? a.bias[co] : 0.f;
-            float r0 = v[co].x + bv, r1 = v[co].y + bv;
-            if (a.relu) { r0 = r0 > 0.f ? r0 : 0.f; r1 = r1 > 0.f ? r1 : 0.f; }
-            if (w0ok) yrow[(long)co * co_stride + ow] = r0;
-            if (w1ok) yrow[(long)co * co_stride + ow + 1] = r1;
-          }
-        }
+          for (int i = 0; i < 4; ++i) slab[(q * 4 + i) * C::BN + p] = acc[g][q][i];
       }
     }
     __syncthreads();   // LDS is re-used by the next segment's first stores
   }
 }
 
+// Adds the partial slabs of every tile that was split across workgroups, in k order, + bias (+ ReLU).
+// One workgroup per (tile, output channel): 512 pixels, a float2 per thread, slab loads four deep.
+template <class C>
+__global__ __launch_bounds__(256) void head_fixup_kernel(HeadArgs a) {
+  __shared__ const float* s_slab[256];
+  __shared__ int s_n;
+  const int t = blockIdx.x / a.Cout, co = blockIdx.x % a.Cout;
+  if (threadIdx.x == 0) {
+    const long its = (long)t * a.KI, ite = its + a.KI;
+    int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
+    long b, e;
+    wg_range(a.total_iters, a.G, gf, b, e);
+    while (e <= its) { ++gf; wg_range(a.total_iters, a.G, gf, b, e); }
+    while (b > its) { --gf; wg_range(a.total_iters, a.G, gf, b, e); }
+    wg_range(a.total_iters, a.G, gl, b, e);
+    while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
+    while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
+    int n = 0;
+    if (gf != gl) {           // gf == gl: computed whole by one workgroup, already in y
+      for (int g = gf; g <= gl && n < 256; ++g) {
+        wg_range(a.total_iters, a.G, g, b, e);
+        if (e <= b) continue;
+        s_slab[n++] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * C::SLAB + co * C::BN;
+      }
+    }
+    s_n = n;
+  }
+  __syncthreads();
+  const int n = s_n;
+  if (n == 0) return;
+  const int tw = t % a.NTW, th = (t / a.NTW) % a.NTH, img = t / (a.NTW * a.NTH);
+  const int co_stride = a.Ho * a.Wo;
+  const int p = threadIdx.x * 2;
+  float2 v = make_float2(0.f, 0.f);
+  int s = 0;
+  for (; s + 4 <= n; s += 4) {
+    const float2 u0 = *reinterpret_cast<const float2*>(s_slab[s] + p), u1 = *reinterpret_cast<const float2*>(s_slab[s + 1] + p);
+    const float2 u2 = *reinterpret_cast<const float2*>(s_slab[s + 2] + p), u3 = *reinterpret_cast<const float2*>(s_slab[s + 3] + p);
+    v.x += u0.x; v.y += u0.y;
+    v.x += u1.x; v.y += u1.y;
+    v.x += u2.x; v.y += u2.y;
+    v.x += u3.x; v.y += u3.y;
+  }
+  for (; s < n; ++s) {
+    const float2 u = *reinterpret_cast<const float2*>(s_slab[s] + p);
+    v.x += u.x; v.y += u.y;
+  }
+  const float bv = a.bias ? a.bias[co] : 0.f;
+  const int oh = th * C::TH + p / C::TW, ow = tw * C::TW + p % C::TW;
+  if (oh >= a.Ho) return;
+  float* yrow = a.y + ((long)img * a.Cout + co) * co_stride + oh * a.Wo;
+  float r0 = v.x + bv, r1 = v.y + bv;
+  if (a.relu) { r0 = r0 > 0.f ? r0 : 0.f; r1 = r1 > 0.f ? r1 : 0.f; }
+  if (ow < a.Wo) yrow[ow] = r0;
+  if (ow + 1 < a.Wo) yrow[ow + 1] = r1;
+}
+
 typedef void (*HeadFn)(HeadArgs);
 struct HeadEntry {
   const char* name;
   int KH, KW, NQ, CK, AREGS, SLAB;
-  HeadFn main_fn;
+  HeadFn main_fn, fix_fn;
 };
 #define HENTRY(KH, KW, NQ, CK)                                                                                        \
   {"head4x4_k" #KH "x" #KW "_m" #NQ "x4", KH, KW, NQ, CK, HCfg<KH, KW, NQ, CK>::AREGS, HCfg<KH, KW, NQ, CK>::SLAB,    \
-   head_kernel<HCfg<KH, KW, NQ, CK>>}
+   head_kernel<HCfg<KH, KW, NQ, CK>>, head_fixup_kernel<HCfg<KH, KW, NQ, CK>>}
 const HeadEntry kHeads[] = {
     HENTRY(5, 5, 3, 8), HENTRY(7, 7, 3, 4),      // kitti_car: 9 channels
     HENTRY(5, 3, 2, 8), HENTRY(7, 5, 2, 4),      // ped/cyc (7) and caltech (6): "3x5" = kernel_w 3 x kernel_h 5
@@ -358,7 +334,7 @@ bool head_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp) {
   const HeadEntry& k = kHeads[hp->entry];
   hp->NTH = cdiv(Ho, 16);
   hp->NTW = cdiv(Wo, 32);
-  hp->KI = cdiv(d.Cin, k.CK);
+  hp->KI = cdiv(d.Cin, k.CK);       // <= 256 contributors per tile (fix-up slab list)
   const long tiles = (long)d.N * hp->NTH * hp->NTW;
   hp->total_iters = tiles * hp->KI;
   const int genv = tune_env("MSCNN_TUNE_GRID", d.tune_grid);   // tuning knob
@@ -367,8 +343,7 @@ bool head_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp) {
   if (G < 1) G = 1;
   hp->G = (int)G;
   hp->tiles = (int)tiles;
-  hp->weight_bytes = (size_t)hp->KI * k.NQ * k.AREGS * 64 * sizeof(float);
-  hp->packed_bytes = hp->weight_bytes + ((size_t)tiles * sizeof(unsigned) + 15) / 16 * 16;      // + the tiles' arrival counters
+  hp->packed_bytes = (size_t)hp->KI * k.NQ * k.AREGS * 64 * sizeof(float);
   hp->ws_bytes = (size_t)hp->G * 2 * k.SLAB * sizeof(float);
   return true;
 }
@@ -382,7 +357,6 @@ int head_pack(const mscnn_conv_desc& d, const HeadPlan& hp, const float* w, floa
   if (blocks > 4096) blocks = 4096;
   head_pack_kernel<<<(int)blocks, 256, 0, st>>>(w, packed, d.Cout, d.Cin, k.KH * k.KW, k.NQ, k.AREGS, k.CK, hp.KI);
   MSCNN_POST_LAUNCH();
-  MSCNN_HIP_TRY(hipMemsetAsync(reinterpret_cast<unsigned char*>(packed) + hp.weight_bytes, 0, hp.packed_bytes - hp.weight_bytes, st));
   return MSCNN_OK;
 }
 
@@ -395,12 +369,11 @@ int head_forward(const mscnn_conv_desc& d, const HeadPlan& hp, int Ho, int Wo, c
   }
   HeadArgs a;
   a.x = x; a.wp = packed; a.bias = bias; a.y = y; a.ws = static_cast<float*>(workspace);
-  // (the counters share the layer's packed-weight buffer: kernel-private state that outlives the launch -- the shared workspace is
-  // overwritten by other layers in between -- so one forward at a time per packed buffer, as for the workspace)
-  a.arrivals = reinterpret_cast<unsigned*>(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(packed)) + hp.weight_bytes);
   a.N = d.N; a.Cin = d.Cin; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.Ho = Ho; a.Wo = Wo; a.pad_h = d.pad_h; a.pad_w = d.pad_w;
   a.NTH = hp.NTH; a.NTW = hp.NTW; a.KI = hp.KI; a.G = hp.G; a.relu = d.relu; a.total_iters = hp.total_iters;
   k.main_fn<<<hp.G, 256, 0, st>>>(a);
+  MSCNN_POST_LAUNCH();
+  k.fix_fn<<<hp.tiles * d.Cout, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }
