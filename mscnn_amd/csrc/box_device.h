@@ -3,6 +3,10 @@
 #include <type_traits>
 #include <hip/hip_runtime.h>
 
+#ifdef MSCNN_BO_TRACE
+extern __device__ unsigned long long* g_bo_trace;      // boxoutput.hip, trace build only
+#endif
+
 namespace mscnn_dev {
 
 typedef unsigned long long u64;
@@ -108,6 +112,9 @@ __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, 
   u64 removed = 0, mykeep = 0;
   if (removed_init != nullptr && wave == 0 && lane < W) removed = removed_init[lane];
   for (int c = 0; c < nchunks; ++c) {
+#ifdef MSCNN_BO_TRACE
+    if (tid == 0 && g_bo_trace && c < 64) g_bo_trace[64 + c] = __builtin_amdgcn_s_memrealtime();
+#endif
     const u64* cur_rows = buf + (size_t)(c & 1) * 64 * W;
     if (wave != 0) {
       if (c + 1 < nchunks) {

@@ -30,6 +30,18 @@
 #include "nms_large.h"
 #include <cfloat>
 
+#ifdef MSCNN_BO_TRACE
+// debug build only (make -C mscnn_amd/csrc trace; tools/bo_trace.py): thread 0 of the one-workgroup kernels stamps s_memrealtime
+// (100 MHz) at its phase boundaries into a buffer handed over by mscnn_debug_set_bo_trace
+__device__ unsigned long long* g_bo_trace = nullptr;
+#define BO_STAMP(slot) do { if (threadIdx.x == 0 && g_bo_trace) g_bo_trace[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int mscnn_debug_set_bo_trace(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_bo_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#else
+#define BO_STAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 using namespace mscnn_dev;
@@ -122,6 +134,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   __shared__ u64 s_prefix;
   __shared__ int s_need, s_fill, s_done;
   const int tid = threadIdx.x;
+  BO_STAMP(0);
   const int n = cnt[CNT_CAND];
   int K = n;
   if (max_nms_num > 0 && K > max_nms_num) K = max_nms_num;
@@ -142,6 +155,10 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
       rk[j] = i < n ? keys[i] : 0ull;
     }
   }
+  BO_STAMP(1);
+#ifdef MSCNN_BO_TRACE
+  if (tid == 0 && g_bo_trace) { g_bo_trace[30] = (unsigned long long)n; g_bo_trace[31] = (unsigned long long)K; }
+#endif
   u64 thresh = 0;             // keep keys >= thresh
   if (n > K) {
     // radix select, MSB first, 8 bits per pass: find the K-th largest key.  The bucket walk is a 64-lane suffix scan
@@ -201,6 +218,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
     thresh = s_prefix;        // exactly K keys are >= thresh (keys are unique)
   }
   __syncthreads();
+  BO_STAMP(2);
   int P = 1;
   while (P < K) P <<= 1;
   if (inreg) {
@@ -225,15 +243,18 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   const int P2 = P < 1024 ? 1024 : P;
   for (int i = K + tid; i < P2; i += kSortThreads) sk[i] = 0ull;
   __syncthreads();
+  BO_STAMP(3);
   if (P2 == 1024) { u64 r[1] = {sk[tid]}; bitonic_desc_regs<1>(r, sk, tid); }
   else if (P2 == 2048) { u64 r[2] = {sk[tid], sk[tid + 1024]}; bitonic_desc_regs<2>(r, sk, tid); }
   else { u64 r[4] = {sk[tid], sk[tid + 1024], sk[tid + 2048], sk[tid + 3072]}; bitonic_desc_regs<4>(r, sk, tid); }
+  BO_STAMP(4);
   for (int i = tid; i < K; i += kSortThreads) {
     const int aid = (int)(unsigned)(sk[i] & 0xffffffffull);
     sorted_box[i] = box_by_anchor[aid];
     sorted_score[i] = score_by_anchor[aid];
     sorted_aid[i] = aid;
   }
+  BO_STAMP(5);
 }
 
 // mask[i][cb] bit t set <=> j = cb*64+t > i and IoU(box_i, box_j) > thr.  Upper-triangle blocks only.
@@ -278,9 +299,11 @@ __global__ __launch_bounds__(256) void nms_scan_emit_kernel(const u64* __restric
   __shared__ int pre[64];
   __shared__ int s_total;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  BO_STAMP(8);
   const int n = cnt[CNT_K];
   if (n <= 0) return;
   const u64 mykeep = greedy_scan(mask, n, wpr, W, dyn_lds);
+  BO_STAMP(9);
   if (wave == 0) {
     keepw[lane] = mykeep;
     // exclusive prefix of popcounts over chunks
@@ -315,6 +338,7 @@ __global__ __launch_bounds__(256) void nms_scan_emit_kernel(const u64* __restric
     if (e.aids) e.aids[row] = e.sorted_aid[k];
   }
   __syncthreads();
+  BO_STAMP(10);
   if (tid == 0) { cnt[CNT_ROWS] = row0 + kept_total; cnt[CNT_CAND] = 0; }
 }
 
