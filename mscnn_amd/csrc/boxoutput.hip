@@ -142,10 +142,10 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   if (tid == 0) { cnt[CNT_K] = K; s_fill = 0; }
   if (K == 0) return;
 
-  // The candidate keys of a frame (a few thousand .. ~12 k) are read ONCE, kRegKeys per thread with all loads in flight together, and
+  // The candidate keys of a frame (27 k of the 45.6 k anchors on the 7s-576 bench frame; up to 32 k here) are read ONCE, kRegKeys per thread with all loads in flight together, and
   // every pass below works on the registers: the passes used to re-read the list from L2 with one dependent round trip per 1024
   // keys each (3-4 select passes + the compaction: ~50 round trips, most of the kernel's 70 us).  Longer lists take the loops.
-  constexpr int kRegKeys = 12;
+  constexpr int kRegKeys = 32;
   const bool inreg = n <= kRegKeys * kSortThreads;
   u64 rk[kRegKeys];
   if (inreg) {
@@ -258,28 +258,36 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
 }
 
 // mask[i][cb] bit t set <=> j = cb*64+t > i and IoU(box_i, box_j) > thr.  Upper-triangle blocks only.
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ boxes, const int* __restrict__ cnt_k,
-                                                      int n_fixed, float thr, int mode, u64* __restrict__ mask, int wpr) {
+// 256 threads per 64 x 64 block: wave v tests its 64 rows against columns 16v .. 16v+15 and the four 16-bit pieces meet in LDS
+// (one wave per block did 64 dependent IoUs -- with their divisions -- per lane, 2 waves per CU: 20 us for K = 2000; round 3).
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float4* __restrict__ boxes, const int* __restrict__ cnt_k,
+                                                       int n_fixed, float thr, int mode, u64* __restrict__ mask, int wpr) {
   const int n = cnt_k ? *cnt_k : n_fixed;
   const int rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
   __shared__ float4 cbox[64];
-  const int t = threadIdx.x;
+  __shared__ unsigned part[4][64];
+  const int t = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j0 = cb * 64;
-  if (j0 + t < n) cbox[t] = boxes[j0 + t];
+  if (wv == 0 && j0 + t < n) cbox[t] = boxes[j0 + t];
   __syncthreads();
   const int i = rb * 64 + t;
-  if (i >= n) return;
-  const float4 a = boxes[i];
-  const int jn = min(64, n - j0);
-  u64 bits = 0;
-  for (int q = 0; q < jn; ++q) {
-    const int j = j0 + q;
-    if (j <= i) continue;
-    const float4 b = cbox[q];
-    if (box_iou(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, mode) > thr) bits |= 1ull << q;
+  unsigned bits = 0;
+  if (i < n) {
+    const float4 a = boxes[i];
+    const int jn = min(64, n - j0);
+#pragma unroll 4
+    for (int q = wv * 16; q < wv * 16 + 16; ++q) {
+      const int j = j0 + q;
+      if (q >= jn || j <= i) continue;
+      const float4 b = cbox[q];
+      if (box_iou(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, mode) > thr) bits |= 1u << (q & 15);
+    }
   }
-  mask[(size_t)i * wpr + cb] = bits;
+  part[wv][t] = bits;
+  __syncthreads();
+  if (wv == 0 && i < n)
+    mask[(size_t)i * wpr + cb] = (u64)part[0][t] | ((u64)part[1][t] << 16) | ((u64)part[2][t] << 32) | ((u64)part[3][t] << 48);
 }
 
 struct EmitArgs {
@@ -549,7 +557,7 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
       const float thr = d->iou_thr;
       const int mode = d->nms_mode;
       auto launch_mask = [&](const float4* tile, const int* tile_n) {
-        nms_mask_kernel<<<dim3(kTileWords, kTileWords), 64, 0, st>>>(tile, tile_n, 0, thr, mode, mask, kTileWords);
+        nms_mask_kernel<<<dim3(kTileWords, kTileWords), 256, 0, st>>>(tile, tile_n, 0, thr, mode, mask, kTileWords);
       };
       MSCNN_HIP_TRY((big_nms_tiles<RoiTr>(sbox, cnt + CNT_K, 0, kcap, RoiTr::Params{thr, mode}, mask,
                                           reinterpret_cast<u64*>(ws + L.rinit), reinterpret_cast<int*>(ws + L.kidx),
@@ -561,7 +569,7 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
     }
     select_sort_kernel<<<1, kSortThreads, 0, st>>>(keys, box, score, sbox, sscore, said, cnt, d->max_nms_num);
     MSCNN_POST_LAUNCH();
-    nms_mask_kernel<<<dim3(kblocks, kblocks), 64, 0, st>>>(sbox, cnt + CNT_K, 0, d->iou_thr, d->nms_mode, mask, L.wpr);
+    nms_mask_kernel<<<dim3(kblocks, kblocks), 256, 0, st>>>(sbox, cnt + CNT_K, 0, d->iou_thr, d->nms_mode, mask, L.wpr);
     MSCNN_POST_LAUNCH();
     EmitArgs e{sbox, sscore, said, rois_out, props_out, anchor_ids_out, cap, img, d->max_post_nms_num};
     nms_scan_emit_kernel<<<1, 256, (size_t)2 * 64 * kblocks * sizeof(u64), st>>>(mask, L.wpr, kblocks, e, cnt);
@@ -614,7 +622,7 @@ extern "C" int mscnn_nms_greedy_f32(const float* boxes_xywh, int n, float iou_th
     MSCNN_HIP_TRY(hipMemsetAsync(state, 0, BIG_STATE_WORDS * sizeof(int), st));
     MSCNN_HIP_TRY(hipMemsetAsync(keep_out, 0, (size_t)n, st));
     auto launch_mask = [&](const float4* tile, const int* tile_n) {
-      nms_mask_kernel<<<dim3(kTileWords, kTileWords), 64, 0, st>>>(tile, tile_n, 0, iou_thr, nms_mode, bmask, kTileWords);
+      nms_mask_kernel<<<dim3(kTileWords, kTileWords), 256, 0, st>>>(tile, tile_n, 0, iou_thr, nms_mode, bmask, kTileWords);
     };
     MSCNN_HIP_TRY((big_nms_tiles<RoiTr>(reinterpret_cast<const float4*>(boxes_xywh), nullptr, n, n, RoiTr::Params{iou_thr, nms_mode},
                                         bmask, reinterpret_cast<u64*>(ws + B.rinit), kidx,
@@ -625,7 +633,7 @@ extern "C" int mscnn_nms_greedy_f32(const float* boxes_xywh, int n, float iou_th
   }
   const int wpr = (n + 63) / 64;
   u64* mask = static_cast<u64*>(workspace);
-  nms_mask_kernel<<<dim3(wpr, wpr), 64, 0, st>>>(reinterpret_cast<const float4*>(boxes_xywh), nullptr, n, iou_thr, nms_mode,
+  nms_mask_kernel<<<dim3(wpr, wpr), 256, 0, st>>>(reinterpret_cast<const float4*>(boxes_xywh), nullptr, n, iou_thr, nms_mode,
                                                   mask, wpr);
   MSCNN_POST_LAUNCH();
   nms_scan_bytes_kernel<<<1, 256, (size_t)2 * 64 * wpr * sizeof(u64), st>>>(mask, n, wpr, wpr, keep_out);

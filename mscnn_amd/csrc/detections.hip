@@ -187,35 +187,41 @@ __global__ __launch_bounds__(256) void det_emit_big_kernel(const int* __restrict
   if (ids) ids[row] = ssrc[k];
 }
 
-__global__ __launch_bounds__(64) void det_mask_kernel(const DetBox* __restrict__ boxes, const int* __restrict__ cnt,
-                                                      double overlap, u64* __restrict__ mask, int wpr) {
+// (256 threads per 64 x 64 block, the four waves split the columns -- as nms_mask_kernel of boxoutput.hip)
+__global__ __launch_bounds__(256) void det_mask_kernel(const DetBox* __restrict__ boxes, const int* __restrict__ cnt,
+                                                       double overlap, u64* __restrict__ mask, int wpr) {
   const int n = cnt[DC_N];
   const int rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
   __shared__ DetBox cbox[64];
-  const int t = threadIdx.x;
+  __shared__ unsigned part[4][64];
+  const int t = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j0 = cb * 64;
-  if (j0 + t < n) cbox[t] = boxes[j0 + t];
+  if (wv == 0 && j0 + t < n) cbox[t] = boxes[j0 + t];
   __syncthreads();
   const int i = rb * 64 + t;
-  if (i >= n) return;
-  const DetBox A = boxes[i];
-  const double as_a = A.w * A.h, xe_a = A.x + A.w, ye_a = A.y + A.h;
-  const int jn = min(64, n - j0);
-  u64 bits = 0;
-  for (int q = 0; q < jn; ++q) {
-    if (j0 + q <= i) continue;
-    const DetBox B = cbox[q];
-    const double iw = fmin(xe_a, B.x + B.w) - fmax(A.x, B.x);
-    if (iw <= 0) continue;
-    const double ih = fmin(ye_a, B.y + B.h) - fmax(A.y, B.y);
-    if (ih <= 0) continue;
-    double o = iw * ih;
-    const double u = as_a + B.w * B.h - o;
-    o = o / u;
-    if (o > overlap) bits |= 1ull << q;
+  unsigned bits = 0;
+  if (i < n) {
+    const DetBox A = boxes[i];
+    const double as_a = A.w * A.h, xe_a = A.x + A.w, ye_a = A.y + A.h;
+    const int jn = min(64, n - j0);
+    for (int q = wv * 16; q < wv * 16 + 16; ++q) {
+      if (q >= jn || j0 + q <= i) continue;
+      const DetBox B = cbox[q];
+      const double iw = fmin(xe_a, B.x + B.w) - fmax(A.x, B.x);
+      if (iw <= 0) continue;
+      const double ih = fmin(ye_a, B.y + B.h) - fmax(A.y, B.y);
+      if (ih <= 0) continue;
+      double o = iw * ih;
+      const double u = as_a + B.w * B.h - o;
+      o = o / u;
+      if (o > overlap) bits |= 1u << (q & 15);
+    }
   }
-  mask[(size_t)i * wpr + cb] = bits;
+  part[wv][t] = bits;
+  __syncthreads();
+  if (wv == 0 && i < n)
+    mask[(size_t)i * wpr + cb] = (u64)part[0][t] | ((u64)part[1][t] << 16) | ((u64)part[2][t] << 32) | ((u64)part[3][t] << 48);
 }
 
 __global__ __launch_bounds__(256) void det_scan_emit_kernel(const u64* __restrict__ mask, int wpr,
@@ -344,7 +350,7 @@ static int detections_launch(const mscnn_detections_desc* desc, int cascade, flo
     MSCNN_POST_LAUNCH();
     const double overlap = desc->nms_overlap;
     auto launch_mask = [&](const DetBox* tile, const int* tile_n) {
-      det_mask_kernel<<<dim3(kTileWords, kTileWords), 64, 0, st>>>(tile, tile_n, overlap, mask, kTileWords);
+      det_mask_kernel<<<dim3(kTileWords, kTileWords), 256, 0, st>>>(tile, tile_n, overlap, mask, kTileWords);
     };
     MSCNN_HIP_TRY((big_nms_tiles<DetTr>(sbox, cnt + DC_N, 0, R, DetTr::Params{overlap}, mask, reinterpret_cast<u64*>(ws + L.rinit), kidx,
                                         reinterpret_cast<DetBox*>(ws + L.kbox), cnt + DC_BIG, launch_mask, st)));
@@ -354,7 +360,7 @@ static int detections_launch(const mscnn_detections_desc* desc, int cascade, flo
   }
   det_transform_sort_kernel<<<1, kSortThreads, 0, st>>>(a, sbox, sprob, ssrc, tbox, tprob, cnt);
   MSCNN_POST_LAUNCH();
-  det_mask_kernel<<<dim3(L.wpr, L.wpr), 64, 0, st>>>(sbox, cnt, desc->nms_overlap, mask, L.wpr);
+  det_mask_kernel<<<dim3(L.wpr, L.wpr), 256, 0, st>>>(sbox, cnt, desc->nms_overlap, mask, L.wpr);
   MSCNN_POST_LAUNCH();
   det_scan_emit_kernel<<<1, 256, (size_t)2 * 64 * L.wpr * sizeof(u64), st>>>(mask, L.wpr, sbox, sprob, ssrc, dets_out, ids_out, cnt,
                                                                                 count_out_dev);
