@@ -77,7 +77,8 @@ enum { CNT_CAND = 0, CNT_ROWS = 1, CNT_REAL = 2, CNT_K = 3, CNT_BIG = 4 /* + BIG
 
 __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a, u64* __restrict__ keys,
                                                             float4* __restrict__ box_by_anchor,
-                                                            float* __restrict__ score_by_anchor, int* __restrict__ cnt) {
+                                                            float* __restrict__ score_by_anchor, int* __restrict__ cnt,
+                                                            unsigned* __restrict__ ghist) {
   const int total = a.head_off[a.num_heads];
   const int aid = blockIdx.x * 256 + threadIdx.x;
   if (aid >= total) return;
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a, u64* _
   if (bbw >= a.min_size && bbh >= a.min_size) {
     const int pos = atomicAdd(&cnt[CNT_CAND], 1);
     keys[pos] = ((u64)orderable(fg) << 32) | (unsigned)aid;
+    if (ghist) atomicAdd(&ghist[orderable(fg) >> 16], 1u);      // the keys' top 16 bits, for select_sort_kernel's first step
     box_by_anchor[aid] = make_float4(bbx, bby, bbw, bbh);
     score_by_anchor[aid] = fg;
   }
@@ -128,11 +130,12 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
                                                                    float4* __restrict__ sorted_box,
                                                                    float* __restrict__ sorted_score,
                                                                    int* __restrict__ sorted_aid, int* __restrict__ cnt,
-                                                                   int max_nms_num) {
+                                                                   int max_nms_num, unsigned* __restrict__ ghist) {
   __shared__ u64 sk[kSortCap];
   __shared__ unsigned hist[256];
   __shared__ u64 s_prefix;
   __shared__ int s_need, s_fill, s_done;
+  __shared__ int s_wtot[kSortThreads / 64];
   const int tid = threadIdx.x;
   BO_STAMP(0);
   const int n = cnt[CNT_CAND];
@@ -166,7 +169,38 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
     // upper 32 bits that is normally after 3-4 passes: the anchor-id passes only separate equal scores).
     if (tid == 0) { s_prefix = 0; s_need = K; s_done = 0; }
     __syncthreads();
-    for (int pass = 0; pass < 8; ++pass) {
+    // The first two digits come from the 65536-bin histogram of the keys' top 16 bits that decode_filter_kernel counted while it
+    // ran on the whole chip: the score's sign, exponent and 7 mantissa bits are nearly the same for thousands of candidates, so
+    // the LDS histogram of those two passes was 27 k atomics onto a handful of addresses (most of the select's 27 us on the bench
+    // frame).  Thread t owns bins 65535 - 64 t .. 65472 - 64 t (descending key order); the thread whose running total crosses K
+    // walks its bins.
+    int first_pass = 0;
+    if (ghist) {
+      const uint4* hp = reinterpret_cast<const uint4*>(ghist + (65536 - 64 * (tid + 1)));
+      unsigned mine = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { const uint4 v = hp[q]; mine += v.x + v.y + v.z + v.w; }
+      int incl = (int)mine;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d) incl += v;
+      }
+      if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+      __syncthreads();
+      for (int w = 0; w < (tid >> 6); ++w) incl += s_wtot[w];
+      if (incl >= K && incl - (int)mine < K) {            // exactly one thread: the bins hold all n > K candidates
+        int rem = K - (incl - (int)mine);
+        int b = 65535 - 64 * tid;
+        unsigned c = ghist[b];
+        while ((int)c < rem) { rem -= (int)c; --b; c = ghist[b]; }
+        s_need = rem;
+        s_prefix = (u64)(unsigned)b << 48;
+        if ((int)c == rem) s_done = 1;
+      }
+      __syncthreads();
+      first_pass = 2;
+    }
+    for (int pass = first_pass; pass < 8 && !s_done; ++pass) {
       const int shift = 56 - 8 * pass;
       if (tid < 256) hist[tid] = 0;
       __syncthreads();
@@ -218,6 +252,11 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
     thresh = s_prefix;        // exactly K keys are >= thresh (keys are unique)
   }
   __syncthreads();
+  if (ghist) {      // back to zero for the next image of the batch (the forward zeroes the table once before the first)
+    uint4* hz = reinterpret_cast<uint4*>(ghist + (65536 - 64 * (tid + 1)));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) hz[q] = make_uint4(0u, 0u, 0u, 0u);
+  }
   BO_STAMP(2);
   int P = 1;
   while (P < K) P <<= 1;
@@ -429,9 +468,10 @@ __global__ __launch_bounds__(256) void nms_scan_bytes_kernel(const u64* __restri
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t kHistBins = 65536;      // the candidates' top 16 key bits (decode_filter_kernel -> select_sort_kernel)
 
 struct WsLayout {
-  size_t cnt, keys, box, score, sbox, sscore, said, mask, rinit, kidx, kbox, total;
+  size_t cnt, hist, keys, box, score, sbox, sscore, said, mask, rinit, kidx, kbox, total;
   int anchors, wpr, kcap, sortP;
   bool big;
 };
@@ -447,6 +487,7 @@ WsLayout layout_for(int anchors, int max_nms_num) {
   const size_t rows = L.big ? (size_t)L.kcap : (size_t)kMaxK;
   size_t o = 0;
   L.cnt = o; o += align_up(CNT_WORDS * sizeof(int), 256);
+  L.hist = o; o += L.big ? 0 : kHistBins * sizeof(unsigned);      // right behind the counters: one memset zeroes both
   L.keys = o; o += align_up((L.big ? (size_t)L.sortP : (size_t)anchors) * sizeof(u64), 256);
   L.box = o; o += align_up((size_t)anchors * sizeof(float4), 256);
   L.score = o; o += align_up((size_t)anchors * sizeof(float), 256);
@@ -541,13 +582,14 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
   a.do_norm = d->do_bbox_norm;
   for (int k = 0; k < 4; ++k) { a.mean[k] = d->bbox_mean[k]; a.stdv[k] = d->bbox_std[k]; }
 
-  MSCNN_HIP_TRY(hipMemsetAsync(cnt, 0, CNT_WORDS * sizeof(int), st));
+  unsigned* ghist = L.big ? nullptr : reinterpret_cast<unsigned*>(ws + L.hist);
+  MSCNN_HIP_TRY(hipMemsetAsync(cnt, 0, L.big ? CNT_WORDS * sizeof(int) : (L.hist - L.cnt) + kHistBins * sizeof(unsigned), st));
   const int kcap = L.kcap;
   const int kblocks = cdiv(kcap < kMaxK ? kcap : kMaxK, 64);
   for (int img = 0; img < d->num; ++img) {
     a.image = img;
     if (L.big) MSCNN_HIP_TRY(hipMemsetAsync(keys, 0, (size_t)L.sortP * sizeof(u64), st));     // zero keys = padding, sorts last
-    decode_filter_kernel<<<cdiv(anchors, 256), 256, 0, st>>>(a, keys, box, score, cnt);
+    decode_filter_kernel<<<cdiv(anchors, 256), 256, 0, st>>>(a, keys, box, score, cnt, ghist);
     MSCNN_POST_LAUNCH();
     if (L.big) {
       // every candidate sorted in HBM, the first K = min(n, max_nms_num) gathered, tiled greedy NMS, rows from the kept list
@@ -567,7 +609,7 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
       MSCNN_POST_LAUNCH();
       continue;
     }
-    select_sort_kernel<<<1, kSortThreads, 0, st>>>(keys, box, score, sbox, sscore, said, cnt, d->max_nms_num);
+    select_sort_kernel<<<1, kSortThreads, 0, st>>>(keys, box, score, sbox, sscore, said, cnt, d->max_nms_num, ghist);
     MSCNN_POST_LAUNCH();
     nms_mask_kernel<<<dim3(kblocks, kblocks), 256, 0, st>>>(sbox, cnt + CNT_K, 0, d->iou_thr, d->nms_mode, mask, L.wpr);
     MSCNN_POST_LAUNCH();
