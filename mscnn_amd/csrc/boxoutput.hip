@@ -136,13 +136,16 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   __shared__ u64 s_prefix;
   __shared__ int s_need, s_fill, s_done;
   __shared__ int s_wtot[kSortThreads / 64];
+  constexpr int kListCap = 1024;
+  __shared__ u64 lst[kListCap];
+  __shared__ int s_lfill;
   const int tid = threadIdx.x;
   BO_STAMP(0);
   const int n = cnt[CNT_CAND];
   int K = n;
   if (max_nms_num > 0 && K > max_nms_num) K = max_nms_num;
   if (K > kMaxK) K = kMaxK;   // host guarantees this cannot bind (checked against the anchor count)
-  if (tid == 0) { cnt[CNT_K] = K; s_fill = 0; }
+  if (tid == 0) { cnt[CNT_K] = K; s_fill = 0; s_lfill = 0; }
   if (K == 0) return;
 
   // The candidate keys of a frame (27 k of the 45.6 k anchors on the 7s-576 bench frame; up to 32 k here) are read ONCE, kRegKeys per thread with all loads in flight together, and
@@ -163,6 +166,8 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   if (tid == 0 && g_bo_trace) { g_bo_trace[30] = (unsigned long long)n; g_bo_trace[31] = (unsigned long long)K; }
 #endif
   u64 thresh = 0;             // keep keys >= thresh
+  bool filled = false;        // the sort buffer already holds the K keys (histogram + list path)
+  unsigned mine = 1;          // this thread's share of the global histogram (0: nothing to zero afterwards)
   if (n > K) {
     // radix select, MSB first, 8 bits per pass: find the K-th largest key.  The bucket walk is a 64-lane suffix scan
     // (4 buckets per lane); the passes stop as soon as a bucket holds exactly the keys still needed (with the score in the
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
     int first_pass = 0;
     if (ghist) {
       const uint4* hp = reinterpret_cast<const uint4*>(ghist + (65536 - 64 * (tid + 1)));
-      unsigned mine = 0;
+      mine = 0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) { const uint4 v = hp[q]; mine += v.x + v.y + v.z + v.w; }
       int incl = (int)mine;
@@ -199,7 +204,44 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
       }
       __syncthreads();
       first_pass = 2;
+      if (inreg) {
+        // One sweep over the register keys: bins above the threshold bin go straight to the sort buffer, the threshold bin's own
+        // keys (a few dozen) to a list, where the `need` largest are found by rank (keys are unique) -- no further digit passes,
+        // each of which cost ~3 us of barriers and a 32-key loop per thread whatever the histogram looked like.
+        const unsigned bstar = (unsigned)(s_prefix >> 48);
+#pragma unroll
+        for (int j = 0; j < kRegKeys; ++j) {
+          const u64 k = rk[j];
+          if (tid + j * kSortThreads >= n) continue;
+          const unsigned t16 = (unsigned)(k >> 48);
+          if (t16 > bstar) {
+            const int pos = atomicAdd(&s_fill, 1);
+            if (pos < kMaxK) sk[pos] = k;
+          } else if (t16 == bstar) {
+            const int pos = atomicAdd(&s_lfill, 1);
+            if (pos < kListCap) lst[pos] = k;
+          }
+        }
+        __syncthreads();
+        const int Ln = s_lfill, need = s_need;
+        if (Ln <= kListCap) {
+          for (int t = tid; t < Ln; t += kSortThreads) {
+            const u64 my = lst[t];
+            int rank = 0;
+            for (int u = 0; u < Ln; ++u) rank += lst[u] > my ? 1 : 0;
+            if (rank < need) {
+              const int pos = atomicAdd(&s_fill, 1);
+              if (pos < kMaxK) sk[pos] = my;
+            }
+          }
+          filled = true;
+        } else {
+          __syncthreads();
+          if (tid == 0) s_fill = 0;      // (a bin with more than kListCap keys: the digit passes below, then the general compaction)
+        }
+      }
     }
+    if (!filled)
     for (int pass = first_pass; pass < 8 && !s_done; ++pass) {
       const int shift = 56 - 8 * pass;
       if (tid < 256) hist[tid] = 0;
@@ -252,7 +294,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
     thresh = s_prefix;        // exactly K keys are >= thresh (keys are unique)
   }
   __syncthreads();
-  if (ghist) {      // back to zero for the next image of the batch (the forward zeroes the table once before the first)
+  if (ghist && mine != 0) {      // back to zero for the next image of the batch (the forward zeroes the table before the first)
     uint4* hz = reinterpret_cast<uint4*>(ghist + (65536 - 64 * (tid + 1)));
 #pragma unroll
     for (int q = 0; q < 16; ++q) hz[q] = make_uint4(0u, 0u, 0u, 0u);
@@ -260,7 +302,8 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   BO_STAMP(2);
   int P = 1;
   while (P < K) P <<= 1;
-  if (inreg) {
+  if (filled) {
+  } else if (inreg) {
 #pragma unroll
     for (int j = 0; j < kRegKeys; ++j) {
       const u64 k = rk[j];
