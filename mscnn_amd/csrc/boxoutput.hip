@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   __shared__ int s_wtot[kSortThreads / 64];
   constexpr int kListCap = 1024;
   __shared__ u64 lst[kListCap];
-  __shared__ int s_lfill;
+  __shared__ int s_lfill, s_cross;
   const int tid = threadIdx.x;
   BO_STAMP(0);
   const int n = cnt[CNT_CAND];
@@ -194,13 +194,26 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
       __syncthreads();
       for (int w = 0; w < (tid >> 6); ++w) incl += s_wtot[w];
       if (incl >= K && incl - (int)mine < K) {            // exactly one thread: the bins hold all n > K candidates
-        int rem = K - (incl - (int)mine);
-        int b = 65535 - 64 * tid;
-        unsigned c = ghist[b];
-        while ((int)c < rem) { rem -= (int)c; --b; c = ghist[b]; }
-        s_need = rem;
-        s_prefix = (u64)(unsigned)b << 48;
-        if ((int)c == rem) s_done = 1;
+        s_need = K - (incl - (int)mine);
+        s_cross = tid;
+      }
+      __syncthreads();
+      if (tid < 64) {      // that thread's 64 bins, one per lane (descending), and the same running-total test inside them
+        const int b = 65535 - 64 * s_cross - tid;
+        const int c = (int)ghist[b];
+        int in2 = c;
+        for (int d = 1; d < 64; d <<= 1) {
+          const int v = __shfl_up(in2, d, 64);
+          if (tid >= d) in2 += v;
+        }
+        const int need0 = s_need;
+        const int first = __ffsll((long long)__ballot(in2 >= need0)) - 1;
+        if (tid == first) {
+          const int rem = need0 - (in2 - c);
+          s_need = rem;
+          s_prefix = (u64)(unsigned)b << 48;
+          if (c == rem) s_done = 1;
+        }
       }
       __syncthreads();
       first_pass = 2;
