@@ -225,12 +225,17 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
 #pragma unroll
         for (int j = 0; j < kRegKeys; ++j) {
           const u64 k = rk[j];
-          if (tid + j * kSortThreads >= n) continue;
+          const bool valid = tid + j * kSortThreads < n;
           const unsigned t16 = (unsigned)(k >> 48);
-          if (t16 > bstar) {
-            const int pos = atomicAdd(&s_fill, 1);
+          if (valid && t16 > bstar) {                     // (one LDS atomic per wave and key slot, not per key)
+            const u64 takers = __ballot(1);
+            const int leader = __ffsll((long long)takers) - 1, lane = tid & 63;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_fill, __popcll(takers));
+            base = __shfl(base, leader, 64);
+            const int pos = base + __popcll(takers & ((1ull << lane) - 1ull));
             if (pos < kMaxK) sk[pos] = k;
-          } else if (t16 == bstar) {
+          } else if (valid && t16 == bstar) {
             const int pos = atomicAdd(&s_lfill, 1);
             if (pos < kListCap) lst[pos] = k;
           }
