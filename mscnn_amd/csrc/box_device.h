@@ -87,65 +87,74 @@ __device__ __forceinline__ u64 wave_or64(u64 v) {
 // W, `buf`: unused since round 3 (kept for the callers' launch geometry: 256 threads, waves 1-3 idle).  Result: lane c of wave 0
 // returns the keep-word of chunk c.  `removed_init` (optional, one word per chunk): boxes already suppressed from outside -- by the
 // kept boxes of earlier tiles in the tiled path of nms_large.h; they are neither kept nor do they suppress anything.
+// NB = static bound on the earlier chunks gathered per step (>= nchunks - 1): the loads of a step are a fixed number of
+// instructions -- a chunk that does not exist yet, like a row that was not kept, is an out-of-range offset -- so the compiler can
+// count them (s_waitcnt vmcnt(k)) and lets the diagonal pass run under them; with a run-time number it waited for all of them first.
+template <int NB>
+__device__ __forceinline__ u64 greedy_scan_wave(const u64* __restrict__ mask, int n, int wpr, const u64* __restrict__ removed_init) {
+  const int lane = threadIdx.x & 63;
+  const int nchunks = (n + 63) >> 6;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(mask), 0, n * wpr * 8, 0x00020000);
+  const unsigned lane_row = (unsigned)(lane * wpr * 8);          // byte offset of row `lane` of chunk 0
+  const unsigned chunk_step = (unsigned)(64 * wpr * 8);          // ... from one chunk's row to the next chunk's
+  constexpr unsigned kOobOff = 0x80000000u;
+  auto ld = [&](unsigned voff) -> u64 {
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(msrc, voff, 0, 0);
+    return ((u64)w[1] << 32) | w[0];
+  };
+  u64 mykeep = 0;
+  u64 dg = ld(lane_row);                                          // mask[lane][0]
+  u64 n1 = ld(nchunks > 1 ? lane_row + 8u : kOobOff);             // mask[lane][1]
+  u64 removed_c = removed_init ? removed_init[0] : 0ull;          // wave-uniform
+  for (int c = 0; c < nchunks; ++c) {
+#ifdef MSCNN_BO_TRACE
+    if (threadIdx.x == 0 && g_bo_trace && c < 64) g_bo_trace[64 + c] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const bool more = c + 1 < nchunks;
+    const unsigned col = (unsigned)(c + 1) * 8u;
+    u64 v[NB];
+#pragma unroll
+    for (int cc = 0; cc < NB; ++cc) {
+      const u64 kw = readlane64(mykeep, cc);                        // (0 for the chunks still to come)
+      const bool want = more && cc < c && ((kw >> lane) & 1ull);
+      v[cc] = ld(want ? lane_row + col + (unsigned)cc * chunk_step : kOobOff);
+    }
+    const unsigned nrow = lane_row + col + (unsigned)(c + 1) * chunk_step;
+    const u64 dg_n = ld(more ? nrow : kOobOff);                    // mask[64 (c+1) + lane][c + 1]
+    const u64 n1_n = ld(c + 2 < nchunks ? nrow + 8u : kOobOff);
+    const int valid = min(64, n - c * 64);
+    u64 live = ~removed_c;
+    if (valid < 64) live &= (1ull << valid) - 1ull;
+    u64 keep = 0;
+    while (live) {                                     // wave-uniform: scalar loop over the KEPT boxes of the chunk
+      const int i = __ffsll((long long)live) - 1;
+      keep |= 1ull << i;
+      live &= ~readlane64(dg, i);                      // boxes it suppresses
+      live &= ~((2ull << i) - 1ull);                   // boxes up to and including i are decided
+    }
+    if (lane == c) mykeep = keep;
+    u64 acc = ((keep >> lane) & 1ull) ? n1 : 0ull;
+#pragma unroll
+    for (int cc = 0; cc < NB; ++cc) acc |= v[cc];
+    acc = wave_or64(acc);
+    removed_c = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(acc >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)acc);
+    if (removed_init && more) removed_c |= removed_init[c + 1];
+    dg = dg_n; n1 = n1_n;
+  }
+  return mykeep;
+}
+
 __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, int wpr, int W, u64* buf,
                                            const u64* __restrict__ removed_init = nullptr) {
   (void)W; (void)buf;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nchunks = (n + 63) >> 6;
   u64 mykeep = 0;
-  if (wave == 0) {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(mask), 0, n * wpr * 8, 0x00020000);
-    const unsigned lane_row = (unsigned)(lane * wpr * 8);          // byte offset of row `lane` of chunk 0
-    const unsigned chunk_step = (unsigned)(64 * wpr * 8);          // ... from one chunk's row to the next chunk's
-    auto ld = [&](unsigned voff, unsigned soff) -> u64 {
-      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(msrc, voff, soff, 0);
-      return ((u64)w[1] << 32) | w[0];
-    };
-    u64 dg = ld(lane_row, 0);                                       // mask[lane][0]
-    u64 n1 = nchunks > 1 ? ld(lane_row + 8u, 0) : 0ull;             // mask[lane][1]
-    u64 removed_c = removed_init ? removed_init[0] : 0ull;          // wave-uniform
-    for (int c = 0; c < nchunks; ++c) {
-#ifdef MSCNN_BO_TRACE
-      if (tid == 0 && g_bo_trace && c < 64) g_bo_trace[64 + c] = __builtin_amdgcn_s_memrealtime();
-#endif
-      const bool more = c + 1 < nchunks;
-      u64 v[63];
-      u64 dg_n = 0, n1_n = 0;
-      if (more) {
-        const unsigned col = (unsigned)(c + 1) * 8u;
-#pragma unroll
-        for (int cc = 0; cc < 63; ++cc) {
-          if (cc < c) {                                              // (wave-uniform)
-            const u64 kw = readlane64(mykeep, cc);
-            v[cc] = ld(((kw >> lane) & 1ull) ? lane_row + col : 0x80000000u, (unsigned)cc * chunk_step);
-          }
-        }
-        dg_n = ld(lane_row + col, (unsigned)(c + 1) * chunk_step);               // mask[64 (c+1) + lane][c + 1]
-        if (c + 2 < nchunks) n1_n = ld(lane_row + col + 8u, (unsigned)(c + 1) * chunk_step);
-      }
-      const int valid = min(64, n - c * 64);
-      u64 live = ~removed_c;
-      if (valid < 64) live &= (1ull << valid) - 1ull;
-      u64 keep = 0;
-      while (live) {                                     // wave-uniform: scalar loop over the KEPT boxes of the chunk
-        const int i = __ffsll((long long)live) - 1;
-        keep |= 1ull << i;
-        live &= ~readlane64(dg, i);                      // boxes it suppresses
-        live &= ~((2ull << i) - 1ull);                   // boxes up to and including i are decided
-      }
-      if (lane == c) mykeep = keep;
-      if (more) {
-        u64 acc = ((keep >> lane) & 1ull) ? n1 : 0ull;
-#pragma unroll
-        for (int cc = 0; cc < 63; ++cc)
-          if (cc < c) acc |= v[cc];
-        acc = wave_or64(acc);
-        removed_c = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(acc >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)acc);
-        if (removed_init) removed_c |= removed_init[c + 1];
-      }
-      dg = dg_n; n1 = n1_n;
-    }
+  if (threadIdx.x < 64) {
+    const int nchunks = (n + 63) >> 6;
+    if (nchunks <= 9) mykeep = greedy_scan_wave<8>(mask, n, wpr, removed_init);
+    else if (nchunks <= 17) mykeep = greedy_scan_wave<16>(mask, n, wpr, removed_init);
+    else if (nchunks <= 33) mykeep = greedy_scan_wave<32>(mask, n, wpr, removed_init);
+    else mykeep = greedy_scan_wave<63>(mask, n, wpr, removed_init);
   }
   __syncthreads();
   return mykeep;
