@@ -62,101 +62,97 @@ __device__ __forceinline__ u64 readlane64(u64 v, int lane) {
   return ((u64)hi << 32) | lo;
 }
 
-// OR of a 64-bit value over the 64 lanes (every lane gets the result).
-__device__ __forceinline__ u64 wave_or64(u64 v) {
-  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    lo |= (unsigned)__shfl_xor((int)lo, d, 64);
-    hi |= (unsigned)__shfl_xor((int)hi, d, 64);
-  }
-  return ((u64)hi << 32) | lo;
-}
-
-// Greedy scan over the upper-triangular bit matrix (nmsMax, box_output_layer.cpp:38-63): boxes in chunks of 64, one wavefront,
-// no LDS and no barrier inside the scan (round 3; rounds 1-2 staged every chunk's 64 mask rows through LDS with three producer
-// waves and OR-ed the kept rows' words into a removed-bitmap: ~1.8 us per chunk, 57 us for 2000 boxes, paced by that OR loop and
-// the chunk barrier -- tools/bo_trace.py).  What chunk c needs is ONE word: which of its 64 boxes are already suppressed,
-//     removed(c) = OR over the kept rows i < 64 c of mask[i][c]      (column c of the bit matrix).
+// (Round 3 also tried a one-wavefront form without LDS or barriers -- chunk c + 1's removed word gathered as a COLUMN of the bit
+// matrix from L2, kept rows only, while chunk c's diagonal pass runs: correct, but 2.8 us per chunk against 1.8 here, because the
+// gather can only be issued once the previous chunk's kept set is known and the matrix, written by other XCDs, comes from memory.)
+// Greedy scan over the upper-triangular bit matrix (nmsMax, box_output_layer.cpp:38-63) by one 256-thread
+// workgroup.  Wave 0 owns the removed-bitmap (lane w = boxes [64w, 64w+64)) and walks the boxes in chunks of 64:
 //   * diagonal pass, all scalar: the next surviving box is s_ff1 of the live word; its diagonal mask word comes from a
 //     v_readlane with a scalar lane index -- one iteration per KEPT box, not per box;
-//   * column c + 1 is gathered straight from L2 while that pass runs: lane l asks for mask[64 cc + l][c + 1] of every earlier
-//     chunk cc whose box l was kept (a buffer load per earlier chunk, all in flight together; rows not kept are an out-of-range
-//     offset and read as 0); chunk c's own rows come from a word prefetched one chunk ahead, as does its diagonal word;
-//   * one 64-lane OR (12 lane exchanges) turns the gathered words into removed(c + 1).
-// W, `buf`: unused since round 3 (kept for the callers' launch geometry: 256 threads, waves 1-3 idle).  Result: lane c of wave 0
-// returns the keep-word of chunk c.  `removed_init` (optional, one word per chunk): boxes already suppressed from outside -- by the
-// kept boxes of earlier tiles in the tiled path of nms_large.h; they are neither kept nor do they suppress anything.
-// NB = static bound on the earlier chunks gathered per step (>= nchunks - 1): the loads of a step are a fixed number of
-// instructions -- a chunk that does not exist yet, like a row that was not kept, is an out-of-range offset -- so the compiler can
-// count them (s_waitcnt vmcnt(k)) and lets the diagonal pass run under them; with a run-time number it waited for all of them first.
-template <int NB>
-__device__ __forceinline__ u64 greedy_scan_wave(const u64* __restrict__ mask, int n, int wpr, const u64* __restrict__ removed_init) {
-  const int lane = threadIdx.x & 63;
-  const int nchunks = (n + 63) >> 6;
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(mask), 0, n * wpr * 8, 0x00020000);
-  const unsigned lane_row = (unsigned)(lane * wpr * 8);          // byte offset of row `lane` of chunk 0
-  const unsigned chunk_step = (unsigned)(64 * wpr * 8);          // ... from one chunk's row to the next chunk's
-  constexpr unsigned kOobOff = 0x80000000u;
-  auto ld = [&](unsigned voff) -> u64 {
-    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(msrc, voff, 0, 0);
-    return ((u64)w[1] << 32) | w[0];
-  };
-  u64 mykeep = 0;
-  u64 dg = ld(lane_row);                                          // mask[lane][0]
-  u64 n1 = ld(nchunks > 1 ? lane_row + 8u : kOobOff);             // mask[lane][1]
-  u64 removed_c = removed_init ? removed_init[0] : 0ull;          // wave-uniform
-  for (int c = 0; c < nchunks; ++c) {
-#ifdef MSCNN_BO_TRACE
-    if (threadIdx.x == 0 && g_bo_trace && c < 64) g_bo_trace[64 + c] = __builtin_amdgcn_s_memrealtime();
-#endif
-    const bool more = c + 1 < nchunks;
-    const unsigned col = (unsigned)(c + 1) * 8u;
-    u64 v[NB];
-#pragma unroll
-    for (int cc = 0; cc < NB; ++cc) {
-      const u64 kw = readlane64(mykeep, cc);                        // (0 for the chunks still to come)
-      const bool want = more && cc < c && ((kw >> lane) & 1ull);
-      v[cc] = ld(want ? lane_row + col + (unsigned)cc * chunk_step : kOobOff);
-    }
-    const unsigned nrow = lane_row + col + (unsigned)(c + 1) * chunk_step;
-    const u64 dg_n = ld(more ? nrow : kOobOff);                    // mask[64 (c+1) + lane][c + 1]
-    const u64 n1_n = ld(c + 2 < nchunks ? nrow + 8u : kOobOff);
-    const int valid = min(64, n - c * 64);
-    u64 live = ~removed_c;
-    if (valid < 64) live &= (1ull << valid) - 1ull;
-    u64 keep = 0;
-    while (live) {                                     // wave-uniform: scalar loop over the KEPT boxes of the chunk
-      const int i = __ffsll((long long)live) - 1;
-      keep |= 1ull << i;
-      live &= ~readlane64(dg, i);                      // boxes it suppresses
-      live &= ~((2ull << i) - 1ull);                   // boxes up to and including i are decided
-    }
-    if (lane == c) mykeep = keep;
-    u64 acc = ((keep >> lane) & 1ull) ? n1 : 0ull;
-#pragma unroll
-    for (int cc = 0; cc < NB; ++cc) acc |= v[cc];
-    acc = wave_or64(acc);
-    removed_c = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(acc >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)acc);
-    if (removed_init && more) removed_c |= removed_init[c + 1];
-    dg = dg_n; n1 = n1_n;
-  }
-  return mykeep;
-}
-
+//   * the kept rows' words (w >= c) are OR-ed into the removed-bitmap from LDS, four independent reads at a time.
+// Waves 1-3 stream the NEXT chunk's 64 mask rows (words c+1.. only) from L2 into the other half of a double buffer in LDS
+// meanwhile: lane = word, one row per load instruction (coalesced), all of a thread's rows in flight at once.
+// W = words per row actually used (<= 64).  `buf` = dynamic LDS of 2 * 64 * W u64.  Result: lane c of wave 0 returns the
+// keep-word of chunk c.  `removed_init` (optional, W words): boxes already suppressed from outside -- by the kept boxes of
+// earlier tiles in the tiled path of nms_large.h; they are neither kept nor do they suppress anything.
 __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, int wpr, int W, u64* buf,
                                            const u64* __restrict__ removed_init = nullptr) {
-  (void)W; (void)buf;
-  u64 mykeep = 0;
-  if (threadIdx.x < 64) {
-    const int nchunks = (n + 63) >> 6;
-    if (nchunks <= 9) mykeep = greedy_scan_wave<8>(mask, n, wpr, removed_init);
-    else if (nchunks <= 17) mykeep = greedy_scan_wave<16>(mask, n, wpr, removed_init);
-    else if (nchunks <= 33) mykeep = greedy_scan_wave<32>(mask, n, wpr, removed_init);
-    else mykeep = greedy_scan_wave<63>(mask, n, wpr, removed_init);
-  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunks = (n + 63) >> 6;
+  // rows r = r0, r0 + rstep, ... of chunk c; this thread moves word `lane` of each.  The producers are software-pipelined across
+  // the chunk barrier: the rows of chunk c + 2 are requested while chunk c is scanned and parked in LDS one iteration later, so
+  // the L2 round trip of a chunk's rows overlaps a whole scan step instead of being waited for inside it (round 3: 63 -> see DESIGN.md).
+  constexpr int kBatch = 22;                             // ceil(64 / 3): every row of a producer wave in one batch
+  // (buffer loads: a row past n or a word this lane does not need is an out-of-range offset and reads as 0 -- no branch and no
+  // 64-bit address arithmetic per row; the per-row form with both was 15 instructions x 22 rows per chunk and paced the scan)
+  const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u64*>(mask), 0, n * wpr * 8, 0x00020000);
+  auto load_rows = [&](int c, int r0, int rstep, u64 (&v)[kBatch]) {
+    const bool need = lane < W && lane >= c && lane < wpr;      // words left of the diagonal are never read
+    const unsigned off0 = need ? (unsigned)(((c * 64 + r0) * wpr + lane) * 8) : 0x80000000u;
+    const unsigned step = (unsigned)(rstep * wpr * 8);
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      // (rows r >= 64 of the batch belong to the next chunk or lie past n: they are loaded into registers nobody stores)
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(msrc, off0 + (unsigned)j * step, 0, 0);
+      v[j] = ((u64)w[1] << 32) | w[0];
+    }
+  };
+  auto store_rows = [&](int b, int r0, int rstep, const u64 (&v)[kBatch]) {
+    if (lane >= W) return;
+    u64* dst = buf + (size_t)b * 64 * W;
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      const int r = r0 + j * rstep;
+      if (r < 64) dst[r * W + lane] = v[j];
+    }
+  };
+  u64 v[kBatch];
+  load_rows(0, wave, 4, v);                              // chunk 0: all four waves, 16 rows each
+  store_rows(0, wave, 4, v);
+  if (wave != 0 && nchunks > 1) load_rows(1, wave - 1, 3, v);      // in flight across the barrier
   __syncthreads();
+  u64 removed = 0, mykeep = 0;
+  if (removed_init != nullptr && wave == 0 && lane < W) removed = removed_init[lane];
+  for (int c = 0; c < nchunks; ++c) {
+#ifdef MSCNN_BO_TRACE
+    if (tid == 0 && g_bo_trace && c < 64) g_bo_trace[64 + c] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const u64* cur_rows = buf + (size_t)(c & 1) * 64 * W;
+    if (wave != 0) {
+      if (c + 1 < nchunks) {
+        store_rows((c + 1) & 1, wave - 1, 3, v);         // requested one step ago
+        if (c + 2 < nchunks) load_rows(c + 2, wave - 1, 3, v);
+      }
+    } else {
+      const int valid = min(64, n - c * 64);
+      const u64 dg = cur_rows[min(lane, 63) * W + c];    // diagonal word of row (c*64 + lane): bits j > lane it suppresses
+      u64 live = ~readlane64(removed, c);
+      if (valid < 64) live &= (1ull << valid) - 1ull;
+      u64 keep = 0;
+      while (live) {                                     // wave-uniform: scalar loop over the KEPT boxes of the chunk
+        const int i = __ffsll((long long)live) - 1;
+        keep |= 1ull << i;
+        live &= ~readlane64(dg, i);                      // boxes it suppresses
+        live &= ~((2ull << i) - 1ull);                   // boxes up to and including i are decided
+      }
+      if (lane == c) mykeep = keep;
+      if (lane < W) {
+        u64 kk = keep, acc = 0;
+        while (kk) {                                     // uniform loop over kept rows, four LDS reads in flight
+          const int i0 = __ffsll((long long)kk) - 1; kk &= kk - 1;
+          const int i1 = kk ? __ffsll((long long)kk) - 1 : i0; kk &= kk - 1;     // (kk & (kk - 1) of 0 is 0)
+          const int i2 = kk ? __ffsll((long long)kk) - 1 : i0; kk &= kk - 1;
+          const int i3 = kk ? __ffsll((long long)kk) - 1 : i0; kk &= kk - 1;
+          const u64 r0 = cur_rows[i0 * W + lane], r1 = cur_rows[i1 * W + lane];
+          const u64 r2 = cur_rows[i2 * W + lane], r3 = cur_rows[i3 * W + lane];
+          acc |= (r0 | r1) | (r2 | r3);
+        }
+        removed |= acc;
+      }
+    }
+    __syncthreads();
+  }
   return mykeep;
 }
 
