@@ -216,6 +216,12 @@ MSCNN_API int mscnn_softmax_fwd_f32(const float* x, float* y, int outer, int C, 
 MSCNN_API int mscnn_roipool_fwd_f32(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W,
                           int pooled_h, int pooled_w, float spatial_scale, float pad_ratio,
                           int C_total, int c_offset, void* stream);
+/* The same ROIs pooled twice over the same map with two context paddings (roi_pool_org + roi_pool_ctx of the deploy nets,
+ * roi_pooling_layer.cu:19-104 twice) into two disjoint channel windows [c_offset_x, c_offset_x + C) of one [R][C_total][ph][pw]
+ * output, in one launch. */
+MSCNN_API int mscnn_roipool_pair_fwd_f32(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W,
+                                         int pooled_h, int pooled_w, float spatial_scale, float pad_ratio_a, int c_offset_a,
+                                         float pad_ratio_b, int c_offset_b, int C_total, void* stream);
 
 /* ROIAlign -- ROIAlignLayer<Dtype>::Forward_gpu (roi_align_layer.cu:21-112): out[R][C][pooled_h+1][pooled_w+1] bilinear
  * samples on the grid of the (context-padded) roi; the WiderFace cascade deploy follows it with a 2x2 stride-1 AVE Pooling. */

@@ -101,6 +101,8 @@ def lib():
         L.mscnn_softmax_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.mscnn_roipool_fwd_f32.argtypes = ([C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_float, C.c_float] + [C.c_int] * 2
                                             + [C.c_void_p])
+        L.mscnn_roipool_pair_fwd_f32.argtypes = ([C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int]
+                                                 + [C.c_void_p])
         L.mscnn_roialign_fwd_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_void_p]
         L.mscnn_eltwise_fwd_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.mscnn_boxoutput_workspace_bytes.restype = C.c_size_t
@@ -346,6 +348,16 @@ def roipool(feat, rois, pooled_h, pooled_w, spatial_scale, pad_ratio=0.0, out=No
         out = torch.empty((R, c_total, pooled_h, pooled_w), dtype=torch.float32, device=feat.device)
     _check(lib().mscnn_roipool_fwd_f32(_dev(feat), _dev(rois), _dev(out), R, N, Cc, H, W, pooled_h, pooled_w,
                                        spatial_scale, pad_ratio, c_total, c_offset, _stream()))
+    return out
+
+
+def roipool_pair(feat, rois, pooled_h, pooled_w, spatial_scale, pad_a, pad_b):
+    """Two ROI poolings (context paddings pad_a / pad_b) into channels [0, C) and [C, 2C) of one output, one launch."""
+    N, Cc, H, W = feat.shape
+    R = rois.shape[0]
+    out = torch.empty((R, 2 * Cc, pooled_h, pooled_w), dtype=torch.float32, device=feat.device)
+    _check(lib().mscnn_roipool_pair_fwd_f32(_dev(feat), _dev(rois), _dev(out), R, N, Cc, H, W, pooled_h, pooled_w, spatial_scale,
+                                            pad_a, 0, pad_b, Cc, 2 * Cc, _stream()))
     return out
 
 

@@ -260,7 +260,13 @@ class SoftmaxLayer : public Layer<Dtype> {
 template <typename Dtype>
 class ROIPoolingLayer : public Layer<Dtype> {
  public:
-  explicit ROIPoolingLayer(const LayerParameter& param) : Layer<Dtype>(param), window_(nullptr), window_c_total_(0), window_c_offset_(0) {}
+  explicit ROIPoolingLayer(const LayerParameter& param)
+      : Layer<Dtype>(param), window_(nullptr), window_c_total_(0), window_c_offset_(0), partner_(nullptr), skip_(false) {}
+  // Net-level fusion: two ROIPooling layers over the same map and ROIs whose tops feed one fused-away Concat (roi_pool_org +
+  // roi_pool_ctx) run as ONE launch -- the first of the pair does both windows and tells the second to skip its next Forward
+  // (Net clears that at the start of every ForwardFromTo, so a range that starts between the two still computes the second).
+  bool PairWith(ROIPoolingLayer* second);
+  void set_skip(bool s) { skip_ = s; }
   virtual bool SetOutputWindow(Blob<Dtype>* target, int c_total, int c_offset) {
     window_ = target; window_c_total_ = c_total; window_c_offset_ = c_offset;
     return true;
@@ -279,6 +285,8 @@ class ROIPoolingLayer : public Layer<Dtype> {
   Dtype spatial_scale_, pad_ratio_;
   Blob<Dtype>* window_;
   int window_c_total_, window_c_offset_;
+  ROIPoolingLayer* partner_;
+  bool skip_;
 };
 
 // include/caffe/layers/roi_align_layer.hpp -- tops are (R, C, pooled_h + 1, pooled_w + 1) grid samples

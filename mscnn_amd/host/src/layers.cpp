@@ -534,13 +534,30 @@ void ROIPoolingLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const v
   top[0]->Reshape(bottom[1]->num(), channels_, pooled_height_, pooled_width_);   // :37-46
 }
 template <typename Dtype>
+bool ROIPoolingLayer<Dtype>::PairWith(ROIPoolingLayer* b) {
+  if (!b || b == this || !window_ || b->window_ != window_ || b->window_c_total_ != window_c_total_) return false;
+  const ROIPoolingParameter pa = this->layer_param_.roi_pooling_param(), pb = b->layer_param_.roi_pooling_param();
+  if (pa.pooled_h() != pb.pooled_h() || pa.pooled_w() != pb.pooled_w() || pa.spatial_scale() != pb.spatial_scale()) return false;
+  partner_ = b;
+  return true;
+}
+
+template <typename Dtype>
 void ROIPoolingLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  if (skip_) { skip_ = false; return; }      // the pair's first layer has written this layer's window in its launch
   Dtype* out = window_ ? nullptr : top[0]->mutable_gpu_data();
   int c_total = channels_, c_offset = 0;
   if (window_) {   // Net fused the following Concat away: write this layer's channels of the concatenated blob directly
     window_->Reshape(bottom[1]->num(), window_c_total_, pooled_height_, pooled_width_);
     out = window_->mutable_gpu_data();
     c_total = window_c_total_; c_offset = window_c_offset_;
+  }
+  if (partner_ && window_ && partner_->channels_ == channels_) {
+    MSCNN_CHECK(mscnn_roipool_pair_fwd_f32(bottom[0]->gpu_data(), bottom[1]->gpu_data(), out, bottom[1]->num(), bottom[0]->num(), channels_,
+                                           height_, width_, pooled_height_, pooled_width_, spatial_scale_, pad_ratio_, c_offset,
+                                           partner_->pad_ratio_, partner_->window_c_offset_, c_total, S()));
+    partner_->set_skip(true);
+    return;
   }
   MSCNN_CHECK(mscnn_roipool_fwd_f32(bottom[0]->gpu_data(), bottom[1]->gpu_data(), out, bottom[1]->num(), bottom[0]->num(), channels_,
                                     height_, width_, pooled_height_, pooled_width_, spatial_scale_, pad_ratio_, c_total, c_offset, S()));

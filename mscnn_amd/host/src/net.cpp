@@ -312,6 +312,11 @@ void Net<Dtype>::ApplyFusion() {
     }
     fused_away_[i] = true;
     fused_producers_[i] = producers;
+    // two poolings of the same map and ROIs: one launch (ROIPoolingLayer::PairWith)
+    if (producers.size() == 2 && bottom_id_vecs_[producers[0]] == bottom_id_vecs_[producers[1]]) {
+      const int first = std::min(producers[0], producers[1]), second = std::max(producers[0], producers[1]);
+      static_cast<ROIPoolingLayer<Dtype>*>(layers_[first].get())->PairWith(static_cast<ROIPoolingLayer<Dtype>*>(layers_[second].get()));
+    }
   }
 }
 
@@ -377,6 +382,8 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   CHECK_LT(end, (int)layers_.size());
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing_) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
+  for (size_t i = 0; i < layers_.size(); ++i)      // (a paired ROIPooling skips only inside the call in which its partner ran)
+    if (string(layers_[i]->type()) == "ROIPooling") static_cast<ROIPoolingLayer<Dtype>*>(layers_[i].get())->set_skip(false);
   {
     // split-fp16 convolutions take the bound of their input from the producing convolution when it runs in this same call
     // from the top (slots zeroed here, once); a partial range makes them measure it themselves

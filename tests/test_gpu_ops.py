@@ -949,6 +949,22 @@ def _random_rois(rng, R, img_h, img_w, batch=1):
     return np.stack([rng.integers(0, batch, R), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
 
 
+@pytest.mark.parametrize("ph,pw,scale,C,R", [(7, 7, 0.125, 24, 97), (7, 5, 0.25, 40, 33), (8, 4, 0.125, 128, 50), (5, 5, 0.25, 16, 200)])
+def test_roipool_pair_bitexact(hip, orc, ph, pw, scale, C, R):
+    """roi_pool_org + roi_pool_ctx in one launch (mscnn_roipool_pair_fwd_f32): both channel windows bit-identical to the oracle's
+    two poolings (max is exact), incl. ROIs outside the map, the whole map, ROIs wider than the LDS column buffer, both pad orders."""
+    rng = np.random.default_rng(11)
+    feat = rng.standard_normal((2, C, 36, 150)).astype(np.float32)
+    rois = _random_rois(rng, R, 36 / scale, 150 / scale, batch=2)
+    rois[0] = [0, -500, -500, -300, -300]
+    rois[1] = [1, 0, 0, 150 / scale - 1, 36 / scale - 1]
+    rois[2] = [0, 20, 20, 20, 20]
+    for pa, pb in ((0.0, 0.25), (0.25, 0.0)):
+        y = hip.roipool_pair(dev(feat), dev(rois), ph, pw, scale, pa, pb).cpu().numpy()
+        assert np.array_equal(y[:, :C], orc.roipool(feat, rois, ph, pw, scale, pa))
+        assert np.array_equal(y[:, C:], orc.roipool(feat, rois, ph, pw, scale, pb))
+
+
 @pytest.mark.parametrize("ph,pw,scale,pad", [(7, 7, 0.125, 0.0), (7, 7, 0.125, 0.25), (7, 5, 0.25, 0.25), (8, 4, 0.125, 0.0)])
 def test_roipool_bitexact(hip, orc, ph, pw, scale, pad):
     rng = np.random.default_rng(7)
