@@ -313,7 +313,19 @@ void Net<Dtype>::ApplyFusion() {
     fused_away_[i] = true;
     fused_producers_[i] = producers;
     // two poolings of the same map and ROIs: one launch (ROIPoolingLayer::PairWith)
-    if (producers.size() == 2 && bottom_id_vecs_[producers[0]] == bottom_id_vecs_[producers[1]]) {
+    auto source = [&](int blob) {      // through Split layers (their tops share the bottom's data) to the blob that holds the data
+      for (bool moved = true; moved;) {
+        moved = false;
+        for (size_t l = 0; l < layers_.size() && !moved; ++l)
+          if (string(layers_[l]->type()) == "Split")
+            for (int t : top_id_vecs_[l])
+              if (t == blob) { blob = bottom_id_vecs_[l][0]; moved = true; break; }
+      }
+      return blob;
+    };
+    if (producers.size() == 2 && bottom_id_vecs_[producers[0]].size() == 2 && bottom_id_vecs_[producers[1]].size() == 2 &&
+        source(bottom_id_vecs_[producers[0]][0]) == source(bottom_id_vecs_[producers[1]][0]) &&
+        source(bottom_id_vecs_[producers[0]][1]) == source(bottom_id_vecs_[producers[1]][1])) {
       const int first = std::min(producers[0], producers[1]), second = std::max(producers[0], producers[1]);
       static_cast<ROIPoolingLayer<Dtype>*>(layers_[first].get())->PairWith(static_cast<ROIPoolingLayer<Dtype>*>(layers_[second].get()));
     }
