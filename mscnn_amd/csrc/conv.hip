@@ -33,6 +33,7 @@
 #include "winograd.h"
 #include "wino_x3.h"
 #include "wgemm.h"
+#include "conv_c3.h"
 #include "x3_device.h"
 #include <new>
 #include <type_traits>
@@ -990,6 +991,7 @@ struct mscnn_conv_plan {
   // description of the fall-back; tune_flags bit 7 selects it for A/B runs).  Workspace: [V][M][wgemm's stream-K slabs]
   bool use_wg = false;
   mscnn::WgemmPlan wg;
+  bool c3 = false;       // conv1_1: the Cin = 3 VALU kernel of conv_c3.hip (reads the Caffe-layout weights; entry stays -1)
   int wino_m = 2;        // output tile edge: 2 = F(2x2,3x3) (16 planes), 3 = F(3x3,3x3) (25 planes; small ROI maps)
   int tiles_h = 0, tiles_w = 0, T_pad = 0;
   // split-fp16 form of the F(3x3,3x3) path (MSCNN_CONV_ALGO_WINO_F3_X3, wino_x3.hip): x3.BM > 0, wino == nullptr.
@@ -1175,6 +1177,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->Ho = (d.H + 2 * d.pad_h - d.Kh) / d.stride_h + 1;     // conv_layer.cpp:8-22
   p->Wo = (d.W + 2 * d.pad_w - d.Kw) / d.stride_w + 1;
   p->entry = -1;
+  p->c3 = false;
   p->packed_bytes = 0;
   p->ws_bytes = 0;
   p->head.entry = -1;
@@ -1201,6 +1204,13 @@ static void plan_shape(mscnn_conv_plan* p) {
   delete p->wino;
   p->wino = nullptr;
   p->x3 = mscnn::X3Plan();
+  {
+    // conv1_1 (Cin = 3): an output-store-bound layer with K = 27 -- its own VALU kernel (conv_c3.hip) unless the caller asked for a
+    // Winograd form by name; tune_flags bit 11 keeps the MFMA igemm kernel (A/B runs, the bit-identity test)
+    const int algo = tune_env("MSCNN_CONV_ALGO", d.algo);
+    const bool named_wino = algo == MSCNN_CONV_ALGO_WINO_F2 || algo == MSCNN_CONV_ALGO_WINO_F3 || algo == MSCNN_CONV_ALGO_WINO_F4;
+    if (!named_wino && !(d.tune_flags & 2048) && mscnn::c3_plan(d, p->Ho, p->Wo)) { p->c3 = true; return; }
+  }
   if (d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0 || d.Cin > 2048) return;   // KI <= 256
   const bool want16 = tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_F16 && d.Kh == 3 && d.Kw == 3;
   if (!want16 && wino_plan(p)) return;
@@ -1329,6 +1339,7 @@ extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (p->head.entry >= 0) return head_kernel_name(p->head);
   if (p->x3.BM) return p->x3.BM == 256 ? "winograd_f3x3_3x3_x3f16_256" : "winograd_f3x3_3x3_x3f16_128";
   if (p->wino) return p->wino_m == 4 ? "winograd_f4x4_3x3" : p->wino_m == 3 ? "winograd_f3x3_3x3" : "winograd_f2x2_3x3";
+  if (p->c3) return mscnn::c3_kernel_name();
   return p->entry < 0 ? "direct_f32" : kTable[p->entry].name;
 }
 extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_plan* p) {
@@ -1646,6 +1657,10 @@ static int conv_forward_single(const mscnn_conv_plan* p, const float* x, const f
   if (p->head.entry >= 0) {
     MSCNN_REQUIRE(packed, "conv: head kernel needs packed weights (mscnn_conv2d_pack_weights)");
     return head_forward(d, p->head, p->Ho, p->Wo, x, packed, bias, y, workspace, workspace_bytes, st);
+  }
+  if (p->c3) {
+    MSCNN_REQUIRE(w, "conv: the Cin = 3 kernel needs the Caffe-layout weights");
+    return mscnn::c3_forward(d, x, w, bias, y, st);
   }
   if (p->entry < 0) {
     MSCNN_REQUIRE(w, "conv: direct kernel needs the Caffe-layout weights");

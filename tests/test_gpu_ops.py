@@ -122,6 +122,32 @@ def test_conv(hip, orc, case, relu):
     close(y, ref)
 
 
+@pytest.mark.parametrize("case", [(1, 64, 96, 320, True, True), (2, 64, 67, 132, True, False), (1, 16, 130, 36, False, True), (1, 128, 64, 64, True, True),
+                                  (1, 64, 576, 1920, True, True)])
+def test_conv_c3_bit_identical_to_the_igemm_kernel(hip, orc, case):
+    """conv1_1 (Cin = 3, K = 27) on its own VALU kernel (conv_c3.hip) against the MFMA igemm kernel it replaces (tune_flags bit 11):
+    the same k order (taps outer, channels inner, bias last) => equal values everywhere (== treats the -0 a zero-padded MFMA k can
+    leave as +0); ragged heights, widths that are not a multiple of the 128-column tile, batch 2, no bias / no ReLU; and the
+    reference's tolerance against the oracle on the small cases."""
+    N, Cout, H, W, relu, with_bias = case
+    g = torch.Generator(device="cuda").manual_seed(H + W)
+    x = torch.randn((N, 3, H, W), device="cuda", generator=g) * 60.0                  # BGR - mean scale
+    w = torch.randn((Cout, 3, 3, 3), device="cuda", generator=g) * (2.0 / 27) ** 0.5
+    b = torch.randn((Cout,), device="cuda", generator=g) if with_bias else None
+    p = hip.ConvPlan(N, 3, H, W, Cout, 3, 3, (1, 1), relu=relu)
+    assert p.kernel == "conv3x3_c3_valu_f32"
+    p.pack(w)
+    y = p.forward(x, b).clone()
+    q = hip.ConvPlan(N, 3, H, W, Cout, 3, 3, (1, 1), relu=relu, tune_flags=2048)
+    assert q.kernel.startswith("igemm_")
+    q.pack(w)
+    y_ig = q.forward(x, b)
+    assert bool((y == y_ig).all())
+    if H * W <= 50000:
+        ref = orc.conv2d(x.cpu().numpy(), w.cpu().numpy(), None if b is None else b.cpu().numpy(), (1, 1))
+        close(y.cpu().numpy(), orc.relu(ref) if relu else ref)
+
+
 @pytest.mark.parametrize("case", [(1, 512, 72, 240, 9, (5, 5), (2, 2)), (1, 512, 36, 120, 9, (7, 7), (3, 3)), (1, 512, 18, 60, 9, (5, 5), (2, 2)),
                                   (1, 512, 9, 30, 9, (7, 7), (3, 3)), (2, 96, 40, 70, 6, (5, 3), (2, 1)), (3, 64, 20, 33, 12, (5, 5), (2, 2))])
 def test_conv_head_stream_k_is_deterministic(hip, orc, case):
