@@ -77,8 +77,7 @@ enum { CNT_CAND = 0, CNT_ROWS = 1, CNT_REAL = 2, CNT_K = 3, CNT_BIG = 4 /* + BIG
 
 __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a, u64* __restrict__ keys,
                                                             float4* __restrict__ box_by_anchor,
-                                                            float* __restrict__ score_by_anchor, int* __restrict__ cnt,
-                                                            unsigned* __restrict__ ghist) {
+                                                            float* __restrict__ score_by_anchor, int* __restrict__ cnt) {
   const int total = a.head_off[a.num_heads];
   const int aid = blockIdx.x * 256 + threadIdx.x;
   if (aid >= total) return;
@@ -116,7 +115,6 @@ __global__ __launch_bounds__(256) void decode_filter_kernel(DecodeArgs a, u64* _
   if (bbw >= a.min_size && bbh >= a.min_size) {
     const int pos = atomicAdd(&cnt[CNT_CAND], 1);
     keys[pos] = ((u64)orderable(fg) << 32) | (unsigned)aid;
-    if (ghist) atomicAdd(&ghist[orderable(fg) >> 16], 1u);      // the keys' top 16 bits, for select_sort_kernel's first step
     box_by_anchor[aid] = make_float4(bbx, bby, bbw, bbh);
     score_by_anchor[aid] = fg;
   }
@@ -130,15 +128,14 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
                                                                    float4* __restrict__ sorted_box,
                                                                    float* __restrict__ sorted_score,
                                                                    int* __restrict__ sorted_aid, int* __restrict__ cnt,
-                                                                   int max_nms_num, unsigned* __restrict__ ghist) {
+                                                                   int max_nms_num) {
   __shared__ u64 sk[kSortCap];
   __shared__ unsigned hist[256];
   __shared__ u64 s_prefix;
   __shared__ int s_need, s_fill, s_done;
-  __shared__ int s_wtot[kSortThreads / 64];
   constexpr int kListCap = 1024;
   __shared__ u64 lst[kListCap];
-  __shared__ int s_lfill, s_cross;
+  __shared__ int s_lfill;
   const int tid = threadIdx.x;
   BO_STAMP(0);
   const int n = cnt[CNT_CAND];
@@ -166,111 +163,43 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   if (tid == 0 && g_bo_trace) { g_bo_trace[30] = (unsigned long long)n; g_bo_trace[31] = (unsigned long long)K; }
 #endif
   u64 thresh = 0;             // keep keys >= thresh
-  bool filled = false;        // the sort buffer already holds the K keys (histogram + list path)
-  unsigned mine = 1;          // this thread's share of the global histogram (0: nothing to zero afterwards)
+  bool filled = false;        // the sort buffer already holds the K keys (sweep + list path)
   if (n > K) {
     // radix select, MSB first, 8 bits per pass: find the K-th largest key.  The bucket walk is a 64-lane suffix scan
     // (4 buckets per lane); the passes stop as soon as a bucket holds exactly the keys still needed (with the score in the
     // upper 32 bits that is normally after 3-4 passes: the anchor-id passes only separate equal scores).
     if (tid == 0) { s_prefix = 0; s_need = K; s_done = 0; }
     __syncthreads();
-    // The first two digits come from the 65536-bin histogram of the keys' top 16 bits that decode_filter_kernel counted while it
-    // ran on the whole chip: the score's sign, exponent and 7 mantissa bits are nearly the same for thousands of candidates, so
-    // the LDS histogram of those two passes was 27 k atomics onto a handful of addresses (most of the select's 27 us on the bench
-    // frame).  Thread t owns bins 65535 - 64 t .. 65472 - 64 t (descending key order); the thread whose running total crosses K
-    // walks its bins.
-    int first_pass = 0;
-    if (ghist) {
-      const uint4* hp = reinterpret_cast<const uint4*>(ghist + (65536 - 64 * (tid + 1)));
-      mine = 0;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) { const uint4 v = hp[q]; mine += v.x + v.y + v.z + v.w; }
-      int incl = (int)mine;
-      for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d, 64);
-        if ((tid & 63) >= d) incl += v;
-      }
-      if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
-      __syncthreads();
-      for (int w = 0; w < (tid >> 6); ++w) incl += s_wtot[w];
-      if (incl >= K && incl - (int)mine < K) {            // exactly one thread: the bins hold all n > K candidates
-        s_need = K - (incl - (int)mine);
-        s_cross = tid;
-      }
-      __syncthreads();
-      if (tid < 64) {      // that thread's 64 bins, one per lane (descending), and the same running-total test inside them
-        const int b = 65535 - 64 * s_cross - tid;
-        const int c = (int)ghist[b];
-        int in2 = c;
-        for (int d = 1; d < 64; d <<= 1) {
-          const int v = __shfl_up(in2, d, 64);
-          if (tid >= d) in2 += v;
-        }
-        const int need0 = s_need;
-        const int first = __ffsll((long long)__ballot(in2 >= need0)) - 1;
-        if (tid == first) {
-          const int rem = need0 - (in2 - c);
-          s_need = rem;
-          s_prefix = (u64)(unsigned)b << 48;
-          if (c == rem) s_done = 1;
-        }
-      }
-      __syncthreads();
-      first_pass = 2;
-      if (inreg) {
-        // One sweep over the register keys: bins above the threshold bin go straight to the sort buffer, the threshold bin's own
-        // keys (a few dozen) to a list, where the `need` largest are found by rank (keys are unique) -- no further digit passes,
-        // each of which cost ~3 us of barriers and a 32-key loop per thread whatever the histogram looked like.
-        const unsigned bstar = (unsigned)(s_prefix >> 48);
-#pragma unroll
-        for (int j = 0; j < kRegKeys; ++j) {
-          const u64 k = rk[j];
-          const bool valid = tid + j * kSortThreads < n;
-          const unsigned t16 = (unsigned)(k >> 48);
-          if (valid && t16 > bstar) {                     // (one LDS atomic per wave and key slot, not per key)
-            const u64 takers = __ballot(1);
-            const int leader = __ffsll((long long)takers) - 1, lane = tid & 63;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&s_fill, __popcll(takers));
-            base = __shfl(base, leader, 64);
-            const int pos = base + __popcll(takers & ((1ull << lane) - 1ull));
-            if (pos < kMaxK) sk[pos] = k;
-          } else if (valid && t16 == bstar) {
-            const int pos = atomicAdd(&s_lfill, 1);
-            if (pos < kListCap) lst[pos] = k;
-          }
-        }
-        __syncthreads();
-        const int Ln = s_lfill, need = s_need;
-        if (Ln <= kListCap) {
-          for (int t = tid; t < Ln; t += kSortThreads) {
-            const u64 my = lst[t];
-            int rank = 0;
-            for (int u = 0; u < Ln; ++u) rank += lst[u] > my ? 1 : 0;
-            if (rank < need) {
-              const int pos = atomicAdd(&s_fill, 1);
-              if (pos < kMaxK) sk[pos] = my;
-            }
-          }
-          filled = true;
-        } else {
-          __syncthreads();
-          if (tid == 0) s_fill = 0;      // (a bin with more than kListCap keys: the digit passes below, then the general compaction)
-        }
-      }
-    }
-    if (!filled)
-    for (int pass = first_pass; pass < 8 && !s_done; ++pass) {
+    // One digit of the select.  The first two digits (the score's sign, exponent and 7 mantissa bits) are nearly the same for
+    // thousands of candidates: their LDS histogram used to be 27 k atomics onto a handful of addresses (most of the kernel's 27 us
+    // of select on the bench frame), so for those two the lanes of a wave that share a bucket are counted with ballots and ONE
+    // lane adds the count (up to 6 distinct buckets per wave and key slot, the rest fall back to their own atomic).
+    auto digit_pass = [&](int pass) {
       const int shift = 56 - 8 * pass;
       if (tid < 256) hist[tid] = 0;
       __syncthreads();
       const u64 prefix = s_prefix;
       const u64 himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
       if (inreg) {
+        const int lane = tid & 63;
 #pragma unroll
         for (int j = 0; j < kRegKeys; ++j) {
           const u64 k = rk[j];
-          if (tid + j * kSortThreads < n && (k & himask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+          const bool act = tid + j * kSortThreads < n && (k & himask) == prefix;
+          const unsigned bucket = (unsigned)(k >> shift) & 255u;
+          if (pass < 2) {
+            u64 todo = __ballot(act);
+            for (int round = 0; todo && round < 6; ++round) {
+              const int first = __ffsll((long long)todo) - 1;
+              const unsigned b0 = (unsigned)__shfl((int)bucket, first, 64);
+              const u64 same = __ballot(act && bucket == b0) & todo;
+              if (lane == first) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+              todo &= ~same;
+            }
+            if ((todo >> lane) & 1ull) atomicAdd(&hist[bucket], 1u);
+          } else if (act) {
+            atomicAdd(&hist[bucket], 1u);
+          }
         }
       } else {
         for (int i = tid; i < n; i += kSortThreads) {
@@ -307,16 +236,54 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
         }
       }
       __syncthreads();
-      if (s_done) break;
+    };
+    int pass = 0;
+    for (; pass < (inreg ? 2 : 8) && !s_done; ++pass) digit_pass(pass);
+    if (inreg && !s_done) {
+      // After two digits: one sweep over the register keys -- keys whose top 16 bits lie above the threshold's go straight to the
+      // sort buffer, the threshold bin's own keys (a few dozen) to a list, where the `need` largest are found by rank (keys are
+      // unique) -- instead of more digit passes, each ~3 us of barriers and a 32-key loop per thread whatever the histogram holds.
+      const unsigned bstar = (unsigned)(s_prefix >> 48);
+#pragma unroll
+      for (int j = 0; j < kRegKeys; ++j) {
+        const u64 k = rk[j];
+        const bool valid = tid + j * kSortThreads < n;
+        const unsigned t16 = (unsigned)(k >> 48);
+        if (valid && t16 > bstar) {                     // (one LDS atomic per wave and key slot, not per key)
+          const u64 takers = __ballot(1);
+          const int leader = __ffsll((long long)takers) - 1, lane = tid & 63;
+          int base = 0;
+          if (lane == leader) base = atomicAdd(&s_fill, __popcll(takers));
+          base = __shfl(base, leader, 64);
+          const int pos = base + __popcll(takers & ((1ull << lane) - 1ull));
+          if (pos < kMaxK) sk[pos] = k;
+        } else if (valid && t16 == bstar) {
+          const int pos = atomicAdd(&s_lfill, 1);
+          if (pos < kListCap) lst[pos] = k;
+        }
+      }
+      __syncthreads();
+      const int Ln = s_lfill, need = s_need;
+      if (Ln <= kListCap) {
+        for (int t = tid; t < Ln; t += kSortThreads) {
+          const u64 my = lst[t];
+          int rank = 0;
+          for (int u = 0; u < Ln; ++u) rank += lst[u] > my ? 1 : 0;
+          if (rank < need) {
+            const int pos = atomicAdd(&s_fill, 1);
+            if (pos < kMaxK) sk[pos] = my;
+          }
+        }
+        filled = true;
+      } else {
+        __syncthreads();
+        if (tid == 0) s_fill = 0;      // (a bin with more than kListCap keys: the remaining digit passes, then the general compaction)
+        for (; pass < 8 && !s_done; ++pass) digit_pass(pass);
+      }
     }
     thresh = s_prefix;        // exactly K keys are >= thresh (keys are unique)
   }
   __syncthreads();
-  if (ghist && mine != 0) {      // back to zero for the next image of the batch (the forward zeroes the table before the first)
-    uint4* hz = reinterpret_cast<uint4*>(ghist + (65536 - 64 * (tid + 1)));
-#pragma unroll
-    for (int q = 0; q < 16; ++q) hz[q] = make_uint4(0u, 0u, 0u, 0u);
-  }
   BO_STAMP(2);
   int P = 1;
   while (P < K) P <<= 1;
@@ -529,10 +496,9 @@ __global__ __launch_bounds__(256) void nms_scan_bytes_kernel(const u64* __restri
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-constexpr size_t kHistBins = 65536;      // the candidates' top 16 key bits (decode_filter_kernel -> select_sort_kernel)
 
 struct WsLayout {
-  size_t cnt, hist, keys, box, score, sbox, sscore, said, mask, rinit, kidx, kbox, total;
+  size_t cnt, keys, box, score, sbox, sscore, said, mask, rinit, kidx, kbox, total;
   int anchors, wpr, kcap, sortP;
   bool big;
 };
@@ -548,7 +514,6 @@ WsLayout layout_for(int anchors, int max_nms_num) {
   const size_t rows = L.big ? (size_t)L.kcap : (size_t)kMaxK;
   size_t o = 0;
   L.cnt = o; o += align_up(CNT_WORDS * sizeof(int), 256);
-  L.hist = o; o += L.big ? 0 : kHistBins * sizeof(unsigned);      // right behind the counters: one memset zeroes both
   L.keys = o; o += align_up((L.big ? (size_t)L.sortP : (size_t)anchors) * sizeof(u64), 256);
   L.box = o; o += align_up((size_t)anchors * sizeof(float4), 256);
   L.score = o; o += align_up((size_t)anchors * sizeof(float), 256);
@@ -643,14 +608,13 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
   a.do_norm = d->do_bbox_norm;
   for (int k = 0; k < 4; ++k) { a.mean[k] = d->bbox_mean[k]; a.stdv[k] = d->bbox_std[k]; }
 
-  unsigned* ghist = L.big ? nullptr : reinterpret_cast<unsigned*>(ws + L.hist);
-  MSCNN_HIP_TRY(hipMemsetAsync(cnt, 0, L.big ? CNT_WORDS * sizeof(int) : (L.hist - L.cnt) + kHistBins * sizeof(unsigned), st));
+  MSCNN_HIP_TRY(hipMemsetAsync(cnt, 0, CNT_WORDS * sizeof(int), st));
   const int kcap = L.kcap;
   const int kblocks = cdiv(kcap < kMaxK ? kcap : kMaxK, 64);
   for (int img = 0; img < d->num; ++img) {
     a.image = img;
     if (L.big) MSCNN_HIP_TRY(hipMemsetAsync(keys, 0, (size_t)L.sortP * sizeof(u64), st));     // zero keys = padding, sorts last
-    decode_filter_kernel<<<cdiv(anchors, 256), 256, 0, st>>>(a, keys, box, score, cnt, ghist);
+    decode_filter_kernel<<<cdiv(anchors, 256), 256, 0, st>>>(a, keys, box, score, cnt);
     MSCNN_POST_LAUNCH();
     if (L.big) {
       // every candidate sorted in HBM, the first K = min(n, max_nms_num) gathered, tiled greedy NMS, rows from the kept list
@@ -670,7 +634,7 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
       MSCNN_POST_LAUNCH();
       continue;
     }
-    select_sort_kernel<<<1, kSortThreads, 0, st>>>(keys, box, score, sbox, sscore, said, cnt, d->max_nms_num, ghist);
+    select_sort_kernel<<<1, kSortThreads, 0, st>>>(keys, box, score, sbox, sscore, said, cnt, d->max_nms_num);
     MSCNN_POST_LAUNCH();
     nms_mask_kernel<<<dim3(kblocks, kblocks), 256, 0, st>>>(sbox, cnt + CNT_K, 0, d->iou_thr, d->nms_mode, mask, L.wpr);
     MSCNN_POST_LAUNCH();
