@@ -170,10 +170,10 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
     // upper 32 bits that is normally after 3-4 passes: the anchor-id passes only separate equal scores).
     if (tid == 0) { s_prefix = 0; s_need = K; s_done = 0; }
     __syncthreads();
-    // One digit of the select.  The first two digits (the score's sign, exponent and 7 mantissa bits) are nearly the same for
-    // thousands of candidates: their LDS histogram used to be 27 k atomics onto a handful of addresses (most of the kernel's 27 us
-    // of select on the bench frame), so for those two the lanes of a wave that share a bucket are counted with ballots and ONE
-    // lane adds the count (up to 6 distinct buckets per wave and key slot, the rest fall back to their own atomic).
+    // One digit of the select (LDS histogram of the keys that share the prefix found so far + the bucket walk).  A pass costs
+    // 3 - 6 us whatever the histogram holds (barriers, a 32-key loop per thread, same-address LDS atomics on the first digits), so
+    // only the first two are run; see below.  (Tried and measured slower: counting those two digits chip-wide in
+    // decode_filter_kernel -- 27 k device-scope atomics, + 12 us there; and ballot-aggregating the LDS adds -- 50 us.)
     auto digit_pass = [&](int pass) {
       const int shift = 56 - 8 * pass;
       if (tid < 256) hist[tid] = 0;
@@ -181,25 +181,12 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
       const u64 prefix = s_prefix;
       const u64 himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
       if (inreg) {
-        const int lane = tid & 63;
 #pragma unroll
         for (int j = 0; j < kRegKeys; ++j) {
           const u64 k = rk[j];
           const bool act = tid + j * kSortThreads < n && (k & himask) == prefix;
           const unsigned bucket = (unsigned)(k >> shift) & 255u;
-          if (pass < 2) {
-            u64 todo = __ballot(act);
-            for (int round = 0; todo && round < 6; ++round) {
-              const int first = __ffsll((long long)todo) - 1;
-              const unsigned b0 = (unsigned)__shfl((int)bucket, first, 64);
-              const u64 same = __ballot(act && bucket == b0) & todo;
-              if (lane == first) atomicAdd(&hist[b0], (unsigned)__popcll(same));
-              todo &= ~same;
-            }
-            if ((todo >> lane) & 1ull) atomicAdd(&hist[bucket], 1u);
-          } else if (act) {
-            atomicAdd(&hist[bucket], 1u);
-          }
+          if (act) atomicAdd(&hist[bucket], 1u);
         }
       } else {
         for (int i = tid; i < n; i += kSortThreads) {
