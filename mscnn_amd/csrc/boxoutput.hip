@@ -136,6 +136,8 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
   constexpr int kListCap = 1024;
   __shared__ u64 lst[kListCap];
   __shared__ int s_lfill;
+  __shared__ unsigned hist12[4096];
+  __shared__ int s_wtot[kSortThreads / 64];
   const int tid = threadIdx.x;
   BO_STAMP(0);
   const int n = cnt[CNT_CAND];
@@ -186,7 +188,18 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
           const u64 k = rk[j];
           const bool act = tid + j * kSortThreads < n && (k & himask) == prefix;
           const unsigned bucket = (unsigned)(k >> shift) & 255u;
-          if (act) atomicAdd(&hist[bucket], 1u);
+          if (pass < 2) {      // the skewed digits: a wave whose active lanes all share one bucket adds once (one ballot round)
+            const u64 am = __ballot(act);
+            if (am) {
+              const int first = __ffsll((long long)am) - 1;
+              const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bucket, first);
+              const u64 same = __ballot(act && bucket == b0);
+              if (same == am) { if ((tid & 63) == first) atomicAdd(&hist[b0], (unsigned)__popcll(am)); }
+              else if (act) atomicAdd(&hist[bucket], 1u);
+            }
+          } else if (act) {
+            atomicAdd(&hist[bucket], 1u);
+          }
         }
       } else {
         for (int i = tid; i < n; i += kSortThreads) {
@@ -224,18 +237,67 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
       }
       __syncthreads();
     };
+    // The same with 12-bit digits (4096 buckets, thread t owns buckets 4095 - 4 t .. 4092 - 4 t, workgroup-wide running total):
+    // the first 8-bit digit of these keys -- sign + 7 exponent bits -- has 4 - 6 populated buckets, i.e. ~20 lanes of every wave
+    // on one LDS address (20 us for 27 k keys, tools/bo_trace.py); 12 bits spread the same keys over ~40.
+    auto digit_pass12 = [&](int p12) {
+      const int shift = 52 - 12 * p12;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hist12[tid + q * kSortThreads] = 0;
+      __syncthreads();
+      const u64 prefix = s_prefix;
+      const u64 himask = p12 == 0 ? 0ull : (~0ull << (shift + 12));
+#pragma unroll
+      for (int j = 0; j < kRegKeys; ++j) {
+        const u64 k = rk[j];
+        if (tid + j * kSortThreads < n && (k & himask) == prefix) atomicAdd(&hist12[(unsigned)(k >> shift) & 4095u], 1u);
+      }
+      __syncthreads();
+      unsigned c[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = hist12[4095 - (4 * tid + j)];
+      const int mine = (int)(c[0] + c[1] + c[2] + c[3]);
+      int incl = mine;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d) incl += v;
+      }
+      if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+      __syncthreads();
+      for (int w = 0; w < (tid >> 6); ++w) incl += s_wtot[w];
+      const int need = s_need;
+      __syncthreads();                                       // (everybody has read s_need before the one writer below)
+      if (incl >= need && incl - mine < need) {              // exactly one thread: the buckets hold at least `need` keys
+        int rem = need - (incl - mine);
+        int j = 0;
+        for (; j < 3; ++j) {
+          if ((int)c[j] >= rem) break;
+          rem -= (int)c[j];
+        }
+        const int b = 4095 - (4 * tid + j);
+        s_need = rem;
+        s_prefix = prefix | ((u64)b << shift);
+        if ((int)c[j] == rem) s_done = 1;
+      }
+      __syncthreads();
+    };
     int pass = 0;
-    for (; pass < (inreg ? 2 : 8) && !s_done; ++pass) digit_pass(pass);
+    if (inreg) {
+      for (int p12 = 0; p12 < 2 && !s_done; ++p12) { digit_pass12(p12); BO_STAMP(11 + p12); }
+      pass = 3;                                              // 24 bits are fixed: an 8-bit pass would continue at shift 32
+    } else {
+      for (; pass < 8 && !s_done; ++pass) digit_pass(pass);
+    }
     if (inreg && !s_done) {
-      // After two digits: one sweep over the register keys -- keys whose top 16 bits lie above the threshold's go straight to the
+      // After two 12-bit digits: one sweep over the register keys -- keys whose top 24 bits lie above the threshold's go straight to the
       // sort buffer, the threshold bin's own keys (a few dozen) to a list, where the `need` largest are found by rank (keys are
       // unique) -- instead of more digit passes, each ~3 us of barriers and a 32-key loop per thread whatever the histogram holds.
-      const unsigned bstar = (unsigned)(s_prefix >> 48);
+      const unsigned bstar = (unsigned)(s_prefix >> 40);
 #pragma unroll
       for (int j = 0; j < kRegKeys; ++j) {
         const u64 k = rk[j];
         const bool valid = tid + j * kSortThreads < n;
-        const unsigned t16 = (unsigned)(k >> 48);
+        const unsigned t16 = (unsigned)(k >> 40);
         if (valid && t16 > bstar) {                     // (one LDS atomic per wave and key slot, not per key)
           const u64 takers = __ballot(1);
           const int leader = __ffsll((long long)takers) - 1, lane = tid & 63;
@@ -250,6 +312,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
         }
       }
       __syncthreads();
+      BO_STAMP(20);
       const int Ln = s_lfill, need = s_need;
       if (Ln <= kListCap) {
         for (int t = tid; t < Ln; t += kSortThreads) {
@@ -261,6 +324,10 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(const u64* __
             if (pos < kMaxK) sk[pos] = my;
           }
         }
+        BO_STAMP(21);
+#ifdef MSCNN_BO_TRACE
+        if (tid == 0 && g_bo_trace) g_bo_trace[29] = (unsigned long long)Ln;
+#endif
         filled = true;
       } else {
         __syncthreads();

@@ -41,6 +41,9 @@ us = lambda a_, b_: (int(t[b_]) - int(t[a_])) / 100.0      # noqa: E731
 print(f"{a.model} {a.regime}: candidates n = {t[30]}, K = {t[31]}, rows out = {nreal} (net: {n.blob_shape('proposals')[0]})")
 print(f"select_sort_kernel: read n + key loads {us(0, 1):.1f} us, radix select {us(1, 2):.1f}, compaction + pad {us(2, 3):.1f}, "
       f"bitonic network {us(3, 4):.1f}, gather {us(4, 5):.1f}; total {us(0, 5):.1f}")
+if t[11]:
+    print(f"  select detail: digit pass 0 {us(1, 11):.1f} us, pass 1 {us(11, 12) if t[12] else 0:.1f}, sweep {us(12 if t[12] else 11, 20) if t[20] else 0:.1f}, "
+          f"list rank ({t[29]} keys) {us(20, 21) if t[21] else 0:.1f}")
 ch = t[64:128]
 ch = ch[ch != 0]
 dt = np.diff(ch) / 100.0
