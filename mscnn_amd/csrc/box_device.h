@@ -70,6 +70,7 @@ __device__ __forceinline__ u64 readlane64(u64 v, int lane) {
 //   * diagonal pass, all scalar: the next surviving box is s_ff1 of the live word; its diagonal mask word comes from a
 //     v_readlane with a scalar lane index -- one iteration per KEPT box, not per box;
 //   * the kept rows' words (w >= c) are OR-ed into the removed-bitmap from LDS, four independent reads at a time.
+// (r3: the OR is shared by all four waves, see the function body.)
 // Waves 1-3 stream the NEXT chunk's 64 mask rows (words c+1.. only) from L2 into the other half of a double buffer in LDS
 // meanwhile: lane = word, one row per load instruction (coalesced), all of a thread's rows in flight at once.
 // W = words per row actually used (<= 64).  `buf` = dynamic LDS of 2 * 64 * W u64.  Result: lane c of wave 0 returns the
@@ -107,13 +108,23 @@ __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, 
       if (r < 64) dst[r * W + lane] = v[j];
     }
   };
+  // The removed-bitmap lives in LDS (word w = boxes [64 w, 64 w + 64)).  Per chunk: wave 0 runs the scalar diagonal pass while
+  // waves 1-3 move rows; barrier; then ALL FOUR waves OR the chunk's kept rows into the bitmap, 16 candidate rows each (LDS
+  // atomic OR, lane = word), barrier.  (Rounds 1-2 and most of round 3: wave 0 did that OR alone, a chain of ~20 kept rows four
+  // at a time = 0.8 of the 1.8 us a chunk took -- tools/bo_trace.py.)
+  __shared__ u64 s_removed[64];
+  __shared__ u64 s_keepw;
+  auto uniform64 = [](u64 x) -> u64 {      // (readfirstlane returns int: cast back to unsigned before widening)
+    return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32)) << 32) |
+           (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+  };
+  if (tid < 64) s_removed[tid] = (removed_init != nullptr && tid < W) ? removed_init[tid] : 0ull;
   u64 v[kBatch];
   load_rows(0, wave, 4, v);                              // chunk 0: all four waves, 16 rows each
   store_rows(0, wave, 4, v);
   if (wave != 0 && nchunks > 1) load_rows(1, wave - 1, 3, v);      // in flight across the barrier
   __syncthreads();
-  u64 removed = 0, mykeep = 0;
-  if (removed_init != nullptr && wave == 0 && lane < W) removed = removed_init[lane];
+  u64 mykeep = 0;
   for (int c = 0; c < nchunks; ++c) {
 #ifdef MSCNN_BO_TRACE
     if (tid == 0 && g_bo_trace && c < 64) g_bo_trace[64 + c] = __builtin_amdgcn_s_memrealtime();
@@ -127,7 +138,7 @@ __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, 
     } else {
       const int valid = min(64, n - c * 64);
       const u64 dg = cur_rows[min(lane, 63) * W + c];    // diagonal word of row (c*64 + lane): bits j > lane it suppresses
-      u64 live = ~readlane64(removed, c);
+      u64 live = ~uniform64(s_removed[c]);
       if (valid < 64) live &= (1ull << valid) - 1ull;
       u64 keep = 0;
       while (live) {                                     // wave-uniform: scalar loop over the KEPT boxes of the chunk
@@ -137,18 +148,23 @@ __device__ __forceinline__ u64 greedy_scan(const u64* __restrict__ mask, int n, 
         live &= ~((2ull << i) - 1ull);                   // boxes up to and including i are decided
       }
       if (lane == c) mykeep = keep;
-      if (lane < W) {
-        u64 kk = keep, acc = 0;
-        while (kk) {                                     // uniform loop over kept rows, four LDS reads in flight
+      if (lane == 0) s_keepw = keep;
+    }
+    __syncthreads();
+    if (c + 1 < nchunks) {                               // (after the last chunk nobody reads the bitmap)
+      u64 kk = (uniform64(s_keepw) >> (16 * wave)) & 0xffffull;
+      if (lane < W && lane > c && kk) {                  // words <= c are never read again
+        const u64* rows = cur_rows + (size_t)(16 * wave) * W + lane;
+        u64 acc = 0;
+        while (kk) {                                     // uniform loop over this wave's kept rows, four LDS reads in flight
           const int i0 = __ffsll((long long)kk) - 1; kk &= kk - 1;
           const int i1 = kk ? __ffsll((long long)kk) - 1 : i0; kk &= kk - 1;     // (kk & (kk - 1) of 0 is 0)
           const int i2 = kk ? __ffsll((long long)kk) - 1 : i0; kk &= kk - 1;
           const int i3 = kk ? __ffsll((long long)kk) - 1 : i0; kk &= kk - 1;
-          const u64 r0 = cur_rows[i0 * W + lane], r1 = cur_rows[i1 * W + lane];
-          const u64 r2 = cur_rows[i2 * W + lane], r3 = cur_rows[i3 * W + lane];
+          const u64 r0 = rows[i0 * W], r1 = rows[i1 * W], r2 = rows[i2 * W], r3 = rows[i3 * W];
           acc |= (r0 | r1) | (r2 | r3);
         }
-        removed |= acc;
+        if (acc) atomicOr(reinterpret_cast<unsigned long long*>(&s_removed[lane]), acc);
       }
     }
     __syncthreads();
