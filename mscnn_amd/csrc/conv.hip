@@ -1294,7 +1294,9 @@ static void plan_shape(mscnn_conv_plan* p) {
     const long tops[3] = {k.variant == 106 ? 1024 : 0, (k.KH == 1 && k.BN == 128 && k.CK < 64) ? 768 : 0, G};
     bool found = false;
     for (int c = 0; c < 3 && !found; ++c)
-      for (long g2 = tops[c]; g2 > 0 && g2 >= tops[c] - tops[c] / 16 && g2 * 2 <= tiles; --g2)
+      // (how many idle slots an exact divisor may cost: 1/16 for the short 1x1 GEMMs, whose fix-up launch is 18 us of a ~200 us
+      // layer; 1/50 for the 3x3 kernels -- conv1_2's 4320 tiles: G = 480 measured 698 us, G = 512 + stream-K remainder 680)
+      for (long g2 = tops[c]; g2 > 0 && g2 >= tops[c] - tops[c] / (k.KH == 3 ? 50 : 16) && g2 * 2 <= tiles; --g2)
         if (tiles % g2 == 0) { G = g2; found = true; break; }
   }
   // the 25-plane GEMMs of the small layers (conv5_x of 7s-576: 400 tiles on 768 slots): one whole tile per workgroup beats
