@@ -13,6 +13,7 @@ struct WgemmPlan {
   int G;                            // persistent grid (workgroups)
   int full_q;                       // whole tiles per workgroup; the remaining tiles are split stream-K style
   int variant;
+  double model_us;                  // the plan's own time estimate (picks between tile shapes)
   const char* name;
   size_t packed_bytes;              // U in the packed layout Up[p][mt][kc][ck][BM]
   size_t ws_bytes;                  // partial-tile slabs of the stream-K phase

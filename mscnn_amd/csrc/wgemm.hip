@@ -60,13 +60,18 @@ struct WCfg {
   static constexpr int A_BYTES = CK * BM * 4, B_BYTES = CK * BN * 4, STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int STAGE_FLOATS = STAGE_BYTES / 4;
   static constexpr int PA = A_BYTES / 1024, PB = B_BYTES / 1024;      // 1 KB LDS-DMA pieces per chunk
-  static constexpr int PA_W = PA / NW, PB_W = PB / NW;                // ... per wave
+  static constexpr int PA_W = PA / NW, PB_W = (PB + NW - 1) / NW;     // ... per wave
   static constexpr int NP = PA_W + PB_W;
   static constexpr int F4_PER_ROW = BN / 4;                           // 16-byte units per B row
-  static constexpr int ROWS_PER_PIECE = 64 / F4_PER_ROW;              // BN 128: 2 rows, BN 256: 1 row
+  // B pieces: when a 1 KB piece is a whole number of B rows and the pieces divide evenly over the waves (BN 128 / 256), every lane's
+  // source offset is the same for all pieces; otherwise (BN 96: 24 units per row, 12 pieces on 8 waves) each piece has its own lane
+  // offsets, and the waves without a piece in the last slot issue an out-of-range piece into a spare KB behind the ring
+  static constexpr bool B_EVEN = (64 % F4_PER_ROW == 0) && (PB % NW == 0);
+  static constexpr int ROWS_PER_PIECE = B_EVEN ? 64 / F4_PER_ROW : 0; // BN 128: 2 rows, BN 256: 1 row
+  static constexpr int LDS_FLOATS = ST * STAGE_FLOATS + (B_EVEN ? 0 : 256);
   static constexpr int STEPS = CK / 2;                                // MFMA k-pairs per chunk
-  static_assert(PA % NW == 0 && PB % NW == 0 && 64 % F4_PER_ROW == 0, "pieces per wave");
-  static_assert(ST * STAGE_BYTES <= 160 * 1024, "LDS ring");
+  static_assert(PA % NW == 0 && B_BYTES % 1024 == 0, "pieces per wave");
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS ring");
   static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile");
 };
 
@@ -145,7 +150,7 @@ struct SegCursor {
 
 template <class C, int ABL>
 __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs a) {
-  __shared__ __attribute__((aligned(1024))) float lds[C::ST * C::STAGE_FLOATS];
+  __shared__ __attribute__((aligned(1024))) float lds[C::LDS_FLOATS];
   static_assert(C::ST == 3, "the ring protocol below is written for three stages");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -168,6 +173,12 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   const unsigned row_bytes = (unsigned)a.T_pad * 4u;
   const unsigned vA = (unsigned)lane * 16u;
   const unsigned vB = (unsigned)(lane / C::F4_PER_ROW) * row_bytes + (unsigned)(lane % C::F4_PER_ROW) * 16u;
+  unsigned vBj[C::PB_W];                 // (uneven B pieces only) lane offsets of this wave's pieces: 16-byte unit j * 64 + lane of the stage
+#pragma unroll
+  for (int i = 0; i < C::PB_W; ++i) {
+    const int u = (wave * C::PB_W + i) * 64 + lane;
+    vBj[i] = wave * C::PB_W + i < C::PB ? (unsigned)(u / C::F4_PER_ROW) * row_bytes + (unsigned)(u % C::F4_PER_ROW) * 16u : 0x80000000u;
+  }
   const unsigned lds0 = (unsigned)(size_t)lds;
   // per-lane LDS read bases inside a stage (bytes)
   const unsigned a_lane = (unsigned)(khalf * C::BM + wm * C::WM + l31) * 4u;
@@ -178,7 +189,11 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   unsigned p_a = 0, p_b = 0;            // byte offsets of the unit's A slab / first B row
   unsigned vA_eff = vA, vB_eff = vB;
   auto p_begin = [&]() {                // called before piece 0 of a unit
-    if (pu >= nunits) { vA_eff = 0x80000000u; vB_eff = 0x80000000u; }
+    if (pu >= nunits) {
+      vA_eff = 0x80000000u; vB_eff = 0x80000000u;
+#pragma unroll
+      for (int i = 0; i < C::PB_W; ++i) vBj[i] = 0x80000000u;
+    }
     if (p_kc == p_k1 && pu < nunits) {  // next segment
       int t, part;
       pcur.next(t, p_kc, p_k1, part);
@@ -197,10 +212,14 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     if constexpr (i < C::PA_W) {
       const unsigned sa = p_a + (unsigned)p_kc * C::A_BYTES + (unsigned)(wave * C::PA_W + i) * 1024u;
       dma16(rA, vA_eff, sa, ls + (unsigned)(wave * C::PA_W + i) * 1024u);
-    } else {
+    } else if constexpr (C::B_EVEN) {
       const int j = wave * C::PB_W + (i - C::PA_W);
       const unsigned sb = p_b + (unsigned)(p_kc * C::CK + j * C::ROWS_PER_PIECE) * row_bytes;
       dma16(rB, vB_eff, sb, ls + C::A_BYTES + (unsigned)j * 1024u);
+    } else {
+      const int j = wave * C::PB_W + (i - C::PA_W);
+      const unsigned sb = p_b + (unsigned)(p_kc * C::CK) * row_bytes;
+      dma16(rB, vBj[i - C::PA_W], sb, j < C::PB ? ls + C::A_BYTES + (unsigned)j * 1024u : lds0 + (unsigned)(C::ST * C::STAGE_BYTES));
     }
   };
   auto p_end = [&]() {
@@ -416,6 +435,7 @@ const WEntry kW[] = {
     WG_ENTRY("wgemm_256x128_ck32", 1, 0, 256, 128, 4, 2, 32),
     WG_ENTRY("wgemm_128x256_ck32", 2, 0, 128, 256, 2, 4, 32),
     WG_ENTRY("wgemm_128x128_ck32", 3, 0, 128, 128, 2, 4, 32),
+    WG_ENTRY("wgemm_256x96_ck32", 4, 0, 256, 96, 8, 1, 32),       // conv5_x: 480 tile columns = 5 x 96, 250 tiles in one full round
 #ifdef MSCNN_WGEMM_DEV      // schedule A/B (pieces per group, first store group)
     WG_ENTRY_S("wgemm_256x128_ck32_d2", 5, 256, 128, 4, 2, 32, 2, 0),
     WG_ENTRY_S("wgemm_256x128_ck32_d2_s3", 6, 256, 128, 4, 2, 32, 2, 3),
@@ -443,14 +463,21 @@ namespace mscnn {
 bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   const int variant_flags = variant >> 8;
   variant &= 255;
-  if (variant == 0) variant = Cout >= 256 ? 1 : 2;
+  if (variant == 0) {
+    variant = Cout >= 256 ? 1 : 2;
+    // 256 x 96 tiles where the model below says their tile count fits the 256 CUs better than 256 x 128 (conv5_x of the 7s-576 net:
+    // 480 columns = 250 tiles in one full round instead of 200 tiles of 512 padded columns; measured 72 -> see DESIGN.md)
+    if (variant == 1 && !variant_flags) {
+      WgemmPlan p1, p4;
+      if (wgemm_plan(P, Cout, Cin, T, 1, &p1) && wgemm_plan(P, Cout, Cin, T, 4, &p4) && p4.model_us < 0.95 * p1.model_us) variant = 4;
+    }
+  }
   const WEntry* e = nullptr;
   for (const WEntry& w : kW) if (w.variant == variant && w.abl == 0) e = &w;
   if (!e || Cin % e->CK != 0 || Cout % 32 != 0) return false;
   o->P = P; o->Cout = Cout; o->Cin = Cin; o->T = T;
   o->BM = e->BM; o->BN = e->BN; o->CK = e->CK;
   o->T_pad = (T + e->BN - 1) / e->BN * e->BN;
-  if (o->T_pad % 128) o->T_pad = (o->T_pad + 127) / 128 * 128;
   o->MT = (Cout + e->BM - 1) / e->BM; o->NT = o->T_pad / e->BN; o->KI = Cin / e->CK;
   o->G = 256;                   // one 512-thread workgroup per CU
   const long tiles = (long)P * o->MT * o->NT;
@@ -465,6 +492,7 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   const double split = (double)tiles * o->KI / o->G * chunk_us + (double)tiles / o->G * 6.0 + 18.0;
   o->full_q = (int)(tiles / o->G);
   if (rem > 0 && !(split < 0.97 * whole)) o->full_q += 1;       // whole tiles: the last round is simply not full
+  o->model_us = rem > 0 ? (split < 0.97 * whole ? split : whole) : whole;
   if (variant_flags & 1) o->full_q = (int)(tiles / o->G);       // development: force the split
   if (variant_flags & 2) o->full_q = (int)((tiles + o->G - 1) / o->G);   // ... or whole tiles
   o->variant = variant; o->name = e->name;

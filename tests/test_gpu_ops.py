@@ -394,6 +394,16 @@ def test_wgemm_plane_gemm_against_the_igemm_kernel(hip, case):
         assert torch.equal(p.forward(x, b), y_split)
     y_auto, _ = run(0, 0)
     assert torch.equal(y_auto, y_whole) or ((y_auto - y_whole).abs() / torch.clamp(y_whole.abs(), min=1.0)).max().item() < tol
+    # the 256 x 96 tile (variant 4: 12 LDS-DMA pieces of B on 8 waves, pieces that straddle rows): whole tiles are the same fmaf chains
+    y_96, p96 = run(300 + 4 + 512, 0)
+    assert p96.kernel.startswith(f"winograd_f{m}x{m}")
+    if Cin >= 128:
+        assert torch.equal(y_96, y_ig)
+    else:
+        assert rel(y_96, y_ig) < tol
+    y_96s, p96s = run(300 + 4 + 256, 0)
+    assert rel(y_96s, y_whole) < tol
+    assert torch.equal(p96s.forward(x, b), y_96s)
 
 
 @pytest.mark.parametrize("case", [(1, 32, 24, 64, 48), (2, 16, 36, 260, 32), (1, 64, 72, 240, 64), (1, 8, 10, 512, 16), (1, 24, 13, 28, 40)])

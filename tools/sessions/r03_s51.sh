@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/s51; mkdir -p $O; export PYTHONUNBUFFERED=1
+( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 ) > $O/gpu_all.txt 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
