@@ -497,7 +497,7 @@ def main():
                       ("x3_gemm_kernel<128|256> -- the 25 plane GEMMs of the Winograd F(3x3,3x3) layers on v_mfma_f32_32x32x16_f16 with "
                        "every fp32 operand split exactly into fp16 hi + lo: three MFMAs per product pair (all three counted as "
                        "executed FLOPs), fp32 accumulate") if args.dtype == "f16x3" else
-                      "wgemm_kernel<256x128 | 128x256, ck32> (mscnn_amd/csrc/wgemm.hip) -- the batched [Cout x Cin] x [Cin x tiles] GEMMs of the "
+                      "wgemm_kernel<256x128 | 128x256 | 256x96, ck32> (mscnn_amd/csrc/wgemm.hip) -- the batched [Cout x Cin] x [Cin x tiles] GEMMs of the "
                       "Winograd layers (25 planes F(3x3,3x3), 36 planes F(4x4,3x3)) on v_mfma_f32_32x32x2_f32: 8 waves per CU, operands by "
                       "LDS-DMA into a 3-stage ring (+ its fix-up launch where the tile count is split stream-K style)",
             "flops_note": "achieved = FLOPs the kernel's MFMAs execute for the real problem (2 * planes * Cout * Cin * tiles per launch) / "
