@@ -215,3 +215,12 @@ def test_f4_plan_plumbing_without_a_device():
     assert auto(512, 36, 120, 512) == "winograd_f3x3_3x3" and auto(512, 18, 60, 512) == "winograd_f3x3_3x3"          # conv5_x, conv6_1
     assert auto(64, 576, 1920, 64).startswith("igemm_")                                                              # conv1_2 stays direct
     assert auto(512, 72, 240, 512, tune_flags=64) == "winograd_f3x3_3x3"                                             # A/B knob: the round-2 choice
+    # conv1_1 (Cin = 3) has its own VALU kernel; tune_flags bit 11 keeps the MFMA igemm kernel
+    assert auto(3, 576, 1920, 64) == "conv3x3_c3_valu_f32" and auto(3, 576, 1920, 64, tune_flags=2048).startswith("igemm_")
+    assert auto(3, 20, 32, 16).startswith("igemm_")                                                                  # small maps stay on the igemm kernel
+    # the plane GEMM's tile shape is part of the packed-weight layout word: bits 8.. = 200 + wgemm variant.  conv5_x (480 tile
+    # columns = 5 x 96) takes the 256 x 96 tile, conv4_2 (1080 columns) and conv6_1 (120) the 256 x 128 one, Cout = 128 layers 128 x 256
+    L.mscnn_conv2d_plan_weight_layout.restype = __import__("ctypes").c_ulonglong
+    variant = lambda cin, h, w, cout: ((L.mscnn_conv2d_plan_weight_layout(hip.ConvPlan(1, cin, h, w, cout, 3, 3, (1, 1), device="cpu")._p) >> 8) & 0xffff) - 200      # noqa: E731
+    assert variant(512, 36, 120, 512) == 4 and variant(512, 72, 240, 512) == 1 and variant(512, 18, 60, 512) == 1
+    assert variant(128, 288, 960, 128) == 2 and variant(512, 48, 160, 512) == 4                                      # (8s-768's conv5: 864 columns = 9 x 96)
