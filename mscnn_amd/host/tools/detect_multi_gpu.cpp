@@ -111,16 +111,8 @@ void worker(int rank, int world, const Options& opt, const unsigned char* id, st
   const int steps = (opt.images + world - 1) / world;
   double t0 = 0;
   int sum = 0;
-  for (int s = -1; s < steps; ++s) {                       // s = -1: warm-up step on image `rank` (also the consistency check)
-    const int k = s < 0 ? 0 : s * world + rank;            // warm-up: every replica runs image 0
-    if (s == 0) { DIST_CHECK(mscnn_dist_barrier(comm, nullptr)); t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    make_frame(k, H, W, &frame);
-    NET_CHECK(mscnn_net_set_blob(net, "data", frame.data(), frame.size()));
-    NET_CHECK(mscnn_net_forward(net));
-    const void* pack = nullptr;
-    NET_CHECK(mscnn_net_detect_device(net, &p, opt.cap, &pack));
-    const void* gathered = nullptr;
-    DIST_CHECK(mscnn_dist_all_gather(comm, pack, nullptr, &gathered));
+  // the gathered packs of step s: replicas' consistency (warm-up) or rank 0's report
+  auto consume = [&](int s, const void* gathered) {
     const char* g = static_cast<const char*>(gathered);
     for (int r = 0; r < world; ++r) {
       int D = 0, R = 0;
@@ -137,6 +129,33 @@ void worker(int rank, int world, const Options& opt, const unsigned char* id, st
         if (D) printf("   best [%.1f %.1f %.1f %.1f] p=%.4f\n", dets[0], dets[1], dets[2], dets[3], dets[4]);
       }
     }
+  };
+  for (int s = -1; s < steps; ++s) {                       // s = -1: warm-up step on image `rank` (also the consistency check)
+    const int k = s < 0 ? 0 : s * world + rank;            // warm-up: every replica runs image 0
+    if (s == 0) { DIST_CHECK(mscnn_dist_barrier(comm, nullptr)); t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    make_frame(k, H, W, &frame);
+    NET_CHECK(mscnn_net_set_blob(net, "data", frame.data(), frame.size()));
+    NET_CHECK(mscnn_net_forward(net));
+    const void* pack = nullptr;
+    NET_CHECK(mscnn_net_detect_device(net, &p, opt.cap, &pack));
+    const void* gathered = nullptr;
+    if (s < 0) {                                           // warm-up: one blocking exchange
+      DIST_CHECK(mscnn_dist_all_gather(comm, pack, nullptr, &gathered));
+      consume(s, gathered);
+      continue;
+    }
+    // pipelined: this step's collective + D2H copy run on the communicator's own stream under the next image's trunk; the host
+    // takes step s - 1's packs here (two exchanges in flight at most)
+    DIST_CHECK(mscnn_dist_all_gather_begin(comm, pack, nullptr));
+    if (s >= 1) {
+      DIST_CHECK(mscnn_dist_all_gather_end(comm, &gathered));
+      consume(s - 1, gathered);
+    }
+  }
+  if (steps >= 1) {
+    const void* gathered = nullptr;
+    DIST_CHECK(mscnn_dist_all_gather_end(comm, &gathered));
+    consume(steps - 1, gathered);
   }
   DIST_CHECK(mscnn_dist_barrier(comm, nullptr));
   (*seconds)[rank] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
