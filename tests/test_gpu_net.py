@@ -644,3 +644,18 @@ def test_reference_style_user_code_runs_on_the_gpu(tmp_path):
     exe = build_boundary_binary(tmp_path)
     r = subprocess.run([exe, str(tmp_path / "boundary.prototxt")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("BOUNDARY OK"), (r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_generated_deploys_match_the_fingerprints_of_the_shipped_files():
+    """What the GPU box forwards are the reference's deploy files: every generated net (mscnn_amd/zoo.py), built on the device,
+    hashes to the fingerprint tests/golden/make_deploy_fingerprints.py took from the shipped mscnn_deploy.prototxt of the same
+    name (graph, blob shapes, outputs, every TEST-phase parameter) -- the reference checkout itself is not on this box."""
+    import json
+    from deploy_fingerprint import fingerprint
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deploy_fingerprints.json")))
+    assert sorted(want) == sorted(zoo.MODELS)
+    for model in sorted(zoo.MODELS):
+        n = mnet.Net(prototxt_text=zoo.prototxt(model))
+        assert fingerprint(n) == want[model]["sha256"], model
+        del n
+

@@ -131,6 +131,30 @@ def test_generated_net_equals_reference_file(model):
         assert _semantic_params(gen, i) == _semantic_params(ref, i), name
 
 
+@pytest.mark.parametrize("model", sorted(zoo.MODELS))
+def test_generated_net_matches_the_committed_fingerprint_of_the_shipped_file(model):
+    """The same statement on a box WITHOUT the reference checkout (the GPU box): the canonical description of the generated net
+    (graph, blob shapes, outputs, every TEST-phase parameter; tests/deploy_fingerprint.py) hashes to the value
+    tests/golden/make_deploy_fingerprints.py computed from the reference's own mscnn_deploy.prototxt."""
+    import json
+    from deploy_fingerprint import fingerprint
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deploy_fingerprints.json")))
+    assert model in want, "fixture out of date: run tests/golden/make_deploy_fingerprints.py"
+    gen = Net(prototxt_text=zoo.prototxt(model))
+    assert len(gen.layer_names) == want[model]["layers"]
+    assert fingerprint(gen) == want[model]["sha256"], want[model]["file"]
+
+
+@needs_ref
+def test_committed_deploy_fingerprints_are_those_of_the_reference_files():
+    import json
+    from deploy_fingerprint import fingerprint
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deploy_fingerprints.json")))
+    assert sorted(want) == sorted(zoo.MODELS)
+    for model in sorted(zoo.MODELS):
+        assert fingerprint(Net(os.path.join(REF, zoo.MODELS[model][1]))) == want[model]["sha256"], model
+
+
 @needs_ref
 def test_all_reference_deploys_build():
     """Every shipped deploy file (23: KITTI car / ped-cyc, Caltech, CityPersons, cascade-*, WiderFace ROIAlign) goes through
