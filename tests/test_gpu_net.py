@@ -1,6 +1,8 @@
 """Whole-net parity on the GPU: the C++ Caffe-compatible runtime (libmscnn_caffe.so -> libmscnn_hip.so) against the CPU
 oracle, layer by layer with identical inputs (index-exact / 1e-4) and end to end by matched detections (SURVEY.md 7,
 'Tolerance semantics')."""
+import os
+
 import numpy as np
 import pytest
 
