@@ -1599,7 +1599,7 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
     float* gws = M + planes * d.Cout * p->T_pad;
     MSCNN_STAGE_EVENT(0);
     int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st,
-                                  (d.tune_flags & 256) != 0);
+                                  (d.tune_flags & 256) != 0, (d.tune_flags & 4096) != 0);
     if (rc != MSCNN_OK) return rc;
     MSCNN_STAGE_EVENT(1);
     if (p->use_wg) rc = mscnn::wgemm_launch(p->wg, packed, V, M, gws, st);

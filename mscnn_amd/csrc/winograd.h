@@ -13,7 +13,8 @@ int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, i
 // V[xinu][ci][t] = (B^T d B)[xi][nu],  d = the 4x4 input patch of output tile t = (n, ty, tx) (zero outside the image);
 // t < T real tiles, row stride T_pad (columns T..T_pad are written as zeros).
 int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
-                         int tiles_w, int T_pad, hipStream_t st, bool scalar_f4 = false);
+                         int tiles_w, int T_pad, hipStream_t st, bool scalar_f4 = false, bool one_tile_per_lane = false);
+// one_tile_per_lane: F(4x4,3x3) only -- the one-tile-per-lane vector kernel instead of the two-tile one (tune_flags bit 12, A/B runs)
 // scalar_f4: F(4x4,3x3) only -- run the scalar kernels (the bodies of wino_f4_math.h, checked on the host) instead of the vectorised
 // ones; mscnn_conv_desc::tune_flags bit 8, used by the bit-identity test and for A/B runs
 

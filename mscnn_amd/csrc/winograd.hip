@@ -626,6 +626,62 @@ __global__ __launch_bounds__(256) void wino44_input_vec_kernel(const float* __re
   }
 }
 
+// Two horizontally adjacent tiles per lane (tiles_w even): a lane loads 32 contiguous bytes per patch row, the halo between its two
+// tiles is its own data, and every plane store is a float2 -- a wave writes 512-byte runs of V instead of 256 (the input transform
+// sat at 4.6 TB/s against the output transform's 6.1, which reads M in the same 256-byte pattern but writes whole image rows).
+// Same bt6 chains per tile => bit-identical planes.
+__global__ __launch_bounds__(256) void wino44_input_vec2_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int Cin, int H, int W,
+                                                                int pad_h, int tiles_h, int tiles_w, int segs, int T_pad) {
+  const int lane = threadIdx.x & 63;
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);            // wave -> (n, ty, segment of 128 tiles of the tile row)
+  const int ci = blockIdx.y;
+  const int seg = wv % segs, row = wv / segs;                    // row = n * tiles_h + ty
+  if (row >= N * tiles_h) return;
+  const int ty = row % tiles_h, n = row / tiles_h;
+  const int tx = (seg * 64 + lane) * 2;                          // this lane's tiles: tx, tx + 1
+  const bool live = tx < tiles_w;
+  const float* src = x + ((long)n * Cin + ci) * H * W;
+  float da[6][6], db[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int h = 4 * ty - pad_h + i;
+    const bool ok = live && h >= 0 && h < H;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (ok) {
+      const float4* p = reinterpret_cast<const float4*>(src + (long)h * W + 4 * tx);
+      a = p[0]; b = p[1];
+    }
+    float left = __shfl_up(b.w, 1), right = __shfl_down(a.x, 1);
+    // wave borders: the neighbour tile lives in another wave (or outside the image: zero padding)
+    if (lane == 0) left = (ok && tx > 0) ? src[(long)h * W + 4 * tx - 1] : 0.f;
+    if (lane == 63 || tx + 2 >= tiles_w) right = (ok && tx + 2 < tiles_w) ? src[(long)h * W + 4 * tx + 8] : 0.f;
+    da[i][0] = left; da[i][1] = a.x; da[i][2] = a.y; da[i][3] = a.z; da[i][4] = a.w; da[i][5] = b.x;
+    db[i][0] = a.w;  db[i][1] = b.x; db[i][2] = b.y; db[i][3] = b.z; db[i][4] = b.w; db[i][5] = right;
+  }
+  if (!live) return;
+  const long plane_stride = (long)Cin * T_pad;
+  float* dst = V + (long)ci * T_pad + (long)row * tiles_w + tx;
+  float ra[6][6], rb[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float ca[6] = {da[0][j], da[1][j], da[2][j], da[3][j], da[4][j], da[5][j]};
+    const float cb[6] = {db[0][j], db[1][j], db[2][j], db[3][j], db[4][j], db[5][j]};
+    float oa[6], ob[6];
+    wino_f4::bt6(ca, oa);
+    wino_f4::bt6(cb, ob);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { ra[i][j] = oa[i]; rb[i][j] = ob[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float oa[6], ob[6];
+    wino_f4::bt6(ra[i], oa);
+    wino_f4::bt6(rb[i], ob);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<float2*>(dst + (i * 6 + j) * plane_stride) = make_float2(oa[j], ob[j]);
+  }
+}
+
 __global__ __launch_bounds__(256) void wino44_output_vec_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y,
                                                                 float* __restrict__ yp, int N, int Cout, int Ho, int Wo, int tiles_h,
                                                                 int tiles_w, int T, int T_pad, int relu, unsigned* __restrict__ amax) {
@@ -708,12 +764,17 @@ int wino_pack_weights(int m, const float* w, float* packed, int Cout, int Cin, i
 }
 
 int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H, int W, int pad_h, int pad_w, int tiles_h,
-                         int tiles_w, int T_pad, hipStream_t st, bool scalar_f4) {
+                         int tiles_w, int T_pad, hipStream_t st, bool scalar_f4, bool one_tile_per_lane) {
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T_pad, 256), Cin);
   if (m == 4 && pad_w == 1 && W % 4 == 0 && tiles_w * 4 == W && reinterpret_cast<uintptr_t>(x) % 16 == 0 && !scalar_f4) {
-    const int segs = cdiv(tiles_w, 64);
-    wino44_input_vec_kernel<<<dim3(cdiv((long)N * tiles_h * segs, 4), Cin), 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, tiles_h, tiles_w, segs, T_pad);
+    if (tiles_w % 2 == 0 && T_pad % 2 == 0 && reinterpret_cast<uintptr_t>(V) % 8 == 0 && !one_tile_per_lane) {
+      const int segs = cdiv(tiles_w, 128);
+      wino44_input_vec2_kernel<<<dim3(cdiv((long)N * tiles_h * segs, 4), Cin), 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, tiles_h, tiles_w, segs, T_pad);
+    } else {
+      const int segs = cdiv(tiles_w, 64);
+      wino44_input_vec_kernel<<<dim3(cdiv((long)N * tiles_h * segs, 4), Cin), 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, tiles_h, tiles_w, segs, T_pad);
+    }
     // (the GEMM's padding columns T .. T_pad of V are NOT written: every column of M depends on its own column of V only, and the
     // output transform never reads a padding column -- whatever the workspace holds there stays in padding columns)
   } else if (m == 4) {
