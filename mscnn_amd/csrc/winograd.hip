@@ -768,7 +768,10 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T_pad, 256), Cin);
   if (m == 4 && pad_w == 1 && W % 4 == 0 && tiles_w * 4 == W && reinterpret_cast<uintptr_t>(x) % 16 == 0 && !scalar_f4) {
-    if (tiles_w % 2 == 0 && T_pad % 2 == 0 && reinterpret_cast<uintptr_t>(V) % 8 == 0 && !one_tile_per_lane) {
+    // two tiles per lane where that still fills the waves (conv2_x: 240 tiles per row, conv3_x: 120 -- measured in 90 vs 99 us on
+    // conv2_2, 51 vs 52 on conv3_2; conv4_x's 60 tiles would use 30 lanes of 64: 33 vs 29 us, so those keep one tile per lane)
+    const double fill1 = (double)tiles_w / (64.0 * cdiv(tiles_w, 64)), fill2 = 0.5 * tiles_w / (64.0 * cdiv(tiles_w, 128));
+    if (tiles_w % 2 == 0 && T_pad % 2 == 0 && reinterpret_cast<uintptr_t>(V) % 8 == 0 && !one_tile_per_lane && fill2 >= 0.85 * fill1) {
       const int segs = cdiv(tiles_w, 128);
       wino44_input_vec2_kernel<<<dim3(cdiv((long)N * tiles_h * segs, 4), Cin), 256, 0, st>>>(x, V, N, Cin, H, W, pad_h, tiles_h, tiles_w, segs, T_pad);
     } else {
