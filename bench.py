@@ -7,6 +7,8 @@ cls/bbox heads -> final bbox transform + per-class NMS, with the detections deli
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--model M] [--regime dense|mid|sparse]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+A plain `python bench.py --gpus N` with N > 1 (no RANK / WORLD_SIZE in the environment) launches itself under
+torch.distributed.run with N ranks; with fewer than N devices visible it exits non-zero instead of measuring fewer GPUs.
 
 Multi-GPU: independent images per GPU (weak scaling, no data-path collective); per step ONE ncclAllGather of the
 device-resident detection pack of every rank (libmscnn_dist.so calls RCCL directly; mscnn_amd/dist.py).
@@ -219,6 +221,80 @@ class _CudaPtr:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _refuse(msg):
+    print("bench.py: " + msg, file=sys.stderr, flush=True)
+    sys.exit(2)
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    ... bench.py <same arguments>` -- one rank per GPU, rank 0 prints the one JSON line.  Never falls back to fewer GPUs."""
+    if not args.launch_check:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            _refuse(f"--gpus {args.gpus} but only {have} GPU(s) visible to this process: refusing to measure fewer GPUs than asked for")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def _launch_check(args, rank, world, local_rank):
+    """Launcher self-check (tests/test_dist_cpu.py; no GPU, NOT a measurement): the ranks torch.distributed.run started rendezvous over
+    gloo, build the product's exchange (mscnn_amd.dist.RcclGather -> libmscnn_dist.so) on the transport library named by --transport,
+    push K synthetic detection packs through the pipelined all-gather exactly like the timed loop does, and rank 0 prints one JSON
+    line with n_gpus = the ranks the collective really saw and value = null."""
+    import torch.distributed as dist
+    from mscnn_amd import dist as mdist, net as mnet
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.transport:
+        assert mdist.dist_lib().mscnn_dist_use_transport(args.transport.encode()) == 0, mdist.dist_lib().mscnn_dist_last_error().decode()
+
+    def exchange(b):
+        box = [b]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    cap = 16
+    gather = mdist.RcclGather(rank, world, local_rank, cap, exchange)
+    seen, inflight, packs = set(), 0, []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pack = np.zeros(mnet.detect_pack_bytes(cap), np.uint8)
+        pack[:16].view(np.int32)[:] = [1, 1 + rank, cap, 0]
+        pack[16:56].view(np.float64)[:] = [i, rank, 1.0, 1.0, 0.5]
+        packs.append(pack)                                   # (the stub's "device" memory is host memory: keep it alive until end())
+        gather.begin(pack.ctypes.data)
+        inflight += 1
+        if inflight == 2:
+            inflight -= 1
+            seen.add(len(gather.end()))
+    while inflight:
+        inflight -= 1
+        per_rank = gather.end()
+        seen.add(len(per_rank))
+        assert [int(d[0, 1]) for d, _, _ in per_rank] == list(range(world)), "packs out of rank order"
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert seen == {world}, seen
+    gather.close()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "metric": "launcher self-check (no measurement)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "config": {"gather": f"libmscnn_dist: ncclAllGather of the device pack (pipelined, two in flight), "
+                                                                      f"{world} ranks in the communicator", "transport": args.transport or "librccl"}}), flush=True)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,15 +317,26 @@ def main():
                     help="multi-GPU exchange inside the timed loops: pipelined = mscnn_dist_all_gather_begin/_end (the collective and "
                          "the D2H copy of image i on the communicator's own stream under image i + 1's trunk; all K images' packs are on "
                          "the host before the closing barrier), sync = one blocking exchange per image")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher self-check without a GPU (CPU tests): rendezvous + the product's exchange on --transport, no measurement")
+    ap.add_argument("--transport", default="", help="collective library for mscnn_dist_use_transport (an RCCL build elsewhere, or the test stub)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        _refuse(f"--gpus {args.gpus}")
 
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args)                                    # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:      # never a silent fall-back to another GPU count than the one asked for
+        _refuse(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    if args.launch_check:
+        _launch_check(args, rank, world, local_rank)
     # launched by torch.distributed.run (even with one rank): take the multi-GPU path -- process group, direct RCCL gather
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
-    assert torch.cuda.is_available(), "bench.py needs a MI355X"
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        _refuse(f"rank {rank} needs GPU {local_rank}; {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible (bench.py needs MI355X GPUs)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or launched:
@@ -296,7 +383,7 @@ def main():
     pipe = {"on": False, "inflight": 0}
     can_pipeline = hasattr(gather, "begin") and args.gather_mode == "pipelined"
     if gather is not None:
-        gather_kind += " (pipelined, two in flight)" if can_pipeline else " (blocking)"
+        gather_kind += (" (pipelined, two in flight)" if can_pipeline else " (blocking)") + f", {world} ranks in the communicator"
 
     def take(per_rank):
         dets, ids, R = per_rank[rank]

@@ -224,3 +224,45 @@ def test_rccl_gather_overflow_fails_on_every_rank(tmp_path):
         assert "DISTERROR 2 rank 1:" in so and "exceed the detection pack capacity" in so, so
     for rank in range(2):
         assert len(np.load(str(tmp_path / f"seen{rank}.npy"), allow_pickle=True)) == 2
+
+
+# ---- bench.py's own launch path: a plain `python bench.py --gpus N` must measure N GPUs or fail loudly ----------
+def _bench(args, env=None, timeout=300):
+    import subprocess
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_without_enough_devices_fails_loudly():
+    """No launcher in the environment, fewer GPUs visible than asked for (none in this container): non-zero exit and a message naming
+    both counts -- never a silent n_gpus = 1 line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch as _t
+    if _t.cuda.is_available() and _t.cuda.device_count() >= 2:
+        pytest.skip("two real GPUs visible: the refusal path cannot be provoked here")
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], env=env)
+    assert r.returncode != 0 and "--gpus 2 but only" in r.stderr and "refusing" in r.stderr, (r.returncode, r.stderr[-800:])
+    assert "n_gpus" not in r.stdout
+
+
+def test_bench_launched_with_another_world_size_is_refused():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = _bench(["--gpus", "4", "--steps", "2", "--warmup", "1"], env=env)
+    assert r.returncode != 0 and "--gpus 4 but the launcher started WORLD_SIZE=1" in r.stderr, r.stderr[-800:]
+    assert "n_gpus" not in r.stdout
+
+
+def test_bench_gpus_2_launches_itself_with_two_ranks(tmp_path):
+    """`python bench.py --gpus 2 --launch-check` with NO launcher variables: bench.py re-executes itself under torch.distributed.run
+    with two ranks, the ranks rendezvous, the product's RcclGather / libmscnn_dist.so runs its pipelined exchange at world 2 on the
+    transport stub (tests/stub/fake_rccl.c over fake_hip.c), and rank 0 prints ONE JSON line with n_gpus = 2."""
+    import json
+    stubs = _build_stubs(tmp_path)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LD_PRELOAD"] = stubs["fake_hip"]
+    r = _bench(["--gpus", "2", "--steps", "5", "--warmup", "1", "--launch-check", "--transport", stubs["fake_rccl"]], env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["launch_check"] is True and out["value"] is None
+    assert "2 ranks in the communicator" in out["config"]["gather"] and "pipelined" in out["config"]["gather"]

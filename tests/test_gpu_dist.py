@@ -102,3 +102,17 @@ def test_cpp_multi_gpu_host_driver(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith("image")]
     assert len(lines) == 3 and "3 images on 1 GPU(s)" in r.stdout
     assert all(int(l.split("->")[1].split()[0]) > 0 for l in lines), r.stdout      # every frame yields detections
+
+
+def test_bench_plain_gpus_n_refuses_on_a_box_with_fewer_devices():
+    """`python bench.py --gpus N` with no launcher variables launches N ranks by itself; with fewer than N devices visible (this box has
+    one) it must exit non-zero with a message and print no result line -- never n_gpus: 1."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a MI355X")
+    import sys
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and f"--gpus {n} but only {n - 1} GPU(s) visible" in r.stderr, (r.returncode, r.stderr[-1000:])
+    assert "n_gpus" not in r.stdout
