@@ -414,13 +414,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def numerics_since(mark):
+        """What the Net's OWN first-forward checks did since `mark` (no calibration call is made anywhere in this file: every Winograd
+        layer compares itself with the direct kernel on the first frame after a weight / algorithm change and falls back by itself)."""
+        checks, switched, errs = net.auto_calibrate_state()
+        return {"winograd_layers": checks - mark[0], "max_err_vs_direct_kernel": float(f"{max(errs.values(), default=0.0):.3g}"),
+                "tol": CALIBRATION_TOL, "fallback_layers": switched[mark[1]:],
+                "how": "automatic (Net default): first forward after a weight change, tol 5e-5; numerics watch every 100 frames"}
+
+    def numerics_mark():
+        checks, switched, _ = net.auto_calibrate_state()
+        return (checks, len(switched))
+
     numerics = None
-    for i in range(args.warmup):
+    mark = (0, 0)
+    for i in range(max(args.warmup, 1)):
         step(i)
-        if i == 0:      # per-layer numerical calibration on the first frame (untimed): Winograd vs the direct kernel
-            errs, switched = net.calibrate_numerics(CALIBRATION_TOL)
-            numerics = {"winograd_layers": len(errs), "max_err_vs_direct_kernel": float(f"{max(errs.values(), default=0.0):.3g}"),
-                        "tol": CALIBRATION_TOL, "fallback_layers": switched}
+        if i == 0:      # the first frame after the weights were loaded: the layers' own Winograd-vs-direct checks ran inside it (untimed)
+            numerics = numerics_since(mark)
     stats = {"R": [], "D": []}
     sync()
     step_s = []
@@ -446,14 +457,13 @@ def main():
     # headline `value` stays the true-fp32-MFMA path; this is reported beside it as `alt_precision`.
     alt = None
     if args.dtype == "f32" and not args.no_alt:
+        mark = numerics_mark()
         net.set_precision("f16x3")
         a_num = None
         for i in range(max(3, args.warmup // 2)):
             step(i)
-            if i == 0:      # the same per-layer calibration contract as the fp32 path (a layer off the direct sum falls back)
-                errs, sw = net.calibrate_numerics(CALIBRATION_TOL)
-                a_num = {"winograd_layers": len(errs), "max_err_vs_direct_kernel": float(f"{max(errs.values(), default=0.0):.3g}"),
-                         "tol": CALIBRATION_TOL, "fallback_layers": sw}
+            if i == 0:      # the same contract as the fp32 path: the switch re-armed every layer's first-forward check
+                a_num = numerics_since(mark)
         sync()
         a_s = []
         pipe["on"] = can_pipeline
@@ -502,10 +512,12 @@ def main():
             sync()
             return nsteps / (time.perf_counter() - t0)
         he_fallbacks = list((numerics or {}).get("fallback_layers", []))
+        mark = numerics_mark()
         synth.load_into(net, args.regime, style="vgg_like")
         net.set_conv_algo(-1, 0)                              # every convolution back to AUTO (clears calibration marks)
-        step(0)
-        r_errs, r_sw = net.calibrate_numerics(CALIBRATION_TOL)
+        step(0)                                               # first frame on the new weights: the layers check themselves
+        r_num = numerics_since(mark)
+        r_errs, r_sw = {i: 0 for i in range(r_num["winograd_layers"])}, r_num["fallback_layers"]
         v_cal = timed(rs)
         r_rois = float(np.mean(stats["R"][-rs:]))
         wino_layers = [net.layer_names[i] for i in range(len(net.layer_names)) if net.layer_kernel(i).startswith("winograd")]
@@ -515,10 +527,10 @@ def main():
         robust = {"weights": "vgg_like (mscnn_amd/synth.py: centre-weighted taps + a low-pass part, log-normal filter gains, 3 % dead filters, "
                              "biases, conv1_1 scaled for activations of rms ~4 instead of ~1), same frames (BGR - mean, [-123, 151])",
                   "value": round(v_cal, 3), "unit": "images/sec", "steps": rs, "mean_rois": round(r_rois, 1),
-                  "winograd_layers_checked": len(r_errs), "max_err_vs_direct_kernel": float(f"{max(r_errs.values(), default=0.0):.3g}"),
+                  "winograd_layers_checked": len(r_errs), "max_err_vs_direct_kernel": r_num["max_err_vs_direct_kernel"],
                   "tol": CALIBRATION_TOL, "fallback_layers": r_sw,
                   "value_all_direct": round(v_dir, 3), "all_direct_layers": wino_layers + r_sw,
-                  "note": "value = after Net::CalibrateNumerics on this data; value_all_direct = every Winograd layer forced onto the direct "
+                  "note": "value = after the Net's automatic first-forward checks on this data; value_all_direct = every Winograd layer forced onto the direct "
                           "implicit-GEMM kernel (the floor of the fp32 path, whatever the data)"}
         synth.load_into(net, args.regime)                     # back to the headline configuration for the roofline passes
         net.set_conv_algo(-1, 0)
@@ -641,6 +653,9 @@ def main():
                 print("\n# reference CPU path, per layer (caffe time format, tools/caffe.cpp:401-418)", file=sys.stderr)
                 for nm, ty, t in table:
                     print(f"{nm:>28s}\tforward: {t * 1e3:.3f} ms.", file=sys.stderr)
+        wchecks, wsw = net.numerics_watch_state()
+        if numerics is not None:
+            numerics["watch"] = {"period": 100, "checks_so_far": wchecks, "switched": wsw}
         result["parity_ok"] = parity_ok      # null when the reference leg did not run (N > 1 or --no-cpu-baseline)
         if alt:
             alt.setdefault("parity_ok", None)

@@ -61,8 +61,9 @@ MSCNN_DIST_API int mscnn_dist_all_gather(mscnn_dist* d, const void* send_dev, vo
 MSCNN_DIST_API int mscnn_dist_all_gather_device(mscnn_dist* d, const void* send_dev, void* stream, const void** gathered_dev);
 /* The same exchange pipelined: begin() copies the pack (device to device, on `stream`) and enqueues the ncclAllGather + the D2H copy
  * on the communicator's OWN stream behind it, then returns -- the compute stream goes on with the next image while the collective
- * runs; end() waits for the OLDEST exchange in flight and hands out its world * pack_bytes host bytes (valid until two further
- * begin() calls).  At most two exchanges may be in flight; every rank must call begin() / end() in the same order. */
+ * runs; end() waits for the OLDEST exchange in flight and hands out its world * pack_bytes host bytes, valid ONLY UNTIL THE NEXT
+ * begin() (two slots: with one exchange still in flight the next begin() re-uses the slot end() just handed out and overwrites these
+ * bytes asynchronously -- consume or copy them first).  At most two exchanges may be in flight; every rank must call begin() / end() in the same order. */
 MSCNN_DIST_API int mscnn_dist_all_gather_begin(mscnn_dist* d, const void* send_dev, void* stream);
 MSCNN_DIST_API int mscnn_dist_all_gather_end(mscnn_dist* d, const void** gathered_host);
 /* Barrier over the communicator (a 4-byte ncclAllReduce + stream wait): brackets the timed region of the benchmark. */

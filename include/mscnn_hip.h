@@ -56,7 +56,15 @@ MSCNN_API const char* mscnn_version(void);
 typedef struct mscnn_conv_plan mscnn_conv_plan;   /* opaque */
 
 typedef enum {
-  MSCNN_CONV_ALGO_AUTO = 0,     /* Winograd F(3x3,3x3) where the arithmetic-intensity heuristic says it pays, direct otherwise */
+  /* The default.  3x3 / stride 1 / group 1 layers with enough arithmetic intensity run a Winograd form: F(4x4,3x3) (36 planes, points
+   * {0, 1, -1, 2, -1/2, inf}) where the layer has >= 1000 tiles of 4x4 (conv2_1 .. conv4_3, loss1_conv1 of the 7s-576 net), F(3x3,3x3)
+   * (25 planes) below that and on 7x7 ROI maps (conv5_x, conv6_1, roi_c1); the plane GEMMs run on wgemm.hip's kernel.  Cin = 3 runs a
+   * VALU kernel, Cout <= 16 with 5x5 / 7x7 / 3x5 / 5x7 kernels the M = 4 head kernels (or the kw-folded GEMM), everything else the
+   * direct implicit-GEMM kernel.  The Winograd forms carry ~10x the rounding error of the direct sum: callers that go through the
+   * C++ layer (libmscnn_caffe.so) get a per-layer check against DIRECT on the first forward after every weight change, and a
+   * fall-back, without asking (include/mscnn_net.h: mscnn_net_set_auto_calibrate); callers of THIS ABI own that decision and can
+   * make it with mscnn_max_rel_diff_f32 on a DIRECT plan's output. */
+  MSCNN_CONV_ALGO_AUTO = 0,
   MSCNN_CONV_ALGO_DIRECT = 1,   /* never Winograd: the k-ordered implicit-GEMM sum (per-layer numerical fall-back) */
   MSCNN_CONV_ALGO_WINO_F2 = 2,  /* F(2x2,3x3) on whole planes wherever it is legal (small ROI maps: F(3x3,3x3)) */
   MSCNN_CONV_ALGO_WINO_F3 = 3,  /* F(3x3,3x3) wherever it is legal */
@@ -72,8 +80,9 @@ typedef enum {
    * layer (and Cin not a multiple of 32) keeps its fp32 kernel.  mscnn_conv2d_plan_dtype() reports "f16x3". */
   MSCNN_CONV_ALGO_WINO_F3_X3 = 5,
   /* F(4x4,3x3) with the interpolation points {0, 1, -1, 2, -1/2, inf} wherever it is legal (whole planes; ROI maps keep
-   * F(3x3,3x3)): 36 multiplies per 16 outputs, fp32 error of the F(3x3,3x3) form (profiles/r02_study_winograd_f4_numerics.txt).
-   * EXPERIMENTAL: transform arithmetic checked on the host, kernels not yet run on hardware; no default path selects it. */
+   * F(3x3,3x3)): 36 multiplies per 16 outputs, fp32 error 0.8 .. 3.2x (median 1.2x) the F(3x3,3x3) form's over 36 input / filter
+   * distributions (profiles/r03_robustness.txt).  In production since round 3: AUTO selects it for the nine largest 3x3 layers of
+   * the 7s-576 net (A/B per layer: profiles/r03_ab_wino_f4.txt); this value forces it also where AUTO would keep F(3x3,3x3). */
   MSCNN_CONV_ALGO_WINO_F4 = 6
 } mscnn_conv_algo;
 
@@ -102,7 +111,15 @@ MSCNN_API void mscnn_conv2d_plan_destroy(mscnn_conv_plan* plan);
 /* Bytes of device memory the plan needs for packed weights and for split-K partial tiles. */
 MSCNN_API size_t mscnn_conv2d_packed_weight_bytes(const mscnn_conv_plan* plan);
 MSCNN_API size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* plan);
-/* "igemm_mfma_f32" | "direct_f32": which kernel family the plan selected. */
+/* Which kernel family the plan selected (static string):
+ *   "winograd_f4x4_3x3" | "winograd_f3x3_3x3" | "winograd_f2x2_3x3"        input transform -> wgemm plane GEMM -> output transform
+ *   "winograd_f3x3_3x3_x3f16_128" | "..._256"                               the same with split-fp16 plane GEMMs (WINO_F3_X3)
+ *   "igemm_<BM>x<BN>_k3x3_..." | "igemm_<BM>x<BN>_k1x1_..."                 direct implicit GEMM on v_mfma_f32_32x32x2_f32
+ *   "igemm16_..." | "igemm16x3_..."                                          the same on fp16 / split-fp16 operands
+ *   "conv3x3_c3_valu_f32"                                                    Cin = 3 (conv1_1)
+ *   "head4x4_k<Kh>x<Kw>_m<..>" | "head_kwfold_shiftadd_f32" | "head_gemm_shiftadd_f32" | "head_gemm_shiftadd_x3f16"   proposal heads
+ *   "direct_f32"                                                             any stride / group / kernel size (generic kernel)
+ * A name that starts with "winograd" is what the numerical checks of the C++ layer key on. */
 MSCNN_API const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* plan);
 /* Algorithmic FLOPs (2*MACs of the direct convolution the reference computes) of one forward call. */
 MSCNN_API double mscnn_conv2d_plan_flops(const mscnn_conv_plan* plan);

@@ -77,14 +77,26 @@ MSCNN_NET_API int mscnn_net_set_conv_tuning(mscnn_net* net, int layer, int varia
  * layer to layer on the device.  mscnn_net_layer_dtype: what layer i really runs. */
 MSCNN_NET_API int mscnn_net_set_precision(mscnn_net* net, const char* dtype);
 MSCNN_NET_API const char* mscnn_net_layer_dtype(const mscnn_net* net, int layer);
-/* Numerical calibration (call after a forward on representative input): every Winograd convolution is re-computed with the
- * direct k-ordered kernel on the same bottom; layers whose max |dy| / max(1, |y|) exceeds tol run the direct kernel from
- * then on.  *num_switched = how many; mscnn_net_layer_calibration_err gives each layer's measured value. */
+/* Numerics are SAFE BY DEFAULT (no call needed; the reference's flow -- Net(prototxt, TEST); CopyTrainedLayersFrom; Forward,
+ * net.cpp:750-785, 544-555 -- stays as it is): the Winograd forms AUTO picks carry ~10x the rounding error of the direct sum, so
+ * every Convolution layer compares its Winograd result with the direct k-ordered kernel on the FIRST bottom it sees after
+ * construction or a weight change (mscnn_net_set_param, mscnn_net_copy_trained_from, Layer::OnWeightsChanged), metric
+ * max |dy| / max(1, |y|, rms(y)), tolerance 5e-5, and when it is off switches to the direct kernel and recomputes its tops before
+ * that forward returns.  Cost: the first forward after a weight change runs each Winograd layer twice.
+ *   mscnn_net_set_auto_calibrate(net, tol): tol = 0 is the opt-OUT; tol > 0 re-arms every layer's check with that tolerance.
+ *   mscnn_net_auto_calibrate_state: *checks = first-forward checks done so far; returns how many layers fell back and writes up to
+ *   cap of their indices; mscnn_net_layer_calibration_err gives each layer's last measured value.
+ * mscnn_net_calibrate_numerics is the same check on demand (call after a forward on representative input): every convolution that
+ * runs a Winograd form is re-computed with the direct kernel on the same bottom; layers over tol run the direct kernel from then on.
+ * *num_switched = how many. */
+MSCNN_NET_API int mscnn_net_set_auto_calibrate(mscnn_net* net, double tol);
+MSCNN_NET_API int mscnn_net_auto_calibrate_state(const mscnn_net* net, int* checks, int* switched_layers, int cap);
 MSCNN_NET_API int mscnn_net_calibrate_numerics(mscnn_net* net, double tol, int* num_switched);
 MSCNN_NET_API double mscnn_net_layer_calibration_err(const mscnn_net* net, int layer);
 /* The same check on live frames: every period-th whole forward re-computes ONE Winograd layer (round robin over the layers) with the
- * direct kernel on the frame just processed; a layer off by more than tol runs the direct kernel from the next frame on.  period 0
- * switches the watch off (the default).  _state: *checks = layer checks done so far; returns how many layers were switched and
+ * direct kernel on the frame just processed; a layer off by more than tol runs the direct kernel from the next frame on.  ON by
+ * default with period 100, tol 5e-5 (one extra layer + one host sync per 100 frames: < 0.3 % of a 7s-576 stream); period 0
+ * switches the watch off.  _state: *checks = layer checks done so far; returns how many layers were switched and
  * writes up to cap of their indices. */
 MSCNN_NET_API int mscnn_net_set_numerics_watch(mscnn_net* net, int period, double tol);
 MSCNN_NET_API int mscnn_net_numerics_watch_state(const mscnn_net* net, int* checks, int* switched_layers, int cap);

@@ -1394,8 +1394,8 @@ extern "C" int mscnn_conv2d_plan_stage_ms(const mscnn_conv_plan* p, float ms_out
   return MSCNN_OK;
 }
 extern "C" int mscnn_conv2d_plan_publishes_amax(const mscnn_conv_plan* p) {
-  // the F(3x3,3x3) output transforms and every kernel of the implicit-GEMM family (main + fix-up) publish
-  return p && !p->x3h.rows && (p->x3.BM || (p->wino && p->wino_m >= 3) ||
+  // the F(3x3,3x3) output transforms, every kernel of the implicit-GEMM family (main + fix-up) and the Cin = 3 VALU kernel publish
+  return p && !p->x3h.rows && (p->x3.BM || (p->wino && p->wino_m >= 3) || p->c3 ||
                (!p->wino && p->head.entry < 0 && p->entry >= 0 && !(kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202))) ? 1 : 0;
 }
 extern "C" int mscnn_conv2d_plan_set_amax_io(mscnn_conv_plan* p, const uint32_t* in_bound, uint32_t* out_amax) {
@@ -1662,7 +1662,7 @@ static int conv_forward_single(const mscnn_conv_plan* p, const float* x, const f
   }
   if (p->c3) {
     MSCNN_REQUIRE(w, "conv: the Cin = 3 kernel needs the Caffe-layout weights");
-    return mscnn::c3_forward(d, x, w, bias, y, st);
+    return mscnn::c3_forward(d, x, w, bias, y, p->amax_out, st);
   }
   if (p->entry < 0) {
     MSCNN_REQUIRE(w, "conv: direct kernel needs the Caffe-layout weights");

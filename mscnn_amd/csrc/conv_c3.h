@@ -8,6 +8,6 @@ namespace mscnn {
 bool c3_plan(const mscnn_conv_desc& d, int Ho, int Wo);
 const char* c3_kernel_name();
 // x [N][3][H][W], w [Cout][3][3][3] (the Caffe layout, read as it is), y [N][Cout][H][W]
-int c3_forward(const mscnn_conv_desc& d, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
+int c3_forward(const mscnn_conv_desc& d, const float* x, const float* w, const float* bias, float* y, unsigned* amax_out, hipStream_t st);
 
 }  // namespace mscnn

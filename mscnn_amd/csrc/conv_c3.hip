@@ -10,6 +10,7 @@
 // Summation order: taps outer, input channels inner, accumulator starts at 0, bias added last -- the k order of the igemm kernel
 // it replaces (whose fp32 MFMA is an fmaf chain in k), so the two are bit-identical (test_conv_c3_bit_identical_to_the_igemm_kernel).
 #include "conv_c3.h"
+#include "x3_device.h"
 
 namespace {
 
@@ -21,6 +22,7 @@ constexpr int kWStride = 28;           // 27 weights padded to a multiple of 4 f
 
 struct C3Args {
   const float* x; const float* w; const float* bias; float* y;
+  unsigned* amax_out;      // max |y| slots of the split-fp16 hand-over (x3_device.h), nullptr = off
   int N, H, W, Cout, relu, tiles_w, tiles_h;
 };
 
@@ -42,7 +44,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(C3Args a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int yrow = th * kTileH + wave * 2 + (lane >> 5);
   const int x0 = tw * kTileW + (lane & 31) * kPx;
-  if (yrow >= a.H || x0 >= a.W) return;      // (W % 4 == 0: a thread's four pixels are all inside or all outside)
+  unsigned am = 0;                           // bit pattern of this thread's max |y| (published per workgroup when asked for)
+  if (yrow < a.H && x0 < a.W) {              // (W % 4 == 0: a thread's four pixels are all inside or all outside)
 
   // the 3 x 3 x 6 window: rows yrow-1 .. yrow+1, columns x0-1 .. x0+4, zero outside the image
   const long plane = (long)a.H * a.W;
@@ -83,7 +86,10 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(C3Args a) {
     float4 o = make_float4(acc[0] + b, acc[1] + b, acc[2] + b, acc[3] + b);
     if (a.relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
     *reinterpret_cast<float4*>(yout + (long)co * plane) = o;
+    if (a.amax_out) am = max(am, __float_as_uint(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)))));
   }
+  }
+  if (a.amax_out) mscnn::publish_amax(am, a.amax_out, blockIdx.x);      // (every thread: it contains a barrier)
 }
 
 }  // namespace
@@ -98,10 +104,10 @@ bool c3_plan(const mscnn_conv_desc& d, int Ho, int Wo) {
 
 const char* c3_kernel_name() { return "conv3x3_c3_valu_f32"; }
 
-int c3_forward(const mscnn_conv_desc& d, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+int c3_forward(const mscnn_conv_desc& d, const float* x, const float* w, const float* bias, float* y, unsigned* amax_out, hipStream_t st) {
   MSCNN_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0, "conv(c3): x and y must be 16-byte aligned");
   C3Args a;
-  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.amax_out = amax_out;
   a.N = d.N; a.H = d.H; a.W = d.W; a.Cout = d.Cout; a.relu = d.relu;
   a.tiles_w = cdiv(d.W, kTileW); a.tiles_h = cdiv(d.H, kTileH);
   conv3x3_c3_kernel<<<(unsigned)((long)d.N * a.tiles_w * a.tiles_h), 256, 0, st>>>(a);

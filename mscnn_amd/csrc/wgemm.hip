@@ -498,9 +498,13 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   o->variant = variant; o->name = e->name;
   o->packed_bytes = (size_t)P * o->MT * o->KI * e->CK * e->BM * 4;
   o->ws_bytes = tiles > (long)o->full_q * o->G ? (size_t)o->G * e->BM * e->BN * 4 + ((size_t)o->G + 1) * 8 : 0;     // slabs, flags, status
-  const double lim = 4.0e9;
+  // every buffer strictly below 2^31 bytes: the kernel's out-of-range sentinel for lane offsets is 0x80000000 (the empty flush of
+  // segment 0, rows past Cout, the producer's past-the-end pieces) and must lie outside num_records of V, M, Up and the slabs --
+  // larger problems (batch >= 7 at 576 x 1920 in the F(4x4,3x3) form) stay on the per-plane igemm GEMM
+  const double lim = 2147483648.0 - 65536.0;
   if ((double)tiles * o->KI * o->G >= 2.0e9 || o->KI < 1) return false;      // wg_range's 32-bit product
-  if ((double)P * Cin * o->T_pad * 4 >= lim || (double)P * Cout * o->T_pad * 4 >= lim || (double)o->packed_bytes >= lim) return false;
+  if ((double)P * Cin * o->T_pad * 4 >= lim || (double)P * Cout * o->T_pad * 4 >= lim || (double)o->packed_bytes >= lim ||
+      (double)o->ws_bytes >= lim) return false;
   return true;
 }
 

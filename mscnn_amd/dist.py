@@ -112,7 +112,7 @@ class RcclGather:
         _dcheck(dist_lib().mscnn_dist_all_gather_begin(self._h, C.c_void_p(pack_dev_ptr), C.c_void_p(stream or 0)))
 
     def end(self):
-        """Wait for the oldest exchange in flight; returns its per-rank list of (dets, ids, R) (views: valid for two more begins)."""
+        """Wait for the oldest exchange in flight; returns its per-rank list of (dets, ids, R) (zero-copy views of the pinned buffer: valid only until the next begin() -- copy what must live longer)."""
         out = C.c_void_p()
         _dcheck(dist_lib().mscnn_dist_all_gather_end(self._h, C.byref(out)))
         host = (C.c_ubyte * (self.world * self.pack_bytes)).from_address(out.value)

@@ -221,7 +221,7 @@ int mscnn_dist_all_gather_end(mscnn_dist* d, const void** gathered_host) {
   sl.busy = false;
   d->tail ^= 1;
   --d->inflight;
-  *gathered_host = sl.recv_host;      // valid until this slot's next begin (two begins from now)
+  *gathered_host = sl.recv_host;      // valid until the NEXT begin(): with one exchange in flight that begin() takes this very slot
   return 0;
 }
 

@@ -71,7 +71,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   virtual inline const char* type() const { return "Convolution"; }
   virtual inline int MinBottomBlobs() const { return 1; }
   virtual inline int MinTopBlobs() const { return 1; }
-  virtual void OnWeightsChanged() { weights_dirty_ = true; }
+  virtual void OnWeightsChanged() { weights_dirty_ = true; selfcheck_pending_ = true; }
   virtual bool FuseReLU(Dtype negative_slope);
   virtual bool FusePool2x2(Blob<Dtype>* pooled_top);
   virtual double ForwardFlops() const;
@@ -86,6 +86,20 @@ class ConvolutionLayer : public Layer<Dtype> {
   // kernel across precision switches (mscnn_net_set_precision) until an explicit mscnn_net_set_conv_algo clears the mark.
   void set_calibrated_direct(bool on) { calibrated_direct_ = on; }
   bool calibrated_direct() const { return calibrated_direct_; }
+  // Safe by default: the FIRST Forward after construction, after a weight change (OnWeightsChanged) or after a switch to another
+  // non-direct algorithm checks a Winograd result against the direct kernel on the very bottom it was given (ErrorAgainstDirect) and,
+  // when it is off by more than the tolerance, puts the layer on the direct kernel for good and recomputes the tops before Forward
+  // returns -- no caller ever sees an unchecked Winograd result.  kDefaultSelfcheckTol unless set_selfcheck says otherwise; 0 = off.
+  static constexpr double kDefaultSelfcheckTol = 5e-5;
+  void set_selfcheck(double tol) { selfcheck_tol_ = tol; selfcheck_pending_ = true; }
+  double selfcheck_tol() const { return selfcheck_tol_; }
+  // what the last self-check measured; `take` clears the "a check ran since the last take" mark (Net bookkeeping)
+  bool take_selfcheck(double* err, bool* fell_back) {
+    if (!selfcheck_ran_) return false;
+    selfcheck_ran_ = false; *err = selfcheck_err_; *fell_back = selfcheck_fell_back_;
+    selfcheck_fell_back_ = false;
+    return true;
+  }
   void set_tuning(int variant, int grid, int flags);      // A/B measurement knobs (mscnn_conv_desc::tune_*)
   // FLOPs the MFMA pipe executes (Winograd forms: fewer than ForwardFlops) and per-stage HIP-event times of the last
   // Forward {input transform, MFMA GEMM, output transform} -- roofline accounting (bench.py).
@@ -116,6 +130,8 @@ class ConvolutionLayer : public Layer<Dtype> {
   DeviceBuffer packed_, workspace_;
   int algo_, tune_[3];
   bool calibrated_direct_ = false;
+  double selfcheck_tol_ = kDefaultSelfcheckTol, selfcheck_err_ = 0.0;
+  bool selfcheck_pending_ = true, selfcheck_ran_ = false, selfcheck_fell_back_ = false;
   bool profiling_;
   const ConvolutionLayer* amax_src_ = nullptr;
   const unsigned* amax_in_ = nullptr;

@@ -75,9 +75,18 @@ class Net {
   // errors (per layer index, 0 for layers not checked) are left in calibration_err().
   vector<int> CalibrateNumerics(double tol);
   const vector<double>& calibration_err() const { return calib_err_; }
+  // Safe by default (no call needed): every Convolution layer checks its Winograd result against the direct kernel by itself on the
+  // first Forward after construction / CopyTrainedLayersFrom / MarkWeightsChanged and falls back before that Forward returns
+  // (ConvolutionLayer::set_selfcheck); the Net only keeps the books -- calibration_err(), auto_calibrate_checks / _switched -- and
+  // offers the opt-OUT: SetAutoCalibrate(0).  tol > 0 re-arms the check on every layer with that tolerance.
+  void SetAutoCalibrate(double tol);
+  int auto_calibrate_checks() const { return auto_checks_; }
+  const vector<int>& auto_calibrate_switched() const { return auto_switched_; }
   // The same check while a stream of frames runs: every `period`-th whole Forward re-computes ONE Winograd layer (round robin) with
   // the direct kernel on the frame just processed and switches it to the direct kernel for good when it is off by more than tol --
-  // the calibration of the first frame is re-examined on live data at the cost of one extra layer per `period` frames (period 0: off).
+  // the calibration of the first frame is re-examined on live data at the cost of one extra layer per `period` frames.  ON by default
+  // (every kDefaultWatchPeriod-th frame, tolerance 5e-5: < 0.3 % of a 7s-576 stream); period 0 turns it off.
+  static constexpr int kDefaultWatchPeriod = 100;
   void SetNumericsWatch(int period, double tol) { watch_period_ = period; watch_tol_ = tol; watch_frame_ = 0; }
   int numerics_watch_checks() const { return watch_checks_; }
   const vector<int>& numerics_watch_switched() const { return watch_switched_; }
@@ -115,8 +124,10 @@ class Net {
   mutable std::map<int, bool> redirect_dirty_;     // producer ran since the last MaterializeBlob
   vector<double> calib_err_;
   void NumericsWatchStep();
-  int watch_period_ = 0, watch_frame_ = 0, watch_next_ = 0, watch_checks_ = 0;
-  double watch_tol_ = 0.0;
+  int watch_period_ = kDefaultWatchPeriod, watch_frame_ = 0, watch_next_ = 0, watch_checks_ = 0;
+  double watch_tol_ = 5e-5;
+  int auto_checks_ = 0;
+  vector<int> auto_switched_;
   vector<int> watch_switched_;
   DISABLE_COPY_AND_ASSIGN(Net);
 };

@@ -193,6 +193,15 @@ int mscnn_net_numerics_watch_state(const mscnn_net* n, int* checks, int* switche
   for (int i = 0; switched_layers && i < cap && i < (int)sw.size(); ++i) switched_layers[i] = sw[i];
   return (int)sw.size();
 }
+int mscnn_net_set_auto_calibrate(mscnn_net* n, double tol) {
+  return guarded([&] { n->net->SetAutoCalibrate(tol); });
+}
+int mscnn_net_auto_calibrate_state(const mscnn_net* n, int* checks, int* switched_layers, int cap) {
+  const std::vector<int>& sw = n->net->auto_calibrate_switched();
+  if (checks) *checks = n->net->auto_calibrate_checks();
+  for (int i = 0; switched_layers && i < cap && i < (int)sw.size(); ++i) switched_layers[i] = sw[i];
+  return (int)sw.size();
+}
 int mscnn_net_num_blobs(const mscnn_net* n) { return (int)n->net->blobs().size(); }
 const char* mscnn_net_blob_name(const mscnn_net* n, int b) { return n->net->blob_names()[b].c_str(); }
 int mscnn_net_blob_shape(const mscnn_net* n, const char* name, int* dims8, int* ndim) {

@@ -169,6 +169,7 @@ void ConvolutionLayer<Dtype>::set_algo(int algo) {
   CHECK(algo >= 0 && algo <= 6) << "unknown mscnn_conv_algo " << algo;
   if (algo == algo_) return;
   algo_ = algo;
+  if (algo != MSCNN_CONV_ALGO_DIRECT) selfcheck_pending_ = true;      // another arithmetic: its first result is checked again
   if (plan_) { mscnn_conv2d_plan_destroy(plan_); plan_ = nullptr; }
 }
 template <typename Dtype>
@@ -205,7 +206,15 @@ double ConvolutionLayer<Dtype>::ErrorAgainstDirect(const vector<Blob<Dtype>*>& b
   d.group = group_; d.relu = relu_ ? 1 : 0; d.algo = MSCNN_CONV_ALGO_DIRECT; d.tune_variant = d.tune_grid = d.tune_flags = 0;
   mscnn_conv_plan* dp = nullptr;
   MSCNN_CHECK(mscnn_conv2d_plan_create(&d, &dp));
-  DeviceBuffer packed, ws, y, err;
+  // scratch shared by every check of this host thread on this device (kept: a check on a live stream -- the numerics watch -- must
+  // not pay a hipMalloc + a synchronising hipFree of 100s of MB; leaked on thread exit like the shared conv workspace)
+  struct Scratch { DeviceBuffer packed, ws, y, err; };
+  static thread_local Scratch* scratch[64] = {nullptr};
+  int sdev = 0;
+  HIP_CHECK(hipGetDevice(&sdev));
+  CHECK(sdev >= 0 && sdev < 64);
+  if (!scratch[sdev]) scratch[sdev] = new Scratch();
+  DeviceBuffer &packed = scratch[sdev]->packed, &ws = scratch[sdev]->ws, &y = scratch[sdev]->y, &err = scratch[sdev]->err;
   const size_t pb = mscnn_conv2d_packed_weight_bytes(dp), wb = mscnn_conv2d_workspace_bytes(dp);
   float* pk = pb ? static_cast<float*>(packed.Reserve(pb)) : nullptr;
   const float* w = this->blobs_[0]->gpu_data();
@@ -297,6 +306,24 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     // the planned kernel has no pooling epilogue (e.g. a direct-kernel shape): run the pooling the fused-away layer would have
     MSCNN_CHECK(mscnn_pool2d_fwd_f32(top[0]->gpu_data(), pooled_top_->mutable_gpu_data(), top[0]->num(), top[0]->channels(),
                                      top[0]->height(), top[0]->width(), 2, 2, 0, 0, 2, 2, 0, S()));
+  }
+  // Safe by default (header): a Winograd result is never handed out unchecked on new weights -- compare it with the direct kernel
+  // on this very bottom once; off by more than the tolerance => direct kernel from now on, tops recomputed before returning.
+  if (selfcheck_pending_ && bottom[0]->count() > 0) {
+    selfcheck_pending_ = false;
+    if (selfcheck_tol_ > 0 && algo_ != MSCNN_CONV_ALGO_DIRECT && algo_ != MSCNN_CONV_ALGO_F16 &&
+        std::strncmp(mscnn_conv2d_plan_kernel(plan_), "winograd", 8) == 0) {
+      selfcheck_err_ = ErrorAgainstDirect(bottom, top);
+      selfcheck_ran_ = true;
+      if (!(selfcheck_err_ <= selfcheck_tol_)) {      // (NaN counts as a failure)
+        LOG(WARNING) << "layer " << this->layer_param_.name() << ": Winograd result off the direct sum by " << selfcheck_err_ << " > "
+                     << selfcheck_tol_ << " on the first input after a weight change: using the direct kernel";
+        set_algo(MSCNN_CONV_ALGO_DIRECT);
+        calibrated_direct_ = true;
+        selfcheck_fell_back_ = true;
+        Forward_gpu(bottom, top);
+      }
+    }
   }
 }
 

@@ -368,6 +368,13 @@ vector<int> Net<Dtype>::CalibrateNumerics(double tol) {
 }
 
 template <typename Dtype>
+void Net<Dtype>::SetAutoCalibrate(double tol) {
+  CHECK_GE(tol, 0.0);
+  for (size_t i = 0; i < layers_.size(); ++i)
+    if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) c->set_selfcheck(tol);
+}
+
+template <typename Dtype>
 void Net<Dtype>::NumericsWatchStep() {
   const int L = (int)layers_.size();
   for (int k = 0; k < L; ++k) {
@@ -458,6 +465,21 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
     }
   }
   if (timing_) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+  // a paired ROIPooling's skip mark must not outlive the call in which its partner ran (a range that ends between the two, then a
+  // direct Layer::Forward on the second: it has to pool, not skip)
+  for (size_t i = 0; i < layers_.size(); ++i)
+    if (string(layers_[i]->type()) == "ROIPooling") static_cast<ROIPoolingLayer<Dtype>*>(layers_[i].get())->set_skip(false);
+  // books of the layers' own first-forward checks (safe-by-default numerics: ConvolutionLayer::set_selfcheck)
+  for (int i = start; i <= end; ++i)
+    if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) {
+      double e = 0.0;
+      bool fell = false;
+      if (c->take_selfcheck(&e, &fell)) {
+        calib_err_[i] = e;
+        ++auto_checks_;
+        if (fell) auto_switched_.push_back(i);
+      }
+    }
   // The max |x| slots a split-fp16 layer takes from its producer are only valid inside this call: a later Layer::Forward called
   // directly on a layer (caffe time, user code, the boundary tests) must measure its bottom itself instead of trusting the slots of
   // the frame that went through here.

@@ -48,6 +48,7 @@ def lib():
             "mscnn_net_set_conv_algo": [vp, ci, ci], "mscnn_net_set_conv_tuning": [vp, ci, ci, ci, ci],
             "mscnn_net_calibrate_numerics": [vp, C.c_double, vp], "mscnn_net_set_numerics_watch": [vp, ci, C.c_double],
             "mscnn_net_numerics_watch_state": [vp, vp, vp, ci], "mscnn_net_layer_calibration_err": [vp, ci],
+            "mscnn_net_set_auto_calibrate": [vp, C.c_double], "mscnn_net_auto_calibrate_state": [vp, vp, vp, ci],
             "mscnn_net_load_caffemodel": [vp, cs], "mscnn_net_set_stream": [vp], "mscnn_net_num_layers": [vp],
             "mscnn_net_layer_name": [vp, ci], "mscnn_net_layer_type": [vp, ci], "mscnn_net_layer_index": [vp, cs],
             "mscnn_net_layer_num_bottoms": [vp, ci], "mscnn_net_layer_num_tops": [vp, ci], "mscnn_net_layer_bottom": [vp, ci, ci],
@@ -177,6 +178,18 @@ class Net:
         switched = [nm for nm, e in errs.items() if not e <= tol]
         assert len(switched) == n.value
         return errs, switched
+
+    def set_auto_calibrate(self, tol=5e-5):
+        """The first-forward check of every Winograd layer against the direct kernel is ON by default (5e-5); tol = 0 opts out,
+        tol > 0 re-arms it with that tolerance."""
+        _check(lib().mscnn_net_set_auto_calibrate(self._h, tol))
+
+    def auto_calibrate_state(self):
+        """(first-forward checks done so far, [names of the layers they sent to the direct kernel], {layer: last measured error})."""
+        n, sw = C.c_int(), (C.c_int * 64)()
+        k = lib().mscnn_net_auto_calibrate_state(self._h, C.byref(n), sw, 64)
+        errs = {nm: lib().mscnn_net_layer_calibration_err(self._h, i) for i, nm in enumerate(self.layer_names)}
+        return n.value, [self.layer_names[sw[i]] for i in range(min(k, 64))], {nm: e for nm, e in errs.items() if e > 0}
 
     def set_numerics_watch(self, period, tol=5e-5):
         """Every period-th forward re-checks one Winograd layer (round robin) against the direct kernel on the live frame."""

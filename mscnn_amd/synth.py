@@ -53,6 +53,14 @@ def weights(layer_names, layer_types, param_shapes, regime="dense", cls_num=None
         fan_in = int(np.prod(wshape[1:]))
         w = (rng.standard_normal(wshape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
         b = np.zeros(shapes[1], np.float32) if len(shapes) > 1 else None
+        if style == "heavy_tailed" and typ == "Convolution" and len(wshape) == 4 and wshape[2] == 3 and wshape[3] == 3 and not name.startswith("LFCN_"):
+            # a few filters carry almost all of a layer's energy (log-normal gain, sigma 1.3, variance-preserving), tap sums not zero:
+            # activations with isolated huge channels next to near-dead ones -- the statistics on which the Winograd forms lose digits
+            gain = np.exp(1.3 * rng.standard_normal((wshape[0], 1, 1, 1)))
+            dc = 0.15 * np.sqrt(2.0 / fan_in) * rng.standard_normal((wshape[0], wshape[1], 1, 1))
+            w = ((w + dc) * gain / np.sqrt(1.0225 * np.exp(2 * 1.3 ** 2))).astype(np.float32)
+            if b is not None:
+                b = (0.1 * rng.standard_normal(b.shape)).astype(np.float32)
         if style == "vgg_like" and typ == "Convolution" and len(wshape) == 4 and wshape[2] == 3 and wshape[3] == 3 and not name.startswith("LFCN_"):
             tap = np.array([[0.5, 1.0, 0.5], [1.0, 2.0, 1.0], [0.5, 1.0, 0.5]]) / 2.0
             gain = np.exp(0.5 * rng.standard_normal((wshape[0], 1, 1, 1)))

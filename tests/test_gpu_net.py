@@ -661,3 +661,76 @@ def test_generated_deploys_match_the_fingerprints_of_the_shipped_files():
         assert fingerprint(n) == want[model]["sha256"], model
         del n
 
+
+
+def _read_f32(path):
+    raw = np.fromfile(path, np.int32, 1)
+    nd = int(raw[0])
+    shape = np.fromfile(path, np.int32, 1 + nd)[1:]
+    return np.fromfile(path, np.float32, offset=4 * (1 + nd)).reshape(tuple(int(v) for v in shape))
+
+
+def test_default_flow_is_safe_without_a_calibration_call(tmp_path):
+    """the INTEGRATION.md section 2 flow -- Net(prototxt, TEST); CopyTrainedLayersFrom(file); Forward() -- as a C++
+    program against the mirror headers (tests/boundary/run_default_flow.cpp), with heavy-tailed weights in the .caffemodel and NO
+    calibration call anywhere.  (a) default settings: every Winograd layer has checked itself on that first frame, and the blobs the
+    program wrote meet the parity gates against the oracle run on the same file's weights; (b) with the documented knob set to an
+    impossible tolerance every Winograd layer must have fallen back INSIDE that first Forward: the program's blobs are bit-identical
+    to a net whose convolutions were all forced onto the direct kernel."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a MI355X")
+    import subprocess
+    from oracle import pynet
+    from tests import caffemodel_pb
+    from tests.test_cabi import build_boundary_binary
+    model, size = "kitti_ped_cyc/mscnn-7s-576-2x", dict(height=192, width=320, max_nms_num=100)
+    proto = zoo.prototxt(model, **size)
+    n = mnet.Net(prototxt_text=proto)
+    shapes = [n.param_shapes(i) for i in range(len(n.layer_names))]
+    ws = synth.weights(n.layer_names, n.layer_types, shapes, "mid", style="heavy_tailed")
+    (tmp_path / "deploy.prototxt").write_text(proto)
+    (tmp_path / "net.caffemodel").write_bytes(caffemodel_pb.serialize(
+        [(name, n.layer_types[n.layer_names.index(name)], [(a, "shape") for a in arrs]) for name, arrs in ws.items()]))
+    x = synth.frame(192, 320)
+    x.tofile(str(tmp_path / "input.f32"))
+    exe = build_boundary_binary(tmp_path, "run_default_flow.cpp")
+
+    def run(outdir, *extra):
+        os.makedirs(outdir)
+        r = subprocess.run([exe, str(tmp_path / "deploy.prototxt"), str(tmp_path / "net.caffemodel"), str(tmp_path / "input.f32"), outdir, *extra],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "DEFAULT FLOW OK" in r.stdout, (r.stdout[-1500:], r.stderr[-2500:])
+        kern = {l.split()[1]: l.split()[2] for l in r.stdout.splitlines() if l.startswith("LAYER ")}
+        checked = [l.split()[1] for l in r.stdout.splitlines() if l.startswith("LAYER ") and float(l.split()[3]) > 0]
+        cal = [l for l in r.stdout.splitlines() if l.startswith("AUTOCAL")][0].split()
+        assert int(cal[2]) == len(checked)
+        return kern, checked, int(cal[4])
+
+    # (a) defaults
+    kern, checked, switched = run(str(tmp_path / "a"))
+    wino_left = [k for k, v in kern.items() if v.startswith("winograd")]
+    print(f"\nDEFAULT-FLOW heavy_tailed: {len(checked)} first-forward checks, {switched} fall-backs, Winograd left on {wino_left}")
+    assert len(checked) >= 4 and len(checked) == switched + len(wino_left), (checked, switched, kern)
+    ref = pynet.forward(layer_list(n), ws, {"data": x})
+    _SCALE_METRIC[0] = True
+    try:
+        for b in ("conv2_2", "conv3_3", "conv4_3", "conv5_3", "conv6_1", "LFCN_1_5x7", "LFCN_3_3x5"):
+            e = rel_err(_read_f32(str(tmp_path / "a" / (b + ".f32"))), ref[b])
+            assert e < 1e-4, (b, e)
+    finally:
+        _SCALE_METRIC[0] = False
+    assert _read_f32(str(tmp_path / "a" / "proposals.f32")).shape[0] == ref["proposals"].shape[0]
+    # (b) the knob: impossible tolerance => all-direct, decided and recomputed within the first Forward
+    kern_b, checked_b, switched_b = run(str(tmp_path / "b"), "1e-12")
+    assert checked_b == checked and switched_b == len(checked) and not any(v.startswith("winograd") for v in kern_b.values()), kern_b
+    n.set_auto_calibrate(0.0)                                   # the opt-out: nothing is checked ...
+    for name, arrs in ws.items():
+        for p_, a in enumerate(arrs):
+            n.set_param(name, p_, a)
+    for name in checked:                                        # ... and the layers AUTO would run as Winograd forced onto the direct kernel
+        n.set_conv_algo(name, 1)
+    n.set_blob("data", x)
+    n.forward()
+    assert n.auto_calibrate_state()[0] == 0
+    for b in ("conv2_2", "conv4_3", "conv6_1", "LFCN_2_5x7", "proposals", "roi_pool", "fc6", "cls_pred", "bbox_pred"):
+        assert np.array_equal(_read_f32(str(tmp_path / "b" / (b + ".f32"))), n.get_blob(b)), b

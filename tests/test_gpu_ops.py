@@ -563,6 +563,19 @@ def test_winograd_layers_publish_amax(hip):
             yp = torch.empty((1, 96, 12, 24), device="cuda") if pooled else None
             y = plan.forward(x, b, pool_out=yp)
             assert slots.max().item() == y.abs().max().view(torch.int32).item(), (algo, pooled)
+    # the Cin = 3 VALU kernel (conv1_1) publishes too (conv1_2's split-fp16 plan no longer measures 283 MB itself)
+    x3c = torch.randn((1, 3, 72, 136), device="cuda", generator=g) * 50
+    w3c = torch.randn((64, 3, 3, 3), device="cuda", generator=g) * 0.05
+    b3c = torch.randn(64, device="cuda", generator=g)
+    for relu in (False, True):
+        c3 = hip.ConvPlan(1, 3, 72, 136, 64, 3, 3, (1, 1), relu=relu)
+        assert c3.kernel == "conv3x3_c3_valu_f32" and c3.publishes_amax
+        c3.pack(w3c)
+        y0 = c3.forward(x3c, b3c).clone()                       # (no slots: nothing published, same bytes)
+        slots = torch.zeros(hip.AMAX_SLOTS, dtype=torch.int32, device="cuda")
+        c3.set_amax_io(None, slots)
+        y = c3.forward(x3c, b3c)
+        assert torch.equal(y, y0) and slots.max().item() == y.abs().max().view(torch.int32).item(), relu
     head = hip.ConvPlan(1, 512, 36, 60, 9, 5, 5, (2, 2))
     assert not head.publishes_amax
     with pytest.raises(hip.MscnnError):
