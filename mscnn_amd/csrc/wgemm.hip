@@ -50,11 +50,18 @@ struct WgemmArgs {
   unsigned up_bytes, v_bytes, m_bytes;
 };
 
-template <int BM_, int BN_, int WGM_, int WGN_, int CK_, int ST_, int DPG_ = 1, int SK_ = 0>
+template <int BM_, int BN_, int WGM_, int WGN_, int CK_, int ST_, int DPG_ = 1, int SK_ = 0, int FP_ = 1, int LATE_ = 0>
 struct WCfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, CK = CK_, ST = ST_;
   // schedule knobs: LDS-DMA pieces issued per MFMA group (from group 0 on), first group that carries ride-along stores
   static constexpr int DPG = DPG_, SK = SK_;
+  // FP: the finished tile's stores ride along the first FP chunks of the next segment, 1/FP of them per chunk (round 4: all 256
+  // workgroups finish their tiles in lockstep, so with FP = 1 the chip writes a whole round of tiles -- 32 MB -- inside one 3.7 us
+  // chunk, the store queues back up and the waves stall at vmcnt's 63 outstanding operations with their MFMAs behind them);
+  // LATE: a chunk's closing wait is for the unit ONE ahead (issued a whole chunk earlier) instead of the unit two ahead it has just
+  // put in flight -- every LDS-DMA piece gets a full chunk more to land -- at the price of reading the next chunk's first operands
+  // behind the barrier instead of in front of it.
+  static constexpr int FP = FP_, LATE = LATE_;
   static constexpr int NW = WGM * WGN, THREADS = NW * 64;
   static constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
   static constexpr int A_BYTES = CK * BM * 4, B_BYTES = CK * BN * 4, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -151,6 +158,7 @@ struct SegCursor {
 template <class C, int ABL>
 __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs a) {
   __shared__ __attribute__((aligned(1024))) float lds[C::LDS_FLOATS];
+  __shared__ unsigned s_handoff_timeout;
   static_assert(C::ST == 3, "the ring protocol below is written for three stages");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -267,10 +275,12 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   constexpr int NMF = C::MI * C::NI;                      // MFMAs per group
   // ride-along stores of a finished tile: TOTAL of them over the groups SK .. STEPS-1, spread over a group's MFMAs
   constexpr int TOTAL = NMF * 16;
-  constexpr int SPG = (TOTAL + (C::STEPS - C::SK) - 1) / (C::STEPS - C::SK);     // per group
+  static_assert(TOTAL % C::FP == 0, "flush parts");
+  constexpr int TOTP = TOTAL / C::FP;                                            // ... of them per flush chunk (part f: elements f TOTP ..)
+  constexpr int SPG = (TOTP + (C::STEPS - C::SK) - 1) / (C::STEPS - C::SK);      // per group
   constexpr int SPM = (SPG + NMF - 1) / NMF;                                     // per MFMA
   constexpr int DMA_GROUPS = (C::NP + C::DPG - 1) / C::DPG;                      // groups 0 .. DMA_GROUPS-1 carry the unit's pieces
-  static_assert(C::DPG <= NMF && DMA_GROUPS <= C::STEPS && C::SK < C::STEPS, "schedule");
+  static_assert(C::DPG <= NMF && DMA_GROUPS <= C::STEPS && C::SK < C::STEPS && C::STEPS % 2 == 0, "schedule");
   // stores issued behind a chunk's last piece (piece NP-1 sits behind MFMA (NP-1) % DPG of group DMA_GROUPS-1, after that slot's stores)
   constexpr int AFTER_DMA = [] {
     int n = 0;
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
         if (g < C::SK) continue;
         const int lo = (g - C::SK) * SPG + j * SPM, hi_g = (g - C::SK + 1) * SPG;
         int cnt = 0;
-        for (int k = lo; k < lo + SPM && k < hi_g && k < TOTAL; ++k) ++cnt;
+        for (int k = lo; k < lo + SPM && k < hi_g && k < TOTP; ++k) ++cnt;
         const bool after = g > DMA_GROUPS - 1 || (g == DMA_GROUPS - 1 && j > (C::NP - 1) % C::DPG);
         if (after) n += cnt;
       }
@@ -302,17 +312,18 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 0);
   };
 
-  // one chunk = STEPS MFMA groups.  FLUSH: the previous tile's stores ride along (SPM per MFMA); DMA: this chunk carries the
-  // NP pieces of the unit two ahead.
-  auto chunk = [&](auto flush_c, unsigned next_addr) {
-    constexpr bool FLUSH = decltype(flush_c)::value;
+  // one chunk = STEPS MFMA groups.  PART >= 0: part PART of the previous segment's stores rides along (SPM per MFMA); DMA: this chunk
+  // carries the NP pieces of the unit two ahead.
+  auto chunk = [&](auto part_c, unsigned next_addr) {
+    constexpr int PART = decltype(part_c)::value;
+    constexpr bool FLUSH = PART >= 0;
     p_begin();
     static_for<0, C::STEPS>([&](auto sc) {
       constexpr int s = decltype(sc)::value, cur = s & 1, nxt = cur ^ 1;
       if constexpr (!(ABL & 8)) {
-        if constexpr (s + 1 < C::STEPS) WG_READ(nxt, c_addr, s + 1)
-        else WG_READ(nxt, next_addr, 0)
-        lds_wait<NR>();
+        if constexpr (s + 1 < C::STEPS) { WG_READ(nxt, c_addr, s + 1) lds_wait<NR>(); }
+        else if constexpr (!C::LATE) { WG_READ(nxt, next_addr, 0) lds_wait<NR>(); }
+        else lds_wait<0>();                               // (LATE: the next chunk's first operands are read behind the barrier)
       }
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi) lds_pin(av[cur][mi]);
@@ -327,7 +338,7 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
           if constexpr (!(ABL & 2))
             static_for<0, SPM>([&](auto kc_) {
               constexpr int e = (s - C::SK) * SPG + j * SPM + decltype(kc_)::value;
-              if constexpr (e < (s - C::SK + 1) * SPG && e < TOTAL) store_one(std::integral_constant<int, e>{});
+              if constexpr (e < (s - C::SK + 1) * SPG && e < TOTP) store_one(std::integral_constant<int, (FLUSH ? PART : 0) * TOTP + e>{});
             });
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -338,12 +349,26 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
       });
     });
     p_end();
+    if constexpr (ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (C::LATE && !(ABL & 3)) {
+      // the unit ONE ahead must have landed: everything this wave issued before this chunk's own NP pieces and stores (in-order
+      // retirement; the previous chunk's trailing stores are waited for as well -- stricter than needed, they are a chunk old)
+      constexpr int LEFT = C::NP + (FLUSH ? TOTP : 0);
+      wait_vm_barrier<(LEFT < 63 ? LEFT : 63)>();
+      if constexpr (!(ABL & 8)) WG_READ(0, next_addr, 0)
+    }
     // this wave's pieces of the unit two ahead have landed; the stores of a flushed tile issued behind the last piece may still
     // be in flight (the hardware's vmcnt field holds 63)
-    if constexpr (ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (FLUSH) wait_vm_barrier<(AFTER_DMA < 63 ? AFTER_DMA : 63)>();
     else wait_vm_barrier<0>();
     c_addr = next_addr;
+  };
+  auto store_part = [&](auto part_c) {                   // part PART of the flushed segment at once (segments shorter than FP chunks)
+    constexpr int PART = decltype(part_c)::value;
+    if constexpr (!(ABL & 2)) static_for<0, TOTP>([&](auto ec) { store_one(std::integral_constant<int, PART * TOTP + decltype(ec)::value>{}); });
+  };
+  auto with_part = [&](int part, auto&& f) {             // run f(integral_constant<part>) for a wave-uniform run-time part < FP
+    static_for<0, C::FP>([&](auto pc) { if (part == decltype(pc)::value) f(pc); });
   };
 
   int c_stage = 0;
@@ -361,10 +386,20 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     if (tid == 0) __hip_atomic_store(flags + slot, want_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   while (ccur.next(t, k0, k1, part)) {
-    // first chunk of the segment: the previous segment's stores ride along (segment 0: `old` is empty, its offsets out of range)
-    chunk(std::true_type{}, next_stage_addr());
+    // the previous segment's stores ride along this segment's first FP chunks, one part per chunk (segment 0: `old` is empty, its
+    // offsets out of range); a partial sum is published once its last part has been issued
+    int done = 0;
+    for (int kc = k0; kc < k1; ++kc) {
+      const unsigned na = next_stage_addr();
+      if (done < C::FP) {
+        with_part(done, [&](auto pc) { chunk(pc, na); });
+        if (++done == C::FP && old_pub) { publish_flag(); old_pub = false; }
+      } else {
+        chunk(std::integral_constant<int, -1>{}, na);
+      }
+    }
+    for (; done < C::FP; ++done) with_part(done, [&](auto pc) { store_part(pc); });      // (a stream-K piece shorter than FP chunks)
     if (old_pub) { publish_flag(); old_pub = false; }
-    for (int kc = k0 + 1; kc < k1; ++kc) chunk(std::false_type{}, next_stage_addr());
     // ---- segment done: move its accumulators aside.  Whole tile -> M.  Partial without the tile's first chunk -> this
     // workgroup's slab, published for the workgroup that has it.  Partial WITH the first chunk (always the last segment) -> M,
     // after the other contributors' slabs have been added (below). ----
@@ -402,10 +437,15 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
       if (tid == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(flags + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_flag && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
-        if (spins >= (1u << 22)) __hip_atomic_store(flags + a.G, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // status word: hand-off timed out
+        // hand-off timed out (the contributor is not co-resident: CU masking, a shared GPU): never a silently wrong tile -- the status
+        // word is set and the whole tile is stored as NaN, which every downstream check (the layer's first-forward check, the numerics
+        // watch, any parity test) fails on, and the self-check answers by putting the layer on the direct kernel
+        s_handoff_timeout = spins >= (1u << 22) ? 1u : 0u;
+        if (spins >= (1u << 22)) __hip_atomic_store(flags + a.G, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
-      asm volatile("s_barrier" ::: "memory");
+      __syncthreads();
+      const bool poisoned = s_handoff_timeout != 0;
       const unsigned sl2 = (unsigned)s2 * (unsigned)(C::BM * C::BN * 4);
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi)
@@ -415,7 +455,11 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             old[mi][ni][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)(C::BN * 4), 0));
+          if (poisoned)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[mi][ni][r] = __builtin_nanf("");
         }
+      __syncthreads();                                     // (s_handoff_timeout is rewritten for the next contributor)
     }
   }
   // the last tile's stores
@@ -431,11 +475,27 @@ typedef void (*WgemmFn)(WgemmArgs);
 struct WEntry { const char* name; int variant, abl, BM, BN, CK, threads; WgemmFn fn; };
 #define WG_ENTRY(name, v, abl, BM, BN, WGM, WGN, CK) {name, v, abl, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3>, abl>}
 #define WG_ENTRY_S(name, v, BM, BN, WGM, WGN, CK, DPG, SK) {name, v, 0, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3, DPG, SK>, 0>}
+// schedule variants (round 4): variant = tile shape + 16 * schedule; schedule 1: FP 4, 2: FP 8, 3: FP 4 + LATE, 4: FP 2, 5: FP 2 + LATE, 6: FP 8 + LATE, 7: FP 1 + LATE
+#define WG_ENTRY_F(name, v, sch, BM, BN, WGM, WGN, CK, FP, LATE) {name, v + 16 * sch, 0, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3, 1, 0, FP, LATE>, 0>}
 const WEntry kW[] = {
     WG_ENTRY("wgemm_256x128_ck32", 1, 0, 256, 128, 4, 2, 32),
     WG_ENTRY("wgemm_128x256_ck32", 2, 0, 128, 256, 2, 4, 32),
     WG_ENTRY("wgemm_128x128_ck32", 3, 0, 128, 128, 2, 4, 32),
     WG_ENTRY("wgemm_256x96_ck32", 4, 0, 256, 96, 8, 1, 32),       // conv5_x: 480 tile columns = 5 x 96, 250 tiles in one full round
+#ifdef MSCNN_WGEMM_DEV      // round 4 schedule A/B: spread flush (FP) and the late wait
+    WG_ENTRY_F("wgemm_256x128_ck32_fp4", 1, 1, 256, 128, 4, 2, 32, 4, 0),
+    WG_ENTRY_F("wgemm_256x128_ck32_fp8", 1, 2, 256, 128, 4, 2, 32, 8, 0),
+    WG_ENTRY_F("wgemm_256x128_ck32_fp4_late", 1, 3, 256, 128, 4, 2, 32, 4, 1),
+    WG_ENTRY_F("wgemm_256x128_ck32_fp2", 1, 4, 256, 128, 4, 2, 32, 2, 0),
+    WG_ENTRY_F("wgemm_256x128_ck32_fp8_late", 1, 6, 256, 128, 4, 2, 32, 8, 1),
+    WG_ENTRY_F("wgemm_256x128_ck32_late", 1, 7, 256, 128, 4, 2, 32, 1, 1),
+    WG_ENTRY_F("wgemm_128x256_ck32_fp4", 2, 1, 128, 256, 2, 4, 32, 4, 0),
+    WG_ENTRY_F("wgemm_128x256_ck32_fp2", 2, 4, 128, 256, 2, 4, 32, 2, 0),
+    WG_ENTRY_F("wgemm_128x256_ck32_fp4_late", 2, 3, 128, 256, 2, 4, 32, 4, 1),
+    WG_ENTRY_F("wgemm_128x256_ck32_fp2_late", 2, 5, 128, 256, 2, 4, 32, 2, 1),
+    WG_ENTRY_F("wgemm_256x96_ck32_fp4", 4, 1, 256, 96, 8, 1, 32, 4, 0),
+    WG_ENTRY_F("wgemm_256x96_ck32_fp4_late", 4, 3, 256, 96, 8, 1, 32, 4, 1),
+#endif
 #ifdef MSCNN_WGEMM_DEV      // schedule A/B (pieces per group, first store group)
     WG_ENTRY_S("wgemm_256x128_ck32_d2", 5, 256, 128, 4, 2, 32, 2, 0),
     WG_ENTRY_S("wgemm_256x128_ck32_d2_s3", 6, 256, 128, 4, 2, 32, 2, 3),
@@ -460,6 +520,17 @@ const WEntry kW[] = {
 
 namespace mscnn {
 
+// The persistent grid is one workgroup per CU and the stream-K hand-off needs every workgroup co-resident: take the CU count of the
+// current device (256 on an MI355X in SPX mode; fewer in a partition mode), 256 when no device is visible (planning on a CPU box).
+static int device_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  return n;
+}
+
 bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   const int variant_flags = variant >> 8;
   variant &= 255;
@@ -479,7 +550,7 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   o->BM = e->BM; o->BN = e->BN; o->CK = e->CK;
   o->T_pad = (T + e->BN - 1) / e->BN * e->BN;
   o->MT = (Cout + e->BM - 1) / e->BM; o->NT = o->T_pad / e->BN; o->KI = Cin / e->CK;
-  o->G = 256;                   // one 512-thread workgroup per CU
+  o->G = device_cus();          // one 512-thread workgroup per CU
   const long tiles = (long)P * o->MT * o->NT;
   // Whole tiles (ceil(tiles / G) rounds) or the hybrid stream-K split of the last partial round?  Fitted to the measurements of
   // profiles/r03_wgemm.txt (256 x 128 x 32 chunks: 3.7 us each at the sustained clock, ~6 us per tile for its ride-along stores,
