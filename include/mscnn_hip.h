@@ -101,7 +101,7 @@ typedef struct {
    * bit 7 = the Winograd plane GEMMs on the round-2 igemm kernel instead of wgemm.hip's, bit 8 = the scalar (host-checked)
    * F(4x4,3x3) transform kernels instead of the vectorised ones and the generic F(3x3,3x3) output transform on ROI maps instead of the LDS-staged one, bit 9 = never / bit 10 = wherever legal: proposal heads with the
    * kernel's columns folded into M (KH x 1 convolution with KW * Cout channels + shift-and-add), bit 11 = a Cin = 3 layer (conv1_1) on the MFMA igemm kernel instead of its VALU kernel, bit 12 = F(4x4,3x3) input transform with one tile per lane instead of two; tune_variant with WINO_F3_X3: 1 = 128-row, 2 = 256-row GEMM tiles;
-   * tune_variant 300 + v with a Winograd algo: wgemm tile variant v (1: 256 x 128, 2: 128 x 256, 3: 128 x 128; + 256 forces the
+   * tune_variant 300 + v with a Winograd algo: wgemm tile variant v (1: 256 x 128, 2: 128 x 256, 3: 128 x 128, 4: 256 x 96, 5: 256 x 160; + 256 forces the
    * stream-K split, + 512 whole tiles). */
   int tune_variant, tune_grid, tune_flags;
 } mscnn_conv_desc;

@@ -46,22 +46,15 @@ struct WgemmArgs {
   int full_q;                   // whole tiles per workgroup (tile slot + r G, r < full_q); the other tiles are split stream-K style
   unsigned ws_bytes;
   unsigned epoch;               // this launch's tag for the partial-sum hand-off flags (never 0, unique per launch in the process)
-  unsigned long long* dbg;      // development: per-workgroup {shader cycles, 100 MHz ticks} over the kernel (nullptr in the product)
+  unsigned long long* dbg;      // development: [G] {shader cycles, 100 MHz ticks} over the kernel, then [G] {start, end} in 100 MHz ticks (nullptr in the product)
   unsigned up_bytes, v_bytes, m_bytes;
 };
 
-template <int BM_, int BN_, int WGM_, int WGN_, int CK_, int ST_, int DPG_ = 1, int SK_ = 0, int FP_ = 1, int LATE_ = 0>
+template <int BM_, int BN_, int WGM_, int WGN_, int CK_, int ST_, int DPG_ = 1, int SK_ = 0>
 struct WCfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, CK = CK_, ST = ST_;
   // schedule knobs: LDS-DMA pieces issued per MFMA group (from group 0 on), first group that carries ride-along stores
   static constexpr int DPG = DPG_, SK = SK_;
-  // FP: the finished tile's stores ride along the first FP chunks of the next segment, 1/FP of them per chunk (round 4: all 256
-  // workgroups finish their tiles in lockstep, so with FP = 1 the chip writes a whole round of tiles -- 32 MB -- inside one 3.7 us
-  // chunk, the store queues back up and the waves stall at vmcnt's 63 outstanding operations with their MFMAs behind them);
-  // LATE: a chunk's closing wait is for the unit ONE ahead (issued a whole chunk earlier) instead of the unit two ahead it has just
-  // put in flight -- every LDS-DMA piece gets a full chunk more to land -- at the price of reading the next chunk's first operands
-  // behind the barrier instead of in front of it.
-  static constexpr int FP = FP_, LATE = LATE_;
   static constexpr int NW = WGM * WGN, THREADS = NW * 64;
   static constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
   static constexpr int A_BYTES = CK * BM * 4, B_BYTES = CK * BN * 4, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -251,13 +244,19 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     }
   wait_vm_barrier<0>();
 
-  f32x16 acc[C::MI][C::NI], old[C::MI][C::NI];
+  // Two accumulator sets (round 4).  Segment n accumulates into acc[n & 1] while the stores of segment n - 1 are issued straight from
+  // acc[(n - 1) & 1] between its MFMAs -- rounds 1-3 moved a finished tile aside first (64 v_mov + 64 zeroing moves per tile on the
+  // vector ALU the fp32 MFMA shares, and 64 more live registers in every loop that touched both copies).  All register indices stay
+  // compile-time: the segment body is instantiated once per parity.
+  f32x16 acc[2][C::MI][C::NI];
 #pragma unroll
-  for (int mi = 0; mi < C::MI; ++mi)
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni)
+    for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[mi][ni][r] = 0.f; old[mi][ni][r] = 0.f; }
+      for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][mi][ni][r] = 0.f;
   unsigned old_voff[C::MI][C::NI];      // byte offset of the finished tile's 32 x 32 blocks in M (row 0 of the block, this lane's column)
 #pragma unroll
   for (int mi = 0; mi < C::MI; ++mi)
@@ -275,12 +274,10 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   constexpr int NMF = C::MI * C::NI;                      // MFMAs per group
   // ride-along stores of a finished tile: TOTAL of them over the groups SK .. STEPS-1, spread over a group's MFMAs
   constexpr int TOTAL = NMF * 16;
-  static_assert(TOTAL % C::FP == 0, "flush parts");
-  constexpr int TOTP = TOTAL / C::FP;                                            // ... of them per flush chunk (part f: elements f TOTP ..)
-  constexpr int SPG = (TOTP + (C::STEPS - C::SK) - 1) / (C::STEPS - C::SK);      // per group
+  constexpr int SPG = (TOTAL + (C::STEPS - C::SK) - 1) / (C::STEPS - C::SK);     // per group
   constexpr int SPM = (SPG + NMF - 1) / NMF;                                     // per MFMA
   constexpr int DMA_GROUPS = (C::NP + C::DPG - 1) / C::DPG;                      // groups 0 .. DMA_GROUPS-1 carry the unit's pieces
-  static_assert(C::DPG <= NMF && DMA_GROUPS <= C::STEPS && C::SK < C::STEPS && C::STEPS % 2 == 0, "schedule");
+  static_assert(C::DPG <= NMF && DMA_GROUPS <= C::STEPS && C::SK < C::STEPS, "schedule");
   // stores issued behind a chunk's last piece (piece NP-1 sits behind MFMA (NP-1) % DPG of group DMA_GROUPS-1, after that slot's stores)
   constexpr int AFTER_DMA = [] {
     int n = 0;
@@ -289,7 +286,7 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
         if (g < C::SK) continue;
         const int lo = (g - C::SK) * SPG + j * SPM, hi_g = (g - C::SK + 1) * SPG;
         int cnt = 0;
-        for (int k = lo; k < lo + SPM && k < hi_g && k < TOTP; ++k) ++cnt;
+        for (int k = lo; k < lo + SPM && k < hi_g && k < TOTAL; ++k) ++cnt;
         const bool after = g > DMA_GROUPS - 1 || (g == DMA_GROUPS - 1 && j > (C::NP - 1) % C::DPG);
         if (after) n += cnt;
       }
@@ -302,28 +299,29 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   unsigned c_addr = lds0;                                 // LDS address of the stage being multiplied
   WG_READ(0, c_addr, 0);
 
-  auto store_one = [&](auto ec) {                        // element e of the flushed tile: block (e / 16), register e % 16
-    constexpr int e = decltype(ec)::value;
+  // element e of the finished segment (accumulator set Q): block (e / 16), register e % 16
+  auto store_one = [&](auto qc, auto ec) {
+    constexpr int Q = decltype(qc)::value, e = decltype(ec)::value;
     constexpr int blk = e / 16, r = e % 16, mi = blk / C::NI, ni = blk % C::NI, dr = (r & 3) + 8 * (r >> 2);
-    const float v = old[mi][ni][r];
+    const float v = acc[Q][mi][ni][r];
     // (a partial sum bound for another workgroup is stored write-through -- sc1 -- so that the flag that follows needs no L2
     // write-back; the branch is wave-uniform)
     if (old_pub) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 16);
     else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 0);
   };
 
-  // one chunk = STEPS MFMA groups.  PART >= 0: part PART of the previous segment's stores rides along (SPM per MFMA); DMA: this chunk
-  // carries the NP pieces of the unit two ahead.
-  auto chunk = [&](auto part_c, unsigned next_addr) {
-    constexpr int PART = decltype(part_c)::value;
-    constexpr bool FLUSH = PART >= 0;
+  // one chunk = STEPS MFMA groups accumulating into set PAR.  FLUSH: the previous segment's stores (set PAR ^ 1) ride along (SPM per
+  // MFMA); DMA: this chunk carries the NP pieces of the unit two ahead.
+  auto chunk = [&](auto par_c, auto flush_c, unsigned next_addr) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr bool FLUSH = decltype(flush_c)::value;
     p_begin();
     static_for<0, C::STEPS>([&](auto sc) {
       constexpr int s = decltype(sc)::value, cur = s & 1, nxt = cur ^ 1;
       if constexpr (!(ABL & 8)) {
-        if constexpr (s + 1 < C::STEPS) { WG_READ(nxt, c_addr, s + 1) lds_wait<NR>(); }
-        else if constexpr (!C::LATE) { WG_READ(nxt, next_addr, 0) lds_wait<NR>(); }
-        else lds_wait<0>();                               // (LATE: the next chunk's first operands are read behind the barrier)
+        if constexpr (s + 1 < C::STEPS) WG_READ(nxt, c_addr, s + 1)
+        else WG_READ(nxt, next_addr, 0)
+        lds_wait<NR>();
       }
 #pragma unroll
       for (int mi = 0; mi < C::MI; ++mi) lds_pin(av[cur][mi]);
@@ -332,13 +330,13 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, NMF>([&](auto jc) {
         constexpr int j = decltype(jc)::value, mi = j / C::NI, ni = j % C::NI;
-        if constexpr (!(ABL & 4)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi], bv[cur][ni], acc[mi][ni], 0, 0, 0);
+        if constexpr (!(ABL & 4)) acc[PAR][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi], bv[cur][ni], acc[PAR][mi][ni], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (FLUSH && s >= C::SK) {
           if constexpr (!(ABL & 2))
             static_for<0, SPM>([&](auto kc_) {
               constexpr int e = (s - C::SK) * SPG + j * SPM + decltype(kc_)::value;
-              if constexpr (e < (s - C::SK + 1) * SPG && e < TOTP) store_one(std::integral_constant<int, (FLUSH ? PART : 0) * TOTP + e>{});
+              if constexpr (e < (s - C::SK + 1) * SPG && e < TOTAL) store_one(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, e>{});
             });
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -349,26 +347,12 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
       });
     });
     p_end();
-    if constexpr (ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (C::LATE && !(ABL & 3)) {
-      // the unit ONE ahead must have landed: everything this wave issued before this chunk's own NP pieces and stores (in-order
-      // retirement; the previous chunk's trailing stores are waited for as well -- stricter than needed, they are a chunk old)
-      constexpr int LEFT = C::NP + (FLUSH ? TOTP : 0);
-      wait_vm_barrier<(LEFT < 63 ? LEFT : 63)>();
-      if constexpr (!(ABL & 8)) WG_READ(0, next_addr, 0)
-    }
     // this wave's pieces of the unit two ahead have landed; the stores of a flushed tile issued behind the last piece may still
     // be in flight (the hardware's vmcnt field holds 63)
+    if constexpr (ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (FLUSH) wait_vm_barrier<(AFTER_DMA < 63 ? AFTER_DMA : 63)>();
     else wait_vm_barrier<0>();
     c_addr = next_addr;
-  };
-  auto store_part = [&](auto part_c) {                   // part PART of the flushed segment at once (segments shorter than FP chunks)
-    constexpr int PART = decltype(part_c)::value;
-    if constexpr (!(ABL & 2)) static_for<0, TOTP>([&](auto ec) { store_one(std::integral_constant<int, PART * TOTP + decltype(ec)::value>{}); });
-  };
-  auto with_part = [&](int part, auto&& f) {             // run f(integral_constant<part>) for a wave-uniform run-time part < FP
-    static_for<0, C::FP>([&](auto pc) { if (part == decltype(pc)::value) f(pc); });
   };
 
   int c_stage = 0;
@@ -385,24 +369,16 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (tid == 0) __hip_atomic_store(flags + slot, want_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  while (ccur.next(t, k0, k1, part)) {
-    // the previous segment's stores ride along this segment's first FP chunks, one part per chunk (segment 0: `old` is empty, its
-    // offsets out of range); a partial sum is published once its last part has been issued
-    int done = 0;
-    for (int kc = k0; kc < k1; ++kc) {
-      const unsigned na = next_stage_addr();
-      if (done < C::FP) {
-        with_part(done, [&](auto pc) { chunk(pc, na); });
-        if (++done == C::FP && old_pub) { publish_flag(); old_pub = false; }
-      } else {
-        chunk(std::integral_constant<int, -1>{}, na);
-      }
-    }
-    for (; done < C::FP; ++done) with_part(done, [&](auto pc) { store_part(pc); });      // (a stream-K piece shorter than FP chunks)
+  // one segment on accumulator set PAR: its first chunk carries the previous segment's stores (segment 0: that set is empty and its
+  // offsets are out of range); afterwards the flushed set is cleared for the segment after this one, and this segment's destination --
+  // whole tile -> M; partial without the tile's first chunk -> this workgroup's slab, published for the workgroup that has it;
+  // partial WITH the first chunk (always the last segment) -> M, after the other contributors' slabs have been added (below) --
+  // becomes the pending flush.
+  auto segment = [&](auto par_c) {
+    constexpr int PAR = decltype(par_c)::value;
+    chunk(par_c, std::true_type{}, next_stage_addr());
     if (old_pub) { publish_flag(); old_pub = false; }
-    // ---- segment done: move its accumulators aside.  Whole tile -> M.  Partial without the tile's first chunk -> this
-    // workgroup's slab, published for the workgroup that has it.  Partial WITH the first chunk (always the last segment) -> M,
-    // after the other contributors' slabs have been added (below). ----
+    for (int kc = k0 + 1; kc < k1; ++kc) chunk(par_c, std::false_type{}, next_stage_addr());
     const int mt = t % a.MT, nt = (t / a.MT) % a.NT, p = t / (a.MT * a.NT);
     const bool pub = part >= 0 && k0 > 0;
     if (part >= 0 && k0 == 0) fin_tile = t;
@@ -420,54 +396,73 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
         const unsigned to_ws = slab + (unsigned)((row + 4 * khalf) * C::BN + col) * 4u;
         old_voff[mi][ni] = pub ? to_ws : to_m;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { old[mi][ni][r] = acc[mi][ni][r]; acc[mi][ni][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc[PAR ^ 1][mi][ni][r] = 0.f;      // (its stores were issued during this segment's first chunk)
       }
+  };
+  int par = 0;                           // accumulator set of the NEXT segment (the last one computed sits in par ^ 1)
+  while (true) {
+    if (!ccur.next(t, k0, k1, part)) break;
+    segment(std::integral_constant<int, 0>{});
+    par = 1;
+    if (!ccur.next(t, k0, k1, part)) break;
+    segment(std::integral_constant<int, 1>{});
+    par = 0;
   }
-  if (fin_tile >= 0) {
-    // ---- finish the split tile whose first chunks this workgroup computed: add the other contributors' slabs in k order (the
-    // workgroups slot + 1, slot + 2, ... until the tile's chunks are covered; each published its part as ITS first remainder
-    // segment, i.e. earlier in time).  Deterministic: the order of the additions is fixed. ----
-    const int rem_tile0 = a.full_q * a.G, RU = (a.tiles - rem_tile0) * a.KI;
-    const int tile_end = (fin_tile - rem_tile0 + 1) * a.KI;
-    for (int s2 = slot + 1; s2 < a.G; ++s2) {
-      int b, e;
-      wg_range(RU, a.G, s2, b, e);
-      if (b >= tile_end) break;
-      if (e <= b) continue;
-      if (tid == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(flags + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_flag && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
-        // hand-off timed out (the contributor is not co-resident: CU masking, a shared GPU): never a silently wrong tile -- the status
-        // word is set and the whole tile is stored as NaN, which every downstream check (the layer's first-forward check, the numerics
-        // watch, any parity test) fails on, and the self-check answers by putting the layer on the direct kernel
-        s_handoff_timeout = spins >= (1u << 22) ? 1u : 0u;
-        if (spins >= (1u << 22)) __hip_atomic_store(flags + a.G, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      __syncthreads();
-      const bool poisoned = s_handoff_timeout != 0;
-      const unsigned sl2 = (unsigned)s2 * (unsigned)(C::BM * C::BN * 4);
-#pragma unroll
-      for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < C::NI; ++ni) {
-          const unsigned vo = sl2 + (unsigned)((wm * C::WM + mi * 32 + 4 * khalf) * C::BN + wn * C::WN + ni * 32 + l31) * 4u;
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            old[mi][ni][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)(C::BN * 4), 0));
-          if (poisoned)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) old[mi][ni][r] = __builtin_nanf("");
+  // the last segment sits in set par ^ 1
+  auto finish = [&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    if (fin_tile >= 0) {
+      // ---- finish the split tile whose first chunks this workgroup computed: add the other contributors' slabs in k order (the
+      // workgroups slot + 1, slot + 2, ... until the tile's chunks are covered; each published its part as ITS first remainder
+      // segment, i.e. earlier in time).  Deterministic: the order of the additions is fixed. ----
+      const int rem_tile0 = a.full_q * a.G, RU = (a.tiles - rem_tile0) * a.KI;
+      const int tile_end = (fin_tile - rem_tile0 + 1) * a.KI;
+      for (int s2 = slot + 1; s2 < a.G; ++s2) {
+        int b, e;
+        wg_range(RU, a.G, s2, b, e);
+        if (b >= tile_end) break;
+        if (e <= b) continue;
+        if (tid == 0) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(flags + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_flag && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
+          // hand-off timed out (the contributor is not co-resident: CU masking, a shared GPU): never a silently wrong tile -- the status
+          // word is set and the whole tile is stored as NaN, which every downstream check (the layer's first-forward check, the numerics
+          // watch, any parity test) fails on, and the self-check answers by putting the layer on the direct kernel
+          s_handoff_timeout = spins >= (1u << 22) ? 1u : 0u;
+          if (spins >= (1u << 22)) __hip_atomic_store(flags + a.G, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-      __syncthreads();                                     // (s_handoff_timeout is rewritten for the next contributor)
+        __syncthreads();
+        const bool poisoned = s_handoff_timeout != 0;
+        const unsigned sl2 = (unsigned)s2 * (unsigned)(C::BM * C::BN * 4);
+#pragma unroll
+        for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < C::NI; ++ni) {
+            const unsigned vo = sl2 + (unsigned)((wm * C::WM + mi * 32 + 4 * khalf) * C::BN + wn * C::WN + ni * 32 + l31) * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              acc[Q][mi][ni][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)(C::BN * 4), 0));
+            if (poisoned)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[Q][mi][ni][r] = __builtin_nanf("");
+            __builtin_amdgcn_sched_barrier(0);      // one 32 x 32 block's 16 loads in flight at a time
+          }
+        __syncthreads();                                     // (s_handoff_timeout is rewritten for the next contributor)
+      }
     }
-  }
-  // the last tile's stores
-  if (!(ABL & 2) || a.tiles < 0) static_for<0, NMF * 16>([&](auto ec) { store_one(ec); });      // (ablation builds keep the MFMAs alive)
+    // the last tile's stores
+    if (!(ABL & 2) || a.tiles < 0) static_for<0, NMF * 16>([&](auto ec) { store_one(qc, ec); });      // (ablation builds keep the MFMAs alive)
+  };
+  if (par == 1) finish(std::integral_constant<int, 0>{});
+  else finish(std::integral_constant<int, 1>{});
   if (old_pub) publish_flag();
   if (a.dbg && tid == 0) {
+    const unsigned long long end_r = __builtin_amdgcn_s_memrealtime();
     a.dbg[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - dbg_c;
-    a.dbg[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - dbg_r;
+    a.dbg[blockIdx.x * 2 + 1] = end_r - dbg_r;
+    a.dbg[2 * a.G + blockIdx.x * 2] = dbg_r;              // absolute start / end (100 MHz): launch stagger and drain of the grid
+    a.dbg[2 * a.G + blockIdx.x * 2 + 1] = end_r;
   }
 }
 
@@ -475,27 +470,12 @@ typedef void (*WgemmFn)(WgemmArgs);
 struct WEntry { const char* name; int variant, abl, BM, BN, CK, threads; WgemmFn fn; };
 #define WG_ENTRY(name, v, abl, BM, BN, WGM, WGN, CK) {name, v, abl, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3>, abl>}
 #define WG_ENTRY_S(name, v, BM, BN, WGM, WGN, CK, DPG, SK) {name, v, 0, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3, DPG, SK>, 0>}
-// schedule variants (round 4): variant = tile shape + 16 * schedule; schedule 1: FP 4, 2: FP 8, 3: FP 4 + LATE, 4: FP 2, 5: FP 2 + LATE, 6: FP 8 + LATE, 7: FP 1 + LATE
-#define WG_ENTRY_F(name, v, sch, BM, BN, WGM, WGN, CK, FP, LATE) {name, v + 16 * sch, 0, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3, 1, 0, FP, LATE>, 0>}
 const WEntry kW[] = {
     WG_ENTRY("wgemm_256x128_ck32", 1, 0, 256, 128, 4, 2, 32),
     WG_ENTRY("wgemm_128x256_ck32", 2, 0, 128, 256, 2, 4, 32),
     WG_ENTRY("wgemm_128x128_ck32", 3, 0, 128, 128, 2, 4, 32),
     WG_ENTRY("wgemm_256x96_ck32", 4, 0, 256, 96, 8, 1, 32),       // conv5_x: 480 tile columns = 5 x 96, 250 tiles in one full round
-#ifdef MSCNN_WGEMM_DEV      // round 4 schedule A/B: spread flush (FP) and the late wait
-    WG_ENTRY_F("wgemm_256x128_ck32_fp4", 1, 1, 256, 128, 4, 2, 32, 4, 0),
-    WG_ENTRY_F("wgemm_256x128_ck32_fp8", 1, 2, 256, 128, 4, 2, 32, 8, 0),
-    WG_ENTRY_F("wgemm_256x128_ck32_fp4_late", 1, 3, 256, 128, 4, 2, 32, 4, 1),
-    WG_ENTRY_F("wgemm_256x128_ck32_fp2", 1, 4, 256, 128, 4, 2, 32, 2, 0),
-    WG_ENTRY_F("wgemm_256x128_ck32_fp8_late", 1, 6, 256, 128, 4, 2, 32, 8, 1),
-    WG_ENTRY_F("wgemm_256x128_ck32_late", 1, 7, 256, 128, 4, 2, 32, 1, 1),
-    WG_ENTRY_F("wgemm_128x256_ck32_fp4", 2, 1, 128, 256, 2, 4, 32, 4, 0),
-    WG_ENTRY_F("wgemm_128x256_ck32_fp2", 2, 4, 128, 256, 2, 4, 32, 2, 0),
-    WG_ENTRY_F("wgemm_128x256_ck32_fp4_late", 2, 3, 128, 256, 2, 4, 32, 4, 1),
-    WG_ENTRY_F("wgemm_128x256_ck32_fp2_late", 2, 5, 128, 256, 2, 4, 32, 2, 1),
-    WG_ENTRY_F("wgemm_256x96_ck32_fp4", 4, 1, 256, 96, 8, 1, 32, 4, 0),
-    WG_ENTRY_F("wgemm_256x96_ck32_fp4_late", 4, 3, 256, 96, 8, 1, 32, 4, 1),
-#endif
+    WG_ENTRY("wgemm_256x160_ck32", 5, 0, 256, 160, 8, 1, 32),     // conv4_x F(4x4,3x3): 1080 columns = 6.75 x 160 -> 504 tiles = 1.97 rounds (r4)
 #ifdef MSCNN_WGEMM_DEV      // schedule A/B (pieces per group, first store group)
     WG_ENTRY_S("wgemm_256x128_ck32_d2", 5, 256, 128, 4, 2, 32, 2, 0),
     WG_ENTRY_S("wgemm_256x128_ck32_d2_s3", 6, 256, 128, 4, 2, 32, 2, 3),
@@ -536,11 +516,18 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   variant &= 255;
   if (variant == 0) {
     variant = Cout >= 256 ? 1 : 2;
-    // 256 x 96 tiles where the model below says their tile count fits the 256 CUs better than 256 x 128 (conv5_x of the 7s-576 net:
-    // 480 columns = 250 tiles in one full round instead of 200 tiles of 512 padded columns; measured 72 -> see DESIGN.md)
+    // the other 256-row tile shapes where the model below says their tile count fits the CUs better than 256 x 128 (>= 5 %):
+    //   256 x 96  -- conv5_x of the 7s-576 net: 480 columns = 250 tiles in one full round instead of 200 tiles of 512 padded columns (r3);
+    //   256 x 160 -- conv4_x / loss1_conv1 in the F(4x4,3x3) form: 1080 columns = 7 x 160 (3.7 % padding) -> 504 tiles = two nearly full
+    //                rounds of whole tiles, instead of 648 tiles of 128 (6.7 % padding) = 2.53 rounds with a stream-K hand-off (r4).
+    // (the three share BM = 256, i.e. one packed-weight layout: a per-frame ROI count may flip the choice without a re-pack)
     if (variant == 1 && !variant_flags) {
-      WgemmPlan p1, p4;
-      if (wgemm_plan(P, Cout, Cin, T, 1, &p1) && wgemm_plan(P, Cout, Cin, T, 4, &p4) && p4.model_us < 0.95 * p1.model_us) variant = 4;
+      WgemmPlan p1, pc;
+      if (wgemm_plan(P, Cout, Cin, T, 1, &p1)) {
+        double best = 0.95 * p1.model_us;
+        for (int cand : {4, 5})
+          if (wgemm_plan(P, Cout, Cin, T, cand, &pc) && pc.model_us < best) { best = pc.model_us; variant = cand; }
+      }
     }
   }
   const WEntry* e = nullptr;

@@ -163,13 +163,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 //
 // fp32 error of this form is ~10x that of the direct sum (measured 1.2e-5 x layer scale at Cin = 1024, against 1.3e-6
 // direct and the 1e-4 parity bound); MSCNN_WINOGRAD=0 selects the direct ROI-mode kernel instead.
-__device__ __forceinline__ void bt5(const float d[5], float r[5]) {
-  r[0] = 2.f * d[0] - d[1] - 2.f * d[2] + d[3];
-  r[1] = -2.f * d[1] - d[2] + d[3];
-  r[2] = 2.f * d[1] - 3.f * d[2] + d[3];
-  r[3] = d[3] - d[1];
-  r[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-}
+using mscnn::bt5;      // (wino33_device.h: shared with the fused ROI-pooling input stage)
 
 __global__ __launch_bounds__(256) void wino33_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
                                                             int BM, int CK, int MT, int KI) {

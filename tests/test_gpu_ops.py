@@ -404,6 +404,16 @@ def test_wgemm_plane_gemm_against_the_igemm_kernel(hip, case):
     y_96s, p96s = run(300 + 4 + 256, 0)
     assert rel(y_96s, y_whole) < tol
     assert torch.equal(p96s.forward(x, b), y_96s)
+    # the 256 x 160 tile (variant 5, round 4: 20 pieces of B on 8 waves, 8 x 1 waves of 32 x 160): same chains, same contract
+    y_160, p160 = run(300 + 5 + 512, 0)
+    assert p160.kernel.startswith(f"winograd_f{m}x{m}")
+    if Cin >= 128:
+        assert torch.equal(y_160, y_ig)
+    else:
+        assert rel(y_160, y_ig) < tol
+    y_160s, p160s = run(300 + 5 + 256, 0)
+    assert rel(y_160s, y_whole) < tol
+    assert torch.equal(p160s.forward(x, b), y_160s)
 
 
 @pytest.mark.parametrize("case", [(1, 32, 24, 64, 48), (2, 16, 36, 260, 32), (1, 64, 72, 240, 64), (1, 8, 10, 512, 16), (1, 24, 13, 28, 40)])

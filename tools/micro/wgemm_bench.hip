@@ -88,11 +88,21 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   unsigned long long* dbg; CK(hipMalloc(&dbg, 4096 * 16)); CK(hipMemset(dbg, 0, 4096 * 16));
+  mscnn::wgemm_launch(pl, Up, V, M, ws, nullptr, abl);
+  mscnn::wgemm_launch(pl, Up, V, M, ws, nullptr, abl);
+  CK(hipEventRecord(e0));
   mscnn::wgemm_launch(pl, Up, V, M, ws, nullptr, abl, dbg);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms1; CK(hipEventElapsedTime(&ms1, e0, e1));
   CK(hipDeviceSynchronize());
-  std::vector<unsigned long long> hd(pl.G * 2); CK(hipMemcpy(hd.data(), dbg, pl.G * 16, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> hd(pl.G * 4); CK(hipMemcpy(hd.data(), dbg, pl.G * 32, hipMemcpyDeviceToHost));
   double cyc = 0, tick = 0; for (int g = 0; g < pl.G; ++g) { cyc = std::max(cyc, (double)hd[2 * g]); tick = std::max(tick, (double)hd[2 * g + 1]); }
   printf("   longest workgroup: %.0f shader cycles in %.1f us = %.0f MHz\n", cyc, tick / 100.0, cyc / (tick / 100.0));
+  {
+    unsigned long long s0 = ~0ull, s1 = 0, e0_ = ~0ull, e1_ = 0;
+    for (int g = 0; g < pl.G; ++g) { const unsigned long long a_ = hd[2 * pl.G + 2 * g], b_ = hd[2 * pl.G + 2 * g + 1]; if (!a_) continue; s0 = std::min(s0, a_); s1 = std::max(s1, a_); e0_ = std::min(e0_, b_); e1_ = std::max(e1_, b_); }
+    printf("   grid: starts spread over %.1f us, ends over %.1f us, first start -> last end %.1f us; this launch by events %.1f us\n", (s1 - s0) / 100.0, (e1_ - e0_) / 100.0, (e1_ - s0) / 100.0, ms1 * 1e3);
+  }
   const double us = ms * 1e3 / iters;
   const double fl = 2.0 * P * Cout * (double)Cin * T, flp = 2.0 * P * pl.MT * pl.BM * (double)Cin * pl.NT * pl.BN;
   printf("P=%d Cout=%d Cin=%d T=%d(T_pad %d) variant=%d %s abl=%d: tiles %d grid %d  %.1f us  %.1f TFLOP/s real (%.3f of 157.3), %.1f incl. padding\n", P, Cout, Cin,
