@@ -240,6 +240,20 @@ MSCNN_API int mscnn_roipool_pair_fwd_f32(const float* feat, const float* rois, f
                                          int pooled_h, int pooled_w, float spatial_scale, float pad_ratio_a, int c_offset_a,
                                          float pad_ratio_b, int c_offset_b, int C_total, void* stream);
 
+/* The detection sub-net's entry fused: ROIPooling x 2 (roi_pooling_layer.cu:19-104, pad_ratio_a -> channels [0, C), pad_ratio_b ->
+ * channels [C, 2C) of the concatenated blob, concat_layer.cu:28-46) + the 3x3 convolution that consumes it (roi_c1; conv_layer.cu:8-23)
+ * in its Winograd F(3x3,3x3) form: the pooled values go straight into the transform planes of the plane GEMM; the R x 2C x 7 x 7 blob
+ * between the layers (140 MB per 7s-576 frame) is neither written nor read.  `plan` = the convolution's plan (N = R ROIs, Cin = 2C,
+ * H x W = pooled_h x pooled_w); y = its output, bit-identical to mscnn_roipool_pair_fwd_f32 followed by mscnn_conv2d_fwd_f32.
+ *   _can_fuse_roipool: 1 when the plan's kernel family and shape take this path (fp32 F(3x3,3x3), 7 x 7 bins, pad 0, C % 64 == 0);
+ *   _roipool_workspace_bytes: workspace of the fused call (the plan's own + a channel-last copy of the feature map). */
+MSCNN_API int mscnn_conv2d_plan_can_fuse_roipool(const mscnn_conv_plan* plan, int C, int pooled_h, int pooled_w);
+MSCNN_API size_t mscnn_conv2d_roipool_workspace_bytes(const mscnn_conv_plan* plan, int N, int C, int H, int W);
+MSCNN_API int mscnn_conv2d_fwd_roipool_pair_f32(const mscnn_conv_plan* plan, const float* feat, int N, int C, int H, int W,
+                                                const float* rois, float spatial_scale, float pad_ratio_a, float pad_ratio_b,
+                                                const float* packed_w, const float* bias, float* y, void* workspace,
+                                                size_t workspace_bytes, void* stream);
+
 /* ROIAlign -- ROIAlignLayer<Dtype>::Forward_gpu (roi_align_layer.cu:21-112): out[R][C][pooled_h+1][pooled_w+1] bilinear
  * samples on the grid of the (context-padded) roi; the WiderFace cascade deploy follows it with a 2x2 stride-1 AVE Pooling. */
 MSCNN_API int mscnn_roialign_fwd_f32(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W,

@@ -33,6 +33,7 @@
 #include "winograd.h"
 #include "wino_x3.h"
 #include "wgemm.h"
+#include "roipool_wino.h"
 #include "conv_c3.h"
 #include "x3_device.h"
 #include <new>
@@ -1542,6 +1543,40 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
   return mscnn_conv2d_fwd_pool_f32(p, x, w, packed, bias, y, nullptr, workspace, workspace_bytes, stream);
 }
 
+// The fp32 Winograd path: {input stage -> V | plane GEMM V -> M | output transform M -> y}; the input stage is the plan's own
+// transform of x, or the fused ROI pooling (mscnn_conv2d_fwd_roipool_pair_f32).
+template <class InputStage>
+static int wino_forward(const mscnn_conv_plan* p, const float* packed, const float* bias, float* y, float* y_pool, void* workspace,
+                        size_t workspace_bytes, hipStream_t st, InputStage&& input_stage) {
+  const mscnn_conv_desc& d = p->d;
+#define MSCNN_STAGE_EVENT(i) do { if (p->profiling) MSCNN_HIP_TRY(hipEventRecord(p->ev[i], st)); } while (0)
+  MSCNN_REQUIRE(packed, "conv: Winograd path needs packed weights (mscnn_conv2d_pack_weights)");
+  if (!workspace || workspace_bytes < p->ws_bytes) {
+    set_error("conv(winograd): workspace %zu < %zu", workspace_bytes, p->ws_bytes);
+    return MSCNN_ERR_WORKSPACE;
+  }
+  const mscnn_conv_plan* g = p->wino;
+  const size_t planes = (size_t)(p->wino_m + 2) * (p->wino_m + 2);
+  float* V = static_cast<float*>(workspace);
+  float* M = V + planes * d.Cin * p->T_pad;
+  float* gws = M + planes * d.Cout * p->T_pad;
+  MSCNN_STAGE_EVENT(0);
+  int rc = input_stage(V);
+  if (rc != MSCNN_OK) return rc;
+  MSCNN_STAGE_EVENT(1);
+  if (p->use_wg) rc = mscnn::wgemm_launch(p->wg, packed, V, M, gws, st);
+  else rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
+  if (rc != MSCNN_OK) return rc;
+  MSCNN_STAGE_EVENT(2);
+  rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st,
+                             p->wino_m >= 3 ? p->amax_out : nullptr, (d.tune_flags & 256) != 0);
+  if (rc != MSCNN_OK) return rc;
+  MSCNN_STAGE_EVENT(3);
+  p->ev_valid = p->profiling;
+  return MSCNN_OK;
+#undef MSCNN_STAGE_EVENT
+}
+
 extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* x, const float* w, const float* packed,
                                          const float* bias, float* y, float* y_pool, void* workspace, size_t workspace_bytes,
                                          void* stream) {
@@ -1586,34 +1621,42 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
     p->ev_valid = p->profiling;
     return MSCNN_OK;
   }
-  {
-    MSCNN_REQUIRE(packed, "conv: Winograd path needs packed weights (mscnn_conv2d_pack_weights)");
-    if (!workspace || workspace_bytes < p->ws_bytes) {
-      set_error("conv(winograd): workspace %zu < %zu", workspace_bytes, p->ws_bytes);
-      return MSCNN_ERR_WORKSPACE;
-    }
-    const mscnn_conv_plan* g = p->wino;
-    const size_t planes = (size_t)(p->wino_m + 2) * (p->wino_m + 2);
-    float* V = static_cast<float*>(workspace);
-    float* M = V + planes * d.Cin * p->T_pad;
-    float* gws = M + planes * d.Cout * p->T_pad;
-    MSCNN_STAGE_EVENT(0);
-    int rc = wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st,
-                                  (d.tune_flags & 256) != 0, (d.tune_flags & 4096) != 0);
-    if (rc != MSCNN_OK) return rc;
-    MSCNN_STAGE_EVENT(1);
-    if (p->use_wg) rc = mscnn::wgemm_launch(p->wg, packed, V, M, gws, st);
-    else rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
-    if (rc != MSCNN_OK) return rc;
-    MSCNN_STAGE_EVENT(2);
-    rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st,
-                               p->wino_m >= 3 ? p->amax_out : nullptr, (d.tune_flags & 256) != 0);
-    if (rc != MSCNN_OK) return rc;
-    MSCNN_STAGE_EVENT(3);
-    p->ev_valid = p->profiling;
-    return MSCNN_OK;
-  }
+  return wino_forward(p, packed, bias, y, y_pool, workspace, workspace_bytes, st, [&](float* V) {
+    return wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st,
+                                (d.tune_flags & 256) != 0, (d.tune_flags & 4096) != 0);
+  });
 #undef MSCNN_STAGE_EVENT
+}
+
+
+extern "C" int mscnn_conv2d_plan_can_fuse_roipool(const mscnn_conv_plan* p, int C, int pooled_h, int pooled_w) {
+  return p && p->wino && p->wino_m == 3 && !p->x3.BM && p->d.N > 0 && p->d.Cin == 2 * C && p->d.H == pooled_h && p->d.W == pooled_w &&
+                 p->tiles_h == 2 && p->tiles_w == 2 && p->d.Kh == 3 && p->d.Kw == 3 &&
+                 mscnn::roipool_wino33_supported(C, pooled_h, pooled_w, p->d.pad_h, p->d.pad_w)
+             ? 1 : 0;
+}
+static size_t roipool_scratch_offset(const mscnn_conv_plan* p) { return (p->ws_bytes + 255) / 256 * 256; }
+extern "C" size_t mscnn_conv2d_roipool_workspace_bytes(const mscnn_conv_plan* p, int N, int C, int H, int W) {
+  return p ? roipool_scratch_offset(p) + mscnn::roipool_wino33_scratch_bytes(N, C, H, W) : 0;
+}
+extern "C" int mscnn_conv2d_fwd_roipool_pair_f32(const mscnn_conv_plan* p, const float* feat, int N, int C, int H, int W,
+                                                 const float* rois, float spatial_scale, float pad_ratio_a, float pad_ratio_b,
+                                                 const float* packed, const float* bias, float* y, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+  MSCNN_REQUIRE(p, "conv: null plan");
+  if (p->d.N == 0) return MSCNN_OK;
+  MSCNN_REQUIRE(feat && rois && y && N > 0 && H > 0 && W > 0, "conv(roipool): bad argument");
+  MSCNN_REQUIRE(mscnn_conv2d_plan_can_fuse_roipool(p, C, p->d.H, p->d.W), "conv(roipool): this plan does not take the fused ROI-pooling input stage");
+  const size_t need = mscnn_conv2d_roipool_workspace_bytes(p, N, C, H, W);
+  if (!workspace || workspace_bytes < need) {
+    set_error("conv(roipool): workspace %zu < %zu", workspace_bytes, need);
+    return MSCNN_ERR_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  float* featT = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + roipool_scratch_offset(p));
+  return wino_forward(p, packed, bias, y, nullptr, workspace, workspace_bytes, st, [&](float* V) {
+    return mscnn::roipool_wino33_forward(feat, featT, rois, V, p->d.N, N, C, H, W, p->T_pad, spatial_scale, pad_ratio_a, pad_ratio_b, st);
+  });
 }
 
 // Head / direct / igemm forward (everything except the three-stage Winograd path).

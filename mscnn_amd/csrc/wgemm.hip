@@ -446,7 +446,6 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
             if (poisoned)
 #pragma unroll
               for (int r = 0; r < 16; ++r) acc[Q][mi][ni][r] = __builtin_nanf("");
-            __builtin_amdgcn_sched_barrier(0);      // one 32 x 32 block's 16 loads in flight at a time
           }
         __syncthreads();                                     // (s_handoff_timeout is rewritten for the next contributor)
       }
@@ -477,10 +476,10 @@ const WEntry kW[] = {
     WG_ENTRY("wgemm_256x96_ck32", 4, 0, 256, 96, 8, 1, 32),       // conv5_x: 480 tile columns = 5 x 96, 250 tiles in one full round
     WG_ENTRY("wgemm_256x160_ck32", 5, 0, 256, 160, 8, 1, 32),     // conv4_x F(4x4,3x3): 1080 columns = 6.75 x 160 -> 504 tiles = 1.97 rounds (r4)
 #ifdef MSCNN_WGEMM_DEV      // schedule A/B (pieces per group, first store group)
-    WG_ENTRY_S("wgemm_256x128_ck32_d2", 5, 256, 128, 4, 2, 32, 2, 0),
-    WG_ENTRY_S("wgemm_256x128_ck32_d2_s3", 6, 256, 128, 4, 2, 32, 2, 3),
-    WG_ENTRY_S("wgemm_256x128_ck32_d3_s2", 7, 256, 128, 4, 2, 32, 3, 2),
-    WG_ENTRY_S("wgemm_256x128_ck32_d1_s6", 8, 256, 128, 4, 2, 32, 1, 6),
+    WG_ENTRY_S("wgemm_256x128_ck32_d2", 25, 256, 128, 4, 2, 32, 2, 0),
+    WG_ENTRY_S("wgemm_256x128_ck32_d2_s3", 26, 256, 128, 4, 2, 32, 2, 3),
+    WG_ENTRY_S("wgemm_256x128_ck32_d3_s2", 27, 256, 128, 4, 2, 32, 3, 2),
+    WG_ENTRY_S("wgemm_256x128_ck32_d1_s6", 28, 256, 128, 4, 2, 32, 1, 6),
 #endif
 #ifdef MSCNN_WGEMM_DEV      // development ablations (tools/micro/wgemm_bench.hip): bit 0 no loads, 1 no stores, 2 no MFMAs, 3 no LDS reads, 4 no barriers
     WG_ENTRY("wgemm_256x128_ck32", 1, 1, 256, 128, 4, 2, 32),

@@ -19,6 +19,7 @@
 // plane is read / written as contiguous runs.
 #include "winograd.h"
 #include "x3_device.h"
+#include "wino33_device.h"
 #include "wino_f4_math.h"
 #include <cstdint>
 

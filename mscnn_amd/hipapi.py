@@ -91,6 +91,11 @@ def lib():
         L.mscnn_conv2d_fwd_f32.argtypes = [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]
         L.mscnn_conv2d_fwd_pool_f32.argtypes = [C.c_void_p] * 8 + [C.c_size_t, C.c_void_p]
         L.mscnn_conv2d_plan_can_pool.argtypes = [C.c_void_p]
+        L.mscnn_conv2d_plan_can_fuse_roipool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mscnn_conv2d_roipool_workspace_bytes.restype = C.c_size_t
+        L.mscnn_conv2d_roipool_workspace_bytes.argtypes = [C.c_void_p] + [C.c_int] * 4
+        L.mscnn_conv2d_fwd_roipool_pair_f32.argtypes = ([C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_float, C.c_float, C.c_float]
+                                                        + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p])
         L.mscnn_conv2d_plan_weight_layout.argtypes = [C.c_void_p]
         L.mscnn_conv2d_plan_weight_layout.restype = C.c_ulonglong
         L.mscnn_relu_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
@@ -227,6 +232,23 @@ class ConvPlan:
         wsb = self.ws.numel() * 4 if self.ws is not None else 0
         _check(lib().mscnn_conv2d_fwd_pool_f32(self._p, _dev(x), _dev(self.w), _dev(self.packed), _dev(bias), _dev(out),
                                                _dev(pool_out), _dev(self.ws), wsb, _stream()))
+        return out
+
+    def can_fuse_roipool(self, Cc, pooled_h, pooled_w):
+        return bool(lib().mscnn_conv2d_plan_can_fuse_roipool(self._p, Cc, pooled_h, pooled_w))
+
+    def forward_roipool_pair(self, feat, rois, spatial_scale, pad_a, pad_b, bias=None, out=None):
+        """ROIPooling x 2 (pad_a -> channels [0, C), pad_b -> [C, 2C)) fused into this convolution's Winograd input stage
+        (mscnn_conv2d_fwd_roipool_pair_f32): y = conv(concat(roipool(feat, pad_a), roipool(feat, pad_b)))."""
+        N, Cc, H, W = feat.shape
+        need = lib().mscnn_conv2d_roipool_workspace_bytes(self._p, N, Cc, H, W)
+        if self.ws is None or self.ws.numel() * 4 < need:
+            self.ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=feat.device)
+        if out is None:
+            out = torch.empty(self.out_shape(), dtype=torch.float32, device=feat.device)
+        _check(lib().mscnn_conv2d_fwd_roipool_pair_f32(self._p, _dev(feat), N, Cc, H, W, _dev(rois), spatial_scale, pad_a, pad_b,
+                                                       _dev(self.packed), _dev(bias), _dev(out), _dev(self.ws), self.ws.numel() * 4,
+                                                       _stream()))
         return out
 
     def __del__(self):

@@ -57,6 +57,8 @@ class SplitLayer : public Layer<Dtype> {
   virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) { Forward_cpu(bottom, top); }
 };
 
+template <typename Dtype> class ROIPoolingLayer;
+
 // include/caffe/layers/base_conv_layer.hpp + conv_layer.hpp (2-D, dilation 1)
 template <typename Dtype>
 class ConvolutionLayer : public Layer<Dtype> {
@@ -74,6 +76,10 @@ class ConvolutionLayer : public Layer<Dtype> {
   virtual void OnWeightsChanged() { weights_dirty_ = true; selfcheck_pending_ = true; }
   virtual bool FuseReLU(Dtype negative_slope);
   virtual bool FusePool2x2(Blob<Dtype>* pooled_top);
+  // Net-level fusion (round 4): this layer's bottom is the concatenation of a deferred ROIPooling pair (`first` does both windows,
+  // channels [0, C) and [C, 2C) in the order of their Concat offsets).  While the pair is pending and the planned kernel can pool in
+  // its input stage (mscnn_conv2d_plan_can_fuse_roipool) Forward reads the feature map itself; otherwise it asks for the blob.
+  void FuseRoiPoolInput(ROIPoolingLayer<Dtype>* first) { roi_src_ = first; }
   virtual double ForwardFlops() const;
   const char* kernel_name() const;
   const char* dtype() const;              // "f32" | "f16": MFMA operand type of the planned kernel
@@ -129,6 +135,8 @@ class ConvolutionLayer : public Layer<Dtype> {
   Blob<Dtype>* pooled_top_ = nullptr;     // fused Pooling layer's top (FusePool2x2)
   DeviceBuffer packed_, workspace_;
   int algo_, tune_[3];
+  ROIPoolingLayer<Dtype>* roi_src_ = nullptr;
+  bool last_fused_roipool_ = false;       // the last Forward pooled inside its input stage (kernel_name() says so)
   bool calibrated_direct_ = false;
   double selfcheck_tol_ = kDefaultSelfcheckTol, selfcheck_err_ = 0.0;
   bool selfcheck_pending_ = true, selfcheck_ran_ = false, selfcheck_fell_back_ = false;
@@ -283,6 +291,24 @@ class ROIPoolingLayer : public Layer<Dtype> {
   // (Net clears that at the start of every ForwardFromTo, so a range that starts between the two still computes the second).
   bool PairWith(ROIPoolingLayer* second);
   void set_skip(bool s) { skip_ = s; }
+  // Deferred pooling (round 4): when the pair's concatenated blob is read by ONE Convolution that can pool inside its own input
+  // stage (ConvolutionLayer::FuseRoiPoolInput), the first layer's Forward launches nothing: it shapes the blob, remembers its
+  // bottoms and marks the blob pending.  The consumer then computes straight from the feature map; anybody else who wants the
+  // blob's bytes (Net::blob_by_name, a numerical check, a consumer whose plan cannot fuse) calls Materialize(), which runs the
+  // pair kernel on the remembered bottoms.  The blob is never wrong, only late.
+  void set_deferred(bool on) { deferred_ = on; if (!on) pending_ = false; }
+  bool deferred() const { return deferred_; }
+  bool pending() const { return pending_; }
+  void Materialize();
+  const vector<Blob<Dtype>*>& pending_bottoms() const { return pending_bottom_; }
+  ROIPoolingLayer* partner() const { return partner_; }
+  int channels() const { return channels_; }
+  int pooled_height() const { return pooled_height_; }
+  int pooled_width() const { return pooled_width_; }
+  Dtype spatial_scale() const { return spatial_scale_; }
+  Dtype pad_ratio() const { return pad_ratio_; }
+  int window_c_offset() const { return window_c_offset_; }
+  const Blob<Dtype>* window() const { return window_; }
   virtual bool SetOutputWindow(Blob<Dtype>* target, int c_total, int c_offset) {
     window_ = target; window_c_total_ = c_total; window_c_offset_ = c_offset;
     return true;
@@ -303,6 +329,9 @@ class ROIPoolingLayer : public Layer<Dtype> {
   int window_c_total_, window_c_offset_;
   ROIPoolingLayer* partner_;
   bool skip_;
+  bool deferred_ = false, pending_ = false;
+  vector<Blob<Dtype>*> pending_bottom_;
+  void LaunchPair(const vector<Blob<Dtype>*>& bottom);
 };
 
 // include/caffe/layers/roi_align_layer.hpp -- tops are (R, C, pooled_h + 1, pooled_w + 1) grid samples

@@ -69,6 +69,11 @@ class Net {
   // blob_by_name() copies the channel window back into the blob's own storage when the producer has run since the last
   // copy.  Code that reaches into blobs() directly must call this first.
   void MaterializeBlob(int blob_id) const;
+  // Deferred ROI pooling (ROIPoolingLayer::set_deferred): the pair's blob is written now if it is still pending.  Call before writing
+  // -- from outside the Net -- into a blob the pooling reads (the C ABI's blob setters do).
+  void MaterializePending() const;
+  // ... only where `blob_name` is (or shares its data, through Split layers, with) a blob the pending pooling reads
+  void MaterializePendingReadersOf(const string& blob_name) const;
   // Numerical calibration on representative data: call after a Forward.  Every Convolution layer that runs a Winograd
   // form is re-computed with the direct k-ordered kernel on the same bottom; where max |dy| / max(1, |y|) exceeds `tol`
   // the layer is switched to the direct kernel for good (ConvolutionLayer::set_algo).  Returns the layers switched;
@@ -122,6 +127,9 @@ class Net {
   struct Redirect { int target_blob, c_total, c_offset; };
   std::map<int, Redirect> redirect_;               // blob id -> where its data really lives
   mutable std::map<int, bool> redirect_dirty_;     // producer ran since the last MaterializeBlob
+  struct DeferredPool { int first_layer, conv_layer, blob; };      // a ROIPooling pair whose only reader pools in its own input stage
+  vector<DeferredPool> deferred_pools_;
+  int SplitSource(int blob) const;      // through Split layers (their tops share the bottom's data) to the blob that holds the data
   vector<double> calib_err_;
   void NumericsWatchStep();
   int watch_period_ = kDefaultWatchPeriod, watch_frame_ = 0, watch_next_ = 0, watch_checks_ = 0;

@@ -235,6 +235,7 @@ int mscnn_net_get_param(mscnn_net* n, int l, int p, float* host, size_t count) {
 int mscnn_net_set_blob(mscnn_net* n, const char* name, const float* host, size_t count) {
   return guarded([&] {
     CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
+    n->net->MaterializePendingReadersOf(name);      // (a deferred ROI pooling that reads this blob writes its own blob first)
     auto b = n->net->blob_by_name(name);
     CHECK_EQ((size_t)b->count(), count) << "blob " << name << " has shape " << b->shape_string();
     std::memcpy(b->mutable_cpu_data(), host, sizeof(float) * count);
@@ -243,6 +244,7 @@ int mscnn_net_set_blob(mscnn_net* n, const char* name, const float* host, size_t
 int mscnn_net_set_blob_device(mscnn_net* n, const char* name, const float* dev, size_t count) {
   return guarded([&] {
     CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
+    n->net->MaterializePendingReadersOf(name);      // (a deferred ROI pooling that reads this blob writes its own blob first)
     auto b = n->net->blob_by_name(name);
     CHECK_EQ((size_t)b->count(), count) << "blob " << name << " has shape " << b->shape_string();
     HIP_CHECK(hipMemcpyAsync(b->mutable_gpu_data(), dev, sizeof(float) * count, hipMemcpyDeviceToDevice, (hipStream_t)Caffe::stream()));

@@ -199,6 +199,7 @@ double ConvolutionLayer<Dtype>::ErrorAgainstDirect(const vector<Blob<Dtype>*>& b
   Plan(bottom[0]->num(), bottom[0]->height(), bottom[0]->width());
   const std::string kname = mscnn_conv2d_plan_kernel(plan_);
   if (kname.compare(0, 8, "winograd") != 0 || bottom[0]->count() == 0) return 0.0;
+  if (roi_src_ && roi_src_->pending() && bottom[0] == roi_src_->window()) roi_src_->Materialize();      // the check reads the blob
   // a second, direct plan of the same layer with its own packed weights and workspace; everything is released on return
   mscnn_conv_desc d;
   d.N = bottom[0]->num(); d.Cin = channels_; d.H = bottom[0]->height(); d.W = bottom[0]->width(); d.Cout = num_output_;
@@ -261,7 +262,10 @@ void ConvolutionLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const 
 template <typename Dtype>
 double ConvolutionLayer<Dtype>::ForwardFlops() const { return plan_ ? mscnn_conv2d_plan_flops(plan_) : 0; }
 template <typename Dtype>
-const char* ConvolutionLayer<Dtype>::kernel_name() const { return plan_ ? mscnn_conv2d_plan_kernel(plan_) : ""; }
+const char* ConvolutionLayer<Dtype>::kernel_name() const {
+  if (plan_ && last_fused_roipool_ && std::strcmp(mscnn_conv2d_plan_kernel(plan_), "winograd_f3x3_3x3") == 0) return "winograd_f3x3_3x3+roipool_pair";
+  return plan_ ? mscnn_conv2d_plan_kernel(plan_) : "";
+}
 template <typename Dtype>
 const char* ConvolutionLayer<Dtype>::dtype() const { return plan_ ? mscnn_conv2d_plan_dtype(plan_) : "f32"; }
 
@@ -293,6 +297,28 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     const bool handed = amax_trusted_ && amax_src_ && amax_in_ && amax_src_->publishes_amax();
     MSCNN_CHECK(mscnn_conv2d_plan_set_amax_io(plan_, handed ? amax_in_ : nullptr, pub ? amax_out_ : nullptr));
   }
+  // The bottom is the concatenation of a deferred ROIPooling pair that has not been written: pool inside the input stage when the
+  // planned kernel can (fp32 F(3x3,3x3) on 7 x 7 maps) -- the R x 2C x 7 x 7 blob is then neither written nor read -- else ask for it.
+  if (roi_src_ && roi_src_->pending() && bottom[0] == roi_src_->window()) {
+    ROIPoolingLayer<Dtype>* a = roi_src_;
+    ROIPoolingLayer<Dtype>* b = roi_src_->partner();
+    ROIPoolingLayer<Dtype>* lo = a->window_c_offset() == 0 ? a : b;
+    ROIPoolingLayer<Dtype>* hi = lo == a ? b : a;
+    const int C = a->channels();
+    const vector<Blob<Dtype>*>& pb = a->pending_bottoms();
+    if (!selfcheck_pending_ && !pooled_top_ && b && lo->window_c_offset() == 0 && hi->window_c_offset() == C && pb.size() == 2 &&
+        mscnn_conv2d_plan_can_fuse_roipool(plan_, C, a->pooled_height(), a->pooled_width())) {
+      const size_t fbytes = mscnn_conv2d_roipool_workspace_bytes(plan_, pb[0]->num(), C, pb[0]->height(), pb[0]->width());
+      void* fws = shared_ws[dev]->Reserve(fbytes);
+      MSCNN_CHECK(mscnn_conv2d_fwd_roipool_pair_f32(plan_, pb[0]->gpu_data(), pb[0]->num(), C, pb[0]->height(), pb[0]->width(),
+                                                    pb[1]->gpu_data(), a->spatial_scale(), lo->pad_ratio(), hi->pad_ratio(), packed, bias,
+                                                    top[0]->mutable_gpu_data(), fws, fbytes, S()));
+      last_fused_roipool_ = true;
+      return;
+    }
+    a->Materialize();
+  }
+  last_fused_roipool_ = false;
   float* pooled = nullptr;
   if (pooled_top_) {
     // the fused-away Pooling layer's Reshape would run AFTER this Forward (layer.hpp:451-456): shape its top here, so that a
@@ -570,22 +596,39 @@ bool ROIPoolingLayer<Dtype>::PairWith(ROIPoolingLayer* b) {
 }
 
 template <typename Dtype>
+void ROIPoolingLayer<Dtype>::LaunchPair(const vector<Blob<Dtype>*>& bottom) {
+  MSCNN_CHECK(mscnn_roipool_pair_fwd_f32(bottom[0]->gpu_data(), bottom[1]->gpu_data(), window_->mutable_gpu_data(), bottom[1]->num(),
+                                         bottom[0]->num(), channels_, height_, width_, pooled_height_, pooled_width_, spatial_scale_,
+                                         pad_ratio_, window_c_offset_, partner_->pad_ratio_, partner_->window_c_offset_, window_c_total_, S()));
+}
+
+template <typename Dtype>
+void ROIPoolingLayer<Dtype>::Materialize() {
+  if (!pending_) return;
+  pending_ = false;
+  if (pending_bottom_.size() == 2 && pending_bottom_[1]->num() > 0) LaunchPair(pending_bottom_);
+}
+
+template <typename Dtype>
 void ROIPoolingLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
   if (skip_) { skip_ = false; return; }      // the pair's first layer has written this layer's window in its launch
   Dtype* out = window_ ? nullptr : top[0]->mutable_gpu_data();
   int c_total = channels_, c_offset = 0;
   if (window_) {   // Net fused the following Concat away: write this layer's channels of the concatenated blob directly
     window_->Reshape(bottom[1]->num(), window_c_total_, pooled_height_, pooled_width_);
-    out = window_->mutable_gpu_data();
     c_total = window_c_total_; c_offset = window_c_offset_;
   }
   if (partner_ && window_ && partner_->channels_ == channels_) {
-    MSCNN_CHECK(mscnn_roipool_pair_fwd_f32(bottom[0]->gpu_data(), bottom[1]->gpu_data(), out, bottom[1]->num(), bottom[0]->num(), channels_,
-                                           height_, width_, pooled_height_, pooled_width_, spatial_scale_, pad_ratio_, c_offset,
-                                           partner_->pad_ratio_, partner_->window_c_offset_, c_total, S()));
+    if (deferred_) {      // the consumer pools inside its own input stage; the blob is written only when somebody asks (Materialize)
+      pending_bottom_ = bottom;
+      pending_ = true;
+    } else {
+      LaunchPair(bottom);
+    }
     partner_->set_skip(true);
     return;
   }
+  if (window_) out = window_->mutable_gpu_data();
   MSCNN_CHECK(mscnn_roipool_fwd_f32(bottom[0]->gpu_data(), bottom[1]->gpu_data(), out, bottom[1]->num(), bottom[0]->num(), channels_,
                                     height_, width_, pooled_height_, pooled_width_, spatial_scale_, pad_ratio_, c_total, c_offset, S()));
 }

@@ -327,14 +327,65 @@ void Net<Dtype>::ApplyFusion() {
         source(bottom_id_vecs_[producers[0]][0]) == source(bottom_id_vecs_[producers[1]][0]) &&
         source(bottom_id_vecs_[producers[0]][1]) == source(bottom_id_vecs_[producers[1]][1])) {
       const int first = std::min(producers[0], producers[1]), second = std::max(producers[0], producers[1]);
-      static_cast<ROIPoolingLayer<Dtype>*>(layers_[first].get())->PairWith(static_cast<ROIPoolingLayer<Dtype>*>(layers_[second].get()));
+      ROIPoolingLayer<Dtype>* fl = static_cast<ROIPoolingLayer<Dtype>*>(layers_[first].get());
+      if (fl->PairWith(static_cast<ROIPoolingLayer<Dtype>*>(layers_[second].get()))) {
+        // the concatenated blob has ONE reader and it is a Convolution (roi_pool -> roi_c1): the pooling is deferred to that layer's
+        // input stage (ConvolutionLayer::FuseRoiPoolInput); the blob itself is written on demand (MaterializeBlob)
+        const int tb = top_id_vecs_[i][0];
+        int reader = -1, readers = 0;
+        for (size_t l = 0; l < layers_.size(); ++l)
+          for (int bb : bottom_id_vecs_[l]) if (bb == tb && !fused_away_[l]) { reader = (int)l; ++readers; }
+        bool is_output = false;
+        for (int ob : net_output_blob_indices_) is_output = is_output || ob == tb;
+        ConvolutionLayer<Dtype>* conv = readers == 1 ? dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[reader].get()) : nullptr;
+        if (conv && !is_output && reader > second) {
+          fl->set_deferred(true);
+          conv->FuseRoiPoolInput(fl);
+          DeferredPool dp;
+          dp.first_layer = first; dp.conv_layer = reader; dp.blob = tb;
+          deferred_pools_.push_back(dp);
+        }
+      }
     }
   }
 }
 
 template <typename Dtype>
+int Net<Dtype>::SplitSource(int blob) const {
+  for (bool moved = true; moved;) {
+    moved = false;
+    for (size_t l = 0; l < layers_.size() && !moved; ++l)
+      if (string(layers_[l]->type()) == "Split")
+        for (int t : top_id_vecs_[l])
+          if (t == blob) { blob = bottom_id_vecs_[l][0]; moved = true; break; }
+  }
+  return blob;
+}
+
+template <typename Dtype>
+void Net<Dtype>::MaterializePendingReadersOf(const string& blob_name) const {
+  if (deferred_pools_.empty() || !has_blob(blob_name)) return;
+  const int src = SplitSource(blob_names_index_.find(blob_name)->second);
+  for (size_t k = 0; k < deferred_pools_.size(); ++k) {
+    const int fl = deferred_pools_[k].first_layer;
+    for (int bb : bottom_id_vecs_[fl])
+      if (SplitSource(bb) == src) static_cast<ROIPoolingLayer<Dtype>*>(layers_[fl].get())->Materialize();
+  }
+}
+
+template <typename Dtype>
+void Net<Dtype>::MaterializePending() const {
+  for (size_t k = 0; k < deferred_pools_.size(); ++k)
+    static_cast<ROIPoolingLayer<Dtype>*>(layers_[deferred_pools_[k].first_layer].get())->Materialize();
+}
+
+template <typename Dtype>
 void Net<Dtype>::MaterializeBlob(int blob_id) const {
   typename std::map<int, Redirect>::const_iterator it = redirect_.find(blob_id);
+  // a deferred ROIPooling pair's blob (asked for directly, or as the home of a redirected roi_pool_org / roi_pool_ctx): write it now
+  for (size_t k = 0; k < deferred_pools_.size(); ++k)
+    if (deferred_pools_[k].blob == blob_id || (it != redirect_.end() && it->second.target_blob == deferred_pools_[k].blob))
+      static_cast<ROIPoolingLayer<Dtype>*>(layers_[deferred_pools_[k].first_layer].get())->Materialize();
   if (it == redirect_.end() || !redirect_dirty_[blob_id]) return;
   const Redirect& rd = it->second;
   const Blob<Dtype>* src = blobs_[rd.target_blob].get();
@@ -403,6 +454,11 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   if (timing_) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
   for (size_t i = 0; i < layers_.size(); ++i)      // (a paired ROIPooling skips only inside the call in which its partner ran)
     if (string(layers_[i]->type()) == "ROIPooling") static_cast<ROIPoolingLayer<Dtype>*>(layers_[i].get())->set_skip(false);
+  // a deferred ROI pooling still pending from an earlier call reads blobs this range is about to rewrite without re-running the
+  // pooling itself: write its blob first, from the bottoms it was given (the reference's blob would hold exactly that)
+  for (size_t k = 0; k < deferred_pools_.size(); ++k)
+    if (start <= deferred_pools_[k].first_layer && end < deferred_pools_[k].first_layer)
+      static_cast<ROIPoolingLayer<Dtype>*>(layers_[deferred_pools_[k].first_layer].get())->Materialize();
   {
     // split-fp16 convolutions take the bound of their input from the producing convolution when it runs in this same call
     // from the top (slots zeroed here, once); a partial range makes them measure it themselves

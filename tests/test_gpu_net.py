@@ -734,3 +734,50 @@ def test_default_flow_is_safe_without_a_calibration_call(tmp_path):
     assert n.auto_calibrate_state()[0] == 0
     for b in ("conv2_2", "conv4_3", "conv6_1", "LFCN_2_5x7", "proposals", "roi_pool", "fc6", "cls_pred", "bbox_pred"):
         assert np.array_equal(_read_f32(str(tmp_path / "b" / (b + ".f32"))), n.get_blob(b)), b
+
+
+def test_roi_pooling_deferred_into_roi_c1():
+    """Round 4: the ROIPooling pair's blob has one reader, roi_c1, whose Winograd input stage pools straight from the feature map
+    (mscnn_conv2d_fwd_roipool_pair_f32): the blob is not written during Forward, and still (a) every blob behind it is bit-identical
+    to the net without fusion, (b) asking for roi_pool / roi_pool_org / roi_pool_ctx by name yields the reference's bytes (written on
+    demand), (c) a partial range that rewrites conv4_3 without re-running the pooling first saves the pending blob, (d) a plan that
+    cannot fuse (f16x3 mode) falls back to the written blob."""
+    txt = zoo.prototxt("kitti_car/mscnn-7s-576", height=192, width=640, max_nms_num=300)
+    x = synth.frame(192, 640)
+    n = mnet.Net(prototxt_text=txt)
+    u = mnet.Net(prototxt_text=txt, fusion=False)
+    for net in (n, u):
+        synth.load_into(net, "mid")
+        net.set_blob("data", x)
+        net.forward()
+        net.forward()                                    # (the first forward ran the layers' own numerical checks on the written blob)
+    names = n.layer_names
+    i_c1 = names.index("roi_c1")
+    assert n.layer_kernel(i_c1) == "winograd_f3x3_3x3+roipool_pair" and u.layer_kernel(i_c1) == "winograd_f3x3_3x3"
+    assert n.blob_shape("proposals")[0] >= 8
+    for b in ("roi_c1", "fc6", "cls_pred", "bbox_pred"):
+        assert np.array_equal(n.get_blob(b), u.get_blob(b)), b
+    for b in ("roi_pool_org", "roi_pool", "roi_pool_ctx"):      # (b) on demand
+        assert np.array_equal(n.get_blob(b), u.get_blob(b)), b
+    # (c) pending again after a new forward; then conv1_1 .. conv4_3 of ANOTHER frame without the pooling layers: roi_pool must still
+    # be the first frame's, as in the reference where the blob was written when the layer ran
+    n.forward()
+    want = u.get_blob("roi_pool")
+    n.set_blob("data", synth.frame(192, 640, seed=77))
+    n.forward(0, names.index("relu4_3"))
+    assert not np.array_equal(n.get_blob("conv4_3"), u.get_blob("conv4_3"))
+    assert np.array_equal(n.get_blob("roi_pool"), want)
+    # ... and writing a blob the pending pooling reads (C ABI setter) does the same
+    n.set_blob("data", x)
+    n.forward()
+    n.set_blob("conv4_3", np.zeros(n.blob_shape("conv4_3"), np.float32))
+    assert np.array_equal(n.get_blob("roi_pool"), want)
+    # (d) f16x3: the split-fp16 plan has its own input transform -> the blob is written and read
+    n.set_blob("data", x)
+    n.set_precision("f16x3")
+    n.forward()
+    n.forward()
+    assert not n.layer_kernel(i_c1).endswith("+roipool_pair")
+    u.set_precision("f16x3")
+    u.forward()
+    assert np.array_equal(n.get_blob("fc6"), u.get_blob("fc6"))

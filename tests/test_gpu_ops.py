@@ -1346,3 +1346,47 @@ def test_preprocess_bitexact(hip, orc, org, out):
     img = rng.integers(0, 256, (*org, 3), dtype=np.uint8)
     y = hip.preprocess(torch.from_numpy(img).cuda(), out[0], out[1]).cpu().numpy()
     assert np.array_equal(y, orc.preprocess(img, out[0], out[1]))
+
+
+def _kitti_like_rois(rng, R, H8, W8, batch=1):
+    """Proposals as BoxOutput leaves them (image coordinates, stride-8 map of H8 x W8): log-uniform widths, some ROIs leaving the image,
+    some degenerate (zero / negative size), some far larger than the 32-column LDS segment of the fused kernel."""
+    w = np.exp(rng.uniform(np.log(6), np.log(8 * W8 * 0.9), R)); h = w * rng.uniform(0.3, 1.6, R)
+    x1 = rng.uniform(-40, 8 * W8 - 10, R); y1 = rng.uniform(-30, 8 * H8 - 10, R)
+    rois = np.stack([rng.integers(0, batch, R).astype(np.float64), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    rois[3, 3] = rois[3, 1] - 5.0                  # x2 < x1
+    rois[5, 1:] = [8 * W8 + 50, 10, 8 * W8 + 90, 60]      # entirely right of the map: every bin empty
+    rois[7, 1:] = [-300, -200, 8 * W8 + 300, 8 * H8 + 200]   # covers everything (several column segments)
+    return rois
+
+
+@pytest.mark.parametrize("case", [(37, 64, 24, 40, 96, 1), (133, 128, 36, 120, 64, 1), (700, 512, 72, 240, 512, 1), (21, 64, 20, 28, 64, 2)])
+def test_conv_roipool_pair_fused_is_bit_identical(hip, orc, case):
+    """mscnn_conv2d_fwd_roipool_pair_f32 (roipool_wino.hip: both ROI poolings + the F(3x3,3x3) input transform of roi_c1 in one pass
+    over a channel-last copy of the map) against the unfused sequence mscnn_roipool_pair_fwd_f32 -> mscnn_conv2d_fwd_f32 with the
+    same plan: the pooled values are exact and the transform uses the same expressions, so y must be BIT-IDENTICAL; the pooled
+    blob of the unfused path is held to the oracle (roi_pooling_layer.cpp:48-139) bit for bit on a subset of ROIs."""
+    R, Cc, H8, W8, Cout, batch = case
+    rng = np.random.default_rng(R)
+    feat = np.maximum(rng.standard_normal((batch, Cc, H8, W8)), 0).astype(np.float32) * 3.0
+    rois = _kitti_like_rois(rng, R, H8, W8, batch)
+    w = (rng.standard_normal((Cout, 2 * Cc, 3, 3)) * np.sqrt(2.0 / (2 * Cc * 9))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    plan = hip.ConvPlan(R, 2 * Cc, 7, 7, Cout, 3, 3, (0, 0), relu=True, algo=hip.ALGO_WINO_F3)
+    assert plan.kernel == "winograd_f3x3_3x3" and plan.can_fuse_roipool(Cc, 7, 7)
+    assert not plan.can_fuse_roipool(Cc, 7, 5) and not plan.can_fuse_roipool(Cc // 2, 7, 7)
+    plan.pack(dev(w))
+    fd, rd, bd = dev(feat), dev(rois), dev(b)
+    pooled = hip.roipool_pair(fd, rd, 7, 7, 0.125, 0.0, 0.25)
+    y_ref = plan.forward(pooled, bd).clone()
+    y = plan.forward_roipool_pair(fd, rd, 0.125, 0.0, 0.25, bd)
+    assert torch.equal(y, y_ref)
+    sub = np.r_[0:min(R, 12), R - 3:R]
+    want = np.concatenate([orc.roipool(feat, rois[sub], 7, 7, 0.125, 0.0), orc.roipool(feat, rois[sub], 7, 7, 0.125, 0.25)], 1)
+    assert np.array_equal(pooled[torch.as_tensor(sub, device="cuda")].cpu().numpy(), want)
+    # a changing ROI count through the same plan (plan_set_batch): a last workgroup with fewer than its four ROIs
+    plan.set_batch(R - 6)
+    y3 = plan.forward_roipool_pair(fd, rd[:R - 6].contiguous(), 0.125, 0.0, 0.25, bd)
+    assert torch.equal(y3, y_ref[:R - 6])
+    plan.set_batch(5)                               # below 8 ROIs the plan leaves Winograd: nothing to fuse into
+    assert not plan.can_fuse_roipool(Cc, 7, 7)

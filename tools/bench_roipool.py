@@ -1,25 +1,42 @@
 #!/usr/bin/env python3
-"""ROI pooling timing on the mscnn-7s-576 geometry (conv4_3: 512x72x240, 7x7 bins, 700 proposals, pad 0 and 0.25).
-MSCNN_ROIPOOL_PERBIN=1 selects the per-output kernel for an A/B comparison."""
+"""ROI pooling + roi_c1 input stage on the mscnn-7s-576 geometry (conv4_3: 512 x 72 x 240, 7 x 7 bins, pad 0 / 0.25): the two-launch
+path of round 3 (roipool_rows_kernel<2> writes the R x 1024 x 7 x 7 blob, wino33_input_kernel reads it back) against round 4's fused
+input stage (nchw_to_nhwc_kernel + roipool_wino33_kernel -> V), per stage by HIP events.  ROIs: tools/data/rois_7s576_mid.npy = the 676
+proposals of the benchmark frame (seed 1701, "mid" regime) as the reference's CPU BoxOutput leaves them."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mscnn_amd import hipapi as hip
-rng = np.random.default_rng(0)
-R = 700
+rois_np = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "rois_7s576_mid.npy")).astype(np.float32)
+R = len(rois_np)
 torch.manual_seed(0)
 feat = torch.relu(torch.randn(1, 512, 72, 240, device="cuda"))
-# KITTI-car-like proposals: widths 20..400 px, aspect ~0.4-0.8
-w = np.exp(rng.uniform(np.log(20), np.log(400), R)); h = w * rng.uniform(0.4, 0.8, R)
-x1 = rng.uniform(0, 1920 - w); y1 = rng.uniform(100, 576 - h).clip(0)
-rois = torch.tensor(np.stack([np.zeros(R), x1, y1, x1 + w, y1 + h], 1).astype(np.float32), device="cuda")
-out = torch.empty(R, 1024, 7, 7, device="cuda")
-def both():
-    hip.roipool(feat, rois, 7, 7, 0.125, 0.0, out=out, c_total=1024, c_offset=0)
-    hip.roipool(feat, rois, 7, 7, 0.125, 0.25, out=out, c_total=1024, c_offset=512)
-for _ in range(3): both()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-torch.cuda.synchronize(); e0.record()
-for _ in range(20): both()
-e1.record(); torch.cuda.synchronize()
-print(f"roipool org+ctx: {e0.elapsed_time(e1)/20*1e3:.1f} us  (perbin={os.environ.get('MSCNN_ROIPOOL_PERBIN','0')} dbg={os.environ.get('MSCNN_ROIPOOL_DBG','0')} cpb={os.environ.get('MSCNN_ROIPOOL_CPB','0')})  checksum {float(out.sum()):.6e}")
+rois = torch.tensor(rois_np, device="cuda")
+w = torch.randn(512, 1024, 3, 3, device="cuda") * 0.01
+b = torch.randn(512, device="cuda")
+plan = hip.ConvPlan(R, 1024, 7, 7, 512, 3, 3, (0, 0), relu=True)
+plan.pack(w)
+plan.set_profiling(True)
+ev = lambda: torch.cuda.Event(enable_timing=True)
+
+
+def timed(fn, n=30):
+    for _ in range(3):
+        fn()
+    e0, e1 = ev(), ev()
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+pooled = hip.roipool_pair(feat, rois, 7, 7, 0.125, 0.0, 0.25)
+y0 = plan.forward(pooled, b).clone()
+y1 = plan.forward_roipool_pair(feat, rois, 0.125, 0.0, 0.25, b).clone()
+print(f"R = {R}; fused == unfused bitwise: {bool(torch.equal(y0, y1))}")
+t_pool = timed(lambda: hip.roipool_pair(feat, rois, 7, 7, 0.125, 0.0, 0.25))
+t_conv = timed(lambda: plan.forward(pooled, b)); st_u = plan.stage_ms()
+t_fused = timed(lambda: plan.forward_roipool_pair(feat, rois, 0.125, 0.0, 0.25, b)); st_f = plan.stage_ms()
+print(f"unfused: roipool pair {t_pool:.1f} us + roi_c1 {t_conv:.1f} us (input transform {st_u[0]*1e3:.1f}, gemm {st_u[1]*1e3:.1f}, out {st_u[2]*1e3:.1f}) = {t_pool + t_conv:.1f} us")
+print(f"fused:   roi_c1 {t_fused:.1f} us (transpose + pooling + transform {st_f[0]*1e3:.1f}, gemm {st_f[1]*1e3:.1f}, out {st_f[2]*1e3:.1f})")
