@@ -526,6 +526,10 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
         double best = 0.95 * p1.model_us;
         for (int cand : {4, 5})
           if (wgemm_plan(P, Cout, Cin, T, cand, &pc) && pc.model_us < best) { best = pc.model_us; variant = cand; }
+        // a problem that does not even give every other CU a 256 x 128 tile (conv6_1: 50 tiles): 128 x 128 tiles, split stream-K style,
+        // put four times as many workgroups on useful chunks -- 39.7 -> 27.4 us stand-alone (profiles/r04_ab_wgemm_tiles.txt).  Only
+        // there: per FLOP the small tile moves twice the operands, which the model's MFMA-bound chunk time does not see.
+        if ((long)P * p1.MT * p1.NT * 2 < p1.G && wgemm_plan(P, Cout, Cin, T, 3, &pc) && pc.model_us < best) { best = pc.model_us; variant = 3; }
       }
     }
   }
