@@ -32,6 +32,7 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kNB = 4;        // bins whose 8 squares are loaded together (32 loads in flight per lane)
 constexpr int kLevels = 4;    // L0 (the map itself, channel-last) + sliding maxima over 2 x 2, 4 x 4, 8 x 8
 
 struct RpwArgs {
@@ -47,10 +48,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// max of three / two floats in one instruction.  Against the reference's `if (v > m) m = v` chain (roi_pooling_layer.cu:66-71): NaNs are
+// skipped by both; a tie between -0 and +0 may come out with the other sign (equal values; post-ReLU maps hold no -0 anyway).
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 // hides a value's history from the optimiser (no instruction): keeps it from sharing sub-expressions across unrolled iterations
 __device__ __forceinline__ void launder(float& v) { asm volatile("" : "+v"(v)); }
 
-// One wave = one ROI x 64 channels, both windows (pass 0: pad_a -> channels [0, C) of the concatenated blob, pass 1: pad_b -> [C, 2C));
+// One wave = one ROI x 64 channels of one window (blockIdx.z 0: pad_a -> channels [0, C) of the concatenated blob, 1: pad_b -> [C, 2C));
 // one workgroup = kRois consecutive ROIs, so that the 16-byte units the waves produce (a lane's four tiles of one plane) leave through
 // LDS as whole 128-byte lines of V: written straight from the lanes they are 64 partial lines per store instruction, 11 KB apart,
 // and the kernel ran at 0.86 TB/s (330 us, tools/sessions/r04_s7.sh).
@@ -84,8 +92,8 @@ __global__ __launch_bounds__(kRois * 64) void roipool_wino33_kernel(RpwArgs a) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rF, lane_off, off, 0));
   };
 
-#pragma unroll 1
-  for (int q = 0; q < 2; ++q) {
+  {
+    const int q = blockIdx.z;      // the window: a workgroup pools ONE of the two (1360 half-size workgroups spread over the CUs better than 680)
     // ---- window geometry and bin edges: roi_pooling_layer.cu:33-59, the same float expressions (context padding, no clipping of
     // the ROI itself, edges clipped to the map); every value is wave-uniform
     const float pad_ratio = q == 0 ? a.pad_a : a.pad_b;
@@ -103,14 +111,14 @@ __global__ __launch_bounds__(kRois * 64) void roipool_wino33_kernel(RpwArgs a) {
     // per bin column: width (0 = empty), and -- for the loads -- a clamped copy that always lies inside the map (an empty bin reads one
     // valid pixel and is overwritten with 0 below: no branch around the loads)
     int bw_[PW];
-    unsigned wsB[PW], wcl[PW];
+    unsigned wsB[PW], weB[PW];
 #pragma unroll
     for (int pw = 0; pw < PW; ++pw) {
       const int ws = uni(min(max((int)floorf((float)pw * bin_size_w) + roi_start_w, 0), W));
       const int we = uni(min(max((int)ceilf((float)(pw + 1) * bin_size_w) + roi_start_w, 0), W));
       bw_[pw] = we - ws;
-      wcl[pw] = (unsigned)max(we - ws, 1);
       wsB[pw] = (unsigned)min(ws, W - 1) * pxB;
+      weB[pw] = (unsigned)max(we, min(ws, W - 1) + 1) * pxB;
     }
 
     float pooled[PH * PW];
@@ -123,21 +131,23 @@ __global__ __launch_bounds__(kRois * 64) void roipool_wino33_kernel(RpwArgs a) {
       const unsigned hsB = (unsigned)(row0 + min(hs, H - 1)) * rowB;
       // A bin is the maximum of 2 x 4 squares of the largest level s <= min(h, w), four along the ROI's longer side: exact whenever the
       // bin is at most 2 s by 4 s (s > min(h, w) / 2: every bin up to an aspect ratio of 2 .. 4); longer ones finish in the loop below.
-      // Four bins x 8 squares are in flight together (32 independent loads per lane), then the row's other three.
+      // (The level is the BIN's: one level per bin row -- from the row's narrowest bin -- was measured 1.6x slower, a window clipped
+      // by the map's border has one-column bins that drag every other bin of the row down to s = 1.)  Four bins x 8 squares are in
+      // flight together (32 independent loads per lane), then the row's other three.
+      const unsigned heB = hsB + hcl * rowB;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        constexpr int NB = 4;
+      for (int half = 0; half < (PW + kNB - 1) / kNB; ++half) {
+        constexpr int NB = kNB;
         float v[NB][8];
         int lev[NB];
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
           const int pw = half * NB + bi;
           if (pw < PW) {
-            const unsigned mn = min(hcl, wcl[pw]);
-            const int k = min(3, 31 - __builtin_clz(mn));
+            const int k = min(3, 31 - __builtin_clz(min(hcl, (unsigned)max(bw_[pw], 1))));
             lev[bi] = k;
             const unsigned stepx = pxB << k, stepy = rowB << k;
-            const unsigned xlastB = wsB[pw] + wcl[pw] * pxB - stepx, ylastB = hsB + hcl * rowB - stepy;
+            const unsigned xlastB = weB[pw] - stepx, ylastB = heB - stepy;
             const unsigned base = (unsigned)k * a.level_bytes;
             // along the longer side: start / last / step; across: start / last (byte offsets add up in any order)
             const unsigned al0 = wide ? wsB[pw] : hsB, alL = wide ? xlastB : ylastB, alS = wide ? stepx : stepy;
@@ -152,25 +162,22 @@ __global__ __launch_bounds__(kRois * 64) void roipool_wino33_kernel(RpwArgs a) {
           const int pw = half * NB + bi;
           if (pw < PW) {
             const int w = bw_[pw];
-            float m = -FLT_MAX;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-              if (v[bi][i] > m) m = v[bi][i];
-            const int s = 1 << lev[bi];
+            float m = max3(v[bi][0], v[bi][1], v[bi][2]);
+            m = max3(m, v[bi][3], v[bi][4]);
+            m = max3(m, v[bi][5], v[bi][6]);
+            m = max3(m, v[bi][7], -FLT_MAX);
+            const int s_ = 1 << lev[bi];
             const int across_len = wide ? h : w, along_len = wide ? w : h;
-            if (across_len > 2 * s || along_len > 4 * s) {           // (wave-uniform, rare) more squares than the batch covered
-              const unsigned base = (unsigned)lev[bi] * a.level_bytes;
+            if (across_len > 2 * s_ || along_len > 4 * s_) {           // (wave-uniform, rare) more squares than the batch covered
               const unsigned stepx = pxB << lev[bi], stepy = rowB << lev[bi];
-              const unsigned xlastB = wsB[pw] + wcl[pw] * pxB - stepx, ylastB = hsB + hcl * rowB - stepy;
-              for (unsigned yB = hsB; yB < hsB + hcl * rowB; yB += stepy)
-                for (unsigned xB = wsB[pw]; xB < wsB[pw] + wcl[pw] * pxB; xB += 4 * stepx) {
+              const unsigned xlastB = weB[pw] - stepx, ylastB = heB - stepy, base = (unsigned)lev[bi] * a.level_bytes;
+              for (unsigned yB = hsB; yB < heB; yB += stepy)
+                for (unsigned xB = wsB[pw]; xB < weB[pw]; xB += 4 * stepx) {
                   const unsigned rb = base + min(yB, ylastB);
                   const float u0 = load_at(rb + min(xB, xlastB)), u1 = load_at(rb + min(xB + stepx, xlastB));
                   const float u2 = load_at(rb + min(xB + 2 * stepx, xlastB)), u3 = load_at(rb + min(xB + 3 * stepx, xlastB));
-                  if (u0 > m) m = u0;
-                  if (u1 > m) m = u1;
-                  if (u2 > m) m = u2;
-                  if (u3 > m) m = u3;
+                  m = max3(m, u0, u1);
+                  m = max3(m, u2, u3);
                 }
             }
             pooled[ph * PW + pw] = (h <= 0 || w <= 0) ? 0.f : m;      // empty bins are 0 (roi_pooling_layer.cu:56-58)
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(kRois * 64) void roipool_wino33_kernel(RpwArgs a) {
 #pragma unroll
         for (int k = 0; k < PH * PW; ++k)
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pooled[k]), rV, vl, rb + (unsigned)(k % 25) * pb + (unsigned)(k / 25) * 4u, 0);
-      continue;
+      return;
     }
 #endif
     // ---- V = B^T d B of the ROI's 2 x 2 tiles (patch rows / columns 3 t .. 3 t + 4 of the 7 x 7 map, zero beyond it): the operation
@@ -327,7 +334,7 @@ int roipool_wino33_forward(const float* feat, float* maps, const float* rois, fl
   a.spatial_scale = spatial_scale; a.pad_a = pad_a; a.pad_b = pad_b;
   // channel block on grid.x: workgroups go round-robin over the 8 XCDs by linear id, so XCD j only ever touches channel blocks
   // == j (mod 8) of the maps -- with C = 512 exactly one 64-channel slice (4 x 4.4 MB) per XCD's L2
-  roipool_wino33_kernel<7, 7><<<dim3(C / 64, cdiv(R, kRois)), kRois * 64, 0, st>>>(a);
+  roipool_wino33_kernel<7, 7><<<dim3(C / 64, cdiv(R, kRois), 2), kRois * 64, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

@@ -550,7 +550,8 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   const long rem = tiles % o->G;
   const double chunk_us = (double)e->BM * e->BN * e->CK / 128.0 / 2214.0;                       // MFMA-bound time of one K chunk
   const double whole = (double)((tiles + o->G - 1) / o->G) * (o->KI * chunk_us + 6.0);
-  const double split = (double)tiles * o->KI / o->G * chunk_us + (double)tiles / o->G * 6.0 + 18.0;
+  const double handoff_us = 18.0 * (double)(e->BM * e->BN) / (256.0 * 128.0);      // a slab hand-off moves BM x BN floats (128 KB: 18 us measured)
+  const double split = (double)tiles * o->KI / o->G * chunk_us + (double)tiles / o->G * 6.0 + handoff_us;
   o->full_q = (int)(tiles / o->G);
   if (rem > 0 && !(split < 0.97 * whole)) o->full_q += 1;       // whole tiles: the last round is simply not full
   o->model_us = rem > 0 ? (split < 0.97 * whole ? split : whole) : whole;
