@@ -186,6 +186,14 @@ def cpu_baseline(model, regime, R_gpu, net=None, kw=None, layer_table=None, dtyp
                            "sample": f"conv1_1..pool2 of the same frame with 1 BLAS thread: {sample[1]:.2f} s against {t_all:.2f} s on {best}; "
                                      f"whole frame estimated as {dt:.2f} s x that ratio = {est:.1f} s",
                            "seconds_per_image_est": round(est, 1)}
+        try:      # a MEASURED one-thread full frame of this model on this CPU model, taken once (tools/cpu_one_core.py), beside the estimate
+            oc = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_one_core.json")))
+            if oc.get("model") == model and oc.get("cpu") == res["cpu"]:
+                res["one_core"].update({"value": round(1.0 / oc["seconds_per_image"], 5), "seconds_per_image_measured": oc["seconds_per_image"],
+                                        "sample": f"1 full frame, 1 BLAS thread, measured once on this CPU model ({oc['cpu']}; profiles/r04_cpu_one_core.json, "
+                                                  f"tools/cpu_one_core.py): {oc['seconds_per_image']:.1f} s; this run's estimate from conv1_1..pool2: {est:.1f} s"})
+        except (OSError, ValueError, KeyError):
+            pass
         if net is not None:
             res["full_size_parity"] = _full_size_parity(net, x, blobs, kw, dtype)
             if alt_dtype:      # the same reference run checks the alternative precision mode
@@ -212,6 +220,27 @@ def cpu_baseline(model, regime, R_gpu, net=None, kw=None, layer_table=None, dtyp
             "sample": f"oracle restatement (im2col + k-ordered GEMM, OpenMP) on a {h}x{w} frame for trunk+heads+BoxOutput ({t_trunk:.2f} s) "
                       f"and the detection sub-net on {r_sample} ROIs ({t_det:.2f} s), scaled x4 pixels and x{R_gpu}/{r_sample} ROIs",
             "seconds_per_image_est": round(est, 2)}
+
+
+def _measured_traffic():
+    """(bytes of one launch | None, where it comes from, extra fields): profiles/r04_traffic_wgemm.json if its kernel_sources_sha16
+    matches the wgemm.hip / winograd.hip of this tree."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "r04_traffic_wgemm.json")
+    try:
+        t = json.load(open(path))
+        h = hashlib.sha256()
+        for f in ("mscnn_amd/csrc/wgemm.hip", "mscnn_amd/csrc/winograd.hip"):
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        if t.get("kernel_sources_sha16") != h.hexdigest()[:16]:
+            return None, f"profiles/r04_traffic_wgemm.json was measured on other kernel sources ({t.get('kernel_sources_sha16')}): not reported", {}
+        return (int(t["traffic_bytes_per_launch"]),
+                "PMC FETCH_SIZE x 2 + WRITE_SIZE of ONE launch (conv4_2's plane GEMM), rocprofv3 separate passes, tools/pmc_traffic.py -> "
+                "profiles/r04_traffic_wgemm.json (kernel sources unchanged since: sha16 " + t["kernel_sources_sha16"] + ")",
+                {"traffic_launch": "conv4_2", "traffic_algorithmic_bytes": int(t["algorithmic_bytes_per_launch"]),
+                 "traffic_over_algorithmic": round(t["traffic_bytes_per_launch"] / t["algorithmic_bytes_per_launch"], 3)})
+    except (OSError, ValueError, KeyError):
+        return None, "no PMC measurement of this kernel in profiles/ (tools/pmc_traffic.py)", {}
 
 
 class _CudaPtr:
@@ -582,13 +611,13 @@ def main():
         blk_alg = float(flops[idx].sum()) / (blk_ms * 1e-3) / 1e12
         conv_idx = [i for i, t in enumerate(net.layer_types) if t == "Convolution"]
         # HBM bytes of the dominant kernel are a PMC measurement (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): not
-        # something this process can take of itself, so the line carries null and names the file of the latest such run
-        traffic = None
-        tsrc = "not measured in this run; PMC passes of this kernel: profiles/r03_traffic_wgemm.json (tools/pmc_traffic.py)"
+        # something this process can take of itself.  The line carries the latest such measurement (tools/pmc_traffic.py -> profiles/)
+        # only while the kernel sources it was taken on are byte-identical to the ones running now; else null.
+        traffic, tsrc, textra = _measured_traffic()
         peak = FP16_MFMA_PEAK_TFLOPS if args.dtype in ("f16", "f16x3") else FP32_MFMA_PEAK_TFLOPS
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc, **textra,
             **({"frac_of_measured_mfma_peak": round(achieved / FP32_MFMA_MEASURED_TFLOPS, 4),
                 "measured_mfma_peak": FP32_MFMA_MEASURED_TFLOPS} if args.dtype == "f32" else {}),
             "kernel": ("igemm_kernel<Cfg<...,F16>> (igemm16_*): direct 3x3 implicit GEMM on v_mfma_f32_32x32x16_f16, operands rounded to "

@@ -178,6 +178,17 @@ MSCNN_API int mscnn_pool2d_fwd_f32(const float* x, float* y, int N, int C, int H
 MSCNN_API int mscnn_inner_product_fwd_f32(const float* x, const float* w, const float* bias, float* y,
                                 int M, int N, int K, int relu, void* stream);
 
+/* The same InnerProduct (fp32, exact MFMA fmaf chains) on the plane-GEMM kernel of the Winograd layers (wgemm.hip: LDS-DMA operand ring,
+ * one barrier per K chunk) -- fc6-class shapes: M >= 192 rows, N % 128 == 0, K % 32 == 0 (mscnn_inner_product_wg_supported).  wt = the
+ * weights transposed once to [K][N] (mscnn_inner_product_wg_pack, N * K * 4 bytes); x is re-packed into the kernel's A layout every
+ * forward inside the workspace; bias and ReLU are applied in the kernel's epilogue.  Results differ from mscnn_inner_product_fwd_f32
+ * only in where the K sum is cut (both are k-ordered chains summed in a fixed order: deterministic, within the 1e-4 bar). */
+MSCNN_API int mscnn_inner_product_wg_supported(int M, int N, int K);
+MSCNN_API size_t mscnn_inner_product_wg_packed_bytes(int N, int K);
+MSCNN_API size_t mscnn_inner_product_wg_workspace_bytes(int M, int N, int K);
+MSCNN_API int mscnn_inner_product_wg_pack(const float* w, float* wt, int N, int K, void* stream);
+MSCNN_API int mscnn_inner_product_wg_fwd(const float* x, const float* wt, const float* bias, float* y, int M, int N, int K, int relu,
+                                         void* workspace, size_t workspace_bytes, void* stream);
 /* fp16-operand InnerProduct (the counterpart of MSCNN_CONV_ALGO_F16; no reference counterpart): w16 = the weights converted
  * once to fp16 [N][K] (mscnn_inner_product_pack_f16, N * K * 2 bytes), x rounded to fp16 on its way into LDS, fp32 accumulate.
  * Needs N >= 64 and K % 8 == 0 (mscnn_inner_product_f16_supported); smaller layers stay on the fp32 entry point. */

@@ -57,7 +57,7 @@ MSCNN_NET_API int mscnn_net_layer_param_shape(const mscnn_net* net, int layer, i
 /* The layer's LayerParameter in prototxt text form (valid until the next call on this thread). */
 MSCNN_NET_API const char* mscnn_net_layer_param_text(const mscnn_net* net, int layer);
 MSCNN_NET_API int mscnn_net_layer_fused_away(const mscnn_net* net, int layer);              /* 1: ReLU folded into its producer */
-MSCNN_NET_API const char* mscnn_net_layer_kernel(const mscnn_net* net, int layer);          /* conv kernel family, "" otherwise */
+MSCNN_NET_API const char* mscnn_net_layer_kernel(const mscnn_net* net, int layer);          /* conv / InnerProduct kernel family, "" otherwise */
 MSCNN_NET_API double mscnn_net_layer_flops(const mscnn_net* net, int layer);                /* of the last forward */
 /* Roofline accounting of Convolution layers: FLOPs the MFMA pipe executes (Winograd forms: fewer than the algorithmic
  * count above) and, with conv profiling on, the HIP-event time of the last forward split into {input transform, MFMA GEMM
@@ -69,6 +69,9 @@ MSCNN_NET_API int mscnn_net_layer_stage_ms(const mscnn_net* net, int layer, floa
  * 2 / 3 Winograd F(2x2,3x3) / F(3x3,3x3) wherever legal); tuning knobs = mscnn_conv_desc::tune_* (A/B runs). */
 MSCNN_NET_API int mscnn_net_set_conv_algo(mscnn_net* net, int layer, int algo);
 MSCNN_NET_API int mscnn_net_set_conv_tuning(mscnn_net* net, int layer, int variant, int grid, int flags);
+/* fp32 kernel of one InnerProduct layer (layer < 0: all): 0 = auto (fc6-class shapes on the plane-GEMM kernel, mscnn_inner_product_wg_*),
+ * 1 = always the stream-K kernel of gemm.hip (A/B runs, second witness).  mscnn_net_layer_kernel reports what the last forward ran. */
+MSCNN_NET_API int mscnn_net_set_inner_product_algo(mscnn_net* net, int layer, int algo);
 /* Arithmetic of the MFMA layers of the whole net: "f32" (default: the path that matches the reference within 1e-4) or "f16"
  * (fp16 operands, fp32 accumulate, no reference counterpart -- BASELINE config 5): 3x3 stride-1 convolutions and InnerProduct
  * layers with N >= 64 switch, everything else keeps its fp32 kernel.  "f16x3": the convolutions that run Winograd F(3x3,3x3)

@@ -13,6 +13,7 @@
 // (W for fc6 is 210 MB: it must stream from HBM once, not once per ROI tile).
 // cls_pred / bbox_pred (N = 5 / 20): one workgroup per row, lanes split K, wave reductions.
 #include "common.h"
+#include "wgemm.h"
 
 namespace {
 
@@ -495,4 +496,96 @@ static int inner_product_gemm(const float* x, const void* w, bool w_is_f16, cons
   else gemm_fixup_kernel<128, 128><<<a.MT * a.NT * 4, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
+}
+
+
+// ---- InnerProduct on the plane-GEMM kernel of wgemm.hip (round 4) --------------------------------------------------------------------
+// fc6 is a plain [R x K] x [K x N] GEMM with K = 12800: gemm_tn_kernel above still has the round-1 structure (operands staged through
+// registers, two barriers per chunk, 0.74 - 0.77 of the MFMA peak, 604 - 630 us); wgemm_kernel (LDS-DMA ring, one barrier per chunk,
+// ride-along stores) runs the same shape at 0.84+.  Mapping: the ROI rows are the kernel's "Cout" side -- x is re-packed per forward
+// into its A layout Up[mt][kc][32][256] (one transposing pass over 35 MB) --, the N outputs its tile columns -- the weights are kept
+// transposed, Wt[K][N], packed once per weight change --, so M = y[R][N] comes out in the blob's own layout and the kernel's epilogue
+// adds bias and ReLU.  96 tiles x 400 chunks are split stream-K over the 256 workgroups (150 chunks each; a tile's partial sums meet
+// in the workgroup that holds its first chunks, in k order: deterministic).
+namespace {
+
+// Up[mt][kc][ck][256] <- x[r][k] (zero rows past M): 256 rows x 32 k per workgroup through LDS, 128-byte reads, 1 KB writes
+__global__ __launch_bounds__(256) void ip_pack_rows_kernel(const float* __restrict__ x, float* __restrict__ up, int M, int K, int KI) {
+  __shared__ float t[32][257];
+  const int kc = blockIdx.x, mt = blockIdx.y, tid = threadIdx.x;
+  const int r0 = mt * 256, k0 = kc * 32;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {      // 256 rows x 8 float4
+    const int v = tid + i * 256, row = v >> 3, k4 = (v & 7) * 4;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + row < M) q = *reinterpret_cast<const float4*>(x + (size_t)(r0 + row) * K + k0 + k4);
+    t[k4][row] = q.x; t[k4 + 1][row] = q.y; t[k4 + 2][row] = q.z; t[k4 + 3][row] = q.w;
+  }
+  __syncthreads();
+  float* dst = up + ((size_t)mt * KI + kc) * (32 * 256);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) dst[i * 256 + tid] = t[i][tid];
+}
+
+// Wt[k][n] = w[n][k]: 32 x 32 tiles
+__global__ __launch_bounds__(256) void ip_transpose_w_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int K) {
+  __shared__ float t[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, k = k0 + tx;
+    t[ty + 8 * i][tx] = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + 8 * i, n = n0 + tx;
+    if (k < K && n < N) wt[(size_t)k * N + n] = t[tx][ty + 8 * i];
+  }
+}
+
+bool ip_wg_plan(int M, int N, int K, mscnn::WgemmPlan* pl) {
+  // rows in 32-row blocks; the tile columns must be the blob's own row stride (N % 128 == 0); below ~200 rows the 256-row tiles are
+  // mostly padding and the stream-K kernel above is the better fit
+  if (M < 192 || N % 128 != 0 || K % 32 != 0 || N < 256) return false;
+  const int Mp = (M + 31) / 32 * 32;
+  return mscnn::wgemm_plan(1, Mp, K, N, 1 + 64, pl) && pl->T_pad == N;
+}
+
+}  // namespace
+
+extern "C" int mscnn_inner_product_wg_supported(int M, int N, int K) {
+  mscnn::WgemmPlan pl;
+  return ip_wg_plan(M, N, K, &pl) ? 1 : 0;
+}
+extern "C" size_t mscnn_inner_product_wg_packed_bytes(int N, int K) { return (size_t)N * K * sizeof(float); }
+extern "C" size_t mscnn_inner_product_wg_workspace_bytes(int M, int N, int K) {
+  mscnn::WgemmPlan pl;
+  if (!ip_wg_plan(M, N, K, &pl)) return 0;
+  return (pl.packed_bytes + 255) / 256 * 256 + pl.ws_bytes;
+}
+extern "C" int mscnn_inner_product_wg_pack(const float* w, float* wt, int N, int K, void* stream) {
+  MSCNN_REQUIRE(w && wt && N > 0 && K > 0, "inner_product wg pack: bad argument");
+  ip_transpose_w_kernel<<<dim3(cdiv(K, 32), cdiv(N, 32)), 256, 0, as_stream(stream)>>>(w, wt, N, K);
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+extern "C" int mscnn_inner_product_wg_fwd(const float* x, const float* wt, const float* bias, float* y, int M, int N, int K, int relu,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  MSCNN_REQUIRE(M >= 0 && N > 0 && K > 0, "inner_product: bad shape M=%d N=%d K=%d", M, N, K);
+  if (M == 0) return MSCNN_OK;
+  mscnn::WgemmPlan pl;
+  MSCNN_REQUIRE(ip_wg_plan(M, N, K, &pl), "inner_product wg: shape M=%d N=%d K=%d is not one the plane-GEMM kernel takes", M, N, K);
+  MSCNN_REQUIRE(x && wt && y && reinterpret_cast<uintptr_t>(x) % 16 == 0, "inner_product wg: null or unaligned pointer");
+  const size_t need = mscnn_inner_product_wg_workspace_bytes(M, N, K);
+  if (!workspace || workspace_bytes < need) {
+    set_error("inner_product wg: workspace %zu < %zu", workspace_bytes, need);
+    return MSCNN_ERR_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  float* up = static_cast<float*>(workspace);
+  float* slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + (pl.packed_bytes + 255) / 256 * 256);
+  ip_pack_rows_kernel<<<dim3(pl.KI, pl.MT), 256, 0, st>>>(x, up, M, K, pl.KI);
+  MSCNN_POST_LAUNCH();
+  return mscnn::wgemm_launch(pl, up, wt, y, pl.ws_bytes ? slabs : nullptr, st, 0, nullptr, bias, relu, (size_t)M * N * sizeof(float));
 }

@@ -25,7 +25,9 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* out);
 
 // abl: development ablations (0 in the product): bit 0 no loads after the prologue, bit 1 no stores, bit 2 no MFMAs, bit 3 no
 // LDS operand reads, bit 4 no barriers; dbg: per-workgroup {shader cycles, 100 MHz ticks} (tools/micro/wgemm_bench.hip)
+// bias / relu: only for a plan of an epilogue variant (variant + 64: InnerProduct on this kernel; bias indexed by column);
+// m_valid_bytes != 0: the bytes of M that exist (Cout was rounded up to the tile grid's 32-row blocks, the caller's buffer was not)
 int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, float* ws, hipStream_t st, int abl = 0,
-                 unsigned long long* dbg = nullptr);
+                 unsigned long long* dbg = nullptr, const float* bias = nullptr, int relu = 0, size_t m_valid_bytes = 0);
 
 }  // namespace mscnn

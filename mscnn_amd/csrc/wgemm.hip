@@ -48,6 +48,7 @@ struct WgemmArgs {
   unsigned epoch;               // this launch's tag for the partial-sum hand-off flags (never 0, unique per launch in the process)
   unsigned long long* dbg;      // development: [G] {shader cycles, 100 MHz ticks} over the kernel, then [G] {start, end} in 100 MHz ticks (nullptr in the product)
   unsigned up_bytes, v_bytes, m_bytes;
+  const float* bias; int relu;  // EPI kernels only: y = acc + bias[column] (nullptr: none), then max(y, 0) when relu -- applied to what goes to M, never to a partial slab
 };
 
 template <int BM_, int BN_, int WGM_, int WGN_, int CK_, int ST_, int DPG_ = 1, int SK_ = 0>
@@ -148,7 +149,7 @@ struct SegCursor {
   }
 };
 
-template <class C, int ABL>
+template <class C, int ABL, int EPI = 0>
 __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs a) {
   __shared__ __attribute__((aligned(1024))) float lds[C::LDS_FLOATS];
   __shared__ unsigned s_handoff_timeout;
@@ -257,6 +258,9 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
       for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][mi][ni][r] = 0.f;
+  float old_bias[C::NI];                // (EPI) bias of this lane's column in each block column of the finished tile
+#pragma unroll
+  for (int ni = 0; ni < C::NI; ++ni) old_bias[ni] = 0.f;
   unsigned old_voff[C::MI][C::NI];      // byte offset of the finished tile's 32 x 32 blocks in M (row 0 of the block, this lane's column)
 #pragma unroll
   for (int mi = 0; mi < C::MI; ++mi)
@@ -303,11 +307,17 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   auto store_one = [&](auto qc, auto ec) {
     constexpr int Q = decltype(qc)::value, e = decltype(ec)::value;
     constexpr int blk = e / 16, r = e % 16, mi = blk / C::NI, ni = blk % C::NI, dr = (r & 3) + 8 * (r >> 2);
-    const float v = acc[Q][mi][ni][r];
+    float v = acc[Q][mi][ni][r];
     // (a partial sum bound for another workgroup is stored write-through -- sc1 -- so that the flag that follows needs no L2
     // write-back; the branch is wave-uniform)
     if (old_pub) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 16);
-    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 0);
+    else {
+      if constexpr (EPI) {
+        v += old_bias[ni];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+      }
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 0);
+    }
   };
 
   // one chunk = STEPS MFMA groups accumulating into set PAR.  FLUSH: the previous segment's stores (set PAR ^ 1) ride along (SPM per
@@ -386,6 +396,13 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     if (pub) { old_rsrc = rW; old_rowb = (unsigned)C::BN * 4u; }
     else { old_rsrc = rM; old_rowb = row_bytes; }
     const unsigned slab = (unsigned)slot * (unsigned)(C::BM * C::BN * 4);
+    if constexpr (EPI) {
+#pragma unroll
+      for (int ni = 0; ni < C::NI; ++ni) {
+        const int col = nt * C::BN + wn * C::WN + ni * 32 + l31;
+        old_bias[ni] = (a.bias && col < a.T_pad) ? a.bias[col] : 0.f;
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
@@ -468,13 +485,16 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
 typedef void (*WgemmFn)(WgemmArgs);
 struct WEntry { const char* name; int variant, abl, BM, BN, CK, threads; WgemmFn fn; };
 #define WG_ENTRY(name, v, abl, BM, BN, WGM, WGN, CK) {name, v, abl, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3>, abl>}
+// variant + 64: the same tile with the bias / ReLU epilogue (abl field 64: never matched by the ablation look-up): InnerProduct on this kernel
+#define WG_ENTRY_EPI(name, v, BM, BN, WGM, WGN, CK) {name, v + 64, 0, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3>, 0, 1>}
 #define WG_ENTRY_S(name, v, BM, BN, WGM, WGN, CK, DPG, SK) {name, v, 0, BM, BN, CK, WGM * WGN * 64, wgemm_kernel<WCfg<BM, BN, WGM, WGN, CK, 3, DPG, SK>, 0>}
 const WEntry kW[] = {
     WG_ENTRY("wgemm_256x128_ck32", 1, 0, 256, 128, 4, 2, 32),
     WG_ENTRY("wgemm_128x256_ck32", 2, 0, 128, 256, 2, 4, 32),
     WG_ENTRY("wgemm_128x128_ck32", 3, 0, 128, 128, 2, 4, 32),
     WG_ENTRY("wgemm_256x96_ck32", 4, 0, 256, 96, 8, 1, 32),       // conv5_x: 480 tile columns = 5 x 96, 250 tiles in one full round
-    WG_ENTRY("wgemm_256x160_ck32", 5, 0, 256, 160, 8, 1, 32),     // conv4_x F(4x4,3x3): 1080 columns = 6.75 x 160 -> 504 tiles = 1.97 rounds (r4)
+    WG_ENTRY("wgemm_256x160_ck32", 5, 0, 256, 160, 8, 1, 32),
+    WG_ENTRY_EPI("wgemm_256x128_ck32_epi", 1, 256, 128, 4, 2, 32),     // conv4_x F(4x4,3x3): 1080 columns = 6.75 x 160 -> 504 tiles = 1.97 rounds (r4)
 #ifdef MSCNN_WGEMM_DEV      // schedule A/B (pieces per group, first store group)
     WG_ENTRY_S("wgemm_256x128_ck32_d2", 25, 256, 128, 4, 2, 32, 2, 0),
     WG_ENTRY_S("wgemm_256x128_ck32_d2_s3", 26, 256, 128, 4, 2, 32, 2, 3),
@@ -570,7 +590,8 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   return true;
 }
 
-int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, float* ws, hipStream_t st, int abl, unsigned long long* dbg) {
+int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, float* ws, hipStream_t st, int abl, unsigned long long* dbg,
+                 const float* bias, int relu, size_t m_valid_bytes) {
   const WEntry* e = nullptr;
   for (const WEntry& w : kW) if (w.variant == p.variant && w.abl == abl) e = &w;
   if (!e) return MSCNN_ERR_BAD_ARG;
@@ -582,6 +603,8 @@ int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, 
   const int rem = a.tiles - p.full_q * p.G;
   if (rem > 0 && !ws) { set_error("wgemm: workspace missing"); return MSCNN_ERR_WORKSPACE; }
   a.up_bytes = (unsigned)p.packed_bytes; a.v_bytes = (unsigned)((size_t)p.P * p.Cin * p.T_pad * 4); a.m_bytes = (unsigned)((size_t)p.P * p.Cout * p.T_pad * 4);
+  if (m_valid_bytes) a.m_bytes = (unsigned)m_valid_bytes;      // (rows beyond the caller's buffer: their stores fall outside num_records and are dropped)
+  a.bias = bias; a.relu = relu;
   // hand-off tag of this launch: unique within the process (monotonic), seeded per process so that flags a previous process left
   // in recycled device memory cannot match either; the workspace needs no clearing between launches
   static std::atomic<unsigned> g_epoch{(unsigned)std::chrono::steady_clock::now().time_since_epoch().count() * 2654435761u};

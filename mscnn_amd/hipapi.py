@@ -74,6 +74,13 @@ def lib():
         L.mscnn_inner_product_x3_workspace_bytes.argtypes = [C.c_int] * 3
         L.mscnn_inner_product_x3_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mscnn_inner_product_x3_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.mscnn_inner_product_wg_supported.argtypes = [C.c_int] * 3
+        L.mscnn_inner_product_wg_packed_bytes.restype = C.c_size_t
+        L.mscnn_inner_product_wg_packed_bytes.argtypes = [C.c_int, C.c_int]
+        L.mscnn_inner_product_wg_workspace_bytes.restype = C.c_size_t
+        L.mscnn_inner_product_wg_workspace_bytes.argtypes = [C.c_int] * 3
+        L.mscnn_inner_product_wg_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.mscnn_inner_product_wg_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]
         L.mscnn_inner_product_pack_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mscnn_inner_product_fwd_f16.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
         for f in ("mscnn_conv2d_plan_flops", "mscnn_conv2d_plan_executed_flops"):
@@ -287,6 +294,26 @@ def pool2d(x, kernel=(2, 2), pad=(0, 0), stride=(2, 2), method="MAX"):
     _check(lib().mscnn_pool2d_fwd_f32(_dev(x), _dev(y), N, Cc, H, W, kernel[0], kernel[1], pad[0], pad[1],
                                       stride[0], stride[1], 0 if method == "MAX" else 1, _stream()))
     return y
+
+
+def inner_product_wg_supported(M, N, K):
+    return bool(lib().mscnn_inner_product_wg_supported(M, N, K))
+
+
+def inner_product_wg(x, w, bias=None, relu=False, wt=None, out=None):
+    """InnerProduct on the plane-GEMM kernel (mscnn_inner_product_wg_*); wt: the transposed weights from a previous call (returned)."""
+    M = x.shape[0]
+    K = x.numel() // M
+    Nn = w.shape[0]
+    if wt is None:
+        wt = torch.empty((K, Nn), dtype=torch.float32, device=x.device)
+        _check(lib().mscnn_inner_product_wg_pack(_dev(w), _dev(wt), Nn, K, _stream()))
+    wb = lib().mscnn_inner_product_wg_workspace_bytes(M, Nn, K)
+    ws = torch.empty((wb + 3) // 4, dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty((M, Nn), dtype=torch.float32, device=x.device)
+    _check(lib().mscnn_inner_product_wg_fwd(_dev(x), _dev(wt), _dev(bias), _dev(y), M, Nn, K, int(relu), _dev(ws), wb, _stream()))
+    torch.cuda.current_stream().synchronize()
+    return y, wt
 
 
 def inner_product(x, w, bias=None, relu=False):

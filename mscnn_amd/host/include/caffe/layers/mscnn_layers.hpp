@@ -215,7 +215,11 @@ class InnerProductLayer : public Layer<Dtype> {
   void set_amax_in(const ConvolutionLayer<Dtype>* src, const unsigned* in) { amax_src_ = src; amax_in_ = in; }
   void set_amax_trusted(bool on) { amax_trusted_ = on; }
   const char* dtype() const { return used_x3_ ? "f16x3" : used_f16_ ? "f16" : "f32"; }
-  virtual void OnWeightsChanged() { w16_dirty_ = true; }
+  // fp32 kernel choice: 0 = auto (fc6-class shapes -- M >= 192 rows, N % 128 == 0 -- on the plane-GEMM kernel of wgemm.hip with the
+  // weights kept transposed, everything else on gemm.hip's stream-K kernel), 1 = always gemm.hip's kernels (A/B runs, second witness)
+  void set_algo(int algo) { algo_ = algo; }
+  const char* kernel_name() const { return used_x3_ ? "x3_gemm" : used_f16_ ? "gemm16_tn" : used_wg_ ? "wgemm_256x128_ck32_epi" : "gemm_tn"; }
+  virtual void OnWeightsChanged() { w16_dirty_ = true; wt_dirty_ = true; }
   virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   virtual inline const char* type() const { return "InnerProduct"; }
@@ -233,6 +237,9 @@ class InnerProductLayer : public Layer<Dtype> {
   const ConvolutionLayer<Dtype>* amax_src_ = nullptr;
   const unsigned* amax_in_ = nullptr;
   DeviceBuffer w16_, x3_ws_;
+  int algo_ = 0;
+  bool wt_dirty_ = true, used_wg_ = false;
+  DeviceBuffer wt_, wg_ws_;               // weights transposed to [K][N]; packed x + partial-sum slabs
 };
 
 // include/caffe/layers/concat_layer.hpp (channel axis)

@@ -121,7 +121,18 @@ const char* mscnn_net_layer_param_text(const mscnn_net* n, int l) {
 int mscnn_net_layer_fused_away(const mscnn_net* n, int l) { return n->net->layer_fused_away()[l] ? 1 : 0; }
 const char* mscnn_net_layer_kernel(const mscnn_net* n, int l) {
   auto* c = dynamic_cast<caffe::ConvolutionLayer<float>*>(n->net->layers()[l].get());
-  return c ? c->kernel_name() : "";
+  if (c) return c->kernel_name();
+  auto* ip = dynamic_cast<caffe::InnerProductLayer<float>*>(n->net->layers()[l].get());
+  return ip ? ip->kernel_name() : "";
+}
+int mscnn_net_set_inner_product_algo(mscnn_net* n, int layer, int algo) {
+  return guarded([&] {
+    CHECK_LT(layer, (int)n->net->layers().size());
+    CHECK(algo == 0 || algo == 1) << "inner product algo: 0 auto, 1 gemm.hip's stream-K kernel";
+    for (int l = (layer < 0 ? 0 : layer); l < (layer < 0 ? (int)n->net->layers().size() : layer + 1); ++l)
+      if (auto* ip = dynamic_cast<caffe::InnerProductLayer<float>*>(n->net->layers()[l].get())) ip->set_algo(algo);
+      else CHECK_LT(layer, 0) << "layer " << n->net->layer_names()[l] << " is not an InnerProduct";
+  });
 }
 double mscnn_net_layer_flops(const mscnn_net* n, int l) { return n->net->layers()[l]->ForwardFlops(); }
 static caffe::ConvolutionLayer<float>* conv_of(const mscnn_net* n, int l) {

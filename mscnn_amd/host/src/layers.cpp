@@ -475,6 +475,7 @@ void InnerProductLayer<Dtype>::Reshape(const vector<Blob<Dtype>*>& bottom, const
 }
 template <typename Dtype>
 void InnerProductLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  used_wg_ = false;
   used_x3_ = x3_ && mscnn_inner_product_x3_supported(N_, K_);
   if (used_x3_) {
     void* pk = w16_.Reserve(mscnn_inner_product_x3_packed_bytes(N_, K_));
@@ -499,6 +500,18 @@ void InnerProductLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, c
     }
     MSCNN_CHECK(mscnn_inner_product_fwd_f16(bottom[0]->gpu_data(), w16, bias_term_ ? this->blobs_[1]->gpu_data() : nullptr,
                                             top[0]->mutable_gpu_data(), M_, N_, K_, relu_ ? 1 : 0, S()));
+    return;
+  }
+  used_wg_ = algo_ == 0 && mscnn_inner_product_wg_supported(M_, N_, K_);
+  if (used_wg_) {      // fc6-class: the plane-GEMM kernel (wgemm.hip) with the weights kept transposed
+    float* wt = static_cast<float*>(wt_.Reserve(mscnn_inner_product_wg_packed_bytes(N_, K_)));
+    if (wt_dirty_) {
+      MSCNN_CHECK(mscnn_inner_product_wg_pack(this->blobs_[0]->gpu_data(), wt, N_, K_, S()));
+      wt_dirty_ = false;
+    }
+    const size_t wb = mscnn_inner_product_wg_workspace_bytes(M_, N_, K_);
+    MSCNN_CHECK(mscnn_inner_product_wg_fwd(bottom[0]->gpu_data(), wt, bias_term_ ? this->blobs_[1]->gpu_data() : nullptr,
+                                           top[0]->mutable_gpu_data(), M_, N_, K_, relu_ ? 1 : 0, wg_ws_.Reserve(wb), wb, S()));
     return;
   }
   MSCNN_CHECK(mscnn_inner_product_fwd_f32(bottom[0]->gpu_data(), this->blobs_[0]->gpu_data(),

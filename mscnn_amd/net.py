@@ -45,7 +45,7 @@ def lib():
             "mscnn_net_create_from_string_ex": [cs, ci, C.c_uint, vp],
             "mscnn_net_layer_executed_flops": [vp, ci], "mscnn_net_set_conv_profiling": [vp, ci], "mscnn_net_layer_stage_ms": [vp, ci, vp],
             "mscnn_net_set_precision": [vp, cs], "mscnn_net_layer_dtype": [vp, ci],
-            "mscnn_net_set_conv_algo": [vp, ci, ci], "mscnn_net_set_conv_tuning": [vp, ci, ci, ci, ci],
+            "mscnn_net_set_conv_algo": [vp, ci, ci], "mscnn_net_set_inner_product_algo": [vp, ci, ci], "mscnn_net_set_conv_tuning": [vp, ci, ci, ci, ci],
             "mscnn_net_calibrate_numerics": [vp, C.c_double, vp], "mscnn_net_set_numerics_watch": [vp, ci, C.c_double],
             "mscnn_net_numerics_watch_state": [vp, vp, vp, ci], "mscnn_net_layer_calibration_err": [vp, ci],
             "mscnn_net_set_auto_calibrate": [vp, C.c_double], "mscnn_net_auto_calibrate_state": [vp, vp, vp, ci],
@@ -162,6 +162,11 @@ class Net:
     def set_conv_algo(self, layer, algo):
         i = layer if isinstance(layer, int) else self.layer_names.index(layer)
         _check(lib().mscnn_net_set_conv_algo(self._h, i, algo))
+
+    def set_inner_product_algo(self, layer, algo):
+        """0 = auto (fc6-class shapes on the plane-GEMM kernel), 1 = always gemm.hip's stream-K kernel; layer -1 = all."""
+        i = layer if isinstance(layer, int) else self.layer_names.index(layer)
+        _check(lib().mscnn_net_set_inner_product_algo(self._h, i, algo))
 
     def set_conv_tuning(self, layer, variant=0, grid=0, flags=0):
         i = layer if isinstance(layer, int) else self.layer_names.index(layer)

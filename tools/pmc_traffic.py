@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """HBM-side traffic per launch of the kernels of one Winograd layer from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
 need separate passes: MI355X_MICROARCH.md, PMC slots), with the guide's gfx950 correction (FETCH_SIZE counts 64 B per 128-B
-request: x2; WRITE_SIZE as is).  Usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json"""
-import collections, csv, json, re, sys
+request: x2; WRITE_SIZE as is).  Usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json [f4|f3] [T_pad]
+The output names the SHA-256 of the kernel sources it was measured on (wgemm.hip, winograd.hip): bench.py puts the figure into
+its roofline object only while those files are unchanged."""
+import collections, csv, hashlib, json, os, re, sys
 
 
 def per_kernel(path, counter):
@@ -22,13 +24,25 @@ def per_kernel(path, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 kb = {k: 2.0 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in set(fetch) | set(write)}
-planes, T_pad = (36, 1152) if len(sys.argv) <= 4 or sys.argv[4] == "f4" else (25, 1920)
+planes, T_pad = (36, 1120) if len(sys.argv) <= 4 or sys.argv[4] == "f4" else (25, 1920)
+if len(sys.argv) > 5:
+    T_pad = int(sys.argv[5])
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sources_sha16():
+    h = hashlib.sha256()
+    for f in ("mscnn_amd/csrc/wgemm.hip", "mscnn_amd/csrc/winograd.hip"):
+        h.update(open(os.path.join(_root, f), "rb").read())
+    return h.hexdigest()[:16]
+
 out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- "
                   "python tools/bench_layers.py --iters 6 --only conv4_2   (conv4_2: 1x512x72x240 -> 512, Winograd "
-                  + ("F(4x4,3x3), 36 planes of 512 x 512 x 1152)" if planes == 36 else "F(3x3,3x3), 25 planes of 512 x 512 x 1920)"),
+                  + (f"F(4x4,3x3), 36 planes of 512 x 512 x {T_pad})" if planes == 36 else f"F(3x3,3x3), 25 planes of 512 x 512 x {T_pad})"),
+       "kernel_sources_sha16": sources_sha16(), "launch": "conv4_2",
        "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
        "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE = 64 B per 128-B request on gfx950 -> x2; WRITE_SIZE taken as is",
-       "kernel": "wgemm_kernel<256x128, ck32> on conv4_2's plane GEMMs",
+       "kernel": "wgemm_kernel on conv4_2's plane GEMMs (tile shape as planned: 256 x 160 since round 4)",
        "traffic_bytes_per_launch": int(1024 * kb.get("gemm", 0.0)),
        "algorithmic_bytes_per_launch": int(planes * (512 * 512 + 512 * T_pad + 512 * T_pad) * 4),
        "layer_traffic_bytes": {k: int(1024 * v) for k, v in kb.items()},
