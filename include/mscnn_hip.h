@@ -257,12 +257,18 @@ MSCNN_API int mscnn_roipool_pair_fwd_f32(const float* feat, const float* rois, f
  * between the layers (140 MB per 7s-576 frame) is neither written nor read.  `plan` = the convolution's plan (N = R ROIs, Cin = 2C,
  * H x W = pooled_h x pooled_w); y = its output, bit-identical to mscnn_roipool_pair_fwd_f32 followed by mscnn_conv2d_fwd_f32.
  *   _can_fuse_roipool: 1 when the plan's kernel family and shape take this path (fp32 F(3x3,3x3), 7 x 7 bins, pad 0, C % 64 == 0);
- *   _roipool_workspace_bytes: workspace of the fused call (the plan's own + a channel-last copy of the feature map). */
+ *   _roipool_workspace_bytes: workspace of the fused call when it builds its maps itself (the plan's own + mscnn_roipool_maps_bytes);
+ *   the pooling reads four "maps" of the feature blob -- a channel-last copy and its sliding maxima over 2 x 2, 4 x 4, 8 x 8 squares
+ *   (mscnn_roipool_maps_bytes, mscnn_roipool_maps_build_f32).  They depend on the feature map only: a caller may build them early, on
+ *   another stream, while the proposals are still being selected, and hand them in as prepared_maps (then feat may be NULL and the
+ *   workspace is the plan's own mscnn_conv2d_workspace_bytes); prepared_maps = NULL builds them inside the call. */
 MSCNN_API int mscnn_conv2d_plan_can_fuse_roipool(const mscnn_conv_plan* plan, int C, int pooled_h, int pooled_w);
 MSCNN_API size_t mscnn_conv2d_roipool_workspace_bytes(const mscnn_conv_plan* plan, int N, int C, int H, int W);
-MSCNN_API int mscnn_conv2d_fwd_roipool_pair_f32(const mscnn_conv_plan* plan, const float* feat, int N, int C, int H, int W,
-                                                const float* rois, float spatial_scale, float pad_ratio_a, float pad_ratio_b,
-                                                const float* packed_w, const float* bias, float* y, void* workspace,
+MSCNN_API size_t mscnn_roipool_maps_bytes(int N, int C, int H, int W);
+MSCNN_API int mscnn_roipool_maps_build_f32(const float* feat, float* maps, int N, int C, int H, int W, void* stream);
+MSCNN_API int mscnn_conv2d_fwd_roipool_pair_f32(const mscnn_conv_plan* plan, const float* feat, const float* prepared_maps, int N, int C,
+                                                int H, int W, const float* rois, float spatial_scale, float pad_ratio_a,
+                                                float pad_ratio_b, const float* packed_w, const float* bias, float* y, void* workspace,
                                                 size_t workspace_bytes, void* stream);
 
 /* ROIAlign -- ROIAlignLayer<Dtype>::Forward_gpu (roi_align_layer.cu:21-112): out[R][C][pooled_h+1][pooled_w+1] bilinear

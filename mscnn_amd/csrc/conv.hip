@@ -1639,23 +1639,32 @@ static size_t roipool_scratch_offset(const mscnn_conv_plan* p) { return (p->ws_b
 extern "C" size_t mscnn_conv2d_roipool_workspace_bytes(const mscnn_conv_plan* p, int N, int C, int H, int W) {
   return p ? roipool_scratch_offset(p) + mscnn::roipool_wino33_scratch_bytes(N, C, H, W) : 0;
 }
-extern "C" int mscnn_conv2d_fwd_roipool_pair_f32(const mscnn_conv_plan* p, const float* feat, int N, int C, int H, int W,
-                                                 const float* rois, float spatial_scale, float pad_ratio_a, float pad_ratio_b,
+extern "C" size_t mscnn_roipool_maps_bytes(int N, int C, int H, int W) { return mscnn::roipool_wino33_scratch_bytes(N, C, H, W); }
+extern "C" int mscnn_roipool_maps_build_f32(const float* feat, float* maps, int N, int C, int H, int W, void* stream) {
+  return mscnn::roipool_wino33_build_maps(feat, maps, N, C, H, W, as_stream(stream));
+}
+extern "C" int mscnn_conv2d_fwd_roipool_pair_f32(const mscnn_conv_plan* p, const float* feat, const float* prepared_maps, int N, int C,
+                                                 int H, int W, const float* rois, float spatial_scale, float pad_ratio_a, float pad_ratio_b,
                                                  const float* packed, const float* bias, float* y, void* workspace,
                                                  size_t workspace_bytes, void* stream) {
   MSCNN_REQUIRE(p, "conv: null plan");
   if (p->d.N == 0) return MSCNN_OK;
-  MSCNN_REQUIRE(feat && rois && y && N > 0 && H > 0 && W > 0, "conv(roipool): bad argument");
+  MSCNN_REQUIRE((feat || prepared_maps) && rois && y && N > 0 && H > 0 && W > 0, "conv(roipool): bad argument");
   MSCNN_REQUIRE(mscnn_conv2d_plan_can_fuse_roipool(p, C, p->d.H, p->d.W), "conv(roipool): this plan does not take the fused ROI-pooling input stage");
-  const size_t need = mscnn_conv2d_roipool_workspace_bytes(p, N, C, H, W);
+  const size_t need = prepared_maps ? p->ws_bytes : mscnn_conv2d_roipool_workspace_bytes(p, N, C, H, W);
   if (!workspace || workspace_bytes < need) {
     set_error("conv(roipool): workspace %zu < %zu", workspace_bytes, need);
     return MSCNN_ERR_WORKSPACE;
   }
   hipStream_t st = as_stream(stream);
-  float* featT = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + roipool_scratch_offset(p));
+  float* own_maps = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + roipool_scratch_offset(p));
   return wino_forward(p, packed, bias, y, nullptr, workspace, workspace_bytes, st, [&](float* V) {
-    return mscnn::roipool_wino33_forward(feat, featT, rois, V, p->d.N, N, C, H, W, p->T_pad, spatial_scale, pad_ratio_a, pad_ratio_b, st);
+    if (!prepared_maps) {
+      const int rc = mscnn::roipool_wino33_build_maps(feat, own_maps, N, C, H, W, st);
+      if (rc != MSCNN_OK) return rc;
+    }
+    return mscnn::roipool_wino33_forward(prepared_maps ? prepared_maps : own_maps, rois, V, p->d.N, N, C, H, W, p->T_pad, spatial_scale,
+                                         pad_ratio_a, pad_ratio_b, st);
   });
 }
 

@@ -311,13 +311,11 @@ bool roipool_wino33_supported(int C, int pooled_h, int pooled_w, int conv_pad_h,
 
 size_t roipool_wino33_scratch_bytes(int N, int C, int H, int W) { return (size_t)kLevels * N * C * H * W * sizeof(float); }
 
-int roipool_wino33_forward(const float* feat, float* maps, const float* rois, float* V, int R, int N, int C, int H, int W, int T_pad,
-                           float spatial_scale, float pad_a, float pad_b, hipStream_t st) {
-  MSCNN_REQUIRE(feat && maps && rois && V, "roipool+transform: null pointer");
-  MSCNN_REQUIRE(R > 0 && N > 0 && C % 64 == 0 && H > 0 && W > 0 && T_pad >= 4 * R && T_pad % 4 == 0, "roipool+transform: bad shape");
-  const double lb = (double)N * C * H * W * 4.0, vb = 25.0 * 2.0 * C * (double)T_pad * 4.0;
-  MSCNN_REQUIRE(kLevels * lb < 4.0e9 && vb < 4.0e9, "roipool+transform: feature maps or transform planes beyond a 32-bit buffer window");
-  MSCNN_REQUIRE(reinterpret_cast<uintptr_t>(V) % 16 == 0 && reinterpret_cast<uintptr_t>(maps) % 16 == 0, "roipool+transform: V and the maps must be 16-byte aligned");
+int roipool_wino33_build_maps(const float* feat, float* maps, int N, int C, int H, int W, hipStream_t st) {
+  MSCNN_REQUIRE(feat && maps, "roipool maps: null pointer");
+  MSCNN_REQUIRE(N > 0 && C % 64 == 0 && H > 0 && W > 0, "roipool maps: bad shape");
+  MSCNN_REQUIRE(kLevels * (double)N * C * H * W * 4.0 < 4.0e9, "roipool maps: beyond a 32-bit buffer window");
+  MSCNN_REQUIRE(reinterpret_cast<uintptr_t>(maps) % 16 == 0, "roipool maps: the maps must be 16-byte aligned");
   const int HW = H * W;
   const long per_level = (long)N * C * HW;
   nchw_to_nhwc_kernel<<<dim3(cdiv(HW, 64), cdiv(C, 64), N), 256, 0, st>>>(feat, maps, C, HW);
@@ -327,6 +325,16 @@ int roipool_wino33_forward(const float* feat, float* maps, const float* rois, fl
     sliding_max_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(maps + (k - 1) * per_level, maps + k * per_level, H, W, C / 4, 1 << (k - 1), total);
     MSCNN_POST_LAUNCH();
   }
+  return MSCNN_OK;
+}
+
+int roipool_wino33_forward(const float* maps, const float* rois, float* V, int R, int N, int C, int H, int W, int T_pad,
+                           float spatial_scale, float pad_a, float pad_b, hipStream_t st) {
+  MSCNN_REQUIRE(maps && rois && V, "roipool+transform: null pointer");
+  MSCNN_REQUIRE(R > 0 && N > 0 && C % 64 == 0 && H > 0 && W > 0 && T_pad >= 4 * R && T_pad % 4 == 0, "roipool+transform: bad shape");
+  const double lb = (double)N * C * H * W * 4.0, vb = 25.0 * 2.0 * C * (double)T_pad * 4.0;
+  MSCNN_REQUIRE(kLevels * lb < 4.0e9 && vb < 4.0e9, "roipool+transform: feature maps or transform planes beyond a 32-bit buffer window");
+  MSCNN_REQUIRE(reinterpret_cast<uintptr_t>(V) % 16 == 0, "roipool+transform: V must be 16-byte aligned");
   RpwArgs a;
   a.maps = maps; a.rois = rois; a.V = V;
   a.R = R; a.C = C; a.H = H; a.W = W; a.T_pad = T_pad;

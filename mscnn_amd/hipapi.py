@@ -101,8 +101,11 @@ def lib():
         L.mscnn_conv2d_plan_can_fuse_roipool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.mscnn_conv2d_roipool_workspace_bytes.restype = C.c_size_t
         L.mscnn_conv2d_roipool_workspace_bytes.argtypes = [C.c_void_p] + [C.c_int] * 4
-        L.mscnn_conv2d_fwd_roipool_pair_f32.argtypes = ([C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.mscnn_conv2d_fwd_roipool_pair_f32.argtypes = ([C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_float, C.c_float, C.c_float]
                                                         + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p])
+        L.mscnn_roipool_maps_bytes.restype = C.c_size_t
+        L.mscnn_roipool_maps_bytes.argtypes = [C.c_int] * 4
+        L.mscnn_roipool_maps_build_f32.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
         L.mscnn_conv2d_plan_weight_layout.argtypes = [C.c_void_p]
         L.mscnn_conv2d_plan_weight_layout.restype = C.c_ulonglong
         L.mscnn_relu_fwd_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
@@ -244,7 +247,7 @@ class ConvPlan:
     def can_fuse_roipool(self, Cc, pooled_h, pooled_w):
         return bool(lib().mscnn_conv2d_plan_can_fuse_roipool(self._p, Cc, pooled_h, pooled_w))
 
-    def forward_roipool_pair(self, feat, rois, spatial_scale, pad_a, pad_b, bias=None, out=None):
+    def forward_roipool_pair(self, feat, rois, spatial_scale, pad_a, pad_b, bias=None, out=None, maps=None):
         """ROIPooling x 2 (pad_a -> channels [0, C), pad_b -> [C, 2C)) fused into this convolution's Winograd input stage
         (mscnn_conv2d_fwd_roipool_pair_f32): y = conv(concat(roipool(feat, pad_a), roipool(feat, pad_b)))."""
         N, Cc, H, W = feat.shape
@@ -253,7 +256,7 @@ class ConvPlan:
             self.ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=feat.device)
         if out is None:
             out = torch.empty(self.out_shape(), dtype=torch.float32, device=feat.device)
-        _check(lib().mscnn_conv2d_fwd_roipool_pair_f32(self._p, _dev(feat), N, Cc, H, W, _dev(rois), spatial_scale, pad_a, pad_b,
+        _check(lib().mscnn_conv2d_fwd_roipool_pair_f32(self._p, _dev(feat), _dev(maps), N, Cc, H, W, _dev(rois), spatial_scale, pad_a, pad_b,
                                                        _dev(self.packed), _dev(bias), _dev(out), _dev(self.ws), self.ws.numel() * 4,
                                                        _stream()))
         return out
@@ -398,6 +401,14 @@ def roipool(feat, rois, pooled_h, pooled_w, spatial_scale, pad_ratio=0.0, out=No
     _check(lib().mscnn_roipool_fwd_f32(_dev(feat), _dev(rois), _dev(out), R, N, Cc, H, W, pooled_h, pooled_w,
                                        spatial_scale, pad_ratio, c_total, c_offset, _stream()))
     return out
+
+
+def roipool_maps(feat, stream=None):
+    """The four maps the fused ROI-pooling stage reads (mscnn_roipool_maps_build_f32), built on `stream` (default: the current one)."""
+    N, Cc, H, W = feat.shape
+    maps = torch.empty(lib().mscnn_roipool_maps_bytes(N, Cc, H, W) // 4, dtype=torch.float32, device=feat.device)
+    _check(lib().mscnn_roipool_maps_build_f32(_dev(feat), _dev(maps), N, Cc, H, W, C.c_void_p(stream.cuda_stream) if stream is not None else _stream()))
+    return maps
 
 
 def roipool_pair(feat, rois, pooled_h, pooled_w, spatial_scale, pad_a, pad_b):

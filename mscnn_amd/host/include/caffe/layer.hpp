@@ -54,6 +54,7 @@ class Layer {
   // Called by Net when the parameter blobs were (re)written on the host (weight injection,
   // CopyTrainedLayersFrom): layers that keep a device-side re-packed copy refresh it here.
   virtual void OnWeightsChanged() {}
+
   // Net-level operator fusion hooks (a fused layer must produce exactly what the pair produced).
   virtual bool FuseReLU(Dtype negative_slope) { return false; }
   // A producer that can also emit the output of the MAX 2x2 / stride 2 / pad 0 Pooling layer that consumes its top writes

@@ -310,7 +310,7 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
         mscnn_conv2d_plan_can_fuse_roipool(plan_, C, a->pooled_height(), a->pooled_width())) {
       const size_t fbytes = mscnn_conv2d_roipool_workspace_bytes(plan_, pb[0]->num(), C, pb[0]->height(), pb[0]->width());
       void* fws = shared_ws[dev]->Reserve(fbytes);
-      MSCNN_CHECK(mscnn_conv2d_fwd_roipool_pair_f32(plan_, pb[0]->gpu_data(), pb[0]->num(), C, pb[0]->height(), pb[0]->width(),
+      MSCNN_CHECK(mscnn_conv2d_fwd_roipool_pair_f32(plan_, pb[0]->gpu_data(), nullptr, pb[0]->num(), C, pb[0]->height(), pb[0]->width(),
                                                     pb[1]->gpu_data(), a->spatial_scale(), lo->pad_ratio(), hi->pad_ratio(), packed, bias,
                                                     top[0]->mutable_gpu_data(), fws, fbytes, S()));
       last_fused_roipool_ = true;

@@ -1418,6 +1418,12 @@ def test_conv_roipool_pair_fused_is_bit_identical(hip, orc, case):
     y_ref = plan.forward(pooled, bd).clone()
     y = plan.forward_roipool_pair(fd, rd, 0.125, 0.0, 0.25, bd)
     assert torch.equal(y, y_ref)
+    # the maps built ahead of time on another stream (mscnn_roipool_maps_build_f32) and handed in: same bytes, no feature pointer needed
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    maps = hip.roipool_maps(fd, stream=side)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(plan.forward_roipool_pair(fd, rd, 0.125, 0.0, 0.25, bd, maps=maps), y_ref)
     sub = np.r_[0:min(R, 12), R - 3:R]
     want = np.concatenate([orc.roipool(feat, rois[sub], 7, 7, 0.125, 0.0), orc.roipool(feat, rois[sub], 7, 7, 0.125, 0.25)], 1)
     assert np.array_equal(pooled[torch.as_tensor(sub, device="cuda")].cpu().numpy(), want)

@@ -63,7 +63,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dF, feat.size() * 4)); CK(hipMalloc(&dT, mscnn::roipool_wino33_scratch_bytes(N, C, H, W))); CK(hipMalloc(&dR, rois.size() * 4)); CK(hipMalloc(&dV, vN * 4));
   CK(hipMemcpy(dF, feat.data(), feat.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dR, rois.data(), rois.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemset(dV, 0xff, vN * 4));
-  if (mscnn::roipool_wino33_forward(dF, dT, dR, dV, R, N, C, H, W, T_pad, 0.125f, 0.f, 0.25f, nullptr)) { printf("launch failed: %s\n", mscnn_last_error()); return 1; }
+  if (mscnn::roipool_wino33_build_maps(dF, dT, N, C, H, W, nullptr) || mscnn::roipool_wino33_forward(dT, dR, dV, R, N, C, H, W, T_pad, 0.125f, 0.f, 0.25f, nullptr)) { printf("launch failed: %s\n", mscnn_last_error()); return 1; }
   CK(hipDeviceSynchronize());
   std::vector<float> V(vN);
   CK(hipMemcpy(V.data(), dV, vN * 4, hipMemcpyDeviceToHost));
@@ -105,9 +105,9 @@ int main(int argc, char** argv) {
       }
   printf("check R=%d C=%d map %dx%d: %zu of %zu values differ\n", R, C, H, W, bad, checked);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) mscnn::roipool_wino33_forward(dF, dT, dR, dV, R, N, C, H, W, T_pad, 0.125f, 0.f, 0.25f, nullptr);
+  for (int i = 0; i < 3; ++i) { mscnn::roipool_wino33_build_maps(dF, dT, N, C, H, W, nullptr); mscnn::roipool_wino33_forward(dT, dR, dV, R, N, C, H, W, T_pad, 0.125f, 0.f, 0.25f, nullptr); }
   CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) mscnn::roipool_wino33_forward(dF, dT, dR, dV, R, N, C, H, W, T_pad, 0.125f, 0.f, 0.25f, nullptr);
+  for (int i = 0; i < iters; ++i) { mscnn::roipool_wino33_build_maps(dF, dT, N, C, H, W, nullptr); mscnn::roipool_wino33_forward(dT, dR, dV, R, N, C, H, W, T_pad, 0.125f, 0.f, 0.25f, nullptr); }
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   printf("transpose + pooling + transform: %.1f us per call\n", ms * 1e3 / iters);
