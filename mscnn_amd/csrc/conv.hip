@@ -1350,7 +1350,7 @@ extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_p
   unsigned long long kind, e, mt, ki;
   if (p->x3h.rows) { kind = 7; e = (unsigned)p->x3h.rows_pad; mt = 0; ki = (unsigned)p->x3h.KG; }
   else if (p->hg) { kind = p->hg_kw ? 10 : 8; e = (unsigned)p->hg->entry; mt = (unsigned)p->hg->MT; ki = (unsigned)p->hg->KI; }
-  else if (p->head.entry >= 0) { kind = 2; e = (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
+  else if (p->head.entry >= 0) { kind = 2; e = p->head.valu >= 0 ? 100u + (unsigned)p->head.valu : (unsigned)p->head.entry; mt = 0; ki = (unsigned)p->head.KI; }
   else if (p->x3.BM) { kind = 6; e = (unsigned)p->x3.BM; mt = (unsigned)p->x3.MT; ki = (unsigned)p->x3.KG; }
   else if (p->wino && p->use_wg) { kind = p->wino_m == 4 ? 9u : 2 + (unsigned)p->wino_m; e = 200u + (unsigned)(p->wg.BM / 128);      /* the packing depends on BM (and CK = 32) only: the 256-row tile shapes share it */ mt = (unsigned)p->wg.MT; ki = (unsigned)p->wg.KI; }
   else if (p->wino) { kind = p->wino_m == 4 ? 9u : 2 + (unsigned)p->wino_m; e = (unsigned)p->wino->entry; mt = (unsigned)p->wino->MT; ki = (unsigned)p->wino->KI; }

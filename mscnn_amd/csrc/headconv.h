@@ -9,7 +9,17 @@ struct HeadPlan {
   int NTH = 0, NTW = 0, KI = 0, G = 0, tiles = 0;
   long total_iters = 0;
   size_t packed_bytes = 0, ws_bytes = 0;
+  // round 4: the packed-FMA kernel of headvalu.hip (valu >= 0: index into its table; the fields above are then its own)
+  int valu = -1;
+  int LPR = 0, RPW = 0, TR = 0, PR = 0, RL = 0;
+  size_t lds_bytes = 0;
 };
+
+bool headv_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp);
+const char* headv_kernel_name(const HeadPlan& hp);
+int headv_pack(const mscnn_conv_desc& d, const HeadPlan& hp, const float* w, float* packed, hipStream_t st);
+int headv_forward(const mscnn_conv_desc& d, const HeadPlan& hp, int Ho, int Wo, const float* x, const float* packed, const float* bias,
+                  float* y, void* workspace, size_t workspace_bytes, hipStream_t st);
 
 bool head_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp);
 const char* head_kernel_name(const HeadPlan& hp);
