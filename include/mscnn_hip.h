@@ -251,6 +251,25 @@ MSCNN_API int mscnn_roipool_pair_fwd_f32(const float* feat, const float* rois, f
                                          int pooled_h, int pooled_w, float spatial_scale, float pad_ratio_a, int c_offset_a,
                                          float pad_ratio_b, int c_offset_b, int C_total, void* stream);
 
+/* Chains of same-resolution 3x3 / pad 1 / stride 1 layers on the fp32 F(4x4,3x3) path (conv2_1 -> conv2_2, conv3_1 -> 3_2 -> 3_3,
+ * conv4_1 -> 4_2 -> 4_3 of the VGG trunk; the reference runs each as its own cuDNN / im2col call, cudnn_conv_layer.cu:11-46,
+ * conv_layer.cu:8-23): the output transform of `plan` writes the input-transform planes of `next` directly -- the activation between the
+ * two layers is neither written (unless y != NULL) nor read; 4.5 instead of 6.5 activation-sized HBM passes per pair.  Bit-identical to
+ * the two separate mscnn_conv2d_fwd_f32 calls.
+ *   _can_chain: 1 when both plans take that path, plan's output is next's input (N, Cout == Cin, H, W) and the map is whole 4x4 tiles
+ *     in 1, 2 or 4 strips of <= 62 tile columns;
+ *   _fwd_chain: x == NULL: the planes of plan's input are already at the start of `workspace` (plan was the `next` of the previous
+ *     call on that memory); next == NULL: ordinary output (y required, y_pool optional as in mscnn_conv2d_fwd_pool_f32) -- the tail of
+ *     a chain; next != NULL: next's planes go to the start of next_workspace (>= next's mscnn_conv2d_workspace_bytes, disjoint from
+ *     `workspace`), y may be NULL, y_pool must be;
+ *   _can_pool_only: 1 when the tail of a chain may also leave its own y unwritten (y == NULL, y_pool != NULL: conv2_2 / conv3_3, whose
+ *     only reader is the fused 2x2 pooling). */
+MSCNN_API int mscnn_conv2d_plan_can_chain(const mscnn_conv_plan* plan, const mscnn_conv_plan* next);
+MSCNN_API int mscnn_conv2d_plan_can_pool_only(const mscnn_conv_plan* plan);
+MSCNN_API int mscnn_conv2d_fwd_chain_f32(const mscnn_conv_plan* plan, const mscnn_conv_plan* next, const float* x, const float* packed,
+                               const float* bias, float* y, float* y_pool, void* workspace, size_t workspace_bytes,
+                               void* next_workspace, size_t next_workspace_bytes, void* stream);
+
 /* The detection sub-net's entry fused: ROIPooling x 2 (roi_pooling_layer.cu:19-104, pad_ratio_a -> channels [0, C), pad_ratio_b ->
  * channels [C, 2C) of the concatenated blob, concat_layer.cu:28-46) + the 3x3 convolution that consumes it (roi_c1; conv_layer.cu:8-23)
  * in its Winograd F(3x3,3x3) form: the pooled values go straight into the transform planes of the plane GEMM; the R x 2C x 7 x 7 blob

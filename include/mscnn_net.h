@@ -93,6 +93,13 @@ MSCNN_NET_API const char* mscnn_net_layer_dtype(const mscnn_net* net, int layer)
  * runs a Winograd form is re-computed with the direct kernel on the same bottom; layers over tol run the direct kernel from then on.
  * *num_switched = how many. */
 MSCNN_NET_API int mscnn_net_set_auto_calibrate(mscnn_net* net, double tol);
+/* Chains of same-resolution F(4x4,3x3) convolutions (conv2_1 -> conv2_2, conv3_1 -> 3_2 -> 3_3, conv4_1 -> 4_2 -> 4_3; mscnn_hip.h:
+ * mscnn_conv2d_fwd_chain_f32): inside a forward the blob between two members is not written -- the producer's output stage writes the
+ * consumer's transform planes.  mscnn_net_get_blob / _blob_device on such a blob re-run its producer on demand (bit-identical to the
+ * unchained forward; the reference's contract that every blob holds its layer's output after Forward, net.cpp:544-555, is kept for
+ * every reader that goes through this ABI).  ON by default (with the other Net-level fusions); on = 0 writes every blob in every
+ * forward (MSCNN_NO_CHAIN=1 does the same process-wide). */
+MSCNN_NET_API int mscnn_net_set_chain_fusion(mscnn_net* net, int on);
 MSCNN_NET_API int mscnn_net_auto_calibrate_state(const mscnn_net* net, int* checks, int* switched_layers, int cap);
 MSCNN_NET_API int mscnn_net_calibrate_numerics(mscnn_net* net, double tol, int* num_switched);
 MSCNN_NET_API double mscnn_net_layer_calibration_err(const mscnn_net* net, int layer);

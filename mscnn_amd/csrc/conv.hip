@@ -1543,11 +1543,12 @@ extern "C" int mscnn_conv2d_fwd_f32(const mscnn_conv_plan* p, const float* x, co
   return mscnn_conv2d_fwd_pool_f32(p, x, w, packed, bias, y, nullptr, workspace, workspace_bytes, stream);
 }
 
-// The fp32 Winograd path: {input stage -> V | plane GEMM V -> M | output transform M -> y}; the input stage is the plan's own
-// transform of x, or the fused ROI pooling (mscnn_conv2d_fwd_roipool_pair_f32).
-template <class InputStage>
-static int wino_forward(const mscnn_conv_plan* p, const float* packed, const float* bias, float* y, float* y_pool, void* workspace,
-                        size_t workspace_bytes, hipStream_t st, InputStage&& input_stage) {
+// The fp32 Winograd path: {input stage -> V | plane GEMM V -> M | output stage M -> y}; the input stage is the plan's own
+// transform of x, the fused ROI pooling (mscnn_conv2d_fwd_roipool_pair_f32) or nothing (planes prepared by the previous layer of a
+// chain); the output stage the plan's own transform or the one that writes the next layer's planes (mscnn_conv2d_fwd_chain_f32).
+template <class InputStage, class OutputStage>
+static int wino_forward_stages(const mscnn_conv_plan* p, const float* packed, void* workspace, size_t workspace_bytes, hipStream_t st,
+                               InputStage&& input_stage, OutputStage&& output_stage) {
   const mscnn_conv_desc& d = p->d;
 #define MSCNN_STAGE_EVENT(i) do { if (p->profiling) MSCNN_HIP_TRY(hipEventRecord(p->ev[i], st)); } while (0)
   MSCNN_REQUIRE(packed, "conv: Winograd path needs packed weights (mscnn_conv2d_pack_weights)");
@@ -1568,13 +1569,22 @@ static int wino_forward(const mscnn_conv_plan* p, const float* packed, const flo
   else rc = launch_igemm(g, V, packed, nullptr, M, nullptr, gws, g->ws_bytes, st, (unsigned)g->packed_bytes, 1);
   if (rc != MSCNN_OK) return rc;
   MSCNN_STAGE_EVENT(2);
-  rc = wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st,
-                             p->wino_m >= 3 ? p->amax_out : nullptr, (d.tune_flags & 256) != 0);
+  rc = output_stage(M);
   if (rc != MSCNN_OK) return rc;
   MSCNN_STAGE_EVENT(3);
   p->ev_valid = p->profiling;
   return MSCNN_OK;
 #undef MSCNN_STAGE_EVENT
+}
+
+template <class InputStage>
+static int wino_forward(const mscnn_conv_plan* p, const float* packed, const float* bias, float* y, float* y_pool, void* workspace,
+                        size_t workspace_bytes, hipStream_t st, InputStage&& input_stage) {
+  const mscnn_conv_desc& d = p->d;
+  return wino_forward_stages(p, packed, workspace, workspace_bytes, st, input_stage, [&](const float* M) {
+    return wino_output_transform(p->wino_m, M, bias, y, y_pool, d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w, p->T_pad, d.relu, st,
+                                 p->wino_m >= 3 ? p->amax_out : nullptr, (d.tune_flags & 256) != 0);
+  });
 }
 
 extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* x, const float* w, const float* packed,
@@ -1628,6 +1638,52 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
 #undef MSCNN_STAGE_EVENT
 }
 
+
+// ---- chains of same-resolution F(4x4,3x3) layers ---------------------------------------------------------------------------------
+static bool is_f4_plane_path(const mscnn_conv_plan* p) { return p && p->wino && p->wino_m == 4 && !p->x3.BM && p->d.N > 0; }
+extern "C" int mscnn_conv2d_plan_can_chain(const mscnn_conv_plan* p, const mscnn_conv_plan* next) {
+  if (!is_f4_plane_path(p) || !is_f4_plane_path(next)) return 0;
+  const mscnn_conv_desc &a = p->d, &b = next->d;
+  return a.N == b.N && a.Cout == b.Cin && p->Ho == b.H && p->Wo == b.W && b.Kh == 3 && b.Kw == 3 && b.pad_h == 1 && b.pad_w == 1 &&
+                 b.stride_h == 1 && b.stride_w == 1 && p->tiles_h == next->tiles_h && p->tiles_w == next->tiles_w &&
+                 !((a.tune_flags | b.tune_flags) & 256) && mscnn::wino44_outin_supported(p->Ho, p->Wo, p->tiles_h, p->tiles_w)
+             ? 1 : 0;
+}
+extern "C" int mscnn_conv2d_plan_can_pool_only(const mscnn_conv_plan* p) {
+  return is_f4_plane_path(p) && mscnn_conv2d_plan_can_pool(p) && p->Wo % 4 == 0 && p->tiles_w * 4 == p->Wo && !(p->d.tune_flags & 256) ? 1 : 0;
+}
+extern "C" int mscnn_conv2d_fwd_chain_f32(const mscnn_conv_plan* p, const mscnn_conv_plan* next, const float* x, const float* packed,
+                                          const float* bias, float* y, float* y_pool, void* workspace, size_t workspace_bytes,
+                                          void* next_workspace, size_t next_workspace_bytes, void* stream) {
+  MSCNN_REQUIRE(p, "conv: null plan");
+  MSCNN_REQUIRE(is_f4_plane_path(p), "conv(chain): the plan does not take the fp32 F(4x4,3x3) path");
+  MSCNN_REQUIRE(!next || mscnn_conv2d_plan_can_chain(p, next), "conv(chain): these two plans do not chain (mscnn_conv2d_plan_can_chain)");
+  MSCNN_REQUIRE(next ? !y_pool : (y != nullptr || (y_pool && mscnn_conv2d_plan_can_pool_only(p))),
+                "conv(chain): y_pool only without a next plan; y may be NULL only with one, or with y_pool where mscnn_conv2d_plan_can_pool_only");
+  MSCNN_REQUIRE(!y_pool || mscnn_conv2d_plan_can_pool(p), "conv: this plan has no fused 2x2 max-pooling epilogue");
+  const mscnn_conv_desc& d = p->d;
+  hipStream_t st = as_stream(stream);
+  if (next) {
+    const size_t vbytes = sizeof(float) * 36 * (size_t)next->d.Cin * next->T_pad;
+    if (!next_workspace || next_workspace_bytes < next->ws_bytes) {
+      set_error("conv(chain): next workspace %zu < %zu", next_workspace_bytes, next->ws_bytes);
+      return MSCNN_ERR_WORKSPACE;
+    }
+    // the planes written for `next` must not touch this plan's own workspace (V is dead by then, M is being read)
+    const unsigned char *a0 = static_cast<const unsigned char*>(workspace), *b0 = static_cast<const unsigned char*>(next_workspace);
+    MSCNN_REQUIRE(b0 + vbytes <= a0 || a0 + p->ws_bytes <= b0, "conv(chain): the next plan's planes overlap this plan's workspace");
+  }
+  auto input_stage = [&](float* V) {
+    if (!x) return (int)MSCNN_OK;      // prepared by the previous layer of the chain
+    return wino_input_transform(p->wino_m, x, V, d.N, d.Cin, d.H, d.W, d.pad_h, d.pad_w, p->tiles_h, p->tiles_w, p->T_pad, st,
+                                (d.tune_flags & 256) != 0, (d.tune_flags & 4096) != 0);
+  };
+  if (!next) return wino_forward(p, packed, bias, y, y_pool, workspace, workspace_bytes, st, input_stage);
+  return wino_forward_stages(p, packed, workspace, workspace_bytes, st, input_stage, [&](const float* M) {
+    return mscnn::wino44_output_into_input(M, bias, y, static_cast<float*>(next_workspace), d.N, d.Cout, p->Ho, p->Wo, p->tiles_h, p->tiles_w,
+                                           p->T_pad, next->T_pad, d.relu, st, p->amax_out);
+  });
+}
 
 extern "C" int mscnn_conv2d_plan_can_fuse_roipool(const mscnn_conv_plan* p, int C, int pooled_h, int pooled_w) {
   return p && p->wino && p->wino_m == 3 && !p->x3.BM && p->d.N > 0 && p->d.Cin == 2 * C && p->d.H == pooled_h && p->d.W == pooled_w &&

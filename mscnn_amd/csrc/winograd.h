@@ -25,4 +25,11 @@ int wino_output_transform(int m, const float* M, const float* bias, float* y, fl
 // amax != nullptr (m >= 3 only): max |y| is published as bit patterns into amax[0 .. kAmaxSlots) (atomicMax, one slot per
 // workgroup; the caller zeroes the slots before the forward and takes the maximum over them)
 
+// F(4x4,3x3) only: the output transform of layer L and the input transform of the same-resolution 3x3 / pad 1 layer L + 1 in one
+// launch -- M (planes of L, row stride T_pad_m) -> V (planes of L + 1, row stride T_pad_v), bias (+ ReLU) of L in between; y of L is
+// written only if y != nullptr.  Bit-identical to wino_output_transform + wino_input_transform.  strip_w / chunk_rows <= 0: chosen here.
+bool wino44_outin_supported(int H, int W, int tiles_h, int tiles_w);
+int wino44_output_into_input(const float* M, const float* bias, float* y, float* V, int N, int C, int H, int W, int tiles_h, int tiles_w,
+                             int T_pad_m, int T_pad_v, int relu, hipStream_t st, unsigned* amax = nullptr, int strip_w = 0, int chunk_rows = 0);
+
 }  // namespace mscnn

@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void wino44_output_vec_kernel(const float* __r
         out[i][j] = u;
       }
       if (oh < Ho) {             // (Wo is a multiple of 4 here: every column of the tile is inside the plane)
-        *reinterpret_cast<float4*>(dst + (long)oh * Wo + 4 * tx) = make_float4(out[i][0], out[i][1], out[i][2], out[i][3]);
+        if (y) *reinterpret_cast<float4*>(dst + (long)oh * Wo + 4 * tx) = make_float4(out[i][0], out[i][1], out[i][2], out[i][3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const unsigned a = wino_f4::abs_bits(out[i][j]); am = a > am ? a : am; }
       } else {
@@ -739,6 +739,134 @@ __global__ __launch_bounds__(256) void wino44_output_vec_kernel(const float* __r
         *reinterpret_cast<float2*>(pd + (long)ph * Wp + 2 * tx) = make_float2(m2[0], m2[1]);
       }
     }
+  }
+  if (amax) mscnn::publish_amax(am, amax, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// ---- F(4x4,3x3) output transform of layer L fused with the F(4x4,3x3) input transform of layer L + 1 ------------------------------
+// For two 3x3 / pad 1 / stride 1 layers of the same resolution (conv2_1 -> conv2_2, conv3_1 -> 3_2 -> 3_3, conv4_1 -> 4_2 -> 4_3) the
+// tile grids coincide: output tile (q, j) of L is rows 4q .. 4q + 3, input tile (p, j) of L + 1 rows 4p - 1 .. 4p + 4.  The unfused pair
+// moves M (2.25 y) + y | y + V (2.25 y) = 6.5 units of the activation through HBM; this kernel moves M + V = 4.5 (+ the halo columns
+// of M) and writes y only when asked to.
+// A workgroup owns one channel and a STRIP of <= 62 tile columns, and walks down the tile rows of its row chunk: a wave = one tile row,
+// a lane = one tile column of the strip + one halo column either side (64 = 62 + 2).  Per step the waves transform RW tile rows
+// of M into a ring of y rows in LDS (RING tile rows x 4 x 256 S floats), then -- one barrier later -- transform the RW input tile
+// rows whose six y rows are complete (the row above, its own four, the first of the row below).  Nothing is re-read vertically inside
+// a chunk; horizontally a strip re-reads its two halo columns (62 / 60).  The arithmetic is at6 / bt6 in the order of the two kernels
+// above, on the same fp32 values, so V (and y) are bit-identical to the unfused pair (tests/test_gpu_ops.py).
+// S strips x RW tile rows per step = the waves of a workgroup: the strips of one tile row belong to ONE workgroup, so that a row of V
+// (and of M) is touched as one contiguous run by one CU -- with the strips spread over workgroups (which land on different XCDs) the
+// 240-byte runs shared their cache lines across L2s and the kernel fell to 3.5 TB/s on the 240-column maps.
+template <int S, int RW, int RING>
+__global__ __launch_bounds__(64 * S * RW) void wino44_outin_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y,
+                                                           float* __restrict__ V, int N, int C, int H, int W, int tiles_h, int tiles_w,
+                                                           int T_pad_m, int T_pad_v, int relu, int strip_w, int chunks,
+                                                           int chunk_rows, unsigned* __restrict__ amax) {
+  static_assert((RING & (RING - 1)) == 0 && RING >= RW + 2, "ring: the tile rows of two consecutive steps");
+  __shared__ float4 ring[RING][4][64 * S];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strip = wave % S, w = wave / S;
+  const int c = blockIdx.y;
+  int b = blockIdx.x;
+  const int chunk = b % chunks;
+  const int n = b / chunks;
+  const int j0 = strip * strip_w, sw = min(strip_w, tiles_w - j0);
+  const int r0 = chunk * chunk_rows, r1 = min(r0 + chunk_rows, tiles_h);
+  const int jq = j0 - 1 + lane;                                  // phase 1: this lane's tile column (halo included)
+  const bool colq = lane < sw + 2 && jq >= 0 && jq < tiles_w;
+  const int jp = j0 + lane;                                      // phase 2: this lane's tile column
+  const bool colp = lane < sw;
+  const long stride_m = (long)C * T_pad_m, stride_v = (long)C * T_pad_v;
+  const float bv = bias ? bias[c] : 0.f;
+  unsigned am = 0;
+  // the 36 plane values of this lane's tile of tile row q (the NEXT step's loads are issued before this step's phase 2, so that M
+  // streams while the input transform computes and stores: without it the kernel is latency-bound on maps that exceed the MALL)
+  float m[36];
+  auto load_m = [&](int q) {
+    if (q <= r1 && q >= 0 && q < tiles_h && colq) {
+      const float* src = M + (long)c * T_pad_m + ((long)n * tiles_h + q) * tiles_w + jq;
+#pragma unroll
+      for (int e = 0; e < 36; ++e) m[e] = src[e * stride_m];
+    }
+  };
+  load_m(r0 - 1 + w);
+  for (int k = 0; r0 - 2 + RW * k < r1; ++k) {
+    // ---- phase 1: M -> y rows of tile row q (one per wave) into the ring
+    const int q = r0 - 1 + RW * k + w;
+    if (q <= r1) {
+      float out[4][4];
+      if (q >= 0 && q < tiles_h && colq) {
+        float r[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          float col[6], o[4];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) col[i] = m[i * 6 + j];
+          wino_f4::at6(col, o);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) r[i][j] = o[i];
+        }
+        const bool own = q >= r0 && q < r1 && lane >= 1 && lane <= sw;
+        float* dst = y ? y + ((long)n * C + c) * H * W + (long)(4 * q) * W + 4 * jq : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float o[4];
+          wino_f4::at6(r[i], o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float u = o[j] + bv;
+            if (relu) u = u > 0.f ? u : 0.f;
+            out[i][j] = u;
+          }
+          if (own) {
+            if (dst) *reinterpret_cast<float4*>(dst + (long)i * W) = make_float4(out[i][0], out[i][1], out[i][2], out[i][3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const unsigned a = wino_f4::abs_bits(out[i][j]); am = a > am ? a : am; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[i][j] = 0.f;            // outside the map: the next layer's zero padding
+      }
+      const int slot = (q - r0 + 1) & (RING - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ring[slot][i][strip * 64 + lane] = make_float4(out[i][0], out[i][1], out[i][2], out[i][3]);
+    }
+    if (r0 - 2 + RW * (k + 1) < r1) load_m(q + RW);
+    __syncthreads();
+    // ---- phase 2: y rows 4p - 1 .. 4p + 4 -> the 36 planes of input tile row p (one per wave)
+    const int p = r0 - 2 + RW * k + w;
+    if (p >= r0 && p < r1 && colp) {
+      const float* base = reinterpret_cast<const float*>(&ring[0][0][0]);
+      float d[6][6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int yr = 4 * (p - r0 + 1) - 1 + i;                  // ring row: (tile row - r0 + 1) * 4 + row in tile
+        const float* row = base + ((yr >> 2) & (RING - 1)) * (1024 * S) + (yr & 3) * (256 * S) + 256 * strip + 4 * lane;
+        const float4 mid = *reinterpret_cast<const float4*>(row + 4);
+        d[i][0] = row[3]; d[i][1] = mid.x; d[i][2] = mid.y; d[i][3] = mid.z; d[i][4] = mid.w; d[i][5] = row[8];
+      }
+      float* dst = V + (long)c * T_pad_v + ((long)n * tiles_h + p) * tiles_w + jp;
+      float r[6][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float o[6];
+        wino_f4::bt6(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i][j] = o[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float o[6];
+        wino_f4::bt6(r[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * stride_v] = o[j];
+      }
+    }
+    __syncthreads();
   }
   if (amax) mscnn::publish_amax(am, amax, blockIdx.y * gridDim.x + blockIdx.x);
 }
@@ -790,6 +918,8 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
 int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
                           int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st, unsigned* amax, bool scalar_f4) {
   MSCNN_REQUIRE(!amax || m >= 3, "winograd: max |y| is published by the F(3x3,3x3) / F(4x4,3x3) output transforms only");
+  MSCNN_REQUIRE(y || (y_pool && m == 4 && Wo % 4 == 0 && tiles_w * 4 == Wo && !scalar_f4),
+                "winograd: only the vector F(4x4,3x3) output transform with fused pooling runs without y");
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T, 256), Cout);
   if (m == 4 && Wo % 4 == 0 && tiles_w * 4 == Wo && reinterpret_cast<uintptr_t>(y) % 16 == 0 && (!y_pool || reinterpret_cast<uintptr_t>(y_pool) % 8 == 0) &&
@@ -809,6 +939,33 @@ int wino_output_transform(int m, const float* M, const float* bias, float* y, fl
   } else {
     wino_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu);
   }
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+bool wino44_outin_supported(int H, int W, int tiles_h, int tiles_w) {
+  const int ns = cdiv(tiles_w, 62);
+  return H % 4 == 0 && W % 4 == 0 && tiles_h * 4 == H && tiles_w * 4 == W && ns <= 4 && ns != 3;
+}
+
+int wino44_output_into_input(const float* M, const float* bias, float* y, float* V, int N, int C, int H, int W, int tiles_h, int tiles_w,
+                             int T_pad_m, int T_pad_v, int relu, hipStream_t st, unsigned* amax, int strip_w, int chunk_rows) {
+  MSCNN_REQUIRE(wino44_outin_supported(H, W, tiles_h, tiles_w), "winograd F(4x4,3x3) chain: the map must be whole 4x4 tiles");
+  MSCNN_REQUIRE(y == nullptr || reinterpret_cast<uintptr_t>(y) % 16 == 0, "winograd F(4x4,3x3) chain: y must be 16-byte aligned");
+  // strips of equal width <= 62 tile columns (60 + 60 for 120 columns, 4 x 60 for 240), all strips of a row in one workgroup
+  const int ns = cdiv(tiles_w, 62);
+  MSCNN_REQUIRE(ns <= 4 && ns != 3, "winograd F(4x4,3x3) chain: 1, 2 or 4 strips of <= 62 tile columns");
+  if (strip_w <= 0 || strip_w > 62 || cdiv(tiles_w, strip_w) != ns) strip_w = cdiv(tiles_w, ns);
+  if (chunk_rows <= 0) {       // row chunks (each re-reads its two halo tile rows) until the launch has two workgroups per CU
+    int chunks = 1;
+    while ((long)N * C * chunks < 512 && tiles_h / (chunks * 2) >= 9) chunks *= 2;
+    chunk_rows = cdiv(tiles_h, chunks);
+  }
+  const int chunks = cdiv(tiles_h, chunk_rows);
+  const dim3 grid(chunks * N, C);
+  if (ns == 1) wino44_outin_kernel<1, 4, 8><<<grid, 256, 0, st>>>(M, bias, y, V, N, C, H, W, tiles_h, tiles_w, T_pad_m, T_pad_v, relu, strip_w, chunks, chunk_rows, amax);
+  else if (ns == 2) wino44_outin_kernel<2, 2, 4><<<grid, 256, 0, st>>>(M, bias, y, V, N, C, H, W, tiles_h, tiles_w, T_pad_m, T_pad_v, relu, strip_w, chunks, chunk_rows, amax);
+  else wino44_outin_kernel<4, 2, 4><<<grid, 512, 0, st>>>(M, bias, y, V, N, C, H, W, tiles_h, tiles_w, T_pad_m, T_pad_v, relu, strip_w, chunks, chunk_rows, amax);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

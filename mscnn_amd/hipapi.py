@@ -99,6 +99,9 @@ def lib():
         L.mscnn_conv2d_fwd_pool_f32.argtypes = [C.c_void_p] * 8 + [C.c_size_t, C.c_void_p]
         L.mscnn_conv2d_plan_can_pool.argtypes = [C.c_void_p]
         L.mscnn_conv2d_plan_can_fuse_roipool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mscnn_conv2d_plan_can_chain.argtypes = [C.c_void_p, C.c_void_p]
+        L.mscnn_conv2d_plan_can_pool_only.argtypes = [C.c_void_p]
+        L.mscnn_conv2d_fwd_chain_f32.argtypes = [C.c_void_p] * 8 + [C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.mscnn_conv2d_roipool_workspace_bytes.restype = C.c_size_t
         L.mscnn_conv2d_roipool_workspace_bytes.argtypes = [C.c_void_p] + [C.c_int] * 4
         L.mscnn_conv2d_fwd_roipool_pair_f32.argtypes = ([C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_float, C.c_float, C.c_float]
@@ -242,6 +245,25 @@ class ConvPlan:
         wsb = self.ws.numel() * 4 if self.ws is not None else 0
         _check(lib().mscnn_conv2d_fwd_pool_f32(self._p, _dev(x), _dev(self.w), _dev(self.packed), _dev(bias), _dev(out),
                                                _dev(pool_out), _dev(self.ws), wsb, _stream()))
+        return out
+
+    @property
+    def can_pool_only(self):
+        return bool(lib().mscnn_conv2d_plan_can_pool_only(self._p))
+
+    def can_chain(self, nxt):
+        return bool(lib().mscnn_conv2d_plan_can_chain(self._p, nxt._p))
+
+    def forward_chain(self, x, nxt, bias=None, out=None, pool_out=None, write_y=True):
+        """mscnn_conv2d_fwd_chain_f32: x None = this plan's planes were prepared (it was the `nxt` of the previous call);
+        nxt given = its planes are written by this plan's output stage (y only if write_y); nxt None = ordinary output."""
+        if out is None and write_y:
+            out = torch.empty(self.out_shape(), dtype=torch.float32, device=self.ws.device)
+        wsb = self.ws.numel() * 4
+        _check(lib().mscnn_conv2d_fwd_chain_f32(self._p, nxt._p if nxt is not None else None, _dev(x), _dev(self.packed), _dev(bias),
+                                                _dev(out) if write_y else None, _dev(pool_out), _dev(self.ws), wsb,
+                                                _dev(nxt.ws) if nxt is not None else None, nxt.ws.numel() * 4 if nxt is not None else 0,
+                                                _stream()))
         return out
 
     def can_fuse_roipool(self, Cc, pooled_h, pooled_w):

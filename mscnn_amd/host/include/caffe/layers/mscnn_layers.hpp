@@ -80,6 +80,24 @@ class ConvolutionLayer : public Layer<Dtype> {
   // channels [0, C) and [C, 2C) in the order of their Concat offsets).  While the pair is pending and the planned kernel can pool in
   // its input stage (mscnn_conv2d_plan_can_fuse_roipool) Forward reads the feature map itself; otherwise it asks for the blob.
   void FuseRoiPoolInput(ROIPoolingLayer<Dtype>* first) { roi_src_ = first; }
+  // Net-level fusion (round 4): `next` is the ONLY reader of this layer's top and a same-resolution 3x3 / pad 1 convolution.  While
+  // the Net marks the pair live (both run in the same ForwardFromTo call) and both planned kernels are the fp32 F(4x4,3x3) form
+  // (mscnn_conv2d_plan_can_chain), this layer's output stage writes next's input-transform planes and NOT its top blob
+  // (top_stale() until someone asks: Net::MaterializeBlob re-runs the layer unchained -- bit-identical kernels).
+  void ChainTo(ConvolutionLayer* next) { chain_next_ = next; }
+  ConvolutionLayer* chain_next() const { return chain_next_; }
+  void set_chain_live(bool on) { chain_live_ = on; if (!on) prepared_ = false; }
+  // The top's only reader is the fused-away 2x2 pooling (conv2_2, conv3_3): while live, an F(4x4,3x3) Forward writes the pooled blob
+  // only (mscnn_conv2d_plan_can_pool_only); the top is top_stale() and re-created on demand like a chain's
+  void set_pool_only_live(bool on) { pool_only_live_ = on; }
+  bool top_stale() const { return top_stale_; }
+  // Forward with the chain (and a prepared input) ignored: writes the top blob from the bottom blob
+  void ForwardUnchained(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    const bool live = chain_live_, po = pool_only_live_;
+    chain_live_ = false; prepared_ = false; pool_only_live_ = false;
+    this->Forward(bottom, top);
+    chain_live_ = live; pool_only_live_ = po;
+  }
   virtual double ForwardFlops() const;
   const char* kernel_name() const;
   const char* dtype() const;              // "f32" | "f16": MFMA operand type of the planned kernel
@@ -137,6 +155,12 @@ class ConvolutionLayer : public Layer<Dtype> {
   int algo_, tune_[3];
   ROIPoolingLayer<Dtype>* roi_src_ = nullptr;
   bool last_fused_roipool_ = false;       // the last Forward pooled inside its input stage (kernel_name() says so)
+  ConvolutionLayer* chain_next_ = nullptr;
+  bool chain_live_ = false, pool_only_live_ = false, top_stale_ = false, last_chained_ = false;
+  bool prepared_ = false;                 // the previous layer of the chain wrote this layer's planes at ws_off_ (this Forward only)
+  size_t ws_off_ = 0, next_off_ = 0;      // this layer's / the next layer's region of the shared workspace while a chain runs
+  bool fuse_next_now_ = false;            // decided by the head of the chain for this Forward
+  bool ChainableNow(int n, int h, int w);
   bool calibrated_direct_ = false;
   double selfcheck_tol_ = kDefaultSelfcheckTol, selfcheck_err_ = 0.0;
   bool selfcheck_pending_ = true, selfcheck_ran_ = false, selfcheck_fell_back_ = false;

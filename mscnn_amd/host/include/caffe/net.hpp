@@ -74,6 +74,12 @@ class Net {
   void MaterializePending() const;
   // ... only where `blob_name` is (or shares its data, through Split layers, with) a blob the pending pooling reads
   void MaterializePendingReadersOf(const string& blob_name) const;
+  // Chains of same-resolution F(4x4,3x3) convolutions (ConvolutionLayer::ChainTo: conv2_1 -> conv2_2, conv3_1 -> 3_2 -> 3_3,
+  // conv4_1 -> 4_2 -> 4_3): the blob between two members is not written while both run in one ForwardFromTo call; blob_by_name()
+  // / MaterializeBlob() re-run the producer unchained when somebody asks for it (bit-identical).  On by default with `fusion`;
+  // MSCNN_NO_CHAIN=1 or SetChainFusion(false) turn it off (every blob is then written by every Forward).
+  void SetChainFusion(bool on) { chain_fusion_ = on; }
+  bool chain_fusion() const { return chain_fusion_; }
   // Numerical calibration on representative data: call after a Forward.  Every Convolution layer that runs a Winograd
   // form is re-computed with the direct k-ordered kernel on the same bottom; where max |dy| / max(1, |y|) exceeds `tol`
   // the layer is switched to the direct kernel for good (ConvolutionLayer::set_algo).  Returns the layers switched;
@@ -129,6 +135,9 @@ class Net {
   mutable std::map<int, bool> redirect_dirty_;     // producer ran since the last MaterializeBlob
   struct DeferredPool { int first_layer, conv_layer, blob; };      // a ROIPooling pair whose only reader pools in its own input stage
   vector<DeferredPool> deferred_pools_;
+  struct ChainPair { int producer, consumer, blob; };              // convolution -> its only reader, a same-resolution 3x3 convolution (-1: read by its fused pooling only)
+  vector<ChainPair> chain_pairs_;
+  bool chain_fusion_ = true;
   int SplitSource(int blob) const;      // through Split layers (their tops share the bottom's data) to the blob that holds the data
   vector<double> calib_err_;
   void NumericsWatchStep();

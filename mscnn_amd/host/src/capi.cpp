@@ -207,6 +207,9 @@ int mscnn_net_numerics_watch_state(const mscnn_net* n, int* checks, int* switche
 int mscnn_net_set_auto_calibrate(mscnn_net* n, double tol) {
   return guarded([&] { n->net->SetAutoCalibrate(tol); });
 }
+int mscnn_net_set_chain_fusion(mscnn_net* n, int on) {
+  return guarded([&] { n->net->SetChainFusion(on != 0); });
+}
 int mscnn_net_auto_calibrate_state(const mscnn_net* n, int* checks, int* switched_layers, int cap) {
   const std::vector<int>& sw = n->net->auto_calibrate_switched();
   if (checks) *checks = n->net->auto_calibrate_checks();

@@ -264,10 +264,20 @@ double ConvolutionLayer<Dtype>::ForwardFlops() const { return plan_ ? mscnn_conv
 template <typename Dtype>
 const char* ConvolutionLayer<Dtype>::kernel_name() const {
   if (plan_ && last_fused_roipool_ && std::strcmp(mscnn_conv2d_plan_kernel(plan_), "winograd_f3x3_3x3") == 0) return "winograd_f3x3_3x3+roipool_pair";
+  if (plan_ && last_chained_ && std::strcmp(mscnn_conv2d_plan_kernel(plan_), "winograd_f4x4_3x3") == 0) return "winograd_f4x4_3x3+into_next";
   return plan_ ? mscnn_conv2d_plan_kernel(plan_) : "";
 }
 template <typename Dtype>
 const char* ConvolutionLayer<Dtype>::dtype() const { return plan_ ? mscnn_conv2d_plan_dtype(plan_) : "f32"; }
+
+// (called by the head of a chain on each later member) plans the layer for the chain's shape and says whether it may take prepared
+// planes this Forward: no first-forward self-check pending, packed weights in place or packable, fp32 F(4x4,3x3) is checked by the caller
+template <typename Dtype>
+bool ConvolutionLayer<Dtype>::ChainableNow(int n, int h, int w) {
+  if (selfcheck_pending_ || roi_src_ || kernel_h_ != 3 || kernel_w_ != 3) return false;
+  Plan(n, h, w);
+  return plan_ != nullptr;
+}
 
 template <typename Dtype>
 void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
@@ -290,7 +300,32 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
   CHECK(dev >= 0 && dev < 64);
   if (!shared_ws[dev]) shared_ws[dev] = new DeviceBuffer();
   const size_t wbytes = mscnn_conv2d_workspace_bytes(plan_);
-  void* ws = wbytes ? shared_ws[dev]->Reserve(wbytes) : nullptr;
+  // A chain of same-resolution F(4x4,3x3) layers (ChainTo): the head -- the first member whose planes nobody prepared -- plans every
+  // member, decides how far the chain goes this Forward and gives each member its own region of the shared buffer (a member's output
+  // stage writes the next member's planes while its own M is still being read), reserving the whole extent ONCE: a Reserve that
+  // grows the buffer later would lose the planes already written.
+  const bool was_prepared = prepared_;
+  prepared_ = false;
+  if (!was_prepared) {
+    ws_off_ = 0;
+    fuse_next_now_ = false;
+    size_t extent = wbytes;
+    if (chain_live_ && chain_next_ && !pooled_top_ && !selfcheck_pending_ && !(roi_src_ && roi_src_->pending())) {
+      const int n = bottom[0]->num(), h = bottom[0]->height(), wd = bottom[0]->width();
+      for (ConvolutionLayer* c = this; c->chain_next_ && c->chain_live_ && !c->pooled_top_ && c->chain_next_->ChainableNow(n, h, wd) &&
+                                       mscnn_conv2d_plan_can_chain(c->plan_, c->chain_next_->plan_); c = c->chain_next_) {
+        ConvolutionLayer* nx = c->chain_next_;
+        const size_t cb = (mscnn_conv2d_workspace_bytes(c->plan_) + 255) / 256 * 256, nb = mscnn_conv2d_workspace_bytes(nx->plan_);
+        c->fuse_next_now_ = true;
+        c->next_off_ = c->ws_off_ >= nb ? 0 : c->ws_off_ + cb;      // ping-pong: back to the front when the front region is large enough
+        nx->ws_off_ = c->next_off_;
+        nx->fuse_next_now_ = false;
+        extent = std::max(extent, std::max(c->ws_off_ + cb, nx->ws_off_ + nb));
+      }
+    }
+    if (extent) shared_ws[dev]->Reserve(extent);
+  }
+  void* ws = wbytes ? static_cast<unsigned char*>(shared_ws[dev]->Reserve(ws_off_ + wbytes)) + ws_off_ : nullptr;
   const float* bias = bias_term_ ? this->blobs_[1]->gpu_data() : nullptr;
   {
     const bool pub = amax_wanted_ && amax_out_ && mscnn_conv2d_plan_publishes_amax(plan_);
@@ -326,8 +361,25 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     pooled_top_->Reshape(top[0]->num(), top[0]->channels(), (top[0]->height() + 1) / 2, (top[0]->width() + 1) / 2);
     if (mscnn_conv2d_plan_can_pool(plan_)) pooled = pooled_top_->mutable_gpu_data();
   }
-  MSCNN_CHECK(mscnn_conv2d_fwd_pool_f32(plan_, bottom[0]->gpu_data(), w, packed, bias, top[0]->mutable_gpu_data(), pooled, ws,
-                                        wbytes, S()));
+  last_chained_ = false;
+  const bool pool_only = pool_only_live_ && pooled && !selfcheck_pending_ && mscnn_conv2d_plan_can_pool_only(plan_);
+  if (was_prepared || fuse_next_now_ || pool_only) {
+    // a member of a running chain: planes prepared by the previous member (x = NULL) and / or written for the next one (its top blob
+    // is then NOT written: top_stale_)
+    ConvolutionLayer* nx = fuse_next_now_ ? chain_next_ : nullptr;
+    const size_t nb = nx ? mscnn_conv2d_workspace_bytes(nx->plan_) : 0;
+    void* nws = nx ? static_cast<unsigned char*>(shared_ws[dev]->Reserve(next_off_ + nb)) + next_off_ : nullptr;
+    MSCNN_CHECK(mscnn_conv2d_fwd_chain_f32(plan_, nx ? nx->plan_ : nullptr, was_prepared ? nullptr : bottom[0]->gpu_data(), packed, bias,
+                                           nx || pool_only ? nullptr : top[0]->mutable_gpu_data(), nx ? nullptr : pooled, ws, wbytes, nws,
+                                           nb, S()));
+    if (nx) { nx->prepared_ = true; top_stale_ = true; last_chained_ = true; }
+    else top_stale_ = pool_only;
+    fuse_next_now_ = false;
+  } else {
+    MSCNN_CHECK(mscnn_conv2d_fwd_pool_f32(plan_, bottom[0]->gpu_data(), w, packed, bias, top[0]->mutable_gpu_data(), pooled, ws,
+                                          wbytes, S()));
+    top_stale_ = false;
+  }
   if (pooled_top_ && !pooled) {
     // the planned kernel has no pooling epilogue (e.g. a direct-kernel shape): run the pooling the fused-away layer would have
     MSCNN_CHECK(mscnn_pool2d_fwd_f32(top[0]->gpu_data(), pooled_top_->mutable_gpu_data(), top[0]->num(), top[0]->channels(),

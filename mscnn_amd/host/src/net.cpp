@@ -5,6 +5,7 @@
 #include "caffe/util/hdf5_lite.hpp"
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -17,6 +18,7 @@
 #include "caffe/layer_factory.hpp"
 #include "caffe/layers/mscnn_layers.hpp"
 #include "caffe/net.hpp"
+#include <algorithm>
 
 namespace caffe {
 
@@ -348,6 +350,48 @@ void Net<Dtype>::ApplyFusion() {
       }
     }
   }
+  // Chains of convolutions (ConvolutionLayer::ChainTo): the top of convolution i is read by exactly one layer that still runs -- a
+  // 3x3 convolution j > i with nothing running in between (the in-place ReLU is fused away) -- and is not a net output.
+  if (const char* e = getenv("MSCNN_NO_CHAIN")) chain_fusion_ = !(e[0] && e[0] != '0');
+  for (size_t i = 0; i < layers_.size(); ++i) {
+    ConvolutionLayer<Dtype>* ci = fused_away_[i] ? nullptr : dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
+    if (!ci || top_id_vecs_[i].size() != 1) continue;
+    const int tb = top_id_vecs_[i][0];
+    int reader = -1, readers = 0;
+    bool only_relu = true;
+    for (size_t l = 0; l < layers_.size(); ++l) {
+      if (l == i) continue;
+      for (int bb : bottom_id_vecs_[l]) {
+        if (bb != tb) continue;
+        if (fused_away_[l]) only_relu = only_relu && string(layers_[l]->type()) == "ReLU";
+        else { reader = (int)l; ++readers; }
+      }
+    }
+    bool is_output = false;
+    for (int ob : net_output_blob_indices_) is_output = is_output || ob == tb;
+    if (readers == 0 && !is_output && !redirect_.count(tb)) {
+      // read by fused-away layers only (its ReLU, the 2x2 pooling in this convolution's epilogue): the top need not be written
+      bool pooled_here = false;
+      for (size_t l = 0; l < layers_.size(); ++l)
+        if (fused_away_[l] && string(layers_[l]->type()) == "Pooling")
+          for (int p : fused_producers_[l]) pooled_here = pooled_here || p == (int)i;
+      if (pooled_here) {
+        ChainPair cp;
+        cp.producer = (int)i; cp.consumer = -1; cp.blob = tb;
+        chain_pairs_.push_back(cp);
+      }
+      continue;
+    }
+    if (readers != 1 || !only_relu || is_output || reader <= (int)i || redirect_.count(tb)) continue;
+    ConvolutionLayer<Dtype>* cj = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[reader].get());
+    bool adjacent = cj != nullptr;
+    for (int l = (int)i + 1; l < reader && adjacent; ++l) adjacent = fused_away_[l];
+    if (!adjacent) continue;
+    ci->ChainTo(cj);
+    ChainPair cp;
+    cp.producer = (int)i; cp.consumer = reader; cp.blob = tb;
+    chain_pairs_.push_back(cp);
+  }
 }
 
 template <typename Dtype>
@@ -364,7 +408,23 @@ int Net<Dtype>::SplitSource(int blob) const {
 
 template <typename Dtype>
 void Net<Dtype>::MaterializePendingReadersOf(const string& blob_name) const {
-  if (deferred_pools_.empty() || !has_blob(blob_name)) return;
+  if (!has_blob(blob_name)) return;
+  {
+    // blobs inside convolution chains that the last Forward did not write and whose value hangs on this blob: written now, from the
+    // bottoms their layers were given (the reference's blobs hold exactly that)
+    std::vector<int> affected(1, blob_names_index_.find(blob_name)->second);
+    for (size_t a = 0; a < affected.size(); ++a)
+      for (size_t k = 0; k < chain_pairs_.size(); ++k) {
+        const int i = chain_pairs_[k].producer;
+        if (!static_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())->top_stale()) continue;
+        for (int bb : bottom_id_vecs_[i])
+          if ((bb == affected[a] || SplitSource(bb) == SplitSource(affected[a])) &&
+              std::find(affected.begin(), affected.end(), chain_pairs_[k].blob) == affected.end())
+            affected.push_back(chain_pairs_[k].blob);
+      }
+    for (size_t a = 1; a < affected.size(); ++a) MaterializeBlob(affected[a]);
+  }
+  if (deferred_pools_.empty()) return;
   const int src = SplitSource(blob_names_index_.find(blob_name)->second);
   for (size_t k = 0; k < deferred_pools_.size(); ++k) {
     const int fl = deferred_pools_[k].first_layer;
@@ -381,6 +441,17 @@ void Net<Dtype>::MaterializePending() const {
 
 template <typename Dtype>
 void Net<Dtype>::MaterializeBlob(int blob_id) const {
+  // the blob between two members of a convolution chain that the last Forward did not write: re-run its producer unchained, from a
+  // bottom that is brought up to date the same way first (same kernels as the chain: bit-identical)
+  for (size_t k = 0; k < chain_pairs_.size(); ++k)
+    if (chain_pairs_[k].blob == blob_id) {
+      const int i = chain_pairs_[k].producer;
+      ConvolutionLayer<Dtype>* c = static_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
+      if (c->top_stale()) {
+        for (int bb : bottom_id_vecs_[i]) MaterializeBlob(bb);
+        c->ForwardUnchained(bottom_vecs_[i], top_vecs_[i]);
+      }
+    }
   typename std::map<int, Redirect>::const_iterator it = redirect_.find(blob_id);
   // a deferred ROIPooling pair's blob (asked for directly, or as the home of a redirected roi_pool_org / roi_pool_ctx): write it now
   for (size_t k = 0; k < deferred_pools_.size(); ++k)
@@ -406,6 +477,8 @@ vector<int> Net<Dtype>::CalibrateNumerics(double tol) {
     calib_err_[i] = 0.0;
     ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
     if (!c || c->algo() == 1 || c->algo() == 4) continue;      // direct already / fp16 mode has its own tolerance policy
+    for (int bb : bottom_id_vecs_[i]) MaterializeBlob(bb);      // (blobs inside a convolution chain are written on demand)
+    for (int tb : top_id_vecs_[i]) MaterializeBlob(tb);
     calib_err_[i] = c->ErrorAgainstDirect(bottom_vecs_[i], top_vecs_[i]);
     if (!(calib_err_[i] <= tol)) {      // (NaN counts as a failure)
       LOG(WARNING) << "layer " << layer_names_[i] << ": Winograd result off the direct sum by " << calib_err_[i] << " > " << tol
@@ -434,6 +507,8 @@ void Net<Dtype>::NumericsWatchStep() {
     if (!c || fused_away_[i] || c->algo() == 1 || c->algo() == 4 || std::strncmp(c->kernel_name(), "winograd", 8) != 0) continue;
     watch_next_ = (i + 1) % L;
     ++watch_checks_;
+    for (int bb : bottom_id_vecs_[i]) MaterializeBlob(bb);      // (blobs inside a convolution chain are written on demand)
+    for (int tb : top_id_vecs_[i]) MaterializeBlob(tb);
     calib_err_[i] = c->ErrorAgainstDirect(bottom_vecs_[i], top_vecs_[i]);
     if (!(calib_err_[i] <= watch_tol_)) {
       LOG(WARNING) << "layer " << layer_names_[i] << ": Winograd result off the direct sum by " << calib_err_[i] << " > " << watch_tol_
@@ -496,6 +571,29 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
     }
     if (any) HIP_CHECK(hipMemsetAsync(amax_slots_, 0, sizeof(unsigned) * MSCNN_AMAX_SLOTS * layers_.size(), (hipStream_t)Caffe::stream()));
   }
+  // convolution chains: a pair is live when both members run in this call; a consumer that runs WITHOUT its producer reads a blob
+  // the last whole Forward may not have written
+  for (size_t k = 0; k < chain_pairs_.size(); ++k) {
+    const ChainPair& cp = chain_pairs_[k];
+    ConvolutionLayer<Dtype>* c = static_cast<ConvolutionLayer<Dtype>*>(layers_[cp.producer].get());
+    if (cp.consumer < 0) {      // (a top read by the fused pooling only)
+      c->set_pool_only_live(fusion_ && chain_fusion_ && start <= cp.producer && cp.producer <= end);
+      if (!(start <= cp.producer && cp.producer <= end)) MaterializeBlob(cp.blob);
+      continue;
+    }
+    const bool both = start <= cp.producer && cp.consumer <= end;
+    c->set_chain_live(fusion_ && chain_fusion_ && both);
+    static_cast<ConvolutionLayer<Dtype>*>(layers_[cp.consumer].get())->set_chain_live(false);
+    // a blob the last Forward left unwritten whose producer does not run in this call: write it now, from the bottom its layer was
+    // given -- this call may rewrite that bottom, or run the consumer from the blob
+    if (!(start <= cp.producer && cp.producer <= end)) MaterializeBlob(cp.blob);
+  }
+  for (size_t k = 0; k < chain_pairs_.size(); ++k) {      // (a consumer that is itself a producer: its own live mark, set above, stands)
+    const ChainPair& cp = chain_pairs_[k];
+    if (cp.consumer < 0) continue;
+    const bool both = start <= cp.producer && cp.consumer <= end;
+    static_cast<ConvolutionLayer<Dtype>*>(layers_[cp.producer].get())->set_chain_live(fusion_ && chain_fusion_ && both);
+  }
   for (int i = start; i <= end; ++i) {
     bool run = !fused_away_[i];
     if (fused_away_[i]) {
@@ -525,6 +623,11 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   // direct Layer::Forward on the second: it has to pool, not skip)
   for (size_t i = 0; i < layers_.size(); ++i)
     if (string(layers_[i]->type()) == "ROIPooling") static_cast<ROIPoolingLayer<Dtype>*>(layers_[i].get())->set_skip(false);
+  for (size_t k = 0; k < chain_pairs_.size(); ++k) {
+    static_cast<ConvolutionLayer<Dtype>*>(layers_[chain_pairs_[k].producer].get())->set_chain_live(false);
+    static_cast<ConvolutionLayer<Dtype>*>(layers_[chain_pairs_[k].producer].get())->set_pool_only_live(false);
+    if (chain_pairs_[k].consumer >= 0) static_cast<ConvolutionLayer<Dtype>*>(layers_[chain_pairs_[k].consumer].get())->set_chain_live(false);
+  }
   // books of the layers' own first-forward checks (safe-by-default numerics: ConvolutionLayer::set_selfcheck)
   for (int i = start; i <= end; ++i)
     if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) {

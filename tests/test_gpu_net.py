@@ -781,3 +781,64 @@ def test_roi_pooling_deferred_into_roi_c1():
     u.set_precision("f16x3")
     u.forward()
     assert np.array_equal(n.get_blob("fc6"), u.get_blob("fc6"))
+
+
+def test_convolution_chains_keep_every_blob_bit_identical():
+    """Round 4: conv2_1 -> conv2_2, conv3_1 -> 3_2 -> 3_3, conv4_1 -> 4_2 -> 4_3 run as chains (mscnn_conv2d_fwd_chain_f32): the blob
+    between two members is not written during a forward.  (a) every blob of the net -- the skipped ones re-created on demand -- is
+    bit-identical to the net with the chains off; (b) the skipped blobs really were skipped (kernel name) and detections agree; (c) a
+    partial range that starts at a consumer runs from the blob; (d) a partial range that rewrites a chain's bottom does not change
+    what a skipped blob of the EARLIER frame reads as; (e) writing such a bottom through the ABI neither."""
+    # (full size: AUTO takes F(4x4,3x3) only where the map has >= 1000 tiles)
+    txt = zoo.prototxt("kitti_car/mscnn-7s-576")
+    x = synth.frame(576, 1920)
+    n = mnet.Net(prototxt_text=txt)
+    u = mnet.Net(prototxt_text=txt)
+    u.set_chain_fusion(False)
+    for net in (n, u):
+        synth.load_into(net, "mid")
+        net.set_blob("data", x)
+        net.forward()
+        net.forward()                                    # (the first forward ran the layers' own numerical checks, unchained)
+    names = n.layer_names
+    producers = ["conv2_1", "conv3_1", "conv3_2", "conv4_1", "conv4_2"]
+    for p in producers:
+        assert n.layer_kernel(names.index(p)) == "winograd_f4x4_3x3+into_next", (p, n.layer_kernel(names.index(p)))
+        assert u.layer_kernel(names.index(p)) == "winograd_f4x4_3x3"
+    for t in ("conv2_2", "conv3_3", "conv4_3"):      # (conv2_2 / conv3_3 write their pooled blob only: read by the fused pooling alone)
+        assert n.layer_kernel(names.index(t)) == "winograd_f4x4_3x3"
+    # (a) tails and everything behind them first (no re-creation involved), then the skipped blobs
+    for b in ("pool2", "conv3_3", "conv4_3", "conv5_3", "fc6", "cls_pred", "bbox_pred", "proposals"):
+        assert np.array_equal(n.get_blob(b), u.get_blob(b)), b
+    for b in producers[::-1] + ["conv2_2"]:
+        assert np.array_equal(n.get_blob(b), u.get_blob(b)), b
+    # (c) from conv3_2 on, with a conv3_1 blob written from outside: both nets compute the same from it
+    z = (u.get_blob("conv3_1") * 0.5).astype(np.float32)
+    for net in (n, u):
+        net.forward()
+        net.set_blob("conv3_1", z)
+        net.forward(names.index("conv3_2"), names.index("relu4_3"))
+    assert np.array_equal(n.get_blob("conv4_3"), u.get_blob("conv4_3"))
+    assert np.array_equal(n.get_blob("conv3_2"), u.get_blob("conv3_2"))
+    # (d) a whole forward, then conv1_1 .. pool2 of ANOTHER frame: conv3_1 / conv3_2 still read as the first frame's
+    for net in (n, u):
+        net.set_blob("data", x)
+        net.forward()
+    want31, want32 = u.get_blob("conv3_1"), u.get_blob("conv3_2")
+    for net in (n, u):
+        net.set_blob("data", synth.frame(576, 1920, seed=77))
+        net.forward(0, names.index("pool2"))
+    assert not np.array_equal(n.get_blob("pool2"), np.zeros(1)) and np.array_equal(n.get_blob("pool2"), u.get_blob("pool2"))
+    assert np.array_equal(n.get_blob("conv3_2"), want32) and np.array_equal(n.get_blob("conv3_1"), want31)
+    # (e) the same through a setter
+    n.set_blob("data", x)
+    n.forward()
+    n.set_blob("pool2", np.zeros(n.blob_shape("pool2"), np.float32))
+    assert np.array_equal(n.get_blob("conv3_2"), want32) and np.array_equal(n.get_blob("conv3_1"), want31)
+    # detections of the chained net = the unchained net's (whole frames)
+    kw = dict(cls_id=2, ratios=(576 / 375.0, 1920 / 1242.0), org_hw=(375, 1242))
+    for net in (n, u):
+        net.set_blob("data", x)
+        net.forward()
+    dn, du = n.detect(**kw), u.detect(**kw)
+    assert dn[0].tobytes() == du[0].tobytes() and np.array_equal(dn[1], du[1]) and len(dn[0]) > 0

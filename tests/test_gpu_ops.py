@@ -1436,3 +1436,47 @@ def test_conv_roipool_pair_fused_is_bit_identical(hip, orc, case):
     assert torch.equal(y3, y3_ref)
     plan.set_batch(5)                               # below 8 ROIs the plan leaves Winograd: nothing to fuse into
     assert not plan.can_fuse_roipool(Cc, 7, 7)
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 64, 48, 72, 240), (1, 16, 32, 32, 144, 480), (2, 8, 16, 24, 40, 200), (1, 8, 8, 8, 288, 960)])
+def test_conv_chain_f4_is_bit_identical(hip, shape):
+    """mscnn_conv2d_fwd_chain_f32: three same-resolution F(4x4,3x3) layers with the activation between them never written -- the
+    output transform of one layer writes the next one's input-transform planes (winograd.hip: wino44_outin_kernel; 1, 2 and 4 strips
+    of tile columns, row chunks, a batch of 2).  Every result is bit-identical to the three separate forwards; y written on request
+    is the separate forward's y; the tail takes the fused pooling."""
+    N, C0, C1, C2, H, W = shape
+    rng = np.random.default_rng(5)
+    x = dev(rng.standard_normal((N, C0, H, W)).astype(np.float32))
+    chans = [C0, C1, C2, C1]
+    plans, ws, bs = [], [], []
+    for i in range(3):
+        p = hip.ConvPlan(N, chans[i], H, W, chans[i + 1], 3, 3, (1, 1), relu=True, algo=hip.ALGO_WINO_F4)
+        assert p.kernel == "winograd_f4x4_3x3"
+        w = dev((rng.standard_normal((chans[i + 1], chans[i], 3, 3)) * np.sqrt(2.0 / (9 * chans[i]))).astype(np.float32))
+        p.pack(w)
+        plans.append(p); ws.append(w); bs.append(dev(rng.standard_normal(chans[i + 1]).astype(np.float32)))
+    a, b, c = plans
+    assert a.can_chain(b) and b.can_chain(c)
+    y1 = a.forward(x, bs[0]).clone()
+    y2 = b.forward(y1, bs[1]).clone()
+    pool_ref = torch.empty((N, chans[3], (H + 1) // 2, (W + 1) // 2), device="cuda")
+    y3 = c.forward(y2, bs[2], pool_out=pool_ref).clone()
+    # the chain: a (own input transform) -> b (prepared) -> c (prepared, ordinary output + pooling)
+    a.forward_chain(x, b, bs[0], write_y=False)
+    y2c = b.forward_chain(None, c, bs[1], write_y=True).clone()
+    pool = torch.empty_like(pool_ref)
+    y3c = c.forward_chain(None, None, bs[2], pool_out=pool)
+    assert torch.equal(y2c, y2) and torch.equal(y3c, y3) and torch.equal(pool, pool_ref)
+    # the tail with ONLY the pooled blob written (its own y has no other reader in the trunk: conv2_2, conv3_3)
+    assert c.can_pool_only
+    a.forward_chain(x, b, bs[0], write_y=False)
+    b.forward_chain(None, c, bs[1], write_y=False)
+    pool2 = torch.zeros_like(pool_ref)
+    assert c.forward_chain(None, None, bs[2], pool_out=pool2, write_y=False) is None and torch.equal(pool2, pool_ref)
+    with pytest.raises(hip.MscnnError, match="y may be NULL only"):
+        c.forward_chain(y2, None, bs[2], write_y=False)
+    # a direct-kernel plan does not chain, and the call says so
+    d = hip.ConvPlan(N, chans[1], H, W, chans[2], 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT)
+    assert not a.can_chain(d)
+    with pytest.raises(hip.MscnnError, match="do not chain"):
+        a.forward_chain(x, d, bs[0])
