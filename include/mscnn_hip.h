@@ -262,8 +262,9 @@ MSCNN_API int mscnn_roipool_pair_fwd_f32(const float* feat, const float* rois, f
  *     call on that memory); next == NULL: ordinary output (y required, y_pool optional as in mscnn_conv2d_fwd_pool_f32) -- the tail of
  *     a chain; next != NULL: next's planes go to the start of next_workspace (>= next's mscnn_conv2d_workspace_bytes, disjoint from
  *     `workspace`), y may be NULL, y_pool must be;
- *   _can_pool_only: 1 when the tail of a chain may also leave its own y unwritten (y == NULL, y_pool != NULL: conv2_2 / conv3_3, whose
- *     only reader is the fused 2x2 pooling). */
+ *   _can_pool_only: 1 when a forward with the fused pooling may leave y itself unwritten (y == NULL, y_pool != NULL, here and in
+ *     mscnn_conv2d_fwd_pool_f32): the F(4x4,3x3) path and the direct MFMA kernels with the pooling epilogue -- conv1_2, conv2_2,
+ *     conv3_3 of the trunk, whose only reader is the pooling layer (283 + 142 + 71 MB per 7s-576 frame not written). */
 MSCNN_API int mscnn_conv2d_plan_can_chain(const mscnn_conv_plan* plan, const mscnn_conv_plan* next);
 MSCNN_API int mscnn_conv2d_plan_can_pool_only(const mscnn_conv_plan* plan);
 MSCNN_API int mscnn_conv2d_fwd_chain_f32(const mscnn_conv_plan* plan, const mscnn_conv_plan* next, const float* x, const float* packed,

@@ -615,7 +615,8 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni) {
           const int o = geo.out_off(a, wn * C::WN + ni * 32 + l31);
-          const unsigned voff = o >= 0 ? (unsigned)(co0 * co_stride + o) * 4u : kOob;
+          // (a.y == nullptr: only the pooled output is wanted -- mscnn_conv2d_plan_can_pool_only; the stores go out of bounds = dropped)
+          const unsigned voff = o >= 0 && (!C::CAN_POOL || a.y) ? (unsigned)(co0 * co_stride + o) * 4u : kOob;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = C::VEC ? acc[mi][ni][r] : acc[mi][ni][r] + bvals[r];     // (VEC = Winograd GEMM: no bias, no ReLU)
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
             const unsigned vo = (co0 + (r & 3) + 8 * (r >> 2) < a.Cout) ? voff : kOob;   // Cout < BM (proposal heads)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, vo,
                                                   (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)co_stride * 4u, 0);
-            if constexpr (C::PUBLISH) { if (vo != kOob) am = max(am, __builtin_bit_cast(unsigned, v) & 0x7fffffffu); }
+            if constexpr (C::PUBLISH) { if (vo != kOob || (C::CAN_POOL && !a.y && o >= 0)) am = max(am, __builtin_bit_cast(unsigned, v) & 0x7fffffffu); }
             if constexpr (C::CAN_POOL) acc[mi][ni][r] = o >= 0 ? v : kNegMax;     // kept for the pooling pass below
           }
         }
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_pool_kernel(IgemmArgs a) {
         if (h >= a.Ho || w >= a.Wo) continue;
         float r = vals[e];
         if (a.relu) r = r > 0.f ? r : 0.f;
-        ybase[(long)co * co_stride + h * a.Wo + w] = r;
+        if (a.y) ybase[(long)co * co_stride + h * a.Wo + w] = r;
         mx = max2(mx, r);
         am = max(am, __builtin_bit_cast(unsigned, r) & 0x7fffffffu);
       }
@@ -1594,7 +1595,8 @@ extern "C" int mscnn_conv2d_fwd_pool_f32(const mscnn_conv_plan* p, const float* 
   MSCNN_REQUIRE(!y_pool || mscnn_conv2d_plan_can_pool(p), "conv: this plan has no fused 2x2 max-pooling epilogue");
   const mscnn_conv_desc& d = p->d;
   if (d.N == 0) return MSCNN_OK;
-  MSCNN_REQUIRE(x && y, "conv: null pointer");
+  MSCNN_REQUIRE(x && (y || (y_pool && mscnn_conv2d_plan_can_pool_only(p))),
+                "conv: null pointer (y may be NULL only with y_pool on a plan where mscnn_conv2d_plan_can_pool_only)");
   hipStream_t st = as_stream(stream);
 #define MSCNN_STAGE_EVENT(i) do { if (p->profiling) MSCNN_HIP_TRY(hipEventRecord(p->ev[i], st)); } while (0)
   if (p->x3.BM) {        // split-fp16 Winograd: {amax + input transform | GEMM | output transform}
@@ -1650,7 +1652,10 @@ extern "C" int mscnn_conv2d_plan_can_chain(const mscnn_conv_plan* p, const mscnn
              ? 1 : 0;
 }
 extern "C" int mscnn_conv2d_plan_can_pool_only(const mscnn_conv_plan* p) {
-  return is_f4_plane_path(p) && mscnn_conv2d_plan_can_pool(p) && p->Wo % 4 == 0 && p->tiles_w * 4 == p->Wo && !(p->d.tune_flags & 256) ? 1 : 0;
+  if (!p || !mscnn_conv2d_plan_can_pool(p)) return 0;
+  if (is_f4_plane_path(p)) return p->Wo % 4 == 0 && p->tiles_w * 4 == p->Wo && !(p->d.tune_flags & 256) ? 1 : 0;
+  // the direct MFMA kernels with the pooling epilogue (conv1_2): y stores are predicated off
+  return !p->wino && !p->x3.BM && !p->x3h.rows && !p->hg && p->head.entry < 0 && !p->c3 && p->entry >= 0 ? 1 : 0;
 }
 extern "C" int mscnn_conv2d_fwd_chain_f32(const mscnn_conv_plan* p, const mscnn_conv_plan* next, const float* x, const float* packed,
                                           const float* bias, float* y, float* y_pool, void* workspace, size_t workspace_bytes,

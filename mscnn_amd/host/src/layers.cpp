@@ -363,7 +363,7 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
   }
   last_chained_ = false;
   const bool pool_only = pool_only_live_ && pooled && !selfcheck_pending_ && mscnn_conv2d_plan_can_pool_only(plan_);
-  if (was_prepared || fuse_next_now_ || pool_only) {
+  if (was_prepared || fuse_next_now_) {
     // a member of a running chain: planes prepared by the previous member (x = NULL) and / or written for the next one (its top blob
     // is then NOT written: top_stale_)
     ConvolutionLayer* nx = fuse_next_now_ ? chain_next_ : nullptr;
@@ -376,9 +376,9 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     else top_stale_ = pool_only;
     fuse_next_now_ = false;
   } else {
-    MSCNN_CHECK(mscnn_conv2d_fwd_pool_f32(plan_, bottom[0]->gpu_data(), w, packed, bias, top[0]->mutable_gpu_data(), pooled, ws,
-                                          wbytes, S()));
-    top_stale_ = false;
+    MSCNN_CHECK(mscnn_conv2d_fwd_pool_f32(plan_, bottom[0]->gpu_data(), w, packed, bias, pool_only ? nullptr : top[0]->mutable_gpu_data(),
+                                          pooled, ws, wbytes, S()));
+    top_stale_ = pool_only;
   }
   if (pooled_top_ && !pooled) {
     // the planned kernel has no pooling epilogue (e.g. a direct-kernel shape): run the pooling the fused-away layer would have

@@ -810,7 +810,7 @@ def test_convolution_chains_keep_every_blob_bit_identical():
     # (a) tails and everything behind them first (no re-creation involved), then the skipped blobs
     for b in ("pool2", "conv3_3", "conv4_3", "conv5_3", "fc6", "cls_pred", "bbox_pred", "proposals"):
         assert np.array_equal(n.get_blob(b), u.get_blob(b)), b
-    for b in producers[::-1] + ["conv2_2"]:
+    for b in producers[::-1] + ["conv2_2", "conv1_2"]:
         assert np.array_equal(n.get_blob(b), u.get_blob(b)), b
     # (c) from conv3_2 on, with a conv3_1 blob written from outside: both nets compute the same from it
     z = (u.get_blob("conv3_1") * 0.5).astype(np.float32)

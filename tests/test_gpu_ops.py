@@ -1480,3 +1480,28 @@ def test_conv_chain_f4_is_bit_identical(hip, shape):
     assert not a.can_chain(d)
     with pytest.raises(hip.MscnnError, match="do not chain"):
         a.forward_chain(x, d, bs[0])
+
+
+def test_conv_pool_only_direct_kernel(hip, orc):
+    """mscnn_conv2d_plan_can_pool_only on the direct MFMA kernel (conv1_2's shape class): y == NULL writes the pooled blob only --
+    the same bytes as the forward that writes both -- also where tiles are split across workgroups (fix-up launch)."""
+    rng = np.random.default_rng(11)
+    for (N, Cin, H, W, Cout) in [(1, 64, 96, 160, 64), (2, 32, 33, 47, 48), (1, 64, 576, 1920, 64)]:
+        x = dev(rng.standard_normal((N, Cin, H, W)).astype(np.float32))
+        w = dev((rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32))
+        b = dev(rng.standard_normal(Cout).astype(np.float32))
+        p = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT)
+        assert p.kernel.startswith("igemm_") and p.can_pool and p.can_pool_only, p.kernel
+        p.pack(w)
+        pool_ref = torch.empty((N, Cout, (H + 1) // 2, (W + 1) // 2), device="cuda")
+        y = p.forward(x, b, pool_out=pool_ref)
+        pool = torch.zeros_like(pool_ref)
+        wsb = p.ws.numel() * 4 if p.ws is not None else 0
+        hip._check(hip.lib().mscnn_conv2d_fwd_pool_f32(p._p, hip._dev(x), hip._dev(w), hip._dev(p.packed), hip._dev(b), None, hip._dev(pool),
+                                                       hip._dev(p.ws), wsb, hip._stream()))
+        assert torch.equal(pool, pool_ref)
+        if H * W < 20000:
+            ref = orc.relu(orc.conv2d(x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), (1, 1)))
+            close(y.cpu().numpy(), ref)
+    q = hip.ConvPlan(1, 512, 36, 120, 512, 3, 3, (1, 1), relu=True, algo=hip.ALGO_WINO_F3)
+    assert q.can_pool and not q.can_pool_only
