@@ -93,7 +93,8 @@ struct Cfg {
   static constexpr bool PUBLISH = VEC_ == 0 && F16_ != 1;
   // PF_ == 3: as PF_ == 1, compiled for 4 workgroups per CU (<= 128 VGPRs; the 1x1 VEC kernel fits: 127, no scratch)
   // PF_ == 4 (fp16 kernels, whose inner loop does not use PF): compiled for 3 workgroups per CU (168 VGPRs, 16 B of scratch)
-  static constexpr int MIN_WG_PER_CU = PF_ == 3 ? 4 : PF_ == 4 ? 3 : 2;
+  // PF_ == 5 (fp32 3x3 kernels): the PF_ == 0 inner loop compiled for 3 workgroups per CU (A/B variant 4 on conv1_2's 64x256 tile)
+  static constexpr int MIN_WG_PER_CU = PF_ == 3 ? 4 : (PF_ == 4 || PF_ == 5) ? 3 : 2;
   static constexpr int KG = CK_ / 8;
   // VEC: 1x1 kernel over planes of exactly 128-pixel rows (the Winograd GEMM operands): the B tile is CK contiguous
   // 512-byte rows, staged with b128 loads / ds_write_b128 and no per-element offset table
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
                 for (int ni = 0; ni < C::NI; ++ni)
                   acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
             }
-      } else if constexpr (C::PF == 0) {
+      } else if constexpr (C::PF == 0 || C::PF == 5) {
 #pragma unroll
         for (int kh = 0; kh < C::KH; ++kh)
 #pragma unroll
@@ -919,6 +920,10 @@ const KernelEntry kTable[] = {
     ENTRY_PF(128, 128, 2, 2, 3, 3, 8, 16),
     ENTRY_PF(128, 128, 2, 2, 3, 3, 8, 32),
     ENTRY_PF(64, 256, 1, 4, 3, 3, 8, 32),
+    // variant 4 (tune_variant 5): the 64x256 tile compiled for three workgroups per CU (<= 168 VGPRs, 188 B of scratch), grid 768:
+    // measured SLOWER on conv1_2 (723 vs 688 us, profiles/r04_ab_conv1_2_occ3.txt) -- A/B variant only
+    {"igemm_64x256_k3x3_tw32_occ3", 64, 256, 3, 3, 8, 32, 8, 0, 0, 0, 1, 4, 4, igemm_kernel<Cfg<64, 256, 1, 4, 3, 3, 8, 32, 0, 0, 0, 5>>,
+     igemm_fixup_kernel<Cfg<64, 256, 1, 4, 3, 3, 8, 32, 0, 0, 0, 5>>, igemm_fixup_pool_kernel<Cfg<64, 256, 1, 4, 3, 3, 8, 32, 0, 0, 0, 5>>},
     // 1x1 (the 16 batched GEMMs of the Winograd path; plane = [rows][128] so a tile is one 128-pixel row)
     {"igemm_128x128_k1x1_ck32_pf", 128, 128, 1, 1, 32, 128, 1, 0, 0, 0, 1, 4, 0, igemm_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1>>,
      igemm_fixup_kernel<Cfg<128, 128, 2, 2, 1, 1, 32, 128, 0, 0, 0, 1>>},
@@ -1284,7 +1289,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   const long tiles = (long)p->MT * p->NT;
   // grid: G workgroups (default 2 per CU; 3 for the 128x128 tiles whose 43 KB of LDS and 168 VGPRs allow it)
   const int genv = tune_env("MSCNN_TUNE_GRID", d.tune_grid);   // tuning knob
-  long G = genv > 0 ? genv : ((k.BM == 128 && k.BN == 128 && k.KH == 3 && k.variant != 200) || k.variant == 201 ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
+  long G = genv > 0 ? genv : ((k.BM == 128 && k.BN == 128 && k.KH == 3 && k.variant != 200) || k.variant == 201 || k.variant == 4 ? 768 : 512);   // 1x1 GEMMs: 512 measured best (768: +4 %)
   if (tiles * p->KI / 4 < G) G = tiles * p->KI / 4;         // never less than ~4 chunks per workgroup
   if (G < 1) G = 1;
   // A slightly smaller grid that divides the tile count exactly needs no stream-K phase and no fix-up launch at all (the 25
