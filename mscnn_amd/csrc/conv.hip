@@ -49,6 +49,7 @@ struct IgemmArgs {
   int N, Cin, H, W, Cout, Ho, Wo, pad_h, pad_w;
   int MT, NTH, NTW, NT, KI, G, relu;
   int xcd_map;         // 1: XCD-aware workgroup -> range mapping
+  int epi_prio;        // 1: the epilogue of a tile runs at wave priority 3 (tune_flags bit 14, A/B)
   float* yp;           // != nullptr: also write the 2x2 / stride-2 max-pooled output [N][Cout][Hp][Wp] (fused PoolingLayer)
   int Hp, Wp;
   int nt_major;        // 1: tile index t = nt * MT + mt (the M tiles of one pixel tile run together; Winograd GEMM)
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
           for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= x3_inv;
     }
     {
+    if (a.epi_prio) __builtin_amdgcn_s_setprio(3);
     const TileGeo<C>& geo = geo_e;
     const int t = t_e, k0 = k0_e, k1 = k1_e, mt = mt_e;
     (void)t;
@@ -623,8 +625,9 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
             float v = C::VEC ? acc[mi][ni][r] : acc[mi][ni][r] + bvals[r];     // (VEC = Winograd GEMM: no bias, no ReLU)
             if (!C::VEC && a.relu) v = v > 0.f ? v : 0.f;
             const unsigned vo = (co0 + (r & 3) + 8 * (r >> 2) < a.Cout) ? voff : kOob;   // Cout < BM (proposal heads)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, vo,
-                                                  (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)co_stride * 4u, 0);
+            if (!C::CAN_POOL || a.y)      // (pool-only forwards: not even issued -- the epilogue is issue-bound next to the other workgroup's MFMAs)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, vo,
+                                                    (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)co_stride * 4u, 0);
             if constexpr (C::PUBLISH) { if (vo != kOob || (C::CAN_POOL && !a.y && o >= 0)) am = max(am, __builtin_bit_cast(unsigned, v) & 0x7fffffffu); }
             if constexpr (C::CAN_POOL) acc[mi][ni][r] = o >= 0 ? v : kNegMax;     // kept for the pooling pass below
           }
@@ -674,6 +677,7 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
     }
     }
     __syncthreads();   // LDS is re-used by the next segment's first stores
+    if (a.epi_prio) __builtin_amdgcn_s_setprio(0);
 #ifdef MSCNN_WG_TRACE
     MSCNN_TRACE_STAMP(trace_slot); ++trace_slot;          // epilogue done
 #endif
@@ -1507,6 +1511,11 @@ static int launch_igemm(const mscnn_conv_plan* p, const float* x, const float* p
     return MSCNN_ERR_BAD_ARG;
   }
   a.xcd_map = (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 1) ? 0 : 1;
+  // the epilogue of a tile at wave priority 3: it is ~600 VALU / store instructions that otherwise take turns with the co-resident
+  // workgroup's MFMAs (10 - 22 us per tile in the phase timeline of conv1_2, during which that other workgroup alone feeds the matrix
+  // pipe at ~58 %).  Measured (profiles/r04_ab_conv1_2_epilogue.txt): conv1_2 693 -> 674 us; neutral on the k7x1 head GEMM, + 2.5 % on
+  // the 128 x 128 tiles -> on for the 64 x 256 3x3 kernel only; tune_flags bit 14 inverts the choice (A/B)
+  a.epi_prio = ((k.BM == 64 && k.BN == 256 && k.KH == 3 && k.KW == 3) ? 1 : 0) ^ ((tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 16384) ? 1 : 0);
 #ifdef MSCNN_WG_TRACE
   a.trace = g_wg_trace;
 #endif

@@ -20,6 +20,7 @@ ap.add_argument("--only", default="")
 ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS probe)")
 ap.add_argument("--ab", default="", help="knob=v1,v2,...  with knob in {algo, variant, grid, flags}")
 ap.add_argument("--fixed", default="", help="other knobs held fixed, e.g. variant=107,grid=1000")
+ap.add_argument("--pool", default="", choices=["", "both", "only"], help="run with the fused 2x2 pooling: y and the pooled blob, or the pooled blob only")
 a = ap.parse_args()
 knob, vals = None, [0]
 if a.ab:
@@ -46,6 +47,15 @@ for name, N, Cin, H, W, Cout, k, pad in LAYERS:
         p.set_profiling(True)
         plans.append(p)
     y = plans[0].forward(x, b)
+    if a.pool:
+        import ctypes as C
+        yp = torch.empty((N, Cout, (y.shape[2] + 1) // 2, (y.shape[3] + 1) // 2), device="cuda")
+        def fwd(p):
+            wsb = p.ws.numel() * 4 if p.ws is not None else 0
+            hip._check(hip.lib().mscnn_conv2d_fwd_pool_f32(p._p, hip._dev(x), hip._dev(w), hip._dev(p.packed), hip._dev(b),
+                                                           hip._dev(y) if a.pool == "both" else None, hip._dev(yp), hip._dev(p.ws), wsb, hip._stream()))
+        for p in plans:
+            p.forward = (lambda p_: (lambda *args, **kw_: fwd(p_)))(p)
     ms = [0.0] * len(plans); st = [[0.0, 0.0, 0.0] for _ in plans]
     for p in plans:
         for _ in range(3):
