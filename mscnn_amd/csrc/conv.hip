@@ -613,8 +613,12 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
         float bvals[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
+#ifdef MSCNN_EPI_NOBIAS      // (dev builds: epilogue ablations, tools/sessions/r04_s30.sh)
+          bvals[r] = 0.f;
+#else
           bvals[r] = C::VEC ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                                   bias_rsrc, (unsigned)co0 * 4u, ((r & 3) + 8 * (r >> 2)) * 4u, 0));
+#endif
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni) {
           const int o = geo.out_off(a, wn * C::WN + ni * 32 + l31);
@@ -634,7 +638,11 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
         }
       }
       if constexpr (C::CAN_POOL) {
+#ifdef MSCNN_EPI_NOPOOL
+        if (false) {
+#else
         if (a.yp) {
+#endif
           // fused PoolingLayer (MAX, 2x2, stride 2, pooling_layer.cu:11-47): window = rows {2i, 2i+1} x cols {2j, 2j+1};
           // pixels outside the plane were set to -FLT_MAX above (ceil-mode windows at odd edges are clipped)
           const int pstride = a.Hp * a.Wp;

@@ -20,8 +20,11 @@ ap.add_argument("--only", default="")
 ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS probe)")
 ap.add_argument("--ab", default="", help="knob=v1,v2,...  with knob in {algo, variant, grid, flags}")
 ap.add_argument("--fixed", default="", help="other knobs held fixed, e.g. variant=107,grid=1000")
+ap.add_argument("--lib", default="", help="another build of libmscnn_hip.so (dev ablations)")
 ap.add_argument("--pool", default="", choices=["", "both", "only"], help="run with the fused 2x2 pooling: y and the pooled blob, or the pooled blob only")
 a = ap.parse_args()
+if a.lib:
+    hip.LIB_PATH = os.path.abspath(a.lib)
 knob, vals = None, [0]
 if a.ab:
     knob, v = a.ab.split("=")
