@@ -614,6 +614,8 @@ def main():
         # something this process can take of itself.  The line carries the latest such measurement (tools/pmc_traffic.py -> profiles/)
         # only while the kernel sources it was taken on are byte-identical to the ones running now; else null.
         traffic, tsrc, textra = _measured_traffic()
+        if args.model != DEFAULT_MODEL or args.dtype != "f32":      # (the measured launch is conv4_2 of the default model's fp32 path)
+            traffic, tsrc, textra = None, "the PMC measurement in profiles/ is of the default model's fp32 plane GEMM (conv4_2): not reported for this run", {}
         peak = FP16_MFMA_PEAK_TFLOPS if args.dtype in ("f16", "f16x3") else FP32_MFMA_PEAK_TFLOPS
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -625,7 +627,7 @@ def main():
                       ("x3_gemm_kernel<128|256> -- the 25 plane GEMMs of the Winograd F(3x3,3x3) layers on v_mfma_f32_32x32x16_f16 with "
                        "every fp32 operand split exactly into fp16 hi + lo: three MFMAs per product pair (all three counted as "
                        "executed FLOPs), fp32 accumulate") if args.dtype == "f16x3" else
-                      "wgemm_kernel<256x128 | 128x256 | 256x96, ck32> (mscnn_amd/csrc/wgemm.hip) -- the batched [Cout x Cin] x [Cin x tiles] GEMMs of the "
+                      "wgemm_kernel<256x128 | 256x160 | 128x256 | 256x96 | 128x128, ck32> (mscnn_amd/csrc/wgemm.hip) -- the batched [Cout x Cin] x [Cin x tiles] GEMMs of the "
                       "Winograd layers (25 planes F(3x3,3x3), 36 planes F(4x4,3x3)) on v_mfma_f32_32x32x2_f32: 8 waves per CU, operands by "
                       "LDS-DMA into a 3-stage ring (+ its fix-up launch where the tile count is split stream-K style)",
             "flops_note": "achieved = FLOPs the kernel's MFMAs execute for the real problem (2 * planes * Cout * Cin * tiles per launch) / "
