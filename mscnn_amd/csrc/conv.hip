@@ -35,6 +35,7 @@
 #include "wgemm.h"
 #include "roipool_wino.h"
 #include "conv_c3.h"
+#include "wconv.h"
 #include "x3_device.h"
 #include <new>
 #include <type_traits>
@@ -1011,6 +1012,8 @@ struct mscnn_conv_plan {
   bool use_wg = false;
   mscnn::WgemmPlan wg;
   bool c3 = false;       // conv1_1: the Cin = 3 VALU kernel of conv_c3.hip (reads the Caffe-layout weights; entry stays -1)
+  bool wc_use = false;   // conv1_2's shape class: the ring kernel of wconv.hip runs the layer; `entry` (64 x 256 igemm, SAME weight packing) stays planned beside it
+  mscnn::WconvPlan wc;
   int wino_m = 2;        // output tile edge: 2 = F(2x2,3x3) (16 planes), 3 = F(3x3,3x3) (25 planes; small ROI maps)
   int tiles_h = 0, tiles_w = 0, T_pad = 0;
   // split-fp16 form of the F(3x3,3x3) path (MSCNN_CONV_ALGO_WINO_F3_X3, wino_x3.hip): x3.BM > 0, wino == nullptr.
@@ -1197,6 +1200,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->Wo = (d.W + 2 * d.pad_w - d.Kw) / d.stride_w + 1;
   p->entry = -1;
   p->c3 = false;
+  p->wc_use = false;
   p->packed_bytes = 0;
   p->ws_bytes = 0;
   p->head.entry = -1;
@@ -1241,7 +1245,8 @@ static void plan_shape(mscnn_conv_plan* p) {
   // choose the table entry with the least padded work; an ROI-mode entry wins whenever it matches the image shape
   double best = 1e300;
   // tune_variant (value + 1): 0 baseline, 1 pipelined LDS reads, 2 128x256 tiles; 1x1 kernels: 0 generic, 101.. vectorised
-  const int tv = tune_env("MSCNN_TUNE_VARIANT", d.tune_variant);
+  const int tv0 = tune_env("MSCNN_TUNE_VARIANT", d.tune_variant);
+  const int tv = tv0 >= 400 ? 0 : tv0;      // (402 addresses wconv.hip's plan, below)
   const bool venv = tv > 0 && d.Kh == 3 && d.Kw == 3;
   // default: pipelined LDS reads for the 128-row tiles (+1..3 % measured on conv2_2..conv4_3), baseline for Cout = 64
   const int want = venv ? tv - 1 : (d.Cout >= 128 ? 1 : 0);
@@ -1333,6 +1338,13 @@ static void plan_shape(mscnn_conv_plan* p) {
     p->x3d_slots_off = p->ws_bytes;
     p->ws_bytes += 4096;
   }
+  // conv1_2's shape class (3x3 / pad 1, 64 output channels, whole 4 x 128 tiles): tune_flags bit 15 selects the ring kernel of wconv.hip
+  // on the SAME packed weights (BM 64, CK 8, one M tile) -- an A/B variant and second witness: in the net it is no faster than the igemm
+  // kernel (profiles/r04_ab_conv1_2_ring.txt); tune_variant 402 also plans maps with fewer than two tiles per CU (tests)
+  if (k.KH == 3 && k.KW == 3 && k.BM == 64 && k.CK == 8 && k.RH == 0 && (k.variant == 0 || k.variant == 1) && p->MT == 1 && d.pad_h == 1 &&
+      d.pad_w == 1 && (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 32768)) {
+    if (mscnn::wconv_plan(d.N, d.Cin, d.H, d.W, d.Cout, d.tune_variant == 402, &p->wc) && p->wc.packed_bytes == p->packed_bytes) p->wc_use = true;
+  }
 }
 
 extern "C" int mscnn_conv2d_plan_create(const mscnn_conv_desc* desc, mscnn_conv_plan** plan_out) {
@@ -1361,6 +1373,7 @@ extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (p->x3.BM) return p->x3.BM == 256 ? "winograd_f3x3_3x3_x3f16_256" : "winograd_f3x3_3x3_x3f16_128";
   if (p->wino) return p->wino_m == 4 ? "winograd_f4x4_3x3" : p->wino_m == 3 ? "winograd_f3x3_3x3" : "winograd_f2x2_3x3";
   if (p->c3) return mscnn::c3_kernel_name();
+  if (p->wc_use) return mscnn::wconv_kernel_name();
   return p->entry < 0 ? "direct_f32" : kTable[p->entry].name;
 }
 extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_plan* p) {
@@ -1414,8 +1427,9 @@ extern "C" int mscnn_conv2d_plan_stage_ms(const mscnn_conv_plan* p, float ms_out
 }
 extern "C" int mscnn_conv2d_plan_publishes_amax(const mscnn_conv_plan* p) {
   // the F(3x3,3x3) output transforms, every kernel of the implicit-GEMM family (main + fix-up) and the Cin = 3 VALU kernel publish
+  // (not the ring kernel of wconv.hip: a split-fp16 consumer of conv1_2 measures its bottom itself)
   return p && !p->x3h.rows && (p->x3.BM || (p->wino && p->wino_m >= 3) || p->c3 ||
-               (!p->wino && p->head.entry < 0 && p->entry >= 0 && !(kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202))) ? 1 : 0;
+               (!p->wino && p->head.entry < 0 && p->entry >= 0 && !p->wc_use && !(kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202))) ? 1 : 0;
 }
 extern "C" int mscnn_conv2d_plan_set_amax_io(mscnn_conv_plan* p, const uint32_t* in_bound, uint32_t* out_amax) {
   MSCNN_REQUIRE(p, "conv plan: null");
@@ -1810,5 +1824,6 @@ static int conv_forward_single(const mscnn_conv_plan* p, const float* x, const f
     return MSCNN_OK;
   }
   MSCNN_REQUIRE(packed, "conv: igemm kernel needs packed weights (mscnn_conv2d_pack_weights)");
+  if (p->wc_use) return mscnn::wconv_launch(p->wc, x, packed, bias, y, y_pool, d.relu, st);
   return launch_igemm(p, x, packed, bias, y, y_pool, workspace, workspace_bytes, st, 0u, 0);
 }

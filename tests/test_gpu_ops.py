@@ -1505,3 +1505,43 @@ def test_conv_pool_only_direct_kernel(hip, orc):
             close(y.cpu().numpy(), ref)
     q = hip.ConvPlan(1, 512, 36, 120, 512, 3, 3, (1, 1), relu=True, algo=hip.ALGO_WINO_F3)
     assert q.can_pool and not q.can_pool_only
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 8, 128), (2, 16, 12, 256), (1, 64, 64, 1024), (3, 40, 16, 128), (1, 48, 8, 384), (1, 64, 576, 1920)])
+def test_wconv_ring_kernel_against_the_igemm_kernel(hip, orc, shape):
+    """conv1_2's shape class on the ring kernel of wconv.hip (one 8-wave workgroup per CU, LDS-DMA ring with dword patch pieces,
+    ride-along epilogue; opt-in: tune_flags bit 15) against the igemm kernel AUTO keeps, on the SAME packed weights: bit-identical --
+    y, the fused 2x2 pooling, the pool-only forward, with and without bias / ReLU --; small cases against the oracle."""
+    N, Cin, H, W = shape
+    rng = np.random.default_rng(17)
+    x = dev(np.maximum(rng.standard_normal((N, Cin, H, W)), 0).astype(np.float32))
+    w = dev((rng.standard_normal((64, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32))
+    b = dev(rng.standard_normal(64).astype(np.float32))
+    # (the igemm kernel on a grid that divides its 8 x 32-pixel tiles: whole tiles there too -- its stream-K split associates the
+    # partial sums of a split tile differently)
+    tiles_ig = N * ((H + 7) // 8) * ((W + 31) // 32)
+    grid_ig = max(g for g in range(1, min(tiles_ig, 768) + 1) if tiles_ig % g == 0)
+    p = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_flags=32768, tune_variant=402)
+    q = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_grid=grid_ig)
+    assert p.kernel == "wconv_64x512_k3x3" and q.kernel.startswith("igemm_64x256"), (p.kernel, q.kernel)
+    assert hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True).kernel != "wconv_64x512_k3x3"      # never AUTO's choice
+    assert p.can_pool and p.can_pool_only and not p.publishes_amax
+    p.pack(w); q.pack(w)
+    assert torch.equal(p.packed, q.packed)
+    pool_p = torch.zeros((N, 64, H // 2, W // 2), device="cuda"); pool_q = torch.zeros_like(pool_p)
+    yp = p.forward(x, b, pool_out=pool_p).clone()
+    yq = q.forward(x, b, pool_out=pool_q)
+    assert torch.equal(yp, yq) and torch.equal(pool_p, pool_q)
+    for _ in range(3):
+        assert torch.equal(p.forward(x, b), yp)
+    pool2 = torch.zeros_like(pool_p)      # the pooled blob alone
+    hip._check(hip.lib().mscnn_conv2d_fwd_pool_f32(p._p, hip._dev(x), hip._dev(w), hip._dev(p.packed), hip._dev(b), None, hip._dev(pool2),
+                                                   None, 0, hip._stream()))
+    assert torch.equal(pool2, pool_p)
+    if H * W <= 20000:
+        ref = orc.relu(orc.conv2d(x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), (1, 1)))
+        close(yp.cpu().numpy(), ref)
+    p2 = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=False, algo=hip.ALGO_DIRECT, tune_flags=32768, tune_variant=402)
+    q2 = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=False, algo=hip.ALGO_DIRECT, tune_grid=grid_ig)
+    p2.pack(w); q2.pack(w)
+    assert torch.equal(p2.forward(x), q2.forward(x))
