@@ -257,7 +257,7 @@ MSCNN_API int mscnn_roipool_pair_fwd_f32(const float* feat, const float* rois, f
  * two layers is neither written (unless y != NULL) nor read; 4.5 instead of 6.5 activation-sized HBM passes per pair.  Bit-identical to
  * the two separate mscnn_conv2d_fwd_f32 calls.
  *   _can_chain: 1 when both plans take that path, plan's output is next's input (N, Cout == Cin, H, W) and the map is whole 4x4 tiles
- *     in 1, 2 or 4 strips of <= 62 tile columns;
+ *     in 1 - 4, 6 or 8 strips of <= 62 tile columns (W <= 1984, W / 4 not in (248, 310] or (372, 434]);
  *   _fwd_chain: x == NULL: the planes of plan's input are already at the start of `workspace` (plan was the `next` of the previous
  *     call on that memory); next == NULL: ordinary output (y required, y_pool optional as in mscnn_conv2d_fwd_pool_f32) -- the tail of
  *     a chain; next != NULL: next's planes go to the start of next_workspace (>= next's mscnn_conv2d_workspace_bytes, disjoint from

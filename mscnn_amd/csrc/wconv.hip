@@ -41,7 +41,7 @@ struct WcArgs {
 };
 
 struct KC {
-  static constexpr int BM = 64, TR = 4, TC = 128, BN = TR * TC, CK = 8, TAPS = 9, ST = 3, NW = 8, THREADS = NW * 64;
+  static constexpr int BM = 64, TR = 4, TC = 128, CK = 8, TAPS = 9, ST = 3, NW = 8, THREADS = NW * 64;      // tile: 64 channels x (4 rows x 128 columns)
   static constexpr int A_BYTES = TAPS * CK * BM * 4;                       // 18432: one chunk of packed weights [tap][ck][64]
   static constexpr int PR = TR + 2, PC = TC + 2, CH_STRIDE = PR * PC;      // patch 6 x 130 per channel
   static constexpr int B_FLOATS = CK * CH_STRIDE;                          // 6240 floats = 24960 bytes

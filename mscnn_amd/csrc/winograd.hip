@@ -760,17 +760,18 @@ __global__ __launch_bounds__(256) void wino44_output_vec_kernel(const float* __r
 template <int S, int RW, int RING>
 __global__ __launch_bounds__(64 * S * RW) void wino44_outin_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y,
                                                            float* __restrict__ V, int N, int C, int H, int W, int tiles_h, int tiles_w,
-                                                           int T_pad_m, int T_pad_v, int relu, int strip_w, int chunks,
-                                                           int chunk_rows, unsigned* __restrict__ amax) {
+                                                           int T_pad_m, int T_pad_v, int relu, int strip_w, int sgroups,
+                                                           int chunks, int chunk_rows, unsigned* __restrict__ amax) {
   static_assert((RING & (RING - 1)) == 0 && RING >= RW + 2, "ring: the tile rows of two consecutive steps");
   __shared__ float4 ring[RING][4][64 * S];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = wave % S, w = wave / S;
   const int c = blockIdx.y;
   int b = blockIdx.x;
+  const int sg = b % sgroups; b /= sgroups;                      // (maps of 6 / 8 strips: two workgroups per tile row, S strips each)
   const int chunk = b % chunks;
   const int n = b / chunks;
-  const int j0 = strip * strip_w, sw = min(strip_w, tiles_w - j0);
+  const int j0 = (sg * S + strip) * strip_w, sw = max(0, min(strip_w, tiles_w - j0));
   const int r0 = chunk * chunk_rows, r1 = min(r0 + chunk_rows, tiles_h);
   const int jq = j0 - 1 + lane;                                  // phase 1: this lane's tile column (halo included)
   const bool colq = lane < sw + 2 && jq >= 0 && jq < tiles_w;
@@ -944,28 +945,32 @@ int wino_output_transform(int m, const float* M, const float* bias, float* y, fl
 }
 
 bool wino44_outin_supported(int H, int W, int tiles_h, int tiles_w) {
-  const int ns = cdiv(tiles_w, 62);
-  return H % 4 == 0 && W % 4 == 0 && tiles_h * 4 == H && tiles_w * 4 == W && ns <= 4 && ns != 3;
+  const int ns = cdiv(tiles_w, 62);      // strips of <= 62 tile columns: 1 .. 4 in one workgroup, 6 / 8 in two
+  return H % 4 == 0 && W % 4 == 0 && tiles_h * 4 == H && tiles_w * 4 == W && ns <= 8 && ns != 5 && ns != 7;
 }
 
 int wino44_output_into_input(const float* M, const float* bias, float* y, float* V, int N, int C, int H, int W, int tiles_h, int tiles_w,
                              int T_pad_m, int T_pad_v, int relu, hipStream_t st, unsigned* amax, int strip_w, int chunk_rows) {
   MSCNN_REQUIRE(wino44_outin_supported(H, W, tiles_h, tiles_w), "winograd F(4x4,3x3) chain: the map must be whole 4x4 tiles");
   MSCNN_REQUIRE(y == nullptr || reinterpret_cast<uintptr_t>(y) % 16 == 0, "winograd F(4x4,3x3) chain: y must be 16-byte aligned");
-  // strips of equal width <= 62 tile columns (60 + 60 for 120 columns, 4 x 60 for 240), all strips of a row in one workgroup
+  // strips of equal width <= 62 tile columns (60 + 60 for 120 columns, 4 x 60 for 240), all strips of a row in one workgroup (six /
+  // eight strips -- the 8s-768 net's 160 / 320-column maps take 3 x 54 and 2 x (3 x 54) -- in two)
   const int ns = cdiv(tiles_w, 62);
-  MSCNN_REQUIRE(ns <= 4 && ns != 3, "winograd F(4x4,3x3) chain: 1, 2 or 4 strips of <= 62 tile columns");
+  const int sgroups = ns > 4 ? 2 : 1, S = ns / sgroups;
   if (strip_w <= 0 || strip_w > 62 || cdiv(tiles_w, strip_w) != ns) strip_w = cdiv(tiles_w, ns);
   if (chunk_rows <= 0) {       // row chunks (each re-reads its two halo tile rows) until the launch has two workgroups per CU
     int chunks = 1;
-    while ((long)N * C * chunks < 512 && tiles_h / (chunks * 2) >= 9) chunks *= 2;
+    while ((long)N * C * chunks * sgroups < 512 && tiles_h / (chunks * 2) >= 9) chunks *= 2;
     chunk_rows = cdiv(tiles_h, chunks);
   }
   const int chunks = cdiv(tiles_h, chunk_rows);
-  const dim3 grid(chunks * N, C);
-  if (ns == 1) wino44_outin_kernel<1, 4, 8><<<grid, 256, 0, st>>>(M, bias, y, V, N, C, H, W, tiles_h, tiles_w, T_pad_m, T_pad_v, relu, strip_w, chunks, chunk_rows, amax);
-  else if (ns == 2) wino44_outin_kernel<2, 2, 4><<<grid, 256, 0, st>>>(M, bias, y, V, N, C, H, W, tiles_h, tiles_w, T_pad_m, T_pad_v, relu, strip_w, chunks, chunk_rows, amax);
-  else wino44_outin_kernel<4, 2, 4><<<grid, 512, 0, st>>>(M, bias, y, V, N, C, H, W, tiles_h, tiles_w, T_pad_m, T_pad_v, relu, strip_w, chunks, chunk_rows, amax);
+  const dim3 grid(sgroups * chunks * N, C);
+#define MSCNN_OUTIN(S_, RW_, RING_) wino44_outin_kernel<S_, RW_, RING_><<<grid, 64 * S_ * RW_, 0, st>>>(M, bias, y, V, N, C, H, W, tiles_h, tiles_w, T_pad_m, T_pad_v, relu, strip_w, sgroups, chunks, chunk_rows, amax)
+  if (S == 1) MSCNN_OUTIN(1, 4, 8);
+  else if (S == 2) MSCNN_OUTIN(2, 2, 4);
+  else if (S == 3) MSCNN_OUTIN(3, 2, 4);
+  else MSCNN_OUTIN(4, 2, 4);
+#undef MSCNN_OUTIN
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

@@ -1438,11 +1438,12 @@ def test_conv_roipool_pair_fused_is_bit_identical(hip, orc, case):
     assert not plan.can_fuse_roipool(Cc, 7, 7)
 
 
-@pytest.mark.parametrize("shape", [(1, 32, 64, 48, 72, 240), (1, 16, 32, 32, 144, 480), (2, 8, 16, 24, 40, 200), (1, 8, 8, 8, 288, 960)])
+@pytest.mark.parametrize("shape", [(1, 32, 64, 48, 72, 240), (1, 16, 32, 32, 144, 480), (2, 8, 16, 24, 40, 200), (1, 8, 8, 8, 288, 960), (1, 8, 16, 8, 44, 640),
+                                   (2, 8, 8, 8, 36, 1280), (1, 8, 8, 8, 24, 1984)])
 def test_conv_chain_f4_is_bit_identical(hip, shape):
     """mscnn_conv2d_fwd_chain_f32: three same-resolution F(4x4,3x3) layers with the activation between them never written -- the
-    output transform of one layer writes the next one's input-transform planes (winograd.hip: wino44_outin_kernel; 1, 2 and 4 strips
-    of tile columns, row chunks, a batch of 2).  Every result is bit-identical to the three separate forwards; y written on request
+    output transform of one layer writes the next one's input-transform planes (winograd.hip: wino44_outin_kernel; 1, 2, 3, 4, 6 and 8
+    strips of tile columns, row chunks, a batch of 2).  Every result is bit-identical to the three separate forwards; y written on request
     is the separate forward's y; the tail takes the fused pooling."""
     N, C0, C1, C2, H, W = shape
     rng = np.random.default_rng(5)
