@@ -79,6 +79,9 @@ class Net {
   // / MaterializeBlob() re-run the producer unchained when somebody asks for it (bit-identical).  On by default with `fusion`;
   // MSCNN_NO_CHAIN=1 or SetChainFusion(false) turn it off (every blob is then written by every Forward).
   void SetChainFusion(bool on) { chain_fusion_ = on; }
+  // Every blob the last Forward left unwritten is written now (the weights are about to change: what the blobs hold must stay what
+  // the layers computed with the OLD weights, as in the reference).  Called by the weight loaders and the C ABI's parameter setter.
+  void MaterializeStale() const;
   bool chain_fusion() const { return chain_fusion_; }
   // Numerical calibration on representative data: call after a Forward.  Every Convolution layer that runs a Winograd
   // form is re-computed with the direct k-ordered kernel on the same bottom; where max |dy| / max(1, |y|) exceeds `tol`

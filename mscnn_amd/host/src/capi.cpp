@@ -233,6 +233,7 @@ int mscnn_net_set_param(mscnn_net* n, int l, int p, const float* host, size_t co
     auto& blobs = n->net->layers()[l]->blobs();
     CHECK_LT(p, (int)blobs.size());
     CHECK_EQ((size_t)blobs[p]->count(), count) << "param size mismatch for layer " << n->net->layer_names()[l];
+    n->net->MaterializeStale();      // (intermediate blobs a chained forward left unwritten: the old weights' outputs, written before they change)
     std::memcpy(blobs[p]->mutable_cpu_data(), host, sizeof(float) * count);
     n->net->layers()[l]->OnWeightsChanged();
   });

@@ -434,6 +434,11 @@ void Net<Dtype>::MaterializePendingReadersOf(const string& blob_name) const {
 }
 
 template <typename Dtype>
+void Net<Dtype>::MaterializeStale() const {
+  for (size_t k = 0; k < chain_pairs_.size(); ++k) MaterializeBlob(chain_pairs_[k].blob);
+}
+
+template <typename Dtype>
 void Net<Dtype>::MaterializePending() const {
   for (size_t k = 0; k < deferred_pools_.size(); ++k)
     static_cast<ROIPoolingLayer<Dtype>*>(layers_[deferred_pools_[k].first_layer].get())->Materialize();
@@ -664,6 +669,8 @@ void Net<Dtype>::Reshape() {
 
 template <typename Dtype>
 void Net<Dtype>::MarkWeightsChanged() {
+  // (the caller has ALREADY written the parameter blobs: blobs still unwritten would be re-created with the new weights -- code that
+  // writes parameters directly and wants the old frame's intermediate blobs calls MaterializeStale() first, as the C ABI's setter does)
   for (size_t i = 0; i < layers_.size(); ++i) layers_[i]->OnWeightsChanged();
 }
 
@@ -739,6 +746,7 @@ bool ShapeMatches(const ParsedBlob& pb, const vector<int>& target) {
 
 template <typename Dtype>
 void Net<Dtype>::CopyTrainedLayersFrom(const string& trained_filename) {
+  MaterializeStale();      // blobs a chained Forward left unwritten are the OLD weights' outputs
   if (trained_filename.size() >= 3 && trained_filename.compare(trained_filename.size() - 3, 3, ".h5") == 0) {   // net.cpp:788-795
     CopyTrainedLayersFromHDF5(trained_filename);
     return;
@@ -820,6 +828,7 @@ void Net<Dtype>::CopyTrainedLayersFrom(const string& trained_filename) {
 // hdf5_get_num_links / H5Lexists / hdf5_load_nd_dataset sequence.
 template <typename Dtype>
 void Net<Dtype>::CopyTrainedLayersFromHDF5(const string& trained_filename) {
+  MaterializeStale();      // blobs a chained Forward left unwritten are the OLD weights' outputs
   string bytes;
   CHECK(ReadFileToString(trained_filename, &bytes)) << "Couldn't open " << trained_filename;
   h5lite::File f(bytes);

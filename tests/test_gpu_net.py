@@ -835,6 +835,14 @@ def test_convolution_chains_keep_every_blob_bit_identical():
     n.forward()
     n.set_blob("pool2", np.zeros(n.blob_shape("pool2"), np.float32))
     assert np.array_equal(n.get_blob("conv3_2"), want32) and np.array_equal(n.get_blob("conv3_1"), want31)
+    # (f) changing a weight after a forward does not change what the skipped blobs of THAT forward read as
+    n.set_blob("data", x)
+    n.forward()
+    w32 = n.get_param("conv3_2", 0)
+    n.set_param("conv3_2", 0, (w32 * 0.5).astype(np.float32))
+    assert np.array_equal(n.get_blob("conv3_2"), want32) and np.array_equal(n.get_blob("conv3_1"), want31)
+    n.set_param("conv3_2", 0, w32)
+    n.forward()      # (first forward after a weight change: conv3_2 checks itself, unchained)
     # detections of the chained net = the unchained net's (whole frames)
     kw = dict(cls_id=2, ratios=(576 / 375.0, 1920 / 1242.0), org_hw=(375, 1242))
     for net in (n, u):
