@@ -100,6 +100,10 @@ MSCNN_NET_API int mscnn_net_set_auto_calibrate(mscnn_net* net, double tol);
  * every reader that goes through this ABI).  ON by default (with the other Net-level fusions); on = 0 writes every blob in every
  * forward (MSCNN_NO_CHAIN=1 does the same process-wide). */
 MSCNN_NET_API int mscnn_net_set_chain_fusion(mscnn_net* net, int on);
+/* The pairs the net registered at construction: producers[i] -> consumers[i] (layer indices; consumers[i] = -1: a top that only its
+ * fused 2x2 pooling reads).  Returns their number and writes up to cap of them; whether a pair actually runs chained is decided per
+ * forward (both planned kernels on the fp32 F(4x4,3x3) path, no numerical check pending, both layers inside the range). */
+MSCNN_NET_API int mscnn_net_chain_pairs(const mscnn_net* net, int* producers, int* consumers, int cap);
 MSCNN_NET_API int mscnn_net_auto_calibrate_state(const mscnn_net* net, int* checks, int* switched_layers, int cap);
 MSCNN_NET_API int mscnn_net_calibrate_numerics(mscnn_net* net, double tol, int* num_switched);
 MSCNN_NET_API double mscnn_net_layer_calibration_err(const mscnn_net* net, int layer);

@@ -5,6 +5,7 @@
 #define MSCNN_CAFFE_NET_HPP_
 
 #include <map>
+#include <utility>
 #include <set>
 #include <string>
 #include <vector>
@@ -83,6 +84,12 @@ class Net {
   // the layers computed with the OLD weights, as in the reference).  Called by the weight loaders and the C ABI's parameter setter.
   void MaterializeStale() const;
   bool chain_fusion() const { return chain_fusion_; }
+  // (producer layer, consumer layer or -1 for a top read by its fused pooling only) of every registered pair
+  vector<std::pair<int, int> > chain_pairs() const {
+    vector<std::pair<int, int> > out;
+    for (size_t k = 0; k < chain_pairs_.size(); ++k) out.push_back(std::make_pair(chain_pairs_[k].producer, chain_pairs_[k].consumer));
+    return out;
+  }
   // Numerical calibration on representative data: call after a Forward.  Every Convolution layer that runs a Winograd
   // form is re-computed with the direct k-ordered kernel on the same bottom; where max |dy| / max(1, |y|) exceeds `tol`
   // the layer is switched to the direct kernel for good (ConvolutionLayer::set_algo).  Returns the layers switched;

@@ -210,6 +210,14 @@ int mscnn_net_set_auto_calibrate(mscnn_net* n, double tol) {
 int mscnn_net_set_chain_fusion(mscnn_net* n, int on) {
   return guarded([&] { n->net->SetChainFusion(on != 0); });
 }
+int mscnn_net_chain_pairs(const mscnn_net* n, int* producers, int* consumers, int cap) {
+  const auto pairs = n->net->chain_pairs();
+  for (int i = 0; i < cap && i < (int)pairs.size(); ++i) {
+    if (producers) producers[i] = pairs[i].first;
+    if (consumers) consumers[i] = pairs[i].second;
+  }
+  return (int)pairs.size();
+}
 int mscnn_net_auto_calibrate_state(const mscnn_net* n, int* checks, int* switched_layers, int cap) {
   const std::vector<int>& sw = n->net->auto_calibrate_switched();
   if (checks) *checks = n->net->auto_calibrate_checks();

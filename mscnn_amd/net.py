@@ -48,7 +48,7 @@ def lib():
             "mscnn_net_set_conv_algo": [vp, ci, ci], "mscnn_net_set_inner_product_algo": [vp, ci, ci], "mscnn_net_set_conv_tuning": [vp, ci, ci, ci, ci],
             "mscnn_net_calibrate_numerics": [vp, C.c_double, vp], "mscnn_net_set_numerics_watch": [vp, ci, C.c_double],
             "mscnn_net_numerics_watch_state": [vp, vp, vp, ci], "mscnn_net_layer_calibration_err": [vp, ci],
-            "mscnn_net_set_auto_calibrate": [vp, C.c_double], "mscnn_net_set_chain_fusion": [vp, ci], "mscnn_net_auto_calibrate_state": [vp, vp, vp, ci],
+            "mscnn_net_set_auto_calibrate": [vp, C.c_double], "mscnn_net_set_chain_fusion": [vp, ci], "mscnn_net_chain_pairs": [vp, vp, vp, ci], "mscnn_net_auto_calibrate_state": [vp, vp, vp, ci],
             "mscnn_net_load_caffemodel": [vp, cs], "mscnn_net_set_stream": [vp], "mscnn_net_num_layers": [vp],
             "mscnn_net_layer_name": [vp, ci], "mscnn_net_layer_type": [vp, ci], "mscnn_net_layer_index": [vp, cs],
             "mscnn_net_layer_num_bottoms": [vp, ci], "mscnn_net_layer_num_tops": [vp, ci], "mscnn_net_layer_bottom": [vp, ci, ci],
@@ -193,6 +193,13 @@ class Net:
         """Chains of same-resolution F(4x4,3x3) convolutions keep the blob between two members out of HBM (on by default); off = every
         blob is written by every forward.  Reading such a blob re-runs its producer on demand -- same bytes either way."""
         _check(lib().mscnn_net_set_chain_fusion(self._h, int(on)))
+
+    def chain_pairs(self):
+        """[(producer layer name, consumer layer name | None)]: convolutions whose top may stay unwritten while a forward runs
+        (consumer None: the top is read by its fused 2x2 pooling only)."""
+        a, b = (C.c_int * 64)(), (C.c_int * 64)()
+        k = lib().mscnn_net_chain_pairs(self._h, a, b, 64)
+        return [(self.layer_names[a[i]], self.layer_names[b[i]] if b[i] >= 0 else None) for i in range(min(k, 64))]
 
     def auto_calibrate_state(self):
         """(first-forward checks done so far, [names of the layers they sent to the direct kernel], {layer: last measured error})."""

@@ -22,8 +22,8 @@ def _device():
 
 
 class Net(mnet.Net):
-    def __init__(self, path=None, prototxt_text=None):
-        super().__init__(path, prototxt_text=prototxt_text, device=_device())
+    def __init__(self, path=None, prototxt_text=None, fusion=None):
+        super().__init__(path, prototxt_text=prototxt_text, device=_device(), fusion=fusion)
 
 
 def graph(n):
@@ -82,6 +82,22 @@ def test_7s576_graph_splits_and_shapes():
         assert n.fused_away(n.layer_names.index(name))
     assert n.fused_away(n.layer_names.index("roi_pool"))                     # ROIPooling x2 write the Concat top directly
     assert sum(t == "Convolution" for t in n.layer_types) == 23 and sum(t == "Pooling" for t in n.layer_types) == 6
+
+
+def test_convolution_chains_are_wired_at_construction(monkeypatch):
+    """Round 4: the Net registers (a) every convolution whose top has exactly one running reader, a 3x3 convolution right behind it
+    (the blob between them may stay unwritten while both run chained), (b) every convolution whose top is read by its fused 2x2
+    pooling alone.  A convolution feeding a Split (conv4_3, conv5_3), a head or a net output is never in the list; without the
+    Net-level fusion (the ReLU layers run) there is none."""
+    n = Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576"))
+    pairs = n.chain_pairs()
+    assert set(p for p in pairs if p[1]) == {("conv1_1", "conv1_2"), ("conv2_1", "conv2_2"), ("conv3_1", "conv3_2"), ("conv3_2", "conv3_3"),
+                                            ("conv4_1", "conv4_2"), ("conv4_2", "conv4_3"), ("conv5_1", "conv5_2"), ("conv5_2", "conv5_3")}
+    assert set(p[0] for p in pairs if p[1] is None) == {"conv1_2", "conv2_2", "conv3_3"}
+    u = Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576"), fusion=False)
+    assert u.chain_pairs() == []
+    c = Net(prototxt_text=zoo.prototxt("caltech/mscnn-7s-480"))
+    assert ("conv3_1", "conv3_2") in c.chain_pairs() and ("conv1_2", None) in c.chain_pairs()
 
 
 def test_other_configs_shapes():
