@@ -1338,11 +1338,12 @@ static void plan_shape(mscnn_conv_plan* p) {
     p->x3d_slots_off = p->ws_bytes;
     p->ws_bytes += 4096;
   }
-  // conv1_2's shape class (3x3 / pad 1, 64 output channels, whole 4 x 128 tiles): tune_flags bit 15 selects the ring kernel of wconv.hip
-  // on the SAME packed weights (BM 64, CK 8, one M tile) -- an A/B variant and second witness: in the net it is no faster than the igemm
-  // kernel (profiles/r04_ab_conv1_2_ring.txt); tune_variant 402 also plans maps with fewer than two tiles per CU (tests)
+  // conv1_2's shape class (3x3 / pad 1, 64 output channels, whole 4 x 128 tiles, at least two of them per CU): the ring kernel of
+  // wconv.hip on the SAME packed weights (BM 64, CK 8, one M tile): -50 us per 7s-576 forward against the igemm kernel, alternating
+  // in one process (profiles/r04_ab_conv1_2_ring.txt); tune_flags bit 15 keeps the igemm kernel (A/B, second witness), tune_variant
+  // 402 also plans maps with fewer than two tiles per CU (tests)
   if (k.KH == 3 && k.KW == 3 && k.BM == 64 && k.CK == 8 && k.RH == 0 && (k.variant == 0 || k.variant == 1) && p->MT == 1 && d.pad_h == 1 &&
-      d.pad_w == 1 && (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 32768)) {
+      d.pad_w == 1 && !(tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 32768)) {
     if (mscnn::wconv_plan(d.N, d.Cin, d.H, d.W, d.Cout, d.tune_variant == 402, &p->wc) && p->wc.packed_bytes == p->packed_bytes) p->wc_use = true;
   }
 }

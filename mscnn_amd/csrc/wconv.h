@@ -1,6 +1,6 @@
 // Internal interface of wconv.hip: the direct 3x3 / pad 1 / stride 1 convolution with 64 output channels (conv1_2 of the VGG trunk:
 // 64 -> 64 channels on the full-resolution map) on the ring / one-barrier structure of wgemm.hip.  conv.hip's plan selects it; every
-// other shape stays on the igemm kernel.  Measured and NOT selected by AUTO (tune_flags bit 15 selects it): see the header of wconv.hip.
+// other shape stays on the igemm kernel (tune_flags bit 15 keeps it there for this one too).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>

@@ -20,11 +20,10 @@
 //     next tile's first chunk; whole tiles only (slot s of the persistent grid takes tiles s, s + G, ...).
 // Summation order: chunk, tap (kh, kw), channel pair -- the k order of the igemm kernel, bias last: bit-identical to it
 // (tests/test_gpu_ops.py::test_wconv_ring_kernel_against_the_igemm_kernel).
-// STATUS (round 4): measured, NOT selected by AUTO (tune_flags bit 15 selects it).  Stand-alone it runs conv1_2 in 654 - 660 us
-// against the igemm kernel's 681 - 688 (0.785 vs 0.75 of the fp32 MFMA peak), but inside the net the igemm kernel reads 662 us
-// (its dword patch loads find conv1_1's output in the MALL; this kernel's prefetch had hidden that latency already) and the frame
-// is the same within noise (206.1 vs 206.7 images/s): both sit at ~0.84 of the peak at the 2.25 GHz the chip holds under this
-// load.  A stream-K tail for the 2160 tiles (8.44 rounds) was tried and dropped -- profiles/r04_ab_conv1_2_ring.txt.
+// STATUS (round 4): AUTO's choice for this shape class (tune_flags bit 15 keeps the igemm kernel).  Stand-alone conv1_2 runs in
+// 654 - 660 us against the igemm kernel's 681 - 688 (0.785 vs 0.75 of the fp32 MFMA peak); in the net, same process, alternating:
+// 4.718 vs 4.768 ms per forward (tools/ab_net_layer.py, profiles/r04_ab_conv1_2_ring.txt).  A stream-K tail for the 2160 tiles
+// (8.44 rounds) was tried and dropped: it produced wrong sums once more than one tile was split.
 #include "wconv.h"
 #include "common.h"
 #include <type_traits>

@@ -1491,7 +1491,7 @@ def test_conv_pool_only_direct_kernel(hip, orc):
         x = dev(rng.standard_normal((N, Cin, H, W)).astype(np.float32))
         w = dev((rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32))
         b = dev(rng.standard_normal(Cout).astype(np.float32))
-        p = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT)
+        p = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_flags=32768)      # (bit 15: conv1_2's shape stays on this kernel)
         assert p.kernel.startswith("igemm_") and p.can_pool and p.can_pool_only, p.kernel
         p.pack(w)
         pool_ref = torch.empty((N, Cout, (H + 1) // 2, (W + 1) // 2), device="cuda")
@@ -1511,7 +1511,7 @@ def test_conv_pool_only_direct_kernel(hip, orc):
 @pytest.mark.parametrize("shape", [(1, 8, 8, 128), (2, 16, 12, 256), (1, 64, 64, 1024), (3, 40, 16, 128), (1, 48, 8, 384), (1, 64, 576, 1920)])
 def test_wconv_ring_kernel_against_the_igemm_kernel(hip, orc, shape):
     """conv1_2's shape class on the ring kernel of wconv.hip (one 8-wave workgroup per CU, LDS-DMA ring with dword patch pieces,
-    ride-along epilogue; opt-in: tune_flags bit 15) against the igemm kernel AUTO keeps, on the SAME packed weights: bit-identical --
+    ride-along epilogue; AUTO's choice for full-resolution maps) against the igemm kernel it replaces (tune_flags bit 15), on the SAME packed weights: bit-identical --
     y, the fused 2x2 pooling, the pool-only forward, with and without bias / ReLU --; small cases against the oracle."""
     N, Cin, H, W = shape
     rng = np.random.default_rng(17)
@@ -1522,10 +1522,11 @@ def test_wconv_ring_kernel_against_the_igemm_kernel(hip, orc, shape):
     # partial sums of a split tile differently)
     tiles_ig = N * ((H + 7) // 8) * ((W + 31) // 32)
     grid_ig = max(g for g in range(1, min(tiles_ig, 768) + 1) if tiles_ig % g == 0)
-    p = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_flags=32768, tune_variant=402)
-    q = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_grid=grid_ig)
+    p = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_variant=402)
+    q = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_flags=32768, tune_grid=grid_ig)
     assert p.kernel == "wconv_64x512_k3x3" and q.kernel.startswith("igemm_64x256"), (p.kernel, q.kernel)
-    assert hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True).kernel != "wconv_64x512_k3x3"      # never AUTO's choice
+    # AUTO takes it where the map has at least two tiles per CU (conv1_2 of the deploy nets), never below
+    assert (hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True).kernel == "wconv_64x512_k3x3") == (N * (H // 4) * (W // 128) >= 512)
     assert p.can_pool and p.can_pool_only and not p.publishes_amax
     p.pack(w); q.pack(w)
     assert torch.equal(p.packed, q.packed)
@@ -1542,7 +1543,7 @@ def test_wconv_ring_kernel_against_the_igemm_kernel(hip, orc, shape):
     if H * W <= 20000:
         ref = orc.relu(orc.conv2d(x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), (1, 1)))
         close(yp.cpu().numpy(), ref)
-    p2 = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=False, algo=hip.ALGO_DIRECT, tune_flags=32768, tune_variant=402)
-    q2 = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=False, algo=hip.ALGO_DIRECT, tune_grid=grid_ig)
+    p2 = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=False, algo=hip.ALGO_DIRECT, tune_variant=402)
+    q2 = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=False, algo=hip.ALGO_DIRECT, tune_flags=32768, tune_grid=grid_ig)
     p2.pack(w); q2.pack(w)
     assert torch.equal(p2.forward(x), q2.forward(x))
