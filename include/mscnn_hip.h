@@ -59,8 +59,9 @@ typedef enum {
   /* The default.  3x3 / stride 1 / group 1 layers with enough arithmetic intensity run a Winograd form: F(4x4,3x3) (36 planes, points
    * {0, 1, -1, 2, -1/2, inf}) where the layer has >= 1000 tiles of 4x4 (conv2_1 .. conv4_3, loss1_conv1 of the 7s-576 net), F(3x3,3x3)
    * (25 planes) below that and on 7x7 ROI maps (conv5_x, conv6_1, roi_c1); the plane GEMMs run on wgemm.hip's kernel.  Cin = 3 runs a
-   * VALU kernel, Cout <= 16 with 5x5 / 7x7 / 3x5 / 5x7 kernels the M = 4 head kernels (or the kw-folded GEMM), everything else the
-   * direct implicit-GEMM kernel.  The Winograd forms carry ~10x the rounding error of the direct sum: callers that go through the
+   * VALU kernel, Cout <= 16 with 5x5 / 7x7 / 3x5 / 5x7 kernels the M = 4 head kernels (or the kw-folded GEMM), a 3x3 / pad 1 layer with
+   * 64 output channels on a full-resolution map (conv1_2: whole 4 x 128 tiles, >= 2 per CU) the ring kernel of wconv.hip, everything
+   * else the direct implicit-GEMM kernel.  The Winograd forms carry ~10x the rounding error of the direct sum: callers that go through the
    * C++ layer (libmscnn_caffe.so) get a per-layer check against DIRECT on the first forward after every weight change, and a
    * fall-back, without asking (include/mscnn_net.h: mscnn_net_set_auto_calibrate); callers of THIS ABI own that decision and can
    * make it with mscnn_max_rel_diff_f32 on a DIRECT plan's output. */
