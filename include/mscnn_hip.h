@@ -190,6 +190,23 @@ MSCNN_API size_t mscnn_inner_product_wg_workspace_bytes(int M, int N, int K);
 MSCNN_API int mscnn_inner_product_wg_pack(const float* w, float* wt, int N, int K, void* stream);
 MSCNN_API int mscnn_inner_product_wg_fwd(const float* x, const float* wt, const float* bias, float* y, int M, int N, int K, int relu,
                                          void* workspace, size_t workspace_bytes, void* stream);
+/* Health of the plane-GEMM kernel's stream-K hand-off (the Winograd layers and the _wg InnerProduct above).  Where a launch splits
+ * its last tiles over workgroups, the workgroup that finishes a tile waits for the others' partial sums; all workgroups of the
+ * persistent grid must be co-resident for that (one per CU).  If a contributor never shows up (CU masking, a partition mode the plan
+ * was not made for, another stream's kernels holding a CU for > ~0.5 s) the finisher gives up: the tile is stored as NaN (every
+ * ReLU behind it keeps a NaN a NaN, as relu_layer.cpp:14-15's std::max does) AND the launch's tag is written to one word of pinned
+ * host memory per device.
+ *   mscnn_wgemm_handoff_event(): that word for the current device -- 0 = no hand-off has ever timed out; any change since the last
+ *     look = at least one launch in between produced a poisoned tile.  Valid once the stream has been synchronised (a plain load).
+ *   mscnn_wgemm_force_whole_tiles(1): from now on no launch of this process splits a tile (the last round of tiles is simply not
+ *     full: a few % slower on the layers that used the split, never waits for anybody).  The answer to a reported event: force,
+ *     then run the frame again -- caffe::Net does exactly that at its synchronisation points (mscnn_net_handoff_state).
+ *   mscnn_debug_wgemm_handoff_fault(drop_publish, spin_limit): fault injection for the tests of the above -- contributors never
+ *     publish (drop_publish != 0), finishers give up after spin_limit polls (0 = the default 2^22).  Never set in production. */
+MSCNN_API unsigned long long mscnn_wgemm_handoff_event(void);
+MSCNN_API void mscnn_wgemm_force_whole_tiles(int on);
+MSCNN_API int mscnn_wgemm_whole_tiles_forced(void);
+MSCNN_API void mscnn_debug_wgemm_handoff_fault(int drop_publish, unsigned spin_limit);
 /* fp16-operand InnerProduct (the counterpart of MSCNN_CONV_ALGO_F16; no reference counterpart): w16 = the weights converted
  * once to fp16 [N][K] (mscnn_inner_product_pack_f16, N * K * 2 bytes), x rounded to fp16 on its way into LDS, fp32 accumulate.
  * Needs N >= 64 and K % 8 == 0 (mscnn_inner_product_f16_supported); smaller layers stay on the fp32 entry point. */

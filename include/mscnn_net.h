@@ -140,6 +140,15 @@ MSCNN_NET_API const float* mscnn_net_blob_device_ptr(mscnn_net* net, const char*
 MSCNN_NET_API int mscnn_net_forward(mscnn_net* net);
 MSCNN_NET_API int mscnn_net_forward_from_to(mscnn_net* net, int from, int to);
 MSCNN_NET_API int mscnn_net_reshape(mscnn_net* net);
+/* Health of the plane-GEMM kernel's stream-K hand-off (mscnn_hip.h: mscnn_wgemm_handoff_event).  A hand-off that times out (a
+ * workgroup of the persistent grid was not co-resident: CU masking, a partition mode, another stream's kernels) can never hand out a
+ * wrong frame through this ABI: the Net reads the kernel's status word wherever it synchronises anyway -- behind BoxOutput's
+ * row-count read inside a forward, behind the copy of mscnn_net_detect and of mscnn_net_get_blob -- and on an event forces
+ * whole-tile scheduling for the rest of the process and runs the frame again before the call returns (cost: one frame twice, once).
+ * Returns how many events this net has answered so far; *whole_tiles_forced (may be NULL) = 1 once the process runs on whole tiles.
+ * (mscnn_net_detect_device + the RCCL exchange, and C++ callers that read Blob::cpu_data() themselves, synchronise outside the Net:
+ * they call caffe::Net::HandoffRecover() / look at mscnn_wgemm_handoff_event() behind their own synchronisation.) */
+MSCNN_NET_API int mscnn_net_handoff_state(const mscnn_net* net, int* whole_tiles_forced);
 /* `caffe time`-style per-layer HIP-event timing (tools/caffe.cpp:380-400); serialises the layers. */
 MSCNN_NET_API int mscnn_net_set_layer_timing(mscnn_net* net, int on);
 MSCNN_NET_API float mscnn_net_layer_ms(const mscnn_net* net, int layer);

@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = C::VEC ? acc[mi][ni][r] : acc[mi][ni][r] + bvals[r];     // (VEC = Winograd GEMM: no bias, no ReLU)
-            if (!C::VEC && a.relu) v = v > 0.f ? v : 0.f;
+            if (!C::VEC && a.relu) v = v < 0.f ? 0.f : v;
             const unsigned vo = (co0 + (r & 3) + 8 * (r >> 2) < a.Cout) ? voff : kOob;   // Cout < BM (proposal heads)
             if (!C::CAN_POOL || a.y)      // (pool-only forwards: not even issued -- the epilogue is issue-bound next to the other workgroup's MFMAs)
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, vo,
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
       const int o = geo.out_off(a, p + q);
       if (o < 0) continue;
       float r = vals[q] + bv;
-      if (a.relu) r = r > 0.f ? r : 0.f;
+      if (a.relu) r = r < 0.f ? 0.f : r;
       ybase[(long)co * co_stride + o] = r;
       am = max(am, __builtin_bit_cast(unsigned, r) & 0x7fffffffu);
     }
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_pool_kernel(IgemmArgs a) {
         const int h = oh + (e >> 1), w = ow + (e & 1);
         if (h >= a.Ho || w >= a.Wo) continue;
         float r = vals[e];
-        if (a.relu) r = r > 0.f ? r : 0.f;
+        if (a.relu) r = r < 0.f ? 0.f : r;
         if (a.y) ybase[(long)co * co_stride + h * a.Wo + w] = r;
         mx = max2(mx, r);
         am = max(am, __builtin_bit_cast(unsigned, r) & 0x7fffffffu);
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const float* __restric
         }
       }
     if (bias) acc += bias[oc];
-    if (relu) acc = acc > 0.f ? acc : 0.f;
+    if (relu) acc = acc < 0.f ? 0.f : acc;
     y[i] = acc;
   }
 }

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(C3Args a) {
         }
     const float b = sb[co];
     float4 o = make_float4(acc[0] + b, acc[1] + b, acc[2] + b, acc[3] + b);
-    if (a.relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
+    if (a.relu) { o.x = o.x < 0.f ? 0.f : o.x; o.y = o.y < 0.f ? 0.f : o.y; o.z = o.z < 0.f ? 0.f : o.z; o.w = o.w < 0.f ? 0.f : o.w; }
     *reinterpret_cast<float4*>(yout + (long)co * plane) = o;
     if (a.amax_out) am = max(am, __float_as_uint(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)))));
   }

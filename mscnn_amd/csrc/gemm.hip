@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {      // (min
             if (m < a.M && n < a.N) {
               float v = acc[i][j][r];
               if (a.bias) v += a.bias[n];
-              if (a.relu) v = v > 0.f ? v : 0.f;
+              if (a.relu) v = v < 0.f ? 0.f : v;
               a.y[(long)m * a.N + n] = v;
             }
           } else {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmArgs a) {
       if (nn + q >= a.N) continue;
       float r = vals[q];
       if (a.bias) r += a.bias[nn + q];
-      if (a.relu) r = r > 0.f ? r : 0.f;
+      if (a.relu) r = r < 0.f ? 0.f : r;
       a.y[(long)m * a.N + nn + q] = r;
     }
   }
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(GemmArgs a) {
             if (m < a.M && n < a.N) {
               float v = acc[i][j][r];
               if (a.bias) v += a.bias[n];
-              if (a.relu) v = v > 0.f ? v : 0.f;
+              if (a.relu) v = v < 0.f ? 0.f : v;
               a.y[(long)m * a.N + n] = v;
             }
           } else {
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void ip_rowwise_kernel(const float* __restrict
     if (m0 + r >= M) continue;
     float v = (red[r][0][n] + red[r][1][n]) + (red[r][2][n] + red[r][3][n]);
     if (bias) v += bias[n];
-    if (relu) v = v > 0.f ? v : 0.f;
+    if (relu) v = v < 0.f ? 0.f : v;
     y[(long)(m0 + r) * N + n] = v;
   }
 }
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void ip_generic_kernel(const float* __restrict
     if (threadIdx.x == 0) {
       float v = (red[0] + red[1]) + (red[2] + red[3]);
       if (bias) v += bias[n];
-      if (relu) v = v > 0.f ? v : 0.f;
+      if (relu) v = v < 0.f ? 0.f : v;
       y[(long)m * N + n] = v;
     }
     __syncthreads();

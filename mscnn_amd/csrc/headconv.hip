@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
           for (int i = 0; i < 4; ++i) {
             const int co = q * 4 + i;
             float v = acc[g][q][i] + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bias_rsrc, 0, (unsigned)co * 4u, 0));
-            if (a.relu) v = v > 0.f ? v : 0.f;
+            if (a.relu) v = v < 0.f ? 0.f : v;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ysrc, co < a.Cout ? voff : kOob,
                                                   (unsigned)co * (unsigned)co_stride * 4u, 0);
           }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void head_fixup_kernel(HeadArgs a) {
   if (oh >= a.Ho) return;
   float* yrow = a.y + ((long)img * a.Cout + co) * co_stride + oh * a.Wo;
   float r0 = v.x + bv, r1 = v.y + bv;
-  if (a.relu) { r0 = r0 > 0.f ? r0 : 0.f; r1 = r1 > 0.f ? r1 : 0.f; }
+  if (a.relu) { r0 = r0 < 0.f ? 0.f : r0; r1 = r1 < 0.f ? 0.f : r1; }
   if (ow < a.Wo) yrow[ow] = r0;
   if (ow + 1 < a.Wo) yrow[ow + 1] = r1;
 }

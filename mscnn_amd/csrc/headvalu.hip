@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void headv_kernel(HvArgs a) {
 #pragma unroll
               for (int p = 0; p < C::PX; ++p) {
                 v[p] = acc[p][cp][e] + bv;
-                if (a.relu) v[p] = v[p] > 0.f ? v[p] : 0.f;
+                if (a.relu) v[p] = v[p] < 0.f ? 0.f : v[p];
               }
               float* dst = yp + (long)co * co_stride;
               if ((a.Wo % 4) == 0) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void headv_fixup_kernel(HvArgs a) {
   float r[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
   if (a.relu)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) r[p] = r[p] > 0.f ? r[p] : 0.f;
+    for (int p = 0; p < 4; ++p) r[p] = r[p] < 0.f ? 0.f : r[p];
   float* dst = a.y + ((long)img * a.Cout + co) * a.Ho * a.Wo + (long)oh * a.Wo + ow;
   if ((a.Wo % 4) == 0) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
   else

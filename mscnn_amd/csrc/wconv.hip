@@ -256,7 +256,7 @@ __global__ __launch_bounds__(KC::THREADS, 2) void wconv_kernel(WcArgs a) {
     constexpr int mi = u / 16, r = u % 16, dr = (r & 3) + 8 * (r >> 2);
     {
       float v0 = acc[Q][mi][0][r] + bias_r[mi][r], v1 = acc[Q][mi][1][r] + bias_r[mi][r];
-      if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+      if (a.relu) { v0 = v0 < 0.f ? 0.f : v0; v1 = v1 < 0.f ? 0.f : v1; }
       if constexpr (k == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rY, old_voff[mi][0], (unsigned)dr * plane_bytes, 0);
       else if constexpr (k == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rY, old_voff[mi][1], (unsigned)dr * plane_bytes, 0);
       else {

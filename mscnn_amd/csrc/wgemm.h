@@ -11,6 +11,7 @@ struct WgemmPlan {
   int P, Cout, Cin, T, T_pad;       // T_pad: row stride of V and M (multiple of the N tile)
   int BM, BN, CK, MT, NT, KI;       // tile shape, tiles per plane, K chunks
   int G;                            // persistent grid (workgroups)
+  int device;                       // the device G was taken from (-1: planned without one); wgemm_launch refuses another
   int full_q;                       // whole tiles per workgroup; the remaining tiles are split stream-K style
   int variant;
   double model_us;                  // the plan's own time estimate (picks between tile shapes)
@@ -29,5 +30,12 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* out);
 // m_valid_bytes != 0: the bytes of M that exist (Cout was rounded up to the tile grid's 32-row blocks, the caller's buffer was not)
 int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, float* ws, hipStream_t st, int abl = 0,
                  unsigned long long* dbg = nullptr, const float* bias = nullptr, int relu = 0, size_t m_valid_bytes = 0);
+
+// Hand-off health (mscnn_hip.h: mscnn_wgemm_handoff_event & co).  event: the epoch of the last launch on the current device whose
+// finisher gave up on a contributor (0: none yet) -- read it after synchronising the stream.
+unsigned long long wgemm_handoff_event();
+void wgemm_force_whole_tiles(int on);
+int wgemm_whole_tiles_forced();
+void wgemm_debug_handoff_fault(int drop_publish, unsigned spin_limit);
 
 }  // namespace mscnn

@@ -49,6 +49,11 @@ struct WgemmArgs {
   unsigned long long* dbg;      // development: [G] {shader cycles, 100 MHz ticks} over the kernel, then [G] {start, end} in 100 MHz ticks (nullptr in the product)
   unsigned up_bytes, v_bytes, m_bytes;
   const float* bias; int relu;  // EPI kernels only: y = acc + bias[column] (nullptr: none), then max(y, 0) when relu -- applied to what goes to M, never to a partial slab
+  // hand-off health: a finisher that gives up on a contributor after spin_limit polls stores this launch's epoch into *status -- one
+  // word of pinned host memory per device that the host reads at its next synchronisation point (mscnn_wgemm_handoff_event)
+  unsigned long long* status;
+  unsigned spin_limit;
+  int drop_publish;             // fault injection (mscnn_debug_wgemm_handoff_fault): contributors never set their flag
 };
 
 template <int BM_, int BN_, int WGM_, int WGN_, int CK_, int ST_, int DPG_ = 1, int SK_ = 0>
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
     else {
       if constexpr (EPI) {
         v += old_bias[ni];
-        if (a.relu) v = v > 0.f ? v : 0.f;
+        if (a.relu) v = v < 0.f ? 0.f : v;      // std::max(v, 0) of relu_layer.cpp:14-15: a NaN stays a NaN
       }
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), old_rsrc, old_voff[mi][ni], (unsigned)dr * old_rowb, 0);
     }
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
   const unsigned long long want_flag = ((unsigned long long)a.epoch << 32) | (unsigned)~a.epoch;
   auto publish_flag = [&]() {      // R1 of the guide's hand-off recipe: every storing wave drains, one barrier, ONE lane sets the flag
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (tid == 0) __hip_atomic_store(flags + slot, want_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && !a.drop_publish) __hip_atomic_store(flags + slot, want_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // one segment on accumulator set PAR: its first chunk carries the previous segment's stores (segment 0: that set is empty and its
   // offsets are out of range); afterwards the flushed set is cleared for the segment after this one, and this segment's destination --
@@ -441,12 +446,17 @@ __global__ __launch_bounds__(C::THREADS, C::NW / 4) void wgemm_kernel(WgemmArgs 
         if (e <= b) continue;
         if (tid == 0) {
           unsigned spins = 0;
-          while (__hip_atomic_load(flags + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_flag && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(4);
-          // hand-off timed out (the contributor is not co-resident: CU masking, a shared GPU): never a silently wrong tile -- the status
-          // word is set and the whole tile is stored as NaN, which every downstream check (the layer's first-forward check, the numerics
-          // watch, any parity test) fails on, and the self-check answers by putting the layer on the direct kernel
-          s_handoff_timeout = spins >= (1u << 22) ? 1u : 0u;
-          if (spins >= (1u << 22)) __hip_atomic_store(flags + a.G, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while (__hip_atomic_load(flags + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want_flag && ++spins < a.spin_limit) __builtin_amdgcn_s_sleep(4);
+          // hand-off timed out (the contributor is not co-resident: CU masking, a shared GPU, another stream's kernels holding its CU):
+          // never a silently wrong tile.  (1) this launch's epoch goes into the device's pinned status word, which the host reads at its
+          // next synchronisation point (Net: behind BoxOutput's and the final stage's sync) and answers by forcing whole-tile
+          // scheduling and running the frame again; (2) the tile is stored as NaN, and every ReLU behind M keeps a NaN a NaN.
+          const bool timed_out = spins >= a.spin_limit;
+          s_handoff_timeout = timed_out ? 1u : 0u;
+          if (timed_out) {
+            __hip_atomic_store(flags + a.G, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.status) __hip_atomic_store(a.status, (unsigned long long)a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
@@ -521,13 +531,55 @@ namespace mscnn {
 
 // The persistent grid is one workgroup per CU and the stream-K hand-off needs every workgroup co-resident: take the CU count of the
 // current device (256 on an MI355X in SPX mode; fewer in a partition mode), 256 when no device is visible (planning on a CPU box).
-static int device_cus() {
+static int device_cus(int* dev_out) {
   int dev = 0, n = 0;
+  *dev_out = -1;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
     (void)hipGetLastError();
     return 256;
   }
+  *dev_out = dev;
   return n;
+}
+
+// ---- hand-off health (process-wide state; see the kernel's time-out branch) ---------------------------------------------------
+namespace {
+std::atomic<int> g_whole_tiles{0};                 // mscnn_wgemm_force_whole_tiles: no launch splits a tile any more
+std::atomic<unsigned> g_spin_limit{1u << 22};      // polls of a contributor's flag before the finisher gives up (~0.5 s)
+std::atomic<int> g_drop_publish{0};                // fault injection
+std::atomic<unsigned long long*> g_status[64];     // one pinned host word per device, allocated by the first split launch on it
+}  // namespace
+
+static unsigned long long* status_word(int dev) {
+  if (dev < 0 || dev >= 64) return nullptr;
+  unsigned long long* w = g_status[dev].load(std::memory_order_acquire);
+  if (w) return w;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  *static_cast<volatile unsigned long long*>(p) = 0ull;
+  unsigned long long* expected = nullptr;
+  if (!g_status[dev].compare_exchange_strong(expected, static_cast<unsigned long long*>(p))) {
+    (void)hipHostFree(p);
+    return expected;
+  }
+  return static_cast<unsigned long long*>(p);
+}
+
+unsigned long long wgemm_handoff_event() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (dev < 0 || dev >= 64) return 0;
+  const unsigned long long* w = g_status[dev].load(std::memory_order_acquire);
+  return w ? *static_cast<const volatile unsigned long long*>(w) : 0ull;
+}
+void wgemm_force_whole_tiles(int on) { g_whole_tiles.store(on ? 1 : 0); }
+int wgemm_whole_tiles_forced() { return g_whole_tiles.load(); }
+void wgemm_debug_handoff_fault(int drop_publish, unsigned spin_limit) {
+  g_drop_publish.store(drop_publish ? 1 : 0);
+  g_spin_limit.store(spin_limit ? spin_limit : (1u << 22));
 }
 
 bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
@@ -560,7 +612,7 @@ bool wgemm_plan(int P, int Cout, int Cin, int T, int variant, WgemmPlan* o) {
   o->BM = e->BM; o->BN = e->BN; o->CK = e->CK;
   o->T_pad = (T + e->BN - 1) / e->BN * e->BN;
   o->MT = (Cout + e->BM - 1) / e->BM; o->NT = o->T_pad / e->BN; o->KI = Cin / e->CK;
-  o->G = device_cus();          // one 512-thread workgroup per CU
+  o->G = device_cus(&o->device);          // one 512-thread workgroup per CU (of the device that is current NOW: the launch checks it)
   const long tiles = (long)P * o->MT * o->NT;
   // Whole tiles (ceil(tiles / G) rounds) or the hybrid stream-K split of the last partial round?  Fitted to the measurements of
   // profiles/r03_wgemm.txt (256 x 128 x 32 chunks: 3.7 us each at the sustained clock, ~6 us per tile for its ride-along stores,
@@ -595,13 +647,26 @@ int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, 
   const WEntry* e = nullptr;
   for (const WEntry& w : kW) if (w.variant == p.variant && w.abl == abl) e = &w;
   if (!e) return MSCNN_ERR_BAD_ARG;
+  // The persistent grid (and the co-residency the stream-K hand-off relies on) was sized for the device that was current when the
+  // plan was made: a plan is not portable between devices / partitions.
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+  if (p.device >= 0 && dev != p.device) {
+    set_error("wgemm: plan made on device %d launched on device %d (re-plan on the device that runs it)", p.device, dev);
+    return MSCNN_ERR_BAD_ARG;
+  }
   WgemmArgs a;
   a.Up = Up; a.V = V; a.M = M; a.ws = ws;
   a.P = p.P; a.MT = p.MT; a.NT = p.NT; a.KI = p.KI; a.Cin = p.Cin; a.Cout = p.Cout; a.T_pad = p.T_pad;
   a.tiles = p.P * p.MT * p.NT; a.G = p.G; a.abl = abl; a.dbg = dbg;
   a.full_q = p.full_q; a.ws_bytes = (unsigned)p.ws_bytes;
-  const int rem = a.tiles - p.full_q * p.G;
+  // (after a reported hand-off time-out the host forces whole tiles: the last round is then simply not full and nothing is handed over)
+  if (g_whole_tiles.load(std::memory_order_relaxed)) a.full_q = (a.tiles + p.G - 1) / p.G;
+  const int rem = a.tiles - a.full_q * p.G;
   if (rem > 0 && !ws) { set_error("wgemm: workspace missing"); return MSCNN_ERR_WORKSPACE; }
+  a.status = rem > 0 ? status_word(dev) : nullptr;
+  a.spin_limit = g_spin_limit.load(std::memory_order_relaxed);
+  a.drop_publish = g_drop_publish.load(std::memory_order_relaxed);
   a.up_bytes = (unsigned)p.packed_bytes; a.v_bytes = (unsigned)((size_t)p.P * p.Cin * p.T_pad * 4); a.m_bytes = (unsigned)((size_t)p.P * p.Cout * p.T_pad * 4);
   if (m_valid_bytes) a.m_bytes = (unsigned)m_valid_bytes;      // (rows beyond the caller's buffer: their stores fall outside num_records and are dropped)
   a.bias = bias; a.relu = relu;
@@ -617,3 +682,8 @@ int wgemm_launch(const WgemmPlan& p, const float* Up, const float* V, float* M, 
 }
 
 }  // namespace mscnn
+
+extern "C" unsigned long long mscnn_wgemm_handoff_event(void) { return mscnn::wgemm_handoff_event(); }
+extern "C" void mscnn_wgemm_force_whole_tiles(int on) { mscnn::wgemm_force_whole_tiles(on); }
+extern "C" int mscnn_wgemm_whole_tiles_forced(void) { return mscnn::wgemm_whole_tiles_forced(); }
+extern "C" void mscnn_debug_wgemm_handoff_fault(int drop_publish, unsigned spin_limit) { mscnn::wgemm_debug_handoff_fault(drop_publish, spin_limit); }

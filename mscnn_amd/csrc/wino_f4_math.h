@@ -151,7 +151,7 @@ WINO_F4_FN unsigned output_tile(const float* M, const float* bias, float* y, flo
     for (int j = 0; j < 4; ++j) {
       const int ow = 4 * tx + j;
       float u = o[j] + b;
-      if (relu) u = u > 0.f ? u : 0.f;
+      if (relu) u = u < 0.f ? 0.f : u;
       const bool in = oh < Ho && ow < Wo;
       if (in) {
         dst[oh * Wo + ow] = u;

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void x3_fixup_kernel(const float* __restrict__
     for (int q = 0; q < 4; ++q) {
       if (col + q >= N) continue;
       float t = o[q] + (bias ? bias[col + q] : 0.f);
-      if (relu) t = t > 0.f ? t : 0.f;
+      if (relu) t = t < 0.f ? 0.f : t;
       y[(size_t)row * N + col + q] = t;
     }
   }
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void x3_head_shift_add_kernel(const float* __r
       acc += T[(size_t)((kh * KW + kw) * Cout + co) * T_pad + (unsigned)(iy * W + ix)];
     }
   }
-  if (relu) acc = acc > 0.f ? acc : 0.f;
+  if (relu) acc = acc < 0.f ? 0.f : acc;
   y[((size_t)co * Ho + oy) * Wo + ox] = acc;
 }
 

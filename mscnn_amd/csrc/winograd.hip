@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     if (oh >= Ho) continue;
     float v0 = r[i][0] + r[i][1] + r[i][2] + b;
     float v1 = r[i][1] - r[i][2] - r[i][3] + b;
-    if (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+    if (relu) { v0 = v0 < 0.f ? 0.f : v0; v1 = v1 < 0.f ? 0.f : v1; }
     const int ow = 2 * tx;
     if (ow < Wo && v0 > pooled) pooled = v0;
     if (ow + 1 < Wo && v1 > pooled) pooled = v1;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void wino33_output_kernel(const float* __restr
       const int ow = 3 * tx + j;
       if (ow >= Wo) continue;
       float u = v[j];
-      if (relu) u = u > 0.f ? u : 0.f;
+      if (relu) u = u < 0.f ? 0.f : u;
       dst[oh * Wo + ow] = u;
       am = max(am, __float_as_uint(u) & 0x7fffffffu);
     }
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void wino33_output_roi_kernel(const float* __r
         const int ow = 3 * tx + j;
         if (ow >= Wo) continue;
         float u = v[j];
-        if (relu) u = u > 0.f ? u : 0.f;
+        if (relu) u = u < 0.f ? 0.f : u;
         dst[oh * Wo + ow] = u;
         am = max(am, __float_as_uint(u) & 0x7fffffffu);
       }
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void wino33_output_pool_kernel(const float* __
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       float v = out[i][j];
-      if (relu) v = v > 0.f ? v : 0.f;
+      if (relu) v = v < 0.f ? 0.f : v;
       const bool in = oh0 + i < Ho && ow0 + j < Wo;
       if (in) am = max(am, __float_as_uint(v) & 0x7fffffffu);
       out[i][j] = in ? v : -3.402823466e+38f;
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void wino44_output_vec_kernel(const float* __r
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float u = o[j] + b;
-        if (relu) u = u > 0.f ? u : 0.f;
+        if (relu) u = u < 0.f ? 0.f : u;
         out[i][j] = u;
       }
       if (oh < Ho) {             // (Wo is a multiple of 4 here: every column of the tile is inside the plane)
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(64 * S * RW) void wino44_outin_kernel(const float* 
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float u = o[j] + bv;
-            if (relu) u = u > 0.f ? u : 0.f;
+            if (relu) u = u < 0.f ? 0.f : u;
             out[i][j] = u;
           }
           if (own) {

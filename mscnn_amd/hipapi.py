@@ -81,6 +81,13 @@ def lib():
         L.mscnn_inner_product_wg_workspace_bytes.argtypes = [C.c_int] * 3
         L.mscnn_inner_product_wg_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mscnn_inner_product_wg_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.mscnn_wgemm_handoff_event.restype = C.c_ulonglong
+        L.mscnn_wgemm_handoff_event.argtypes = []
+        L.mscnn_wgemm_force_whole_tiles.restype = None
+        L.mscnn_wgemm_force_whole_tiles.argtypes = [C.c_int]
+        L.mscnn_wgemm_whole_tiles_forced.argtypes = []
+        L.mscnn_debug_wgemm_handoff_fault.restype = None
+        L.mscnn_debug_wgemm_handoff_fault.argtypes = [C.c_int, C.c_uint]
         L.mscnn_inner_product_pack_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mscnn_inner_product_fwd_f16.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
         for f in ("mscnn_conv2d_plan_flops", "mscnn_conv2d_plan_executed_flops"):
@@ -585,3 +592,22 @@ def detections(bbox_pred, cls_pred, props, cls_id, bbox_mean=(0, 0, 0, 0), bbox_
                                       _dev(count), _dev(ws), wb, _stream()))
     D = int(count.item())
     return dets[:D], ids[:D]
+
+
+# ---- health of the plane-GEMM kernel's stream-K hand-off (mscnn_hip.h) ----
+def wgemm_handoff_event():
+    """Tag of the last launch on the current device whose finisher gave up on a contributor (0: none); synchronise first."""
+    return int(lib().mscnn_wgemm_handoff_event())
+
+
+def wgemm_force_whole_tiles(on=True):
+    lib().mscnn_wgemm_force_whole_tiles(int(bool(on)))
+
+
+def wgemm_whole_tiles_forced():
+    return bool(lib().mscnn_wgemm_whole_tiles_forced())
+
+
+def debug_wgemm_handoff_fault(drop_publish=False, spin_limit=0):
+    """Fault injection for the tests: contributors never publish their partial sums; finishers give up after spin_limit polls."""
+    lib().mscnn_debug_wgemm_handoff_fault(int(bool(drop_publish)), int(spin_limit))

@@ -111,6 +111,16 @@ class Net {
   void SetNumericsWatch(int period, double tol) { watch_period_ = period; watch_tol_ = tol; watch_frame_ = 0; }
   int numerics_watch_checks() const { return watch_checks_; }
   const vector<int>& numerics_watch_switched() const { return watch_switched_; }
+  // Health of the plane-GEMM kernel's stream-K hand-off (include/mscnn_hip.h: mscnn_wgemm_handoff_event).  A launch whose finisher
+  // gave up on a contributor leaves a NaN tile behind and its tag in a pinned status word; the Net looks at that word wherever the
+  // stream has just been synchronised anyway -- behind BoxOutput's row-count read inside ForwardFromTo (covers the trunk and the
+  // heads, whose NaN scores BoxOutput would otherwise silently drop) and, through HandoffRecover(), behind the final stage's / a blob
+  // read's synchronisation (covers roi_c1 and fc6).  The answer is always the same: whole-tile scheduling for the rest of the
+  // process (mscnn_wgemm_force_whole_tiles) and the affected range once more.  handoff_errors() = how often that happened.
+  //   HandoffRecover(): call right after synchronising Caffe::stream() on outputs of the last ForwardFromTo.  false = nothing was
+  //   reported; true = the range has been run again (asynchronously, like any Forward): read the outputs again.
+  bool HandoffRecover();
+  int handoff_errors() const { return handoff_errors_; }
 
  protected:
   void Init(const NetParameter& param);
@@ -156,6 +166,10 @@ class Net {
   int auto_checks_ = 0;
   vector<int> auto_switched_;
   vector<int> watch_switched_;
+  bool HandoffEventPending();      // (the stream must have been synchronised) a new tag in the status word: whole tiles forced, counted
+  unsigned long long handoff_seen_ = 0;
+  int handoff_errors_ = 0;
+  int last_start_ = 0, last_end_ = -1;
   DISABLE_COPY_AND_ASSIGN(Net);
 };
 

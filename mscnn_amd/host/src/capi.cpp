@@ -299,9 +299,14 @@ int mscnn_net_get_blob(mscnn_net* n, const char* name, float* host, size_t capac
   return guarded([&] {
     CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
     auto b = n->net->blob_by_name(name);
+    const float* src = b->cpu_data();      // (synchronises the stream)
+    if (n->net->HandoffRecover()) {        // a hand-off timed out in the forward this blob comes from: the Net has run it again
+      b = n->net->blob_by_name(name);
+      src = b->cpu_data();
+    }
     if (count) *count = (size_t)b->count();
     CHECK_LE((size_t)b->count(), capacity) << "buffer too small for blob " << name;
-    std::memcpy(host, b->cpu_data(), sizeof(float) * b->count());
+    std::memcpy(host, src, sizeof(float) * b->count());
   });
 }
 const float* mscnn_net_blob_device_ptr(mscnn_net* n, const char* name) {
@@ -318,6 +323,10 @@ int mscnn_net_forward_from_to(mscnn_net* n, int from, int to) {
   return guarded([&] { n->net->ForwardFromTo(from, to < 0 ? (int)n->net->layers().size() - 1 : to); });
 }
 int mscnn_net_reshape(mscnn_net* n) { return guarded([&] { n->net->Reshape(); }); }
+int mscnn_net_handoff_state(const mscnn_net* n, int* whole_tiles_forced) {
+  if (whole_tiles_forced) *whole_tiles_forced = mscnn_wgemm_whole_tiles_forced();
+  return n->net->handoff_errors();
+}
 int mscnn_net_set_layer_timing(mscnn_net* n, int on) { n->net->set_layer_timing(on != 0); return 0; }
 float mscnn_net_layer_ms(const mscnn_net* n, int l) { return n->net->layer_ms()[l]; }
 
@@ -407,9 +416,9 @@ int mscnn_net_detect(mscnn_net* n, const mscnn_detect_params* p, double* dets_ho
     CHECK(p && dets_host && num_dets);
     // single-GPU form: the pack is sized by this image's ROI count, so the one D2H copy moves 16 + 44 R bytes
     int R = 0;
-    const int rows = n->net->has_blob("proposals_score") ? n->net->blob_by_name("proposals_score")->num() : 0;
+    int rows = n->net->has_blob("proposals_score") ? n->net->blob_by_name("proposals_score")->num() : 0;
     detect_into_pack(n, p, rows, &R, false);
-    const size_t total = mscnn_net_detect_pack_bytes(rows);
+    size_t total = mscnn_net_detect_pack_bytes(rows);
     if (n->det_host_bytes < total) {
       if (n->det_host) HIP_CHECK(hipHostFree(n->det_host));
       n->det_host = nullptr; n->det_host_bytes = 0;
@@ -419,6 +428,21 @@ int mscnn_net_detect(mscnn_net* n, const mscnn_detect_params* p, double* dets_ho
     hipStream_t st = (hipStream_t)Caffe::stream();
     HIP_CHECK(hipMemcpyAsync(n->det_host, n->det_pack.get(), total, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    if (n->net->HandoffRecover()) {
+      // a stream-K hand-off of roi_c1 / fc6 timed out in the forward these detections come from (mscnn_net_handoff_state): the Net has
+      // run the frame again on whole tiles -- redo this stage on the new outputs
+      rows = n->net->blob_by_name("proposals_score")->num();
+      detect_into_pack(n, p, rows, &R, false);
+      total = mscnn_net_detect_pack_bytes(rows);
+      if (n->det_host_bytes < total) {
+        HIP_CHECK(hipHostFree(n->det_host));
+        n->det_host = nullptr; n->det_host_bytes = 0;
+        HIP_CHECK(hipHostMalloc(&n->det_host, total, hipHostMallocDefault));
+        n->det_host_bytes = total;
+      }
+      HIP_CHECK(hipMemcpyAsync(n->det_host, n->det_pack.get(), total, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
     const char* hp = static_cast<const char*>(n->det_host);
     const int Dd = *reinterpret_cast<const int*>(hp);
     CHECK_LE(Dd, cap) << "detections buffer too small";

@@ -208,6 +208,7 @@ void Net<Dtype>::Init(const NetParameter& in_param) {
   layer_ms_.assign(layers_.size(), 0.f);
   if (fusion_) ApplyFusion();
   WireAmax();
+  handoff_seen_ = mscnn_wgemm_handoff_event();      // (events of launches before this net existed are not its business)
   LOG(INFO) << "Network initialization done.";
 }
 
@@ -527,9 +528,30 @@ void Net<Dtype>::NumericsWatchStep() {
 }
 
 template <typename Dtype>
+bool Net<Dtype>::HandoffEventPending() {
+  const unsigned long long ev = mscnn_wgemm_handoff_event();
+  if (ev == handoff_seen_) return false;
+  handoff_seen_ = ev;
+  ++handoff_errors_;
+  mscnn_wgemm_force_whole_tiles(1);
+  LOG(WARNING) << "a stream-K hand-off of the plane-GEMM kernel timed out (a workgroup of the persistent grid was not co-resident): "
+                  "whole-tile scheduling from now on, running the frame again";
+  return true;
+}
+
+template <typename Dtype>
+bool Net<Dtype>::HandoffRecover() {
+  if (!HandoffEventPending()) return false;
+  if (last_end_ >= last_start_) ForwardFromTo(last_start_, last_end_);
+  return true;
+}
+
+template <typename Dtype>
 Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   CHECK_GE(start, 0);
   CHECK_LT(end, (int)layers_.size());
+  last_start_ = start; last_end_ = end;
+  bool handoff_restarted = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing_) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
   for (size_t i = 0; i < layers_.size(); ++i)      // (a paired ROIPooling skips only inside the call in which its partner ran)
@@ -621,6 +643,14 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
       HIP_CHECK(hipEventRecord(e1, (hipStream_t)Caffe::stream()));
       HIP_CHECK(hipEventSynchronize(e1));
       HIP_CHECK(hipEventElapsedTime(&layer_ms_[i], e0, e1));
+    }
+    // BoxOutput has just synchronised the stream for its row count: everything in front of it has run.  A hand-off that timed out
+    // there left NaN tiles whose scores BoxOutput drops without a trace (NaN >= fg_thr is false, box_output_layer.cpp:128): look at
+    // the status word now (a plain load of pinned memory) and run the range again on whole tiles (once: nothing is split afterwards;
+    // all chains / deferred poolings in front of this layer have completed, so their per-call state is clean).
+    if (!handoff_restarted && std::strcmp(layers_[i]->type(), "BoxOutput") == 0 && HandoffEventPending()) {
+      handoff_restarted = true;
+      i = start - 1;
     }
   }
   if (timing_) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }

@@ -66,6 +66,7 @@ def lib():
             "mscnn_net_detect_cascade": [vp, vp, C.c_float, cs, cs, cs, vp, vp, ci, vp, vp],
             "mscnn_net_detect_pack_bytes": [ci], "mscnn_net_detect_device": [vp, vp, ci, vp],
             "mscnn_net_unpack_detections": [vp, ci, vp, vp, vp, vp],
+            "mscnn_net_handoff_state": [vp, vp],
         }
         for name, args in sig.items():
             getattr(L, name).argtypes = args
@@ -269,6 +270,12 @@ class Net:
 
     def reshape(self):
         _check(lib().mscnn_net_reshape(self._h))
+
+    def handoff_state(self):
+        """(stream-K hand-off time-outs this net has answered by re-running the frame, whole-tile scheduling forced for the process)."""
+        forced = C.c_int()
+        n = lib().mscnn_net_handoff_state(self._h, C.byref(forced))
+        return n, bool(forced.value)
 
     def set_layer_timing(self, on):
         lib().mscnn_net_set_layer_timing(self._h, int(on))

@@ -335,6 +335,71 @@ def test_partial_forward_over_fused_layers():
         assert np.array_equal(n.get_blob(b), want[b]), b
 
 
+def test_handoff_timeout_never_hands_out_a_wrong_frame():
+    """The stream-K hand-off of the plane-GEMM kernel under fault injection (contributors never publish, mscnn_hip.h:
+    mscnn_debug_wgemm_handoff_fault), at the Net level: whatever the layer, the frame that comes out of the C ABI is the correct one and
+    the event is counted (mscnn_net_handoff_state).
+      (a) a time-out in the TRUNK: its NaN head scores would be dropped by BoxOutput without a trace -- the Net sees the status word
+          behind BoxOutput's own synchronisation, forces whole tiles and restarts the range inside the same Forward;
+      (b) a time-out behind BoxOutput (roi_c1): seen behind the final stage's synchronisation (mscnn_net_detect), frame run again;
+      (c) the same through mscnn_net_get_blob."""
+    from mscnn_amd import hipapi as hip
+    n = mnet.Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=192, width=640, max_nms_num=300))
+    synth.load_into(n, "mid")
+    n.set_blob("data", synth.frame(192, 640))
+    kw = dict(cls_id=2, ratios=(192 / 375.0, 640 / 1242.0), org_hw=(375, 1242))
+    blobs = ("conv2_2", "conv4_3", "conv6_1", "proposals_score", "roi_c1", "fc6", "cls_pred", "bbox_pred")
+    convs = [i for i, t in enumerate(n.layer_types) if t == "Convolution"]
+    try:
+        # the truth: every launch on whole tiles (first forward: the layers' own first-input checks run and pass)
+        hip.wgemm_force_whole_tiles(True)
+        n.forward()
+        assert n.auto_calibrate_state()[1] == []
+        n.forward()
+        want = {b: n.get_blob(b) for b in blobs}
+        want_dets = n.detect(**kw)
+        hip.wgemm_force_whole_tiles(False)
+        assert n.handoff_state() == (0, False)
+        wino = [i for i in convs if n.layer_kernel(i).startswith("winograd")]
+        assert len(wino) >= 8 and n.layer_names.index("roi_c1") in wino
+
+        # (a) every Winograd layer splits its tiles, nobody publishes
+        for i in wino:
+            n.set_conv_tuning(i, 300 + 256)
+        n.forward()                                        # (healthy split run: no event, same frame within the split's tolerance)
+        assert n.handoff_state() == (0, False)
+        assert rel_err(n.get_blob("cls_pred"), want["cls_pred"]) < 1e-4
+        hip.debug_wgemm_handoff_fault(True, 64)
+        n.forward()
+        dets = n.detect(**kw)
+        assert n.handoff_state() == (1, True)
+        for b in blobs:
+            assert np.array_equal(n.get_blob(b), want[b]), b
+        assert all(np.array_equal(u, v) for u, v in zip(dets, want_dets))
+        assert n.handoff_state() == (1, True)              # (nothing is split any more: nothing more to report)
+
+        # (b) only roi_c1 splits: the event lies behind BoxOutput and is answered by the final stage
+        hip.wgemm_force_whole_tiles(False)
+        for i in wino:
+            n.set_conv_tuning(i, 300 + (256 if n.layer_names[i] == "roi_c1" else 512))
+        n.forward()
+        assert n.handoff_state() == (1, False)             # not looked at yet: no synchronisation point since roi_c1 ran
+        dets = n.detect(**kw)
+        assert n.handoff_state() == (2, True)
+        assert all(np.array_equal(u, v) for u, v in zip(dets, want_dets))
+
+        # (c) ... or by a blob read
+        hip.wgemm_force_whole_tiles(False)
+        n.forward()
+        got = n.get_blob("cls_pred")
+        assert n.handoff_state() == (3, True)
+        assert np.array_equal(got, want["cls_pred"])
+        assert np.array_equal(n.get_blob("roi_c1"), want["roi_c1"])
+    finally:
+        hip.debug_wgemm_handoff_fault(False, 0)
+        hip.wgemm_force_whole_tiles(False)
+
+
 def test_numerical_calibration_falls_back_per_layer():
     """Net::CalibrateNumerics: Winograd layers are compared with the direct kernel on the current input; with an impossible
     tolerance every one of them must fall back (and the net must still agree with itself), with the default one none does."""

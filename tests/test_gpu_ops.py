@@ -369,7 +369,10 @@ def test_conv_winograd_f4x4_fused_pool(hip, orc, case):
     assert np.array_equal(yp.cpu().numpy(), orc.pool2d(y))
 
 
-@pytest.mark.parametrize("case", [(1, 64, 24, 40, 256, 3), (1, 96, 36, 60, 288, 4), (2, 32, 20, 28, 128, 4), (1, 512, 36, 120, 512, 3), (1, 128, 72, 240, 128, 4)])
+# (the last case: 36 x 8 = 288 tiles of 8 chunks on 256 workgroups -- forced split: 32 tiles, each cut into EIGHT one-chunk parts, every
+# finisher adds seven contributors' slabs)
+@pytest.mark.parametrize("case", [(1, 64, 24, 40, 256, 3), (1, 96, 36, 60, 288, 4), (2, 32, 20, 28, 128, 4), (1, 512, 36, 120, 512, 3), (1, 128, 72, 240, 128, 4),
+                                  (1, 256, 128, 128, 256, 4)])
 def test_wgemm_plane_gemm_against_the_igemm_kernel(hip, case):
     """The plane GEMM of the Winograd layers (wgemm.hip, round 3) against the round-2 igemm kernel on the same planes.  With whole
     tiles both are k-ordered fmaf chains over the same operands, so the layer outputs must be BIT-IDENTICAL (tune_variant 300 + v +
@@ -424,6 +427,53 @@ def test_wgemm_plane_gemm_against_the_igemm_kernel(hip, case):
     y_160s, p160s = run(300 + 5 + 256, 0)
     assert rel(y_160s, y_whole) < tol
     assert torch.equal(p160s.forward(x, b), y_160s)
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_wgemm_handoff_timeout_is_reported_never_silent(hip, relu):
+    """A stream-K hand-off that times out (fault injection: the contributors never publish, the finisher gives up after 64 polls)
+    must be impossible to miss: (1) the launch's tag appears in the device's pinned status word (mscnn_wgemm_handoff_event), (2) the
+    tiles it could not finish are NaN in the layer's output -- also behind the fused ReLU, which keeps a NaN a NaN like
+    relu_layer.cpp:14-15's std::max -- and (3) after mscnn_wgemm_force_whole_tiles(1), the host's answer, the SAME plan (still
+    planned for the split) produces the whole-tile result bit for bit and reports nothing."""
+    N, Cin, H, W, Cout = 1, 256, 128, 128, 256
+    g = torch.Generator(device="cuda").manual_seed(23)
+    x = torch.relu(torch.randn((N, Cin, H, W), device="cuda", generator=g))
+    w = torch.randn((Cout, Cin, 3, 3), device="cuda", generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn((Cout,), device="cuda", generator=g)
+
+    def plan(variant):
+        p = hip.ConvPlan(N, Cin, H, W, Cout, 3, 3, (1, 1), relu=relu, algo=hip.ALGO_WINO_F4, tune_variant=variant)
+        p.pack(w)
+        return p
+    p_whole, p_split = plan(300 + 512), plan(300 + 256)
+    y_whole = p_whole.forward(x, b).clone()
+    y_split = p_split.forward(x, b).clone()
+    torch.cuda.synchronize()
+    assert not torch.isnan(y_split).any()
+    ev0 = hip.wgemm_handoff_event()
+    assert not hip.wgemm_whole_tiles_forced()
+    try:
+        hip.debug_wgemm_handoff_fault(True, 64)
+        y_bad = p_split.forward(x, b).clone()
+        torch.cuda.synchronize()
+        ev1 = hip.wgemm_handoff_event()
+        assert ev1 != ev0 and ev1 != 0                      # (1) reported
+        bad = torch.isnan(y_bad)
+        assert bad.any()                                   # (2) poisoned, ReLU or not
+        assert torch.equal(y_bad[~bad], y_split[~bad])     #     ... and only the split tiles
+        p_whole.forward(x, b)                              # a launch that hands nothing over reports nothing, fault or not
+        torch.cuda.synchronize()
+        assert hip.wgemm_handoff_event() == ev1
+        hip.wgemm_force_whole_tiles(True)                  # (3) the answer
+        y_again = p_split.forward(x, b).clone()
+        torch.cuda.synchronize()
+        assert hip.wgemm_handoff_event() == ev1
+        assert torch.equal(y_again, y_whole)
+    finally:
+        hip.debug_wgemm_handoff_fault(False, 0)
+        hip.wgemm_force_whole_tiles(False)
+    assert torch.equal(p_split.forward(x, b), y_split)
 
 
 @pytest.mark.parametrize("case", [(1, 32, 24, 64, 48), (2, 16, 36, 260, 32), (1, 64, 72, 240, 64), (1, 8, 10, 512, 16), (1, 24, 13, 28, 40)])
