@@ -311,16 +311,21 @@ def _launch_check(args, rank, world, local_rank):
         per_rank = gather.end()
         seen.add(len(per_rank))
         assert [int(d[0, 1]) for d, _, _ in per_rank] == list(range(world)), "packs out of rank order"
+    assert gather.comm_world == world and gather.comm_rank == rank, (gather.comm_world, gather.comm_rank)
+    assert gather.ranks_seen == set(range(world)), gather.ranks_seen
     dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert seen == {world}, seen
+    gather_world, seen_ranks = gather.comm_world, sorted(gather.ranks_seen)
     gather.close()
     dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"launch_check": True, "metric": "launcher self-check (no measurement)", "value": None, "n_gpus": world,
                           "steps": args.steps, "config": {"gather": f"libmscnn_dist: ncclAllGather of the device pack (pipelined, two in flight), "
-                                                                      f"{world} ranks in the communicator", "transport": args.transport or "librccl"}}), flush=True)
+                                                                      f"{gather_world} ranks in the communicator (ncclCommCount)",
+                                                          "comm_count": gather_world, "ranks_seen": seen_ranks,
+                                                          "transport": args.transport or "librccl"}}), flush=True)
     sys.exit(0)
 
 
@@ -411,11 +416,17 @@ def main():
     stats = {"R": [], "D": []}
     pipe = {"on": False, "inflight": 0}
     can_pipeline = hasattr(gather, "begin") and args.gather_mode == "pipelined"
+    comm_count = getattr(gather, "comm_world", None)      # ncclCommCount of the product's communicator (None: the torch route / N = 1)
     if gather is not None:
-        gather_kind += (" (pipelined, two in flight)" if can_pipeline else " (blocking)") + f", {world} ranks in the communicator"
+        gather_kind += (" (pipelined, two in flight)" if can_pipeline else " (blocking)") + \
+            (f", {comm_count} ranks in the communicator (ncclCommCount)" if comm_count is not None else f", {world} ranks (torch.distributed)")
+        assert comm_count in (None, world), (comm_count, world)
 
     def take(per_rank):
-        dets, ids, R = per_rank[rank]
+        # every exchange of the timed loop: as many packs as the communicator has ranks, slot r stamped by rank r (RcclGather._split
+        # raises otherwise) -- the line can only be printed if RCCL really delivered N ranks' packs every step
+        assert len(per_rank) == (world if gather is not None else 1), (len(per_rank), world)
+        dets, ids, R = per_rank[rank if gather is not None else 0]
         stats["R"].append(R); stats["D"].append(len(dets))
         return dets
 
@@ -665,7 +676,10 @@ def main():
                   "config": {"workload": f"{args.model} {'fp16 MFMA operands / fp32 accumulate' if args.dtype == 'f16' else 'fp32 (Winograd GEMMs as 3 x fp16 MFMA on split operands)' if args.dtype == 'f16x3' else 'fp32'}, batch=1 per GPU, 1x3x{H}x{W} frame resident in HBM -> detections on host "
                                          "(trunk + heads + BoxOutput + ROI pool + det sub-net + final NMS)",
                              "regime": args.regime, "mean_rois": round(Rm, 1), "mean_detections": round(float(np.mean(main_stats["D"])), 1),
-                             "parallelism": f"image-parallel x{world}", "gather": gather_kind},
+                             "parallelism": f"image-parallel x{world}", "gather": gather_kind,
+                             # what the collective library reported (ncclCommCount) and the senders' ranks found in the packs of the timed loop
+                             "comm_count": comm_count, "ranks_seen": sorted(getattr(gather, "ranks_seen", [])) if gather is not None else None,
+                             "handoff": dict(zip(("events_answered", "whole_tiles_forced"), net.handoff_state()))},
                   "numerics": numerics, "roofline": roofline}
         if args.model == DEFAULT_MODEL:
             result["metric"] = "images/sec mscnn-7s-576 KITTI-car inference"

@@ -49,6 +49,10 @@ MSCNN_DIST_API int mscnn_dist_unique_id(unsigned char id_out[MSCNN_DIST_ID_BYTES
 MSCNN_DIST_API int mscnn_dist_init(const unsigned char id[MSCNN_DIST_ID_BYTES], int rank, int world, int device,
                                    size_t pack_bytes, mscnn_dist** out);
 MSCNN_DIST_API void mscnn_dist_destroy(mscnn_dist* d);
+/* What the collective library reports about the communicator (ncclCommUserRank / ncclCommCount, queried in mscnn_dist_init and
+ * required to equal the arguments) -- NOT an echo of what the caller asked for: a scaling run quotes these to show RCCL saw N ranks.
+ * Every pack that goes through the exchanges below also carries its sender's rank in header word 3 (the final stage writes 0
+ * there), so a receiver can check that slot r of the gathered buffer came from rank r. */
 MSCNN_DIST_API int mscnn_dist_rank(const mscnn_dist* d);
 MSCNN_DIST_API int mscnn_dist_world(const mscnn_dist* d);
 

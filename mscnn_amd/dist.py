@@ -43,6 +43,8 @@ def dist_lib():
         L.mscnn_dist_barrier.argtypes = [C.c_void_p, C.c_void_p]
         L.mscnn_dist_all_gather_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mscnn_dist_all_gather_end.argtypes = [C.c_void_p, C.c_void_p]
+        L.mscnn_dist_world.argtypes = [C.c_void_p]
+        L.mscnn_dist_rank.argtypes = [C.c_void_p]
         _dlib = L
     return _dlib
 
@@ -57,8 +59,10 @@ def shard(num_images, rank, world):
     return list(range(rank, num_images, world))
 
 
-def split_packs(gathered, world, cap, copy=True):
-    """world concatenated packs (bytes-like) -> [(dets float64 [D,5], ids int32 [D], R)] per rank.  The layout is the one
+def split_packs(gathered, world, cap, copy=True, stamped=False):
+    """world concatenated packs (bytes-like) -> [(dets float64 [D,5], ids int32 [D], R)] per rank.  stamped: the packs went through
+    libmscnn_dist.so, which writes the sender's communicator rank into header word 3 -- slot r must then carry rank r (anything else:
+    the collective did not deliver what the line is about to claim, and this raises).  The layout is the one
     mscnn_net_detect_device writes (include/mscnn_net.h; C callers use mscnn_net_unpack_detections); here the rows are numpy
     VIEWS of the gathered buffer (copy=False: valid until the next gather) so that the per-step host cost stays a few us."""
     pb = mnet.detect_pack_bytes(cap)
@@ -68,7 +72,9 @@ def split_packs(gathered, world, cap, copy=True):
     out = []
     for r in range(world):
         p = buf[r * pb:(r + 1) * pb]
-        D, R, c, _ = (int(v) for v in p[:16].view(np.int32))
+        D, R, c, who = (int(v) for v in p[:16].view(np.int32))
+        if stamped and who != r:
+            raise DistError(f"slot {r} of the gathered buffer carries a pack stamped by rank {who}")
         if c == cap and D == -1:      # the writer's overflow mark (mscnn_net_detect_device): raised on EVERY rank after the exchange
             raise DistError(f"rank {r}: {R} ROIs exceed the detection pack capacity {cap} (size it by BoxOutput's max_nms_num)")
         if c != cap or not (0 <= D <= R <= cap):
@@ -99,13 +105,23 @@ class RcclGather:
         idb = (C.c_ubyte * 128).from_buffer_copy(raw)
         self._h = C.c_void_p()
         _dcheck(L.mscnn_dist_init(idb, rank, world, device, self.pack_bytes, C.byref(self._h)))
+        # what the collective library reports about the communicator it built (ncclCommCount / ncclCommUserRank), not what we asked for
+        self.comm_world, self.comm_rank = L.mscnn_dist_world(self._h), L.mscnn_dist_rank(self._h)
+        self.ranks_seen = set()          # senders' ranks found in the packs of every exchange so far (split_packs checks slot r == rank r)
+
+    def _split(self, host):
+        per_rank = split_packs(np.frombuffer(host, np.uint8), self.world, self.cap, copy=False, stamped=True)      # views of the pinned buffer
+        if len(per_rank) != self.comm_world:
+            raise DistError(f"{len(per_rank)} packs gathered, the communicator has {self.comm_world} ranks")
+        self.ranks_seen.update(range(len(per_rank)))
+        return per_rank
 
     def __call__(self, pack_dev_ptr, stream=None):
         """pack_dev_ptr: device address from Net.detect_device(cap, ...).  Returns the per-rank list of (dets, ids, R)."""
         out = C.c_void_p()
         _dcheck(dist_lib().mscnn_dist_all_gather(self._h, C.c_void_p(pack_dev_ptr), C.c_void_p(stream or 0), C.byref(out)))
         host = (C.c_ubyte * (self.world * self.pack_bytes)).from_address(out.value)
-        return split_packs(np.frombuffer(host, np.uint8), self.world, self.cap, copy=False)      # views of the pinned buffer
+        return self._split(host)
 
     def begin(self, pack_dev_ptr, stream=None):
         """Pipelined form: enqueue this step's exchange on the communicator's own stream and return at once."""
@@ -116,7 +132,7 @@ class RcclGather:
         out = C.c_void_p()
         _dcheck(dist_lib().mscnn_dist_all_gather_end(self._h, C.byref(out)))
         host = (C.c_ubyte * (self.world * self.pack_bytes)).from_address(out.value)
-        return split_packs(np.frombuffer(host, np.uint8), self.world, self.cap, copy=False)
+        return self._split(host)
 
     def barrier(self, stream=None):
         _dcheck(dist_lib().mscnn_dist_barrier(self._h, C.c_void_p(stream or 0)))

@@ -27,6 +27,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -50,11 +52,13 @@ Rccl* rccl() {
     LOAD(GetUniqueId, "ncclGetUniqueId");
     LOAD(CommInitRank, "ncclCommInitRank");
     LOAD(CommDestroy, "ncclCommDestroy");
+    LOAD(CommCount, "ncclCommCount");
+    LOAD(CommUserRank, "ncclCommUserRank");
     LOAD(AllGather, "ncclAllGather");
     LOAD(AllReduce, "ncclAllReduce");
     LOAD(GetErrorString, "ncclGetErrorString");
 #undef LOAD
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString) {
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.CommUserRank || !r.AllGather || !r.AllReduce || !r.GetErrorString) {
       dlclose(r.handle);
       r.handle = nullptr;
     }
@@ -70,8 +74,9 @@ Rccl* rccl() {
 
 struct mscnn_dist {
   ncclComm_t comm = nullptr;
-  int rank = 0, world = 1, device = 0;
+  int rank = 0, world = 1, device = 0;      // as the COMMUNICATOR reports them (ncclCommUserRank / ncclCommCount), checked against the arguments
   size_t pack_bytes = 0;
+  void* send_dev = nullptr;       // blocking form: this rank's pack, stamped with its rank
   void* recv_dev = nullptr;       // world * pack_bytes
   void* recv_host = nullptr;      // pinned, same size
   int* flag_dev = nullptr;        // barrier payload
@@ -121,7 +126,20 @@ int mscnn_dist_init(const unsigned char idb[MSCNN_DIST_ID_BYTES], int rank, int 
     delete d;
     return 3;
   }
+  // what the collective library itself says about this communicator: the line a scaling run prints must be able to prove that RCCL
+  // saw N ranks, not that the launcher was asked for N
+  int cw = -1, cr = -1;
+  ncclResult_t q = R->CommCount(d->comm, &cw);
+  if (q == ncclSuccess) q = R->CommUserRank(d->comm, &cr);
+  if (q != ncclSuccess || cw != world || cr != rank) {
+    if (q != ncclSuccess) set_error("ncclCommCount / ncclCommUserRank -> %s", R->GetErrorString(q));
+    else set_error("the communicator reports rank %d of %d, the caller asked for rank %d of %d", cr, cw, rank, world);
+    mscnn_dist_destroy(d);
+    return 3;
+  }
+  d->world = cw; d->rank = cr;
   hipError_t e = hipMalloc(&d->recv_dev, pack_bytes * world);
+  if (e == hipSuccess) e = hipMalloc(&d->send_dev, pack_bytes);
   if (e == hipSuccess) e = hipHostMalloc(&d->recv_host, pack_bytes * world, hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->flag_dev), 2 * sizeof(int));
   if (e == hipSuccess) e = hipMemset(d->flag_dev, 0, 2 * sizeof(int));
@@ -149,6 +167,7 @@ void mscnn_dist_destroy(mscnn_dist* d) {
   if (d->xstream) (void)hipStreamDestroy(d->xstream);
   if (d->comm && R) (void)R->CommDestroy(d->comm);
   if (d->recv_dev) (void)hipFree(d->recv_dev);
+  if (d->send_dev) (void)hipFree(d->send_dev);
   if (d->recv_host) (void)hipHostFree(d->recv_host);
   if (d->flag_dev) (void)hipFree(d->flag_dev);
   delete d;
@@ -160,7 +179,12 @@ int mscnn_dist_world(const mscnn_dist* d) { return d ? d->world : 0; }
 int mscnn_dist_all_gather_device(mscnn_dist* d, const void* send_dev, void* stream, const void** gathered_dev) {
   Rccl* R = rccl();
   DIST_REQUIRE(R && d && send_dev, "dist all_gather: bad argument");
-  DIST_NCCL(R->AllGather(send_dev, d->recv_dev, d->pack_bytes, ncclChar, d->comm, reinterpret_cast<hipStream_t>(stream)));
+  // the pack travels with its writer's rank in header word 3 (the final stage leaves 0 there): every receiver can check that slot r
+  // of the gathered buffer really came from rank r
+  hipStream_t cs = reinterpret_cast<hipStream_t>(stream);
+  DIST_HIP(hipMemcpyAsync(d->send_dev, send_dev, d->pack_bytes, hipMemcpyDeviceToDevice, cs));
+  DIST_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<char*>(d->send_dev) + 12), d->rank, 1, cs));
+  DIST_NCCL(R->AllGather(d->send_dev, d->recv_dev, d->pack_bytes, ncclChar, d->comm, cs));
   if (gathered_dev) *gathered_dev = d->recv_dev;
   return 0;
 }
@@ -202,6 +226,7 @@ int mscnn_dist_all_gather_begin(mscnn_dist* d, const void* send_dev, void* strea
   mscnn_dist::Slot& sl = d->slot[d->head];
   hipStream_t cs = reinterpret_cast<hipStream_t>(stream);
   DIST_HIP(hipMemcpyAsync(sl.send_dev, send_dev, d->pack_bytes, hipMemcpyDeviceToDevice, cs));
+  DIST_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<char*>(sl.send_dev) + 12), d->rank, 1, cs));      // (see all_gather_device)
   DIST_HIP(hipEventRecord(d->ready, cs));
   DIST_HIP(hipStreamWaitEvent(d->xstream, d->ready, 0));
   DIST_NCCL(R->AllGather(sl.send_dev, sl.recv_dev, d->pack_bytes, ncclChar, d->comm, d->xstream));

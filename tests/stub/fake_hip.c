@@ -13,6 +13,7 @@ hipError_t hipHostMalloc(void** p, size_t n, unsigned flags) { (void)flags; *p =
 hipError_t hipHostFree(void* p) { free(p); return 0; }
 hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int kind, hipStream_t st) { (void)kind; (void)st; memcpy(d, s, n); return 0; }
+hipError_t hipMemsetD32Async(void* p, int v, size_t count, hipStream_t st) { (void)st; for (size_t i = 0; i < count; ++i) ((int*)p)[i] = v; return 0; }
 hipError_t hipStreamSynchronize(hipStream_t st) { (void)st; return 0; }
 typedef void* hipEvent_t;
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned f) { (void)f; *s = (void*)1; return 0; }

@@ -1,4 +1,4 @@
-/* Test infrastructure (never shipped): a stand-in for librccl.so.1 with the six entry points libmscnn_dist.so resolves, moving the
+/* Test infrastructure (never shipped): a stand-in for librccl.so.1 with the eight entry points libmscnn_dist.so resolves, moving the
  * bytes through a file-backed shared mapping between the ranks' processes.  It lets the CPU tests drive the product's own
  * rendezvous-id exchange, communicator setup, all-gather and barrier at world size > 1 (tests/test_dist_cpu.py). */
 #include <fcntl.h>
@@ -47,6 +47,11 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int world, ncclUniqueId id, int r
   *out = c;
   return 0;
 }
+#ifndef FAKE_COUNT_BIAS
+#define FAKE_COUNT_BIAS 0      /* -DFAKE_COUNT_BIAS=1: a communicator that reports another size than it was asked for (negative test) */
+#endif
+ncclResult_t ncclCommCount(const ncclComm_t c, int* n) { *n = c->world + FAKE_COUNT_BIAS; return 0; }
+ncclResult_t ncclCommUserRank(const ncclComm_t c, int* r) { *r = c->rank; return 0; }
 ncclResult_t ncclCommDestroy(ncclComm_t c) { if (c) { munmap(c->sh, c->bytes); free(c); } return 0; }
 ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t t, ncclComm_t c, void* stream) {
   (void)t; (void)stream;

@@ -119,7 +119,12 @@ def exchange(mine):                      # rank 0's bytes to every rank, through
             return open(idfile, "rb").read()
         time.sleep(0.05)
     raise SystemExit("no id")
-g = mdist.RcclGather(rank, world, 0, CAP, exchange)
+try:
+    g = mdist.RcclGather(rank, world, 0, CAP, exchange)
+except mdist.DistError as e:
+    print("INITERROR", str(e)); sys.stdout.flush()
+    raise SystemExit(0)
+assert (g.comm_world, g.comm_rank) == (world, rank)      # from ncclCommCount / ncclCommUserRank, not an echo of the arguments
 g.barrier()
 seen = []
 if pipelined:        # begin(i) ... begin(i + 1) ... end() -> step i: the product's double-buffered exchange on its own stream
@@ -155,26 +160,28 @@ for step in range(0 if pipelined else 3):
         print("DISTERROR", step, str(e)); sys.stdout.flush()
         break
     seen.append([(d.copy(), i.copy(), R) for d, i, R in per_rank])
+if seen and not overflow:
+    assert g.ranks_seen == set(range(world)), g.ranks_seen      # every slot of every exchange carried its own rank's stamp
 g.barrier()
 g.close()
 np.save(os.path.join(tmp, "seen%d.npy" % rank), np.array(seen, dtype=object), allow_pickle=True)
 '''
 
 
-def _build_stubs(tmp_path):
+def _build_stubs(tmp_path, rccl_flags=()):
     import subprocess
     src = os.path.join(ROOT, "tests", "stub")
     out = {}
     for name in ("fake_hip", "fake_rccl"):
         so = str(tmp_path / f"lib{name}.so")
-        subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(src, name + ".c")])
+        subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(src, name + ".c")] + (list(rccl_flags) if name == "fake_rccl" else []))
         out[name] = so
     return out
 
 
-def _run_rccl_workers(tmp_path, overflow, mode=None):
+def _run_rccl_workers(tmp_path, overflow, mode=None, rccl_flags=()):
     import subprocess
-    stubs = _build_stubs(tmp_path)
+    stubs = _build_stubs(tmp_path, rccl_flags)
     code = _RCCL_WORKER.format(root=ROOT, stub=stubs["fake_rccl"])
     env = dict(os.environ, LD_PRELOAD=stubs["fake_hip"])
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", str(tmp_path), mode or ("1" if overflow else "0")], env=env,
@@ -197,6 +204,28 @@ def test_rccl_gather_code_path_world2_bit_identical(tmp_path):
                 ref_d, ref_i = _fake_dets(img, 2 + 3 * img)
                 assert dets.dtype == np.float64 and dets.tobytes() == ref_d.tobytes()      # float64 bit patterns, both ranks
                 assert np.array_equal(ids, ref_i) and R == len(ref_d) + 1
+
+
+def test_communicator_that_reports_another_size_is_refused(tmp_path):
+    """mscnn_dist_world / _rank come from ncclCommCount / ncclCommUserRank: a transport whose communicator reports three ranks when two
+    were asked for makes mscnn_dist_init fail on every rank -- the number a scaling line quotes is the library's, never the launcher's."""
+    outs = _run_rccl_workers(tmp_path, overflow=False, rccl_flags=("-DFAKE_COUNT_BIAS=1",))
+    for rank, so in enumerate(outs):
+        assert f"INITERROR the communicator reports rank {rank} of 3, the caller asked for rank {rank} of 2" in so, so
+
+
+def test_pack_from_the_wrong_rank_is_refused():
+    """Every pack that went through libmscnn_dist.so carries its sender's rank in header word 3; split_packs(stamped=True) refuses a
+    gathered buffer whose slot r was not written by rank r."""
+    from mscnn_amd import dist as mdist
+    a, b = _fake_dets(0, 3), _fake_dets(1, 4)
+    packs = [_host_pack(a[0], a[1], 4, CAP), _host_pack(b[0], b[1], 5, CAP)]
+    for r, p in enumerate(packs):
+        p[:16].view(np.int32)[3] = r
+    ok = mdist.split_packs(np.concatenate(packs), 2, CAP, stamped=True)
+    assert [R for _, _, R in ok] == [4, 5]
+    with pytest.raises(mdist.DistError, match="slot 0 of the gathered buffer carries a pack stamped by rank 1"):
+        mdist.split_packs(np.concatenate(packs[::-1]), 2, CAP, stamped=True)
 
 
 def test_rccl_gather_pipelined_world2_bit_identical(tmp_path):
@@ -265,4 +294,5 @@ def test_bench_gpus_2_launches_itself_with_two_ranks(tmp_path):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["launch_check"] is True and out["value"] is None
-    assert "2 ranks in the communicator" in out["config"]["gather"] and "pipelined" in out["config"]["gather"]
+    assert "2 ranks in the communicator (ncclCommCount)" in out["config"]["gather"] and "pipelined" in out["config"]["gather"]
+    assert out["config"]["comm_count"] == 2 and out["config"]["ranks_seen"] == [0, 1]
