@@ -9,7 +9,7 @@ struct HeadPlan {
   int NTH = 0, NTW = 0, KI = 0, G = 0, tiles = 0;
   long total_iters = 0;
   size_t packed_bytes = 0, ws_bytes = 0;
-  // round 4: the packed-FMA kernel of headvalu.hip (valu >= 0: index into its table; the fields above are then its own)
+  // witness build only (tools/micro/headvalu.hip, `make witness`): valu >= 0 = index into its table; the fields above are then its own
   int valu = -1;
   int LPR = 0, RPW = 0, TR = 0, PR = 0, RL = 0;
   size_t lds_bytes = 0;

@@ -326,10 +326,12 @@ bool head_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp) {
   const bool off = (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 2) != 0;   // A/B switch: heads on the 32-row igemm tile
   hp->entry = -1;
   hp->valu = -1;
-  // round 4: the packed-FMA kernel of headvalu.hip where it covers the shape ("same" padding, maps up to 256 columns); tune_flags
-  // bit 13 asks for the packed-FMA kernel (headvalu.hip) instead of the M = 4 MFMA kernel below: an A/B variant and a second witness
-  // only -- it is slower on every head of the 7s nets (profiles/r04_ab_heads_valu.txt)
+#ifdef MSCNN_HEAD_VALU_WITNESS
+  // (witness build only -- `make witness`, tools/micro/libmscnn_hip_witness.so: tune_flags bit 13 puts the heads on the packed-FMA
+  // kernel of tools/micro/headvalu.hip, a second implementation of the same split that measured 12-45 % slower on every head of the
+  // 7s nets, profiles/r04_ab_heads_valu.txt; retired from the product library in round 5)
   if (!off && (tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 8192) && headv_plan(d, Ho, Wo, hp)) { hp->entry = 0; return true; }
+#endif
   if (off || d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0 || d.Cout > 12 || d.Cin > 1024) return false;
   if ((double)d.Cin * d.H * d.W * 4.0 >= 2.0e9 || (double)d.Cout * Ho * Wo * 4.0 >= 2.0e9) return false;
   const int nq = d.Cout <= 8 ? 2 : 3;
@@ -353,10 +355,17 @@ bool head_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp) {
   return true;
 }
 
-const char* head_kernel_name(const HeadPlan& hp) { return hp.valu >= 0 ? headv_kernel_name(hp) : kHeads[hp.entry].name; }
+const char* head_kernel_name(const HeadPlan& hp) {
+#ifdef MSCNN_HEAD_VALU_WITNESS
+  if (hp.valu >= 0) return headv_kernel_name(hp);
+#endif
+  return kHeads[hp.entry].name;
+}
 
 int head_pack(const mscnn_conv_desc& d, const HeadPlan& hp, const float* w, float* packed, hipStream_t st) {
+#ifdef MSCNN_HEAD_VALU_WITNESS
   if (hp.valu >= 0) return headv_pack(d, hp, w, packed, st);
+#endif
   const HeadEntry& k = kHeads[hp.entry];
   const long total = (long)hp.KI * k.NQ * k.AREGS * 64;
   long blocks = (total + 255) / 256;
@@ -368,7 +377,9 @@ int head_pack(const mscnn_conv_desc& d, const HeadPlan& hp, const float* w, floa
 
 int head_forward(const mscnn_conv_desc& d, const HeadPlan& hp, int Ho, int Wo, const float* x, const float* packed,
                  const float* bias, float* y, void* workspace, size_t workspace_bytes, hipStream_t st) {
+#ifdef MSCNN_HEAD_VALU_WITNESS
   if (hp.valu >= 0) return headv_forward(d, hp, Ho, Wo, x, packed, bias, y, workspace, workspace_bytes, st);
+#endif
   const HeadEntry& k = kHeads[hp.entry];
   if (!workspace || workspace_bytes < hp.ws_bytes) {
     set_error("conv(head): workspace %zu < %zu", workspace_bytes, hp.ws_bytes);

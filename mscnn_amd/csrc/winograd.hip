@@ -919,12 +919,15 @@ int wino_input_transform(int m, const float* x, float* V, int N, int Cin, int H,
 int wino_output_transform(int m, const float* M, const float* bias, float* y, float* y_pool, int N, int Cout, int Ho, int Wo,
                           int tiles_h, int tiles_w, int T_pad, int relu, hipStream_t st, unsigned* amax, bool scalar_f4) {
   MSCNN_REQUIRE(!amax || m >= 3, "winograd: max |y| is published by the F(3x3,3x3) / F(4x4,3x3) output transforms only");
-  MSCNN_REQUIRE(y || (y_pool && m == 4 && Wo % 4 == 0 && tiles_w * 4 == Wo && !scalar_f4),
-                "winograd: only the vector F(4x4,3x3) output transform with fused pooling runs without y");
+  // ONE predicate for "the vector F(4x4,3x3) kernel runs": the pool-only mode (y == NULL) exists in that kernel alone, so the check
+  // below and the dispatch cannot drift apart (a y_pool that is only 4-byte aligned used to pass the check and fall through to the
+  // scalar kernel, which stores through y)
+  const bool use_vec44 = m == 4 && Wo % 4 == 0 && tiles_w * 4 == Wo && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+                         (!y_pool || reinterpret_cast<uintptr_t>(y_pool) % 8 == 0) && !scalar_f4;
+  MSCNN_REQUIRE(y || (y_pool && use_vec44), "winograd: only the vector F(4x4,3x3) output transform with fused pooling (8-byte aligned pooled map) runs without y");
   const int T = N * tiles_h * tiles_w;
   dim3 grid(cdiv(T, 256), Cout);
-  if (m == 4 && Wo % 4 == 0 && tiles_w * 4 == Wo && reinterpret_cast<uintptr_t>(y) % 16 == 0 && (!y_pool || reinterpret_cast<uintptr_t>(y_pool) % 8 == 0) &&
-      !scalar_f4) {
+  if (use_vec44) {
     wino44_output_vec_kernel<<<grid, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu, amax);
   } else if (m == 4) {
     wino44_output_kernel<<<grid, 256, 0, st>>>(M, bias, y, y_pool, N, Cout, Ho, Wo, tiles_h, tiles_w, T, T_pad, relu, amax);

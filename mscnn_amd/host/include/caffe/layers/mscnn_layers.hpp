@@ -20,6 +20,7 @@ class DeviceBuffer {
   DeviceBuffer() : ptr_(nullptr), bytes_(0) {}
   ~DeviceBuffer();
   void* Reserve(size_t bytes);
+  void Release();                          // hipFree now (synchronises the device); the next Reserve allocates again
   void* get() const { return ptr_; }
   size_t bytes() const { return bytes_; }
  private:
@@ -133,6 +134,13 @@ class ConvolutionLayer : public Layer<Dtype> {
   // max |y - y_direct| / max(1, |y_direct|) of the current algorithm against the direct kernel on the given bottom
   // (device scratch only; the layer's tops are not touched).  0 when the layer already runs a direct kernel.
   double ErrorAgainstDirect(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  // the last ErrorAgainstDirect compared two results of an all-zero bottom (a zero warm-up frame): it says nothing about the layer's
+  // numerics on data -- the first-forward check stays armed for the next bottom
+  bool last_check_vacuous() const { return last_check_vacuous_; }
+  // The checks' device scratch (the direct plan's packed weights + workspace + a copy of the largest checked top: up to ~0.6 GB for a
+  // 7s-576 net, kept per host thread and device so that a check on a live stream pays no hipMalloc / synchronising hipFree) is
+  // released by this call; Net::SetNumericsWatch(0, .) / SetAutoCalibrate(0) call it when both checks are switched off.
+  static void ReleaseCheckScratch();
   // max |x| hand-over for the split-fp16 algorithm (mscnn_conv2d_plan_set_amax_io), wired by the Net: `out` is this layer's
   // slot (written when some consumer asked for it: set_amax_wanted), `src` / `in` the layer whose output bounds this layer's
   // bottom and its slot.  A hand-over is used only for forwards the Net marks trusted (the producer ran in the same call).
@@ -163,7 +171,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   bool ChainableNow(int n, int h, int w);
   bool calibrated_direct_ = false;
   double selfcheck_tol_ = kDefaultSelfcheckTol, selfcheck_err_ = 0.0;
-  bool selfcheck_pending_ = true, selfcheck_ran_ = false, selfcheck_fell_back_ = false;
+  bool selfcheck_pending_ = true, selfcheck_ran_ = false, selfcheck_fell_back_ = false, last_check_vacuous_ = false;
   bool profiling_;
   const ConvolutionLayer* amax_src_ = nullptr;
   const unsigned* amax_in_ = nullptr;

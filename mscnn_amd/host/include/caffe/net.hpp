@@ -108,7 +108,7 @@ class Net {
   // the calibration of the first frame is re-examined on live data at the cost of one extra layer per `period` frames.  ON by default
   // (every kDefaultWatchPeriod-th frame, tolerance 5e-5: < 0.3 % of a 7s-576 stream); period 0 turns it off.
   static constexpr int kDefaultWatchPeriod = 100;
-  void SetNumericsWatch(int period, double tol) { watch_period_ = period; watch_tol_ = tol; watch_frame_ = 0; }
+  void SetNumericsWatch(int period, double tol);
   int numerics_watch_checks() const { return watch_checks_; }
   const vector<int>& numerics_watch_switched() const { return watch_switched_; }
   // Health of the plane-GEMM kernel's stream-K hand-off (include/mscnn_hip.h: mscnn_wgemm_handoff_event).  A launch whose finisher
@@ -164,6 +164,7 @@ class Net {
   int watch_period_ = kDefaultWatchPeriod, watch_frame_ = 0, watch_next_ = 0, watch_checks_ = 0;
   double watch_tol_ = 5e-5;
   int auto_checks_ = 0;
+  double auto_tol_ = 5e-5;      // (= ConvolutionLayer::kDefaultSelfcheckTol; 0 once SetAutoCalibrate(0) opted out)
   vector<int> auto_switched_;
   vector<int> watch_switched_;
   bool HandoffEventPending();      // (the stream must have been synchronised) a new tag in the status word: whole tiles forced, counted

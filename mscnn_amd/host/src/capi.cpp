@@ -277,6 +277,7 @@ int mscnn_net_set_image(mscnn_net* n, const char* name, const unsigned char* img
                         const float* mean_bgr) {
   return guarded([&] {
     CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
+    n->net->MaterializePendingReadersOf(name);      // (blobs the last forward left unwritten that hang on this blob are written first, as in the other setters)
     auto b = n->net->blob_by_name(name);
     CHECK(b->num() == 1 && b->channels() == 3) << "set_image: blob " << name << " has shape " << b->shape_string();
     hipStream_t st = (hipStream_t)Caffe::stream();

@@ -194,8 +194,25 @@ bool ConvolutionLayer<Dtype>::StageMs(float ms[3]) const {
   return plan_ && profiling_ && mscnn_conv2d_plan_stage_ms(plan_, ms) == 0;
 }
 
+namespace {
+// scratch shared by every check of this host thread on this device (kept: a check on a live stream -- the numerics watch -- must
+// not pay a hipMalloc + a synchronising hipFree of 100s of MB; ConvolutionLayer::ReleaseCheckScratch frees it, otherwise it is leaked
+// on thread exit like the shared conv workspace)
+struct CheckScratch { DeviceBuffer packed, ws, y, err; };
+thread_local CheckScratch* g_check_scratch[64] = {nullptr};
+}  // namespace
+
+template <typename Dtype>
+void ConvolutionLayer<Dtype>::ReleaseCheckScratch() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_check_scratch[dev]) { (void)hipGetLastError(); return; }
+  delete g_check_scratch[dev];      // (DeviceBuffer's destructor frees)
+  g_check_scratch[dev] = nullptr;
+}
+
 template <typename Dtype>
 double ConvolutionLayer<Dtype>::ErrorAgainstDirect(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+  last_check_vacuous_ = false;
   Plan(bottom[0]->num(), bottom[0]->height(), bottom[0]->width());
   const std::string kname = mscnn_conv2d_plan_kernel(plan_);
   if (kname.compare(0, 8, "winograd") != 0 || bottom[0]->count() == 0) return 0.0;
@@ -207,15 +224,11 @@ double ConvolutionLayer<Dtype>::ErrorAgainstDirect(const vector<Blob<Dtype>*>& b
   d.group = group_; d.relu = relu_ ? 1 : 0; d.algo = MSCNN_CONV_ALGO_DIRECT; d.tune_variant = d.tune_grid = d.tune_flags = 0;
   mscnn_conv_plan* dp = nullptr;
   MSCNN_CHECK(mscnn_conv2d_plan_create(&d, &dp));
-  // scratch shared by every check of this host thread on this device (kept: a check on a live stream -- the numerics watch -- must
-  // not pay a hipMalloc + a synchronising hipFree of 100s of MB; leaked on thread exit like the shared conv workspace)
-  struct Scratch { DeviceBuffer packed, ws, y, err; };
-  static thread_local Scratch* scratch[64] = {nullptr};
   int sdev = 0;
   HIP_CHECK(hipGetDevice(&sdev));
   CHECK(sdev >= 0 && sdev < 64);
-  if (!scratch[sdev]) scratch[sdev] = new Scratch();
-  DeviceBuffer &packed = scratch[sdev]->packed, &ws = scratch[sdev]->ws, &y = scratch[sdev]->y, &err = scratch[sdev]->err;
+  if (!g_check_scratch[sdev]) g_check_scratch[sdev] = new CheckScratch();
+  DeviceBuffer &packed = g_check_scratch[sdev]->packed, &ws = g_check_scratch[sdev]->ws, &y = g_check_scratch[sdev]->y, &err = g_check_scratch[sdev]->err;
   const size_t pb = mscnn_conv2d_packed_weight_bytes(dp), wb = mscnn_conv2d_workspace_bytes(dp);
   float* pk = pb ? static_cast<float*>(packed.Reserve(pb)) : nullptr;
   const float* w = this->blobs_[0]->gpu_data();
@@ -228,10 +241,14 @@ double ConvolutionLayer<Dtype>::ErrorAgainstDirect(const vector<Blob<Dtype>*>& b
   // The metric: max |dy| / max(1, |y|, rms(y)).  On unit-scale activations this is the parity metric of the tests (rms ~ 1 .. 3); on
   // hot ones (rms 10 .. 100, trained nets) an element near zero is the difference of partial sums far larger than itself, where
   // two fp32 summation orders of the DIRECT form already differ by more than 1e-4 of 1 -- the floor follows the blob's scale.
+  MSCNN_CHECK(mscnn_sum_squares_f32(bottom[0]->gpu_data(), (size_t)bottom[0]->count(), sd, S()));
+  double ssx = 0.0;
+  HIP_CHECK(hipMemcpyAsync(&ssx, sd, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)S()));
   MSCNN_CHECK(mscnn_sum_squares_f32(yd, (size_t)top[0]->count(), sd, S()));
   double ss = 0.0;
   HIP_CHECK(hipMemcpyAsync(&ss, sd, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)S()));
   HIP_CHECK(hipStreamSynchronize((hipStream_t)S()));
+  last_check_vacuous_ = !(ssx > 0.0);      // an all-zero bottom: both forms return the bias, the comparison is empty
   const float rms = (float)std::sqrt(ss / (double)top[0]->count());
   MSCNN_CHECK(mscnn_max_rel_diff_f32(top[0]->gpu_data(), yd, (size_t)top[0]->count(), rms > 1.0f ? rms : 1.0f, ed, S()));
   float e = 0.f;
@@ -392,7 +409,8 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     if (selfcheck_tol_ > 0 && algo_ != MSCNN_CONV_ALGO_DIRECT && algo_ != MSCNN_CONV_ALGO_F16 &&
         std::strncmp(mscnn_conv2d_plan_kernel(plan_), "winograd", 8) == 0) {
       selfcheck_err_ = ErrorAgainstDirect(bottom, top);
-      selfcheck_ran_ = true;
+      if (last_check_vacuous_) selfcheck_pending_ = true;      // a zero warm-up frame checks nothing: the next bottom is checked again
+      else selfcheck_ran_ = true;
       if (!(selfcheck_err_ <= selfcheck_tol_)) {      // (NaN counts as a failure)
         LOG(WARNING) << "layer " << this->layer_param_.name() << ": Winograd result off the direct sum by " << selfcheck_err_ << " > "
                      << selfcheck_tol_ << " on the first input after a weight change: using the direct kernel";

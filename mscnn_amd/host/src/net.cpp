@@ -502,6 +502,15 @@ void Net<Dtype>::SetAutoCalibrate(double tol) {
   CHECK_GE(tol, 0.0);
   for (size_t i = 0; i < layers_.size(); ++i)
     if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) c->set_selfcheck(tol);
+  auto_tol_ = tol;
+  // both checks off: give the checks' device scratch back (a direct plan's workspace + a copy of the largest checked top)
+  if (tol == 0.0 && watch_period_ == 0) ConvolutionLayer<Dtype>::ReleaseCheckScratch();
+}
+
+template <typename Dtype>
+void Net<Dtype>::SetNumericsWatch(int period, double tol) {
+  watch_period_ = period; watch_tol_ = tol; watch_frame_ = 0;
+  if (period == 0 && auto_tol_ == 0.0) ConvolutionLayer<Dtype>::ReleaseCheckScratch();
 }
 
 template <typename Dtype>

@@ -47,6 +47,12 @@ DeviceBuffer::~DeviceBuffer() {
   if (ptr_) (void)hipFree(ptr_);
 }
 
+void DeviceBuffer::Release() {
+  if (ptr_) HIP_CHECK(hipFree(ptr_));
+  ptr_ = nullptr;
+  bytes_ = 0;
+}
+
 void* DeviceBuffer::Reserve(size_t bytes) {
   if (bytes > bytes_) {
     if (ptr_) HIP_CHECK(hipFree(ptr_));

@@ -400,6 +400,26 @@ def test_handoff_timeout_never_hands_out_a_wrong_frame():
         hip.wgemm_force_whole_tiles(False)
 
 
+def test_zero_warmup_frame_does_not_use_up_the_first_forward_check():
+    """an all-zero warm-up frame makes the Winograd-vs-direct comparison of the first forward empty (both forms return the
+    bias); the layers' checks must stay armed and run on the first frame that carries data."""
+    n = mnet.Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=96, width=160, max_nms_num=100))
+    synth.load_into(n, "mid")
+    n.set_blob("data", np.zeros(n.blob_shape("data"), np.float32))
+    n.forward()
+    checks0, switched0, _ = n.auto_calibrate_state()
+    n.set_blob("data", synth.frame(96, 160))
+    n.forward()
+    checks1, switched1, errs = n.auto_calibrate_state()
+    wino = [i for i, t in enumerate(n.layer_types) if t == "Convolution" and n.layer_kernel(i).startswith("winograd")]
+    # conv1_2 sees a zero bottom on the zero frame (conv1_1 has no bias in the synthetic regime) -- at least that check was deferred;
+    # after the real frame every Winograd layer has been checked exactly once
+    assert checks0 < len(wino) and checks1 == len(wino), (checks0, checks1, len(wino))
+    assert switched1 == [] and 0 < max(errs.values()) < 5e-5
+    n.forward()
+    assert n.auto_calibrate_state()[0] == checks1
+
+
 def test_numerical_calibration_falls_back_per_layer():
     """Net::CalibrateNumerics: Winograd layers are compared with the direct kernel on the current input; with an impossible
     tolerance every one of them must fall back (and the net must still agree with itself), with the default one none does."""
