@@ -74,7 +74,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   virtual inline const char* type() const { return "Convolution"; }
   virtual inline int MinBottomBlobs() const { return 1; }
   virtual inline int MinTopBlobs() const { return 1; }
-  virtual void OnWeightsChanged() { weights_dirty_ = true; selfcheck_pending_ = true; }
+  virtual void OnWeightsChanged() { weights_dirty_ = true; selfcheck_pending_ = true; wino_checked_ = false; }
   virtual bool FuseReLU(Dtype negative_slope);
   virtual bool FusePool2x2(Blob<Dtype>* pooled_top);
   // Net-level fusion (round 4): this layer's bottom is the concatenation of a deferred ROIPooling pair (`first` does both windows,
@@ -116,7 +116,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   // when it is off by more than the tolerance, puts the layer on the direct kernel for good and recomputes the tops before Forward
   // returns -- no caller ever sees an unchecked Winograd result.  kDefaultSelfcheckTol unless set_selfcheck says otherwise; 0 = off.
   static constexpr double kDefaultSelfcheckTol = 5e-5;
-  void set_selfcheck(double tol) { selfcheck_tol_ = tol; selfcheck_pending_ = true; }
+  void set_selfcheck(double tol) { selfcheck_tol_ = tol; selfcheck_pending_ = true; wino_checked_ = false; }
   double selfcheck_tol() const { return selfcheck_tol_; }
   // what the last self-check measured; `take` clears the "a check ran since the last take" mark (Net bookkeeping)
   bool take_selfcheck(double* err, bool* fell_back) {
@@ -172,6 +172,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   bool calibrated_direct_ = false;
   double selfcheck_tol_ = kDefaultSelfcheckTol, selfcheck_err_ = 0.0;
   bool selfcheck_pending_ = true, selfcheck_ran_ = false, selfcheck_fell_back_ = false, last_check_vacuous_ = false;
+  bool wino_checked_ = false;             // a Winograd result of the current weights / algorithm has been compared with the direct kernel
   bool profiling_;
   const ConvolutionLayer* amax_src_ = nullptr;
   const unsigned* amax_in_ = nullptr;

@@ -169,7 +169,7 @@ void ConvolutionLayer<Dtype>::set_algo(int algo) {
   CHECK(algo >= 0 && algo <= 6) << "unknown mscnn_conv_algo " << algo;
   if (algo == algo_) return;
   algo_ = algo;
-  if (algo != MSCNN_CONV_ALGO_DIRECT) selfcheck_pending_ = true;      // another arithmetic: its first result is checked again
+  if (algo != MSCNN_CONV_ALGO_DIRECT) { selfcheck_pending_ = true; wino_checked_ = false; }      // another arithmetic: its first result is checked again
   if (plan_) { mscnn_conv2d_plan_destroy(plan_); plan_ = nullptr; }
 }
 template <typename Dtype>
@@ -299,6 +299,11 @@ bool ConvolutionLayer<Dtype>::ChainableNow(int n, int h, int w) {
 template <typename Dtype>
 void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
   Plan(bottom[0]->num(), bottom[0]->height(), bottom[0]->width());
+  // AUTO plans per shape: a layer whose first bottoms ran a direct kernel (roi_c1 with a handful of ROIs) may get a Winograd form for a
+  // later one -- the first Winograd result on these weights is checked whenever it comes, not only in the first Forward
+  if (!selfcheck_pending_ && !wino_checked_ && selfcheck_tol_ > 0 && algo_ != MSCNN_CONV_ALGO_DIRECT && algo_ != MSCNN_CONV_ALGO_F16 &&
+      std::strncmp(mscnn_conv2d_plan_kernel(plan_), "winograd", 8) == 0)
+    selfcheck_pending_ = true;
   const float* w = this->blobs_[0]->gpu_data();
   const size_t pbytes = mscnn_conv2d_packed_weight_bytes(plan_);
   float* packed = pbytes ? static_cast<float*>(packed_.Reserve(pbytes)) : nullptr;
@@ -405,13 +410,14 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
   // Safe by default (header): a Winograd result is never handed out unchecked on new weights -- compare it with the direct kernel
   // on this very bottom once; off by more than the tolerance => direct kernel from now on, tops recomputed before returning.
   if (selfcheck_pending_ && bottom[0]->count() > 0) {
-    selfcheck_pending_ = false;
-    if (selfcheck_tol_ > 0 && algo_ != MSCNN_CONV_ALGO_DIRECT && algo_ != MSCNN_CONV_ALGO_F16 &&
-        std::strncmp(mscnn_conv2d_plan_kernel(plan_), "winograd", 8) == 0) {
+    if (!(selfcheck_tol_ > 0 && algo_ != MSCNN_CONV_ALGO_DIRECT && algo_ != MSCNN_CONV_ALGO_F16)) {
+      selfcheck_pending_ = false;      // opted out / an algorithm with nothing to check
+    } else if (std::strncmp(mscnn_conv2d_plan_kernel(plan_), "winograd", 8) == 0) {
+      selfcheck_pending_ = false;
       selfcheck_err_ = ErrorAgainstDirect(bottom, top);
       if (last_check_vacuous_) selfcheck_pending_ = true;      // a zero warm-up frame checks nothing: the next bottom is checked again
-      else selfcheck_ran_ = true;
-      if (!(selfcheck_err_ <= selfcheck_tol_)) {      // (NaN counts as a failure)
+      else selfcheck_ran_ = wino_checked_ = true;
+      if (!last_check_vacuous_ && !(selfcheck_err_ <= selfcheck_tol_)) {      // (NaN counts as a failure)
         LOG(WARNING) << "layer " << this->layer_param_.name() << ": Winograd result off the direct sum by " << selfcheck_err_ << " > "
                      << selfcheck_tol_ << " on the first input after a weight change: using the direct kernel";
         set_algo(MSCNN_CONV_ALGO_DIRECT);
@@ -420,6 +426,7 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
         Forward_gpu(bottom, top);
       }
     }
+    else selfcheck_pending_ = false;      // a direct kernel for THIS shape (see the re-arming at the top of Forward_gpu)
   }
 }
 
