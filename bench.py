@@ -98,7 +98,7 @@ def _full_size_parity(net, x, blobs, kw, dtype="f32"):
         x1 = np.maximum(a[:, None, 0], b[None, :, 0]); y1 = np.maximum(a[:, None, 1], b[None, :, 1])
         x2 = np.minimum(a[:, None, 2], b[None, :, 2]); y2 = np.minimum(a[:, None, 3], b[None, :, 3])
         inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
-        iou = inter / ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])[:, None] + ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :] - inter)
+        iou = inter / (((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None] + ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :] - inter)
         j = iou.argmax(1)
         best_iou, ds = iou[np.arange(len(a)), j], np.abs(dets[:, 4] - dref[j, 4])
         matched = float(((best_iou >= iou_min) & (ds <= dscore)).mean())
@@ -119,6 +119,41 @@ def _full_size_parity(net, x, blobs, kw, dtype="f32"):
             "detections_reference": int(len(dref)), "detections_matched": round(matched, 4), "detections_diag": diag,
             "subnet_err_vs_reference_cpu": {b: float(f"{err(net.get_blob(b), blobs[b]):.3g}") for b in ("cls_pred", "bbox_pred")
                                             if Rg == Rr and np.array_equal(net.get_blob("proposals"), blobs["proposals"].reshape(Rg, 5, 1, 1))}}
+
+
+def _batch_parity(net, mnet, zoo, synth, args, x, kw, B, device):
+    """Image b of a batched forward against the batch-1 forward of the same frame (same library, same weights): detections matched
+    one to one (fp32: IoU >= 0.99, |dscore| <= 1e-4, >= 98 %; fp16: the coverage policy of the fp16 mode)."""
+    one = mnet.Net(prototxt_text=zoo.prototxt(args.model), device=device)
+    synth.load_into(one, args.regime)
+    if args.dtype != "f32":
+        one.set_precision(args.dtype)
+    net.set_blob("data", x)
+    net.forward()
+    f16 = args.dtype == "f16"
+    iou_min, dscore, need = (F16_COVER_IOU, F16_COVER_DSCORE, F16_COVER) if f16 else (0.99, PARITY_BOUND, 0.98)
+    worst, counts = 1.0, []
+    for b in range(B):
+        db, _, Rb = net.detect_image(b, **kw)
+        one.set_blob("data", x[b:b + 1])
+        one.forward()
+        d1, _, R1 = one.detect(**kw)
+        counts.append([int(Rb), int(R1), len(db), len(d1)])
+        if len(db) == 0 or len(d1) == 0:
+            worst = min(worst, 1.0 if len(db) == len(d1) else 0.0)
+            continue
+        a = np.stack([db[:, 0], db[:, 1], db[:, 0] + db[:, 2], db[:, 1] + db[:, 3]], 1)
+        c = np.stack([d1[:, 0], d1[:, 1], d1[:, 0] + d1[:, 2], d1[:, 1] + d1[:, 3]], 1)
+        x1 = np.maximum(a[:, None, 0], c[None, :, 0]); y1 = np.maximum(a[:, None, 1], c[None, :, 1])
+        x2 = np.minimum(a[:, None, 2], c[None, :, 2]); y2 = np.minimum(a[:, None, 3], c[None, :, 3])
+        inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+        iou = inter / (((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None] + ((c[:, 2] - c[:, 0]) * (c[:, 3] - c[:, 1]))[None, :] - inter)
+        near = (iou >= iou_min) & (np.abs(db[:, None, 4] - d1[None, :, 4]) <= dscore)
+        worst = min(worst, float(min(near.any(1).mean(), near.any(0).mean())))
+    del one
+    return {"ok": bool(worst >= need), "worst_image_matched": round(worst, 4), "need": need,
+            "rois_dets_per_image [batched R, batch-1 R, batched D, batch-1 D]": counts,
+            "policy": f"every image of the batch against its own batch-1 forward: mutual match at IoU >= {iou_min}, |dscore| <= {dscore}"}
 
 
 def _cpu_model():
@@ -339,6 +374,11 @@ def main():
                     help="f16: fp16 MFMA operands / fp32 accumulate for the 3x3 convolutions and fc6 (BASELINE config 5); "
                          "f16x3: the Winograd plane GEMMs on the fp16 pipe with exactly split fp32 operands (fp32-grade: same "
                          "parity gates as f32)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="images per forward (default 1 = the headline configuration).  B > 1: the net is built with `dim: B` (the "
+                         "reference's path is batch-generic: box_output_layer.cpp:107, roi_pooling_layer.cpp:62-66), a step = one forward of B "
+                         "resident frames + B per-image final stages, value = B * steps / time; reported BESIDE the batch-1 line (one-round "
+                         "layers of the 480 x 640 stream config become multi-round); N = 1 only")
     ap.add_argument("--regime", default="mid", choices=["dense", "mid", "sparse"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt", action="store_true", help="opt-in (round 5): a second timed loop in the f16x3 mode, reported as alt_precision "
@@ -359,6 +399,8 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         _refuse(f"--gpus {args.gpus}")
+    if args.batch < 1 or (args.batch > 1 and args.gpus > 1):
+        _refuse(f"--batch {args.batch} with --gpus {args.gpus}: the batched mode is a single-GPU side table")
 
     if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
         _self_launch(args)                                    # does not return
@@ -384,12 +426,14 @@ def main():
     from mscnn_amd import net as mnet, synth, zoo
     cfg = MODELS[args.model]
     H, W = cfg["hw"]
-    net = mnet.Net(prototxt_text=zoo.prototxt(args.model), device=local_rank)
+    B = args.batch
+    net = mnet.Net(prototxt_text=zoo.prototxt(args.model, batch=B), device=local_rank)
     synth.load_into(net, args.regime)
     if args.dtype != "f32":
         net.set_precision(args.dtype)
-    # a handful of distinct frames per rank, resident in HBM before the timed region
-    frames = [torch.from_numpy(synth.frame(H, W, seed=1701 + 97 * rank + i, org_hw=cfg["org_hw"])).cuda() for i in range(4)]
+    # a handful of distinct frames per rank (B > 1: of B-frame blobs), resident in HBM before the timed region
+    host_frames = [np.concatenate([synth.frame(H, W, seed=1701 + 97 * rank + i * B + b, org_hw=cfg["org_hw"]) for b in range(B)], 0) for i in range(4)]
+    frames = [torch.from_numpy(f).cuda() for f in host_frames]
     kw = dict(cls_id=cfg["cls_id"], ratios=(H / cfg["org_hw"][0], W / cfg["org_hw"][1]), org_hw=cfg["org_hw"])
     cap = int(zoo.MODELS[args.model][0].get("max_nms_num", 2000))          # BoxOutput's top-K bounds the ROI count
     gather, gather_kind = None, "none"
@@ -435,6 +479,11 @@ def main():
     def step(i):
         net.set_blob("data", frames[i % len(frames)])        # D2D: the frame is already in HBM
         net.forward()
+        if B > 1:                                             # one final stage per image (its NMS never mixes images)
+            out = None
+            for b in range(B):
+                out = take([net.detect_image(b, **kw)])
+            return out
         if gather is None:
             return take([net.detect(**kw)])                   # final stage on device; detections land on the host
         if pipe["on"]:                                        # final stage into the device pack; exchange i runs under image i + 1
@@ -492,7 +541,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * args.steps / elapsed
+    value = world * B * args.steps / elapsed
     main_stats, stats = stats, {"R": [], "D": []}      # the headline loop's ROI / detection counts (later loops append to their own)
 
     # ---- second timed loop, same contract, in the split-fp16 mode (fp32-grade: held to the fp32 parity gates below).  The
@@ -541,7 +590,7 @@ def main():
     # error of the direct sum; the calibration step decides per layer on THIS data which ones stay.  Reported: the layers that fell
     # back, the images/sec that results, and the floor with every Winograd layer on the direct kernel.
     robust = None
-    if args.dtype == "f32" and world == 1 and not args.no_robust:
+    if args.dtype == "f32" and world == 1 and not args.no_robust and B == 1:
         rs = max(5, min(args.steps, 20))
 
         def timed(nsteps):
@@ -675,9 +724,9 @@ def main():
                               "p90": round(float(ss[int(round(0.90 * (len(ss) - 1)))]), 4), "min": round(float(ss[0]), 4),
                               "max": round(float(ss[-1]), 4), "note": "rank 0, wall time per step incl. the host sync at its end"},
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                  "config": {"workload": f"{args.model} {'fp16 MFMA operands / fp32 accumulate' if args.dtype == 'f16' else 'fp32 (Winograd GEMMs as 3 x fp16 MFMA on split operands)' if args.dtype == 'f16x3' else 'fp32'}, batch=1 per GPU, 1x3x{H}x{W} frame resident in HBM -> detections on host "
+                  "config": {"workload": f"{args.model} {'fp16 MFMA operands / fp32 accumulate' if args.dtype == 'f16' else 'fp32 (Winograd GEMMs as 3 x fp16 MFMA on split operands)' if args.dtype == 'f16x3' else 'fp32'}, batch={B} per GPU, {B}x3x{H}x{W} frame{'s' if B > 1 else ''} resident in HBM -> detections on host "
                                          "(trunk + heads + BoxOutput + ROI pool + det sub-net + final NMS)",
-                             "regime": args.regime, "mean_rois": round(Rm, 1), "mean_detections": round(float(np.mean(main_stats["D"])), 1),
+                             "batch": B, "regime": args.regime, "mean_rois": round(Rm, 1), "mean_detections": round(float(np.mean(main_stats["D"])), 1),
                              "parallelism": f"image-parallel x{world}", "gather": gather_kind,
                              # what the collective library reported (ncclCommCount) and the senders' ranks found in the packs of the timed loop
                              "comm_count": comm_count, "ranks_seen": sorted(getattr(gather, "ranks_seen", [])) if gather is not None else None,
@@ -686,7 +735,16 @@ def main():
         if args.model == DEFAULT_MODEL:
             result["metric"] = "images/sec mscnn-7s-576 KITTI-car inference"
         parity_ok = None
-        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (host work; other ranks would idle)
+        if B > 1:
+            # the batched forward against the batch-1 path of the SAME library on the same frames (that path is the one pinned to the
+            # reference's CPU layers at full size: the batch-1 line's parity_ok, tests/test_gpu_net.py; the batched net against the
+            # reference itself: test_whole_net_batch_n_vs_reference at reduced sizes)
+            result["metric"] += f" (batch {B})"
+            result["roofline"]["flops_note"] += f"; one step = one forward of {B} images"
+            result["batch_parity"] = _batch_parity(net, mnet, zoo, synth, args, host_frames[0], kw, B, local_rank)
+            parity_ok = result["batch_parity"]["ok"]
+            result["cpu_baseline"] = None      # (the reference's CPU path is timed beside the batch-1 line)
+        if not args.no_cpu_baseline and world == 1 and B == 1:      # rank 0 at N = 1 only (host work; other ranks would idle)
             table = []
             cb = cpu_baseline(args.model, args.regime, max(1, int(round(Rm))), net=net, kw=kw, layer_table=table, dtype=args.dtype,
                               alt_dtype=alt["dtype"] if alt else None)

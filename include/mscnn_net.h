@@ -140,6 +140,12 @@ MSCNN_NET_API const float* mscnn_net_blob_device_ptr(mscnn_net* net, const char*
 MSCNN_NET_API int mscnn_net_forward(mscnn_net* net);
 MSCNN_NET_API int mscnn_net_forward_from_to(mscnn_net* net, int from, int to);
 MSCNN_NET_API int mscnn_net_reshape(mscnn_net* net);
+/* Input reshape: blob->Reshape(dims) on a net input followed by Net::Reshape() (net.cpp:743-747; matcaffe's
+ * net.blobs('data').reshape([w h c n]); net.reshape()) -- another batch size (dims[0]) or frame size without re-creating the net.
+ * dims in Caffe's order (N, C, H, W).  The whole path is batch-generic like the reference's (conv_layer.cpp:25-40 loops over num_,
+ * box_output_layer.cpp:107 over images, roi_pooling_layer.cpp:62-66 takes the image from column 0 of every ROI): a forward of
+ * N images returns the ROI blobs grouped by image; the final stage then runs once per image (mscnn_net_detect_image). */
+MSCNN_NET_API int mscnn_net_reshape_input(mscnn_net* net, const char* name, const int* dims, int ndim);
 /* Health of the plane-GEMM kernel's stream-K hand-off (mscnn_hip.h: mscnn_wgemm_handoff_event).  A hand-off that times out (a
  * workgroup of the persistent grid was not co-resident: CU masking, a partition mode, another stream's kernels) can never hand out a
  * wrong frame through this ABI: the Net reads the kernel's status word wherever it synchronises anyway -- behind BoxOutput's
@@ -168,6 +174,11 @@ typedef struct {
 } mscnn_detect_params;
 MSCNN_NET_API int mscnn_net_detect(mscnn_net* net, const mscnn_detect_params* p, double* dets_host, int* ids_host,
                                    int cap, int* num_dets, int* num_rois);
+/* The same stage for image `image` of a batched forward (the MATLAB stage is per image: its NMS never mixes images; mscnn_net_detect
+ * itself refuses a net whose input holds more than one image).  ids_host = rows of the net's ROI blobs (bbox_pred, cls_pred,
+ * proposals_score), *num_rois = the image's own ROI count. */
+MSCNN_NET_API int mscnn_net_detect_image(mscnn_net* net, const mscnn_detect_params* p, int image, double* dets_host, int* ids_host,
+                                         int cap, int* num_dets, int* num_rois);
 
 
 /* Final stage of the cascade drivers (examples/kitti_car/run_cascademscnn.m:84-127) for ONE cascade output nn: the decoded boxes

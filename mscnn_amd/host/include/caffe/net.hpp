@@ -53,6 +53,9 @@ class Net {
   inline int num_inputs() const { return (int)net_input_blobs_.size(); }
   inline int num_outputs() const { return (int)net_output_blobs_.size(); }
   inline const vector<Blob<Dtype>*>& input_blobs() const { return net_input_blobs_; }
+  inline const vector<int>& input_blob_indices() const { return net_input_blob_indices_; }
+  // number of ForwardFromTo calls so far (readers that cache something derived from the blobs key it on this)
+  long forward_count() const { return forward_count_; }
   inline const vector<Blob<Dtype>*>& output_blobs() const { return net_output_blobs_; }
   inline const vector<int>& output_blob_indices() const { return net_output_blob_indices_; }
   bool has_blob(const string& blob_name) const;
@@ -171,6 +174,7 @@ class Net {
   unsigned long long handoff_seen_ = 0;
   int handoff_errors_ = 0;
   int last_start_ = 0, last_end_ = -1;
+  long forward_count_ = 0;
   DISABLE_COPY_AND_ASSIGN(Net);
 };
 

@@ -4,6 +4,7 @@
 
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../../include/mscnn_hip.h"
 #include "../../../include/mscnn_net.h"
@@ -21,6 +22,8 @@ struct mscnn_net {
   caffe::DeviceBuffer det_pack;            // detect: [count | dets | ids] in one allocation -> ONE D2H copy, one sync
   void* det_host = nullptr;                // pinned staging for that copy
   size_t det_host_bytes = 0;
+  std::vector<int> row_end;                // detect_image: end row of every image in the ROI blobs, of forward number rows_forward
+  long rows_forward = -1;
   ~mscnn_net() {
     if (det_host) (void)hipHostFree(det_host);
   }
@@ -337,16 +340,28 @@ size_t mscnn_net_detect_pack_bytes(int cap) {
 }
 
 // Final stage into the fixed-capacity device pack [count, R, cap, 0 | cap x 5 doubles | cap ints]; no host transfer.
-static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap, int* R_out, bool with_header) {
+// [row0, row0 + rows) of the ROI blobs (rows < 0: all of them -- the batch-1 form)
+static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap, int* R_out, bool with_header, int row0 = 0, int nrows = -1) {
   CHECK(p != nullptr);
   CHECK(n->net->has_blob("bbox_pred") && n->net->has_blob("cls_pred") && n->net->has_blob("proposals_score"))
       << "net has no bbox_pred / cls_pred / proposals_score outputs";
   auto bbox = n->net->blob_by_name("bbox_pred");
   auto cls = n->net->blob_by_name("cls_pred");
   auto props = n->net->blob_by_name("proposals_score");
-  const int R = props->num();
-  CHECK_EQ(bbox->num(), R);
-  CHECK_EQ(cls->num(), R);
+  const int R_all = props->num();
+  CHECK_EQ(bbox->num(), R_all);
+  CHECK_EQ(cls->num(), R_all);
+  if (nrows < 0) {
+    // the MATLAB stage is written for one image (run_mscnn_detection.m:75-120 runs on the outputs of a batch-1 forward): the NMS
+    // must never mix boxes of different images
+    if (n->net->num_inputs() > 0 && n->net->input_blobs()[0]->num_axes() == 4)
+      CHECK_EQ(n->net->input_blobs()[0]->num(), 1) << "the net's input holds " << n->net->input_blobs()[0]->num()
+                                                   << " images: use mscnn_net_detect_image (one final stage per image)";
+    row0 = 0; nrows = R_all;
+  }
+  CHECK(row0 >= 0 && nrows >= 0 && row0 + nrows <= R_all);
+  const int R = nrows;
+  const int per_row_cls = R_all > 0 ? cls->count() / R_all : 1, per_row_box = R_all > 0 ? bbox->count() / R_all : 4;
   if (with_header && R > cap) {
     // Multi-GPU pack: a rank that fails here alone would leave the others blocked in the all_gather.  Mark the overflow in the header
     // {-1, R, cap, 0} and take part in the exchange: mscnn_net_unpack_detections then fails on EVERY rank, naming the numbers.
@@ -362,8 +377,8 @@ static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap
   }
   CHECK_LE(R, cap) << "detection pack capacity " << cap << " < " << R << " ROIs (size it by BoxOutput's max_nms_num)";
   mscnn_detections_desc d;
-  d.ncls = R > 0 ? cls->count() / R : 1;
-  if (R > 0) CHECK_EQ(bbox->count() / R, 4 * d.ncls);
+  d.ncls = per_row_cls;
+  if (R_all > 0) CHECK_EQ(per_row_box, 4 * d.ncls);
   d.cls_id = p->cls_id;
   for (int k = 0; k < 4; ++k) { d.bbox_mean[k] = p->bbox_mean[k]; d.bbox_std[k] = p->bbox_std[k]; }
   d.proposal_thr = p->proposal_thr;
@@ -382,8 +397,34 @@ static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap
     HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hdr + 2), cap, 1, st));
     HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hdr + 3), 0, 1, st));
   }
-  MSCNN_CHECK(mscnn_detections_fwd(&d, bbox->gpu_data(), cls->gpu_data(), props->gpu_data(), R, dets, ids, hdr, ws, wb, st));
+  MSCNN_CHECK(mscnn_detections_fwd(&d, bbox->gpu_data() + (size_t)row0 * per_row_box, cls->gpu_data() + (size_t)row0 * per_row_cls,
+                                   props->gpu_data() + (size_t)row0 * 6, R, dets, ids, hdr, ws, wb, st));
   if (R_out) *R_out = R;
+}
+
+// Row range of image `image` in the ROI blobs: BoxOutput emits image after image (box_output_layer.cpp:107), column 0 of every row
+// is its image (:156).  One small D2H read of the proposals blob per forward (cached until the next forward).
+static void image_rows(mscnn_net* n, int image, int* row0, int* rows) {
+  CHECK(n->net->has_blob("proposals_score")) << "net has no proposals_score output";
+  auto props = n->net->blob_by_name("proposals_score");
+  const int R = props->num(), num = n->net->num_inputs() > 0 ? n->net->input_blobs()[0]->num() : 1;
+  CHECK(image >= 0 && image < num) << "image " << image << " of a batch of " << num;
+  if (n->rows_forward != n->net->forward_count() || (int)n->row_end.size() != num) {
+    const float* h = props->cpu_data();      // (synchronises the stream)
+    n->row_end.assign(num, 0);
+    int prev = 0;
+    for (int r = 0; r < R; ++r) {
+      const int img = (int)h[(size_t)r * 6];
+      CHECK(img >= prev && img < num) << "proposals are not grouped by image";
+      // (the dummy row [0 0 0 0 0 0] the layer emits when nothing survives in the whole batch carries score 0 and image 0)
+      prev = img;
+      n->row_end[img] = r + 1;
+    }
+    for (int i = 1; i < num; ++i) if (n->row_end[i] < n->row_end[i - 1]) n->row_end[i] = n->row_end[i - 1];
+    n->rows_forward = n->net->forward_count();
+  }
+  *row0 = image > 0 ? n->row_end[image - 1] : 0;
+  *rows = n->row_end[image] - *row0;
 }
 
 int mscnn_net_detect_device(mscnn_net* n, const mscnn_detect_params* p, int cap, const void** pack_dev) {
@@ -455,6 +496,62 @@ int mscnn_net_detect(mscnn_net* n, const mscnn_detect_params* p, double* dets_ho
     }
     *num_dets = Dd;
     if (num_rois) *num_rois = R;
+  });
+}
+
+int mscnn_net_detect_image(mscnn_net* n, const mscnn_detect_params* p, int image, double* dets_host, int* ids_host, int cap,
+                           int* num_dets, int* num_rois) {
+  return guarded([&] {
+    CHECK(p && dets_host && num_dets);
+    int row0 = 0, rows = 0, R = 0;
+    image_rows(n, image, &row0, &rows);
+    if (n->net->HandoffRecover()) image_rows(n, image, &row0, &rows);      // (image_rows synchronised the stream: see mscnn_net_handoff_state)
+    hipStream_t st = (hipStream_t)Caffe::stream();
+    size_t total = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      detect_into_pack(n, p, rows, &R, false, row0, rows);
+      total = mscnn_net_detect_pack_bytes(rows);
+      if (n->det_host_bytes < total) {
+        if (n->det_host) HIP_CHECK(hipHostFree(n->det_host));
+        n->det_host = nullptr; n->det_host_bytes = 0;
+        HIP_CHECK(hipHostMalloc(&n->det_host, total, hipHostMallocDefault));
+        n->det_host_bytes = total;
+      }
+      HIP_CHECK(hipMemcpyAsync(n->det_host, n->det_pack.get(), total, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (attempt == 1 || !n->net->HandoffRecover()) break;
+      image_rows(n, image, &row0, &rows);      // the frame has been run again on whole tiles: once more on the new outputs
+    }
+    const char* hp = static_cast<const char*>(n->det_host);
+    const int Dd = *reinterpret_cast<const int*>(hp);
+    CHECK_LE(Dd, cap) << "detections buffer too small";
+    CHECK_LE(Dd, rows);
+    const size_t prow = (size_t)(rows > 0 ? rows : 1);
+    if (Dd > 0) {
+      std::memcpy(dets_host, hp + 16, sizeof(double) * 5 * Dd);
+      if (ids_host) {
+        std::memcpy(ids_host, hp + 16 + sizeof(double) * 5 * prow, sizeof(int) * Dd);
+        for (int i = 0; i < Dd; ++i) ids_host[i] += row0;      // rows of the net's ROI blobs, not of the image's range
+      }
+    }
+    *num_dets = Dd;
+    if (num_rois) *num_rois = R;
+  });
+}
+
+int mscnn_net_reshape_input(mscnn_net* n, const char* name, const int* dims, int ndim) {
+  return guarded([&] {
+    CHECK(n->net->has_blob(name)) << "Unknown blob name " << name;
+    CHECK(dims && ndim >= 1 && ndim <= 8);
+    bool is_input = false;
+    for (int i = 0; i < n->net->num_inputs(); ++i)
+      is_input = is_input || n->net->blob_names()[n->net->input_blob_indices()[i]] == name;
+    CHECK(is_input) << "blob " << name << " is not a net input";
+    n->net->MaterializePendingReadersOf(name);
+    n->net->MaterializeStale();      // (blobs the last forward left unwritten belong to the OLD shape)
+    std::vector<int> shape(dims, dims + ndim);
+    n->net->blob_by_name(name)->Reshape(shape);      // blob->Reshape + net->Reshape: matcaffe's net.blobs('data').reshape(..); net.reshape()
+    n->net->Reshape();
   });
 }
 

@@ -560,6 +560,7 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   CHECK_GE(start, 0);
   CHECK_LT(end, (int)layers_.size());
   last_start_ = start; last_end_ = end;
+  ++forward_count_;
   bool handoff_restarted = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing_) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }

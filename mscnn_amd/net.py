@@ -67,6 +67,7 @@ def lib():
             "mscnn_net_detect_pack_bytes": [ci], "mscnn_net_detect_device": [vp, vp, ci, vp],
             "mscnn_net_unpack_detections": [vp, ci, vp, vp, vp, vp],
             "mscnn_net_handoff_state": [vp, vp],
+            "mscnn_net_reshape_input": [vp, cs, vp, ci], "mscnn_net_detect_image": [vp, vp, ci, vp, vp, ci, vp, vp],
         }
         for name, args in sig.items():
             getattr(L, name).argtypes = args
@@ -271,6 +272,11 @@ class Net:
     def reshape(self):
         _check(lib().mscnn_net_reshape(self._h))
 
+    def reshape_input(self, name, shape):
+        """net.blobs[name].reshape(*shape); net.reshape() -- another batch / frame size on the same net (Caffe order N, C, H, W)."""
+        dims = (C.c_int * len(shape))(*[int(v) for v in shape])
+        _check(lib().mscnn_net_reshape_input(self._h, name.encode(), dims, len(shape)))
+
     def handoff_state(self):
         """(stream-K hand-off time-outs this net has answered by re-running the frame, whole-tile scheduling forced for the process)."""
         forced = C.c_int()
@@ -311,6 +317,16 @@ class Net:
         D = C.c_int(); R = C.c_int()
         _check(lib().mscnn_net_detect_cascade(self._h, C.byref(p), det_thr, bbox_blob.encode(), prob_blob.encode(), proposal_blob.encode(),
                                               dets.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), cap, C.byref(D), C.byref(R)))
+        return dets[:D.value].copy(), ids[:D.value].copy(), R.value
+
+    def detect_image(self, image, cls_id, ratios, org_hw, bbox_mean=(0, 0, 0, 0), bbox_std=(0.1, 0.1, 0.2, 0.2), proposal_thr=-10.0,
+                     nms_overlap=0.5, cap=4096):
+        """The final stage for image `image` of a batched forward; returns (dets[D,5], rows of the net's ROI blobs[D], the image's R)."""
+        p = self._params(cls_id, ratios, org_hw, bbox_mean, bbox_std, proposal_thr, nms_overlap)
+        dets = np.zeros((cap, 5), np.float64); ids = np.zeros(cap, np.int32)
+        D = C.c_int(); R = C.c_int()
+        _check(lib().mscnn_net_detect_image(self._h, C.byref(p), image, dets.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), cap,
+                                            C.byref(D), C.byref(R)))
         return dets[:D.value].copy(), ids[:D.value].copy(), R.value
 
     def detect(self, cls_id, ratios, org_hw, bbox_mean=(0, 0, 0, 0), bbox_std=(0.1, 0.1, 0.2, 0.2), proposal_thr=-10.0,

@@ -118,11 +118,11 @@ def _detection_subnet(L, feat, scale, cls_num, roi_pooled, roi_c1_pad, fc6, stag
 
 def mscnn_deploy(height, width, cls_num, head_kernels, field_w, field_h, n_heads=7, fg_thr=-5, iou_thr=0.65,
                  max_nms_num=2000, roi_pooled=(7, 7), upsample2x=False, roi_c1_pad=0, fc6=4096, min_size=None,
-                 stages=1, ensemble_3rd=False, outputs=False, proposal_bbox_reg=False):
+                 stages=1, ensemble_3rd=False, outputs=False, proposal_bbox_reg=False, batch=1):
     """head_kernels: [(kw, kh) small, (kw, kh) large], e.g. [(5, 5), (7, 7)] or [(3, 5), (5, 7)] (names are WxH).
     stages / ensemble_3rd / outputs: the cascade deploys (see _detection_subnet); proposal_bbox_reg: BoxOutput carries the
     bbox_reg_param normalisation (citypersons)."""
-    L = ['name: "MSCNN"', 'input: "data"', "input_dim: 1", "input_dim: 3", f"input_dim: {height}", f"input_dim: {width}"]
+    L = ['name: "MSCNN"', 'input: "data"', f"input_dim: {batch}", "input_dim: 3", f"input_dim: {height}", f"input_dim: {width}"]      # (the shipped files: dim 1)
     bottom = "data"
     heads = []
     cout_head = cls_num + 4
@@ -177,11 +177,11 @@ def mscnn_deploy(height, width, cls_num, head_kernels, field_w, field_h, n_heads
 WIDERFACE_FIELDS = [12, 16, 24, 32, 48, 64, 96, 128, 196, 256, 384, 480]
 
 
-def widerface_cascade_deploy(height=512, width=512, max_nms_num=3000, min_size=5):
+def widerface_cascade_deploy(height=512, width=512, max_nms_num=3000, min_size=5, batch=1):
     """examples/widerface/cascade-mscnn-12s-align: a 3x3 `rpn_k_conv` per scale feeding 1x1 proposal heads named by their
     field size (12 heads on conv4_3 / conv5_3 / pool5 / an AVE-pooled pool6), ROIAlign 5x5 + 2x2 AVE pooling instead of
     ROIPooling, three cascade stages with the third-stage ensemble."""
-    L = ['name: "MSCNN"', 'input: "data"', "input_dim: 1", "input_dim: 3", f"input_dim: {height}", f"input_dim: {width}"]
+    L = ['name: "MSCNN"', 'input: "data"', f"input_dim: {batch}", "input_dim: 3", f"input_dim: {height}", f"input_dim: {width}"]      # (the shipped files: dim 1)
     bottom = "data"
     heads = []
 

@@ -224,6 +224,107 @@ def test_full_size_parity_vgg_like_weights():
           f"{worst:.2e}; calibration: max {rep['calibration_max']:.2e}, fall-backs {rep['calibration_fallbacks']}")
 
 
+BATCHED = [   # model, reduced input, batch, original image size
+    ("kitti_car/mscnn-7s-576", dict(height=192, width=640, max_nms_num=300), 2, (375, 1242)),
+    ("kitti_car/mscnn-7s-576", dict(height=96, width=320, max_nms_num=120), 4, (375, 1242)),
+    ("caltech/mscnn-7s-480", dict(height=240, width=320, max_nms_num=150), 4, (480, 640)),
+    ("kitti_ped_cyc/mscnn-7s-576-2x", dict(height=192, width=448, max_nms_num=200), 2, (375, 1242)),
+]
+
+
+@pytest.mark.parametrize("model,size,batch,org_hw", BATCHED)
+def test_whole_net_batch_n_vs_reference(model, size, batch, org_hw):
+    """A `dim: N` forward of the whole net (the reference's path is batch-generic: conv_layer.cpp:25-40 loops over num_,
+    box_output_layer.cpp:107 over images, roi_pooling_layer.cpp:62-66 reads the image from column 0 of every ROI) against the
+    reference's own CPU layers run on the same N-image blob: trunk / heads 1e-4, BoxOutput (per image, rows grouped by image) and
+    the ROI poolings over mixed images bit-exact on identical inputs, the detection sub-net (fused ROI pooling + roi_c1 over the
+    ROIs of all images) 1e-4, and the final stage PER IMAGE (mscnn_net_detect_image) selection-exact against the oracle on that
+    image's rows.  Also: mscnn_net_detect refuses the batched net, and every image's trunk agrees with its own batch-1 forward."""
+    from oracle import pynet, pyoracle as orc, pyref
+    backend = pyref if pyref.available() else None      # (the GPU box has oracle/_ref; without it the C restatement pinned to it)
+    n = mnet.Net(prototxt_text=zoo.prototxt(model, batch=batch, **size))
+    ws = synth.load_into(n, "mid")
+    N, _, H, W = n.blob_shape("data")
+    assert N == batch
+    x = np.concatenate([synth.frame(H, W, seed=1701 + 13 * i, org_hw=org_hw) for i in range(N)], 0)
+    n.set_blob("data", x)
+    n.forward()
+    layers = layer_list(n)
+    names = [l[0] for l in layers]
+    ref = pynet.forward(layers, ws, {"data": x}, backend=backend)
+    for b in ("conv1_2", "conv3_3", "conv4_3", "conv5_3", "conv6_1", "pool6"):
+        assert n.blob_shape(b)[0] == N
+        assert rel_err(n.get_blob(b), ref[b]) < 1e-4, b
+    for l in layers:
+        if l[0].startswith("LFCN_"):
+            assert rel_err(n.get_blob(l[3][0]), ref[l[3][0]]) < 1e-4, l[0]
+    # BoxOutput on the device's own head blobs: bit-identical rows, grouped by image, every image present
+    bo = [l for l in layers if l[1] == "BoxOutput"][0]
+    r2 = pynet.forward([bo], ws, {b: n.get_blob(b) for b in bo[2]}, backend=backend)
+    rois = n.get_blob("proposals")
+    R = rois.shape[0]
+    assert np.array_equal(rois, r2["proposals"]) and np.array_equal(n.get_blob("proposals_score"), r2["proposals_score"])
+    img_of = rois.reshape(R, 5)[:, 0].astype(int)
+    assert np.all(np.diff(img_of) >= 0) and set(img_of) == set(range(N)), np.bincount(img_of, minlength=N)
+    # ROI poolings over mixed images (and the Deconvolution of the -2x nets in front of them)
+    parts = []
+    for l in layers:
+        if l[1] == "ROIPooling":
+            parts.append(pynet.forward([l], ws, {l[2][0]: n.get_blob(l[2][0]), l[2][1]: rois}, backend=backend)[l[3][0]])
+            assert np.array_equal(n.get_blob(l[3][0]), parts[-1]), l[0]
+    assert np.array_equal(n.get_blob("roi_pool"), np.concatenate(parts, axis=1))
+    # the detection sub-net on the device's own ROI features
+    sub = layers[names.index("roi_pool") + 1:]
+    r3 = pynet.forward(sub, ws, {"roi_pool": n.get_blob("roi_pool")}, backend=backend)
+    for b in ("roi_c1", "fc6", "cls_pred", "bbox_pred"):
+        assert rel_err(n.get_blob(b), r3[b]) < 1e-4, b
+    # final stage per image
+    kw = dict(cls_id=2, ratios=(H / float(org_hw[0]), W / float(org_hw[1])), org_hw=org_hw)
+    with pytest.raises(mnet.NetError, match="mscnn_net_detect_image"):
+        n.detect(**kw)
+    bbox, cls, props = n.get_blob("bbox_pred"), n.get_blob("cls_pred"), n.get_blob("proposals_score").reshape(R, 6)
+    total = 0
+    for i in range(N):
+        rows = np.flatnonzero(img_of == i)
+        dets, ids, Ri = n.detect_image(i, **kw)
+        assert Ri == len(rows)
+        dref, iref = orc.detections(bbox[rows], cls[rows], props[rows], **kw)
+        assert np.array_equal(ids, rows[iref]) and rel_err(dets, dref) < 1e-4, i
+        total += len(dets)
+    assert total > 0
+    # each image alone (batch 1 through the input-reshape entry of the same net): same trunk within the fp32 bar
+    n.reshape_input("data", (1, 3, H, W))
+    for i in (0, N - 1):
+        n.set_blob("data", x[i:i + 1])
+        n.forward()
+        assert n.blob_shape("conv4_3")[0] == 1
+        assert rel_err(n.get_blob("conv4_3"), ref["conv4_3"][i:i + 1]) < 1e-4
+        assert rel_err(n.get_blob("conv6_1"), ref["conv6_1"][i:i + 1]) < 1e-4
+
+
+def test_input_reshape_entry_equals_a_net_built_at_that_shape():
+    """mscnn_net_reshape_input (blob->Reshape + Net::Reshape, net.cpp:743-747): a net built with `dim: 1` and reshaped to 3 images --
+    and to another frame size -- is bit-identical, on every blob asked for, to a net built at that shape."""
+    model, size = "kitti_car/mscnn-7s-576", dict(height=96, width=160, max_nms_num=100)
+    a = mnet.Net(prototxt_text=zoo.prototxt(model, **size))
+    synth.load_into(a, "mid")
+    a.set_blob("data", synth.frame(96, 160))
+    a.forward()
+    for shape in ((3, 3, 96, 160), (2, 3, 128, 224), (1, 3, 96, 160)):
+        b = mnet.Net(prototxt_text=zoo.prototxt(model, batch=shape[0], height=shape[2], width=shape[3], max_nms_num=100))
+        synth.load_into(b, "mid")
+        x = np.concatenate([synth.frame(shape[2], shape[3], seed=7 + i) for i in range(shape[0])], 0)
+        a.reshape_input("data", shape)
+        assert a.blob_shape("conv4_3")[0] == shape[0] and a.blob_shape("conv4_3")[2:] == (shape[2] // 8, shape[3] // 8)
+        for m in (a, b):
+            m.set_blob("data", x)
+            m.forward()
+        for blob in ("conv2_2", "conv4_3", "pool6", "proposals_score", "roi_pool", "fc6", "cls_pred", "bbox_pred"):
+            assert np.array_equal(a.get_blob(blob), b.get_blob(blob)), (shape, blob)
+    with pytest.raises(mnet.NetError, match="is not a net input"):
+        a.reshape_input("conv4_3", (1, 512, 4, 4))
+
+
 def test_caffemodel_file_drives_the_device_net(tmp_path):
     """SURVEY 8(f1) on the GPU: a .caffemodel written by the protobuf runtime (tests/caffemodel_pb.py: new-style, legacy 4-D and
     double_data blobs) is loaded into a DEVICE net through Net::CopyTrainedLayersFrom (net.cpp:750-803), forwarded on the HIP
