@@ -257,25 +257,53 @@ def cpu_baseline(model, regime, R_gpu, net=None, kw=None, layer_table=None, dtyp
             "seconds_per_image_est": round(est, 2)}
 
 
-def _measured_traffic():
-    """(bytes of one launch | None, where it comes from, extra fields): profiles/r04_traffic_wgemm.json if its kernel_sources_sha16
-    matches the wgemm.hip / winograd.hip of this tree."""
+def _kernel_sources_sha16():
     import hashlib
-    path = os.path.join(ROOT, "profiles", "r04_traffic_wgemm.json")
+    h = hashlib.sha256()
+    for f in ("mscnn_amd/csrc/wgemm.hip", "mscnn_amd/csrc/winograd.hip"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _measured_traffic():
+    """(bytes of one launch | None, where it comes from, extra fields): the newest profiles/rNN_traffic_wgemm.json whose
+    kernel_sources_sha16 matches the wgemm.hip / winograd.hip of this tree."""
+    sha = _kernel_sources_sha16()
+    seen = []
+    for rnd in ("r05", "r04"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_wgemm.json")
+        try:
+            t = json.load(open(path))
+            if t.get("kernel_sources_sha16") != sha:
+                seen.append(f"profiles/{rnd}_traffic_wgemm.json ({t.get('kernel_sources_sha16')})")
+                continue
+            return (int(t["traffic_bytes_per_launch"]),
+                    "PMC FETCH_SIZE x 2 + WRITE_SIZE of ONE launch (conv4_2's plane GEMM), rocprofv3 separate passes, tools/pmc_traffic.py -> "
+                    f"profiles/{rnd}_traffic_wgemm.json (kernel sources unchanged since: sha16 " + t["kernel_sources_sha16"] + ")",
+                    {"traffic_launch": "conv4_2", "traffic_algorithmic_bytes": int(t["algorithmic_bytes_per_launch"]),
+                     "traffic_over_algorithmic": round(t["traffic_bytes_per_launch"] / t["algorithmic_bytes_per_launch"], 3)})
+        except (OSError, ValueError, KeyError):
+            continue
+    if seen:
+        return None, "measured on other kernel sources: " + ", ".join(seen) + ": not reported", {}
+    return None, "no PMC measurement of this kernel in profiles/ (tools/pmc_traffic.py)", {}
+
+
+def _measured_mfma_busy():
+    """MFMA-pipe utilisation of the plane-GEMM kernel from the PMC counters (tools/pmc_mfma.py -> profiles/r05_mfma_busy.json), under the
+    same rule as `traffic`: reported only while wgemm.hip / winograd.hip are byte-identical to the sources it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r05_mfma_busy.json")
     try:
         t = json.load(open(path))
-        h = hashlib.sha256()
-        for f in ("mscnn_amd/csrc/wgemm.hip", "mscnn_amd/csrc/winograd.hip"):
-            h.update(open(os.path.join(ROOT, f), "rb").read())
-        if t.get("kernel_sources_sha16") != h.hexdigest()[:16]:
-            return None, f"profiles/r04_traffic_wgemm.json was measured on other kernel sources ({t.get('kernel_sources_sha16')}): not reported", {}
-        return (int(t["traffic_bytes_per_launch"]),
-                "PMC FETCH_SIZE x 2 + WRITE_SIZE of ONE launch (conv4_2's plane GEMM), rocprofv3 separate passes, tools/pmc_traffic.py -> "
-                "profiles/r04_traffic_wgemm.json (kernel sources unchanged since: sha16 " + t["kernel_sources_sha16"] + ")",
-                {"traffic_launch": "conv4_2", "traffic_algorithmic_bytes": int(t["algorithmic_bytes_per_launch"]),
-                 "traffic_over_algorithmic": round(t["traffic_bytes_per_launch"] / t["algorithmic_bytes_per_launch"], 3)})
+        if t.get("kernel_sources_sha16") != _kernel_sources_sha16():
+            return {"mfma_busy": None, "mfma_busy_source": f"profiles/r05_mfma_busy.json was measured on other kernel sources ({t.get('kernel_sources_sha16')}): not reported"}
+        return {"mfma_busy": t["mfma_busy_time_weighted"],
+                "mfma_busy_per_layer": {k: {"busy": v.get("mfma_busy"), "clock_ghz": v.get("clock_ghz"), "avg_us": v.get("avg_us")} for k, v in t["layers"].items()},
+                "mfma_busy_source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the kernel stand-alone per layer, time-weighted "
+                                    "(rocprofv3 --pmc, tools/pmc_mfma.py -> profiles/r05_mfma_busy.json; profiled clock in clock_ghz: busy x clock / 2.4 "
+                                    "is the fraction of the 157.3 TFLOP/s peak the pipe was issued at, tile padding included)"}
     except (OSError, ValueError, KeyError):
-        return None, "no PMC measurement of this kernel in profiles/ (tools/pmc_traffic.py)", {}
+        return {"mfma_busy": None, "mfma_busy_source": "no PMC measurement in profiles/ (tools/pmc_mfma.py)"}
 
 
 class _CudaPtr:
@@ -682,6 +710,7 @@ def main():
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc, **textra,
+            **(_measured_mfma_busy() if args.model == DEFAULT_MODEL and args.dtype == "f32" else {}),
             **({"frac_of_measured_mfma_peak": round(achieved / FP32_MFMA_MEASURED_TFLOPS, 4),
                 "measured_mfma_peak": FP32_MFMA_MEASURED_TFLOPS} if args.dtype == "f32" else {}),
             "kernel": ("igemm_kernel<Cfg<...,F16>> (igemm16_*): direct 3x3 implicit GEMM on v_mfma_f32_32x32x16_f16, operands rounded to "
