@@ -545,6 +545,8 @@ def main():
         checks, switched, _ = net.auto_calibrate_state()
         return (checks, len(switched))
 
+    from mscnn_amd import hipapi as _hipapi
+    handoff_ev0 = _hipapi.wgemm_handoff_event()      # the device's hand-off status word before any frame
     numerics = None
     mark = (0, 0)
     for i in range(max(args.warmup, 1)):
@@ -759,7 +761,8 @@ def main():
                              "parallelism": f"image-parallel x{world}", "gather": gather_kind,
                              # what the collective library reported (ncclCommCount) and the senders' ranks found in the packs of the timed loop
                              "comm_count": comm_count, "ranks_seen": sorted(getattr(gather, "ranks_seen", [])) if gather is not None else None,
-                             "handoff": dict(zip(("events_answered", "whole_tiles_forced"), net.handoff_state()))},
+                             "handoff": {**dict(zip(("events_answered", "whole_tiles_forced"), net.handoff_state())),
+                                         "status_word_changed": _hipapi.wgemm_handoff_event() != handoff_ev0}},
                   "numerics": numerics, "roofline": roofline}
         if args.model == DEFAULT_MODEL:
             result["metric"] = "images/sec mscnn-7s-576 KITTI-car inference"
@@ -805,6 +808,11 @@ def main():
         result["stage_ms"] = {k: round(v, 3) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1]) if v > 0.0005}
         if parity_ok is False:
             rc = 3
+        if result["config"]["handoff"]["status_word_changed"] and result["config"]["handoff"]["events_answered"] == 0:
+            # a stream-K hand-off timed out somewhere in this run and no synchronisation point of the Net answered it (the asynchronous
+            # multi-GPU pack path synchronises outside the Net): the frames of that step may carry a poisoned tile -- not a valid line
+            print("bench.py: a wgemm hand-off time-out was reported and not answered: the line is INVALID", file=sys.stderr)
+            rc = 4
     if dist is not None:
         dist.barrier()
         if hasattr(gather, "close"):
