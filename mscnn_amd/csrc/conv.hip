@@ -36,6 +36,7 @@
 #include "roipool_wino.h"
 #include "conv_c3.h"
 #include "wconv.h"
+#include "wf2conv.h"
 #include "x3_device.h"
 #include <new>
 #include <type_traits>
@@ -1014,6 +1015,10 @@ struct mscnn_conv_plan {
   bool c3 = false;       // conv1_1: the Cin = 3 VALU kernel of conv_c3.hip (reads the Caffe-layout weights; entry stays -1)
   bool wc_use = false;   // conv1_2's shape class: the ring kernel of wconv.hip runs the layer; `entry` (64 x 256 igemm, SAME weight packing) stays planned beside it
   mscnn::WconvPlan wc;
+  // (round 5) the same shape class as ONE-launch Winograd F(2x2,3x3) (wf2conv.hip): its own packed filters (packed_bytes), no workspace;
+  // AUTO's choice where it covers the map; tune_flags bit 16 keeps the ring kernel (A/B, the direct witness)
+  bool wf_use = false;
+  mscnn::Wf2Plan wf;
   int wino_m = 2;        // output tile edge: 2 = F(2x2,3x3) (16 planes), 3 = F(3x3,3x3) (25 planes; small ROI maps)
   int tiles_h = 0, tiles_w = 0, T_pad = 0;
   // split-fp16 form of the F(3x3,3x3) path (MSCNN_CONV_ALGO_WINO_F3_X3, wino_x3.hip): x3.BM > 0, wino == nullptr.
@@ -1201,6 +1206,7 @@ static void plan_shape(mscnn_conv_plan* p) {
   p->entry = -1;
   p->c3 = false;
   p->wc_use = false;
+  p->wf_use = false;
   p->packed_bytes = 0;
   p->ws_bytes = 0;
   p->head.entry = -1;
@@ -1346,6 +1352,18 @@ static void plan_shape(mscnn_conv_plan* p) {
       d.pad_w == 1 && !(tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 32768)) {
     if (mscnn::wconv_plan(d.N, d.Cin, d.H, d.W, d.Cout, d.tune_variant == 402, &p->wc) && p->wc.packed_bytes == p->packed_bytes) p->wc_use = true;
   }
+  // (round 5) ... and, for AUTO, the one-launch Winograd F(2x2,3x3) kernel of wf2conv.hip where the map is whole 8 x 32 blocks with at
+  // least two of them per CU: 2.25x fewer multiplies with nothing but x and the pooled map / y in HBM.  Not under DIRECT (the
+  // numerical fall-back and the direct witness of the layers' first-forward check) nor under the fp16 / split-fp16 algorithms.
+  if (p->entry >= 0 && k.KH == 3 && k.KW == 3 && k.BM == 64 && k.RH == 0 && (k.variant == 0 || k.variant == 1) && p->MT == 1 && d.pad_h == 1 && d.pad_w == 1 &&
+      d.stride_h == 1 && d.stride_w == 1 && d.group == 1 && tune_env("MSCNN_CONV_ALGO", d.algo) == MSCNN_CONV_ALGO_AUTO &&
+      !(tune_env("MSCNN_TUNE_FLAGS", d.tune_flags) & 65536) && mscnn::wf2_plan(d.N, d.Cin, d.H, d.W, d.Cout, &p->wf) &&
+      (p->wf.tiles >= 512 || d.tune_variant == 403)) {
+    p->wf_use = true;
+    p->wc_use = false;
+    p->packed_bytes = p->wf.packed_bytes;
+    p->ws_bytes = 0;
+  }
 }
 
 extern "C" int mscnn_conv2d_plan_create(const mscnn_conv_desc* desc, mscnn_conv_plan** plan_out) {
@@ -1374,6 +1392,7 @@ extern "C" const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* p) {
   if (p->x3.BM) return p->x3.BM == 256 ? "winograd_f3x3_3x3_x3f16_256" : "winograd_f3x3_3x3_x3f16_128";
   if (p->wino) return p->wino_m == 4 ? "winograd_f4x4_3x3" : p->wino_m == 3 ? "winograd_f3x3_3x3" : "winograd_f2x2_3x3";
   if (p->c3) return mscnn::c3_kernel_name();
+  if (p->wf_use) return mscnn::wf2_kernel_name();
   if (p->wc_use) return mscnn::wconv_kernel_name();
   return p->entry < 0 ? "direct_f32" : kTable[p->entry].name;
 }
@@ -1386,6 +1405,7 @@ extern "C" unsigned long long mscnn_conv2d_plan_weight_layout(const mscnn_conv_p
   else if (p->x3.BM) { kind = 6; e = (unsigned)p->x3.BM; mt = (unsigned)p->x3.MT; ki = (unsigned)p->x3.KG; }
   else if (p->wino && p->use_wg) { kind = p->wino_m == 4 ? 9u : 2 + (unsigned)p->wino_m; e = 200u + (unsigned)(p->wg.BM / 128);      /* the packing depends on BM (and CK = 32) only: the 256-row tile shapes share it */ mt = (unsigned)p->wg.MT; ki = (unsigned)p->wg.KI; }
   else if (p->wino) { kind = p->wino_m == 4 ? 9u : 2 + (unsigned)p->wino_m; e = (unsigned)p->wino->entry; mt = (unsigned)p->wino->MT; ki = (unsigned)p->wino->KI; }
+  else if (p->wf_use) { kind = 11; e = 0; mt = 1; ki = (unsigned)p->wf.KI; }
   else if (p->entry >= 0) { kind = 1; e = (unsigned)p->entry; mt = (unsigned)p->MT; ki = (unsigned)p->KI; }   // (entry distinguishes fp16 packs)
   else return 0;   // direct kernel: reads the Caffe layout
   return kind | (e << 8) | (mt << 24) | (ki << 44);
@@ -1403,6 +1423,7 @@ extern "C" const char* mscnn_conv2d_plan_dtype(const mscnn_conv_plan* p) {
 extern "C" double mscnn_conv2d_plan_executed_flops(const mscnn_conv_plan* p) {
   if (!p) return 0;
   if (p->x3h.rows) return 3.0 * mscnn_conv2d_plan_flops(p);
+  if (p->wf_use) return mscnn_conv2d_plan_flops(p) * (16.0 / 36.0);      // F(2x2,3x3): 16 multiplies per 4 outputs instead of 36
   if (!p->wino && !p->x3.BM)
     return mscnn_conv2d_plan_flops(p) * ((p->head.entry < 0 && p->entry >= 0 && kTable[p->entry].variant == 210) ? 3.0 : 1.0);
   const mscnn_conv_desc& d = p->d;
@@ -1430,7 +1451,7 @@ extern "C" int mscnn_conv2d_plan_publishes_amax(const mscnn_conv_plan* p) {
   // the F(3x3,3x3) output transforms, every kernel of the implicit-GEMM family (main + fix-up) and the Cin = 3 VALU kernel publish
   // (not the ring kernel of wconv.hip: a split-fp16 consumer of conv1_2 measures its bottom itself)
   return p && !p->x3h.rows && (p->x3.BM || (p->wino && p->wino_m >= 3) || p->c3 ||
-               (!p->wino && p->head.entry < 0 && p->entry >= 0 && !p->wc_use && !(kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202))) ? 1 : 0;
+               (!p->wino && p->head.entry < 0 && p->entry >= 0 && !p->wc_use && !p->wf_use && !(kTable[p->entry].variant >= 200 && kTable[p->entry].variant <= 202))) ? 1 : 0;
 }
 extern "C" int mscnn_conv2d_plan_set_amax_io(mscnn_conv_plan* p, const uint32_t* in_bound, uint32_t* out_amax) {
   MSCNN_REQUIRE(p, "conv plan: null");
@@ -1487,6 +1508,7 @@ extern "C" int mscnn_conv2d_pack_weights(const mscnn_conv_plan* p, const float* 
   }
   if (p->entry < 0) return MSCNN_OK;   // direct kernel reads the Caffe layout
   MSCNN_REQUIRE(w && packed, "conv pack: null pointer");
+  if (p->wf_use) return mscnn::wf2_pack(p->wf, w, packed, as_stream(stream));
   const KernelEntry& k = kTable[p->entry];
   const long total = (long)p->MT * p->KI * k.KH * k.KW * k.CK * k.BM;
   long blocks = (total + 255) / 256;
@@ -1825,6 +1847,7 @@ static int conv_forward_single(const mscnn_conv_plan* p, const float* x, const f
     return MSCNN_OK;
   }
   MSCNN_REQUIRE(packed, "conv: igemm kernel needs packed weights (mscnn_conv2d_pack_weights)");
+  if (p->wf_use) return mscnn::wf2_launch(p->wf, x, packed, bias, y, y_pool, d.relu, st);
   if (p->wc_use) return mscnn::wconv_launch(p->wc, x, packed, bias, y, y_pool, d.relu, st);
   return launch_igemm(p, x, packed, bias, y, y_pool, workspace, workspace_bytes, st, 0u, 0);
 }

@@ -1558,6 +1558,46 @@ def test_conv_pool_only_direct_kernel(hip, orc):
     assert q.can_pool and not q.can_pool_only
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 8, 32), (2, 16, 16, 96), (1, 64, 64, 256), (3, 40, 24, 64), (1, 64, 576, 1920)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_wf2conv_one_launch_winograd_f2x2(hip, orc, shape, relu):
+    """conv1_2's shape class as ONE-launch Winograd F(2x2,3x3) (wf2conv.hip: input transform, 16 plane products on
+    v_mfma_f32_16x16x4_f32 and output transform inside one workgroup; AUTO's choice for full-resolution maps since round 5): against the
+    oracle / the direct ring kernel within the fp32 bar, the fused MAX 2x2 pooling bit-identical to pooling the layer's own output, the
+    pool-only forward bit-identical to both, image borders (every tile row / column position incl. single-block maps), batch, odd
+    channel-chunk counts, with and without bias."""
+    N, Cin, H, W = shape
+    rng = np.random.default_rng(29)
+    x = dev(np.maximum(rng.standard_normal((N, Cin, H, W)), 0).astype(np.float32))
+    w = dev((rng.standard_normal((64, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32))
+    b = dev(rng.standard_normal(64).astype(np.float32))
+    p = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=relu, tune_variant=403)      # (403: also maps with < 512 blocks)
+    assert p.kernel == "winograd2x2_fused_k3x3_c64", p.kernel
+    assert p.can_pool and p.can_pool_only and not p.publishes_amax
+    assert abs(p.executed_flops / p.flops - 16.0 / 36.0) < 1e-9
+    p.pack(w)
+    pool = torch.full((N, 64, H // 2, W // 2), -7.0, device="cuda")
+    y = p.forward(x, b, pool_out=pool).clone()
+    assert torch.equal(pool, torch.nn.functional.max_pool2d(y, 2))
+    pool2 = torch.full_like(pool, -9.0)
+    hip._check(hip.lib().mscnn_conv2d_fwd_pool_f32(p._p, hip._dev(x), hip._dev(w), hip._dev(p.packed), hip._dev(b), None, hip._dev(pool2),
+                                                   None, 0, hip._stream()))
+    assert torch.equal(pool2, pool)
+    for _ in range(2):
+        assert torch.equal(p.forward(x, b), y)
+    d = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=relu, algo=hip.ALGO_DIRECT)
+    d.pack(w)
+    yd = d.forward(x, b)
+    err = ((y - yd).abs() / torch.clamp(yd.abs(), min=1.0)).max().item()
+    assert err < 2e-5, err
+    if H * W <= 20000:
+        ref = orc.conv2d(x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), (1, 1))
+        close(y.cpu().numpy(), orc.relu(ref) if relu else ref)
+        y0 = p.forward(x)                                  # no bias
+        ref0 = orc.conv2d(x.cpu().numpy(), w.cpu().numpy(), np.zeros(64, np.float32), (1, 1))
+        close(y0.cpu().numpy(), orc.relu(ref0) if relu else ref0)
+
+
 @pytest.mark.parametrize("shape", [(1, 8, 8, 128), (2, 16, 12, 256), (1, 64, 64, 1024), (3, 40, 16, 128), (1, 48, 8, 384), (1, 64, 576, 1920)])
 def test_wconv_ring_kernel_against_the_igemm_kernel(hip, orc, shape):
     """conv1_2's shape class on the ring kernel of wconv.hip (one 8-wave workgroup per CU, LDS-DMA ring with dword patch pieces,
@@ -1576,7 +1616,12 @@ def test_wconv_ring_kernel_against_the_igemm_kernel(hip, orc, shape):
     q = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_flags=32768, tune_grid=grid_ig)
     assert p.kernel == "wconv_64x512_k3x3" and q.kernel.startswith("igemm_64x256"), (p.kernel, q.kernel)
     # AUTO takes it where the map has at least two tiles per CU (conv1_2 of the deploy nets), never below
-    assert (hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True).kernel == "wconv_64x512_k3x3") == (N * (H // 4) * (W // 128) >= 512)
+    # (round 5: where the map is whole 8 x 32 blocks, >= 512 of them, AUTO prefers the one-launch Winograd F(2x2,3x3) kernel of wf2conv.hip;
+    # tune_flags bit 16 keeps the ring kernel)
+    fused = H % 8 == 0 and W % 32 == 0 and N * (H // 8) * (W // 32) >= 512
+    auto_k = hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True).kernel
+    assert auto_k == ("winograd2x2_fused_k3x3_c64" if fused else "wconv_64x512_k3x3" if N * (H // 4) * (W // 128) >= 512 else auto_k)
+    assert (hip.ConvPlan(N, Cin, H, W, 64, 3, 3, (1, 1), relu=True, tune_flags=65536).kernel == "wconv_64x512_k3x3") == (N * (H // 4) * (W // 128) >= 512)
     assert p.can_pool and p.can_pool_only and not p.publishes_amax
     p.pack(w); q.pack(w)
     assert torch.equal(p.packed, q.packed)

@@ -213,8 +213,11 @@ def test_f4_plan_plumbing_without_a_device():
     assert auto(128, 288, 960, 128) == "winograd_f4x4_3x3" and auto(64, 288, 960, 128) == "winograd_f4x4_3x3"        # conv2_2, conv2_1
     assert auto(128, 144, 480, 256) == "winograd_f4x4_3x3" and auto(256, 72, 240, 512) == "winograd_f4x4_3x3"        # conv3_1, conv4_1
     assert auto(512, 36, 120, 512) == "winograd_f3x3_3x3" and auto(512, 18, 60, 512) == "winograd_f3x3_3x3"          # conv5_x, conv6_1
-    assert auto(64, 576, 1920, 64) == "wconv_64x512_k3x3" and auto(64, 576, 1920, 64, tune_flags=32768).startswith("igemm_")      # conv1_2 stays direct (its own ring kernel)
-    assert auto(64, 288, 960, 64).startswith("igemm_")                                                               # (not whole 4 x 128 tiles)
+    # conv1_2: the one-launch Winograd F(2x2,3x3) kernel (round 5); tune_flags bit 16 -> the direct ring kernel, + bit 15 -> the igemm kernel
+    assert auto(64, 576, 1920, 64) == "winograd2x2_fused_k3x3_c64" and auto(64, 576, 1920, 64, tune_flags=65536) == "wconv_64x512_k3x3"
+    assert auto(64, 576, 1920, 64, tune_flags=65536 | 32768).startswith("igemm_") and auto(64, 576, 1920, 64, algo=hip.ALGO_DIRECT) == "wconv_64x512_k3x3"
+    assert auto(64, 288, 960, 64) == "winograd2x2_fused_k3x3_c64" and auto(64, 288, 960, 64, tune_flags=65536).startswith("igemm_")   # (not whole 4 x 128 tiles: no ring kernel)
+    assert auto(64, 100, 960, 64).startswith("igemm_")                                                               # (not whole 8 x 32 blocks either)
     assert auto(512, 72, 240, 512, tune_flags=64) == "winograd_f3x3_3x3"                                             # A/B knob: the round-2 choice
     # conv1_1 (Cin = 3) has its own VALU kernel; tune_flags bit 11 keeps the MFMA igemm kernel
     assert auto(3, 576, 1920, 64) == "conv3x3_c3_valu_f32" and auto(3, 576, 1920, 64, tune_flags=2048).startswith("igemm_")
