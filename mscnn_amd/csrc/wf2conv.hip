@@ -26,6 +26,7 @@
 // (~2x the rounding error of the direct sum); the layer's own first-forward check against the direct kernel applies as to the others.
 #include "wf2conv.h"
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -48,10 +49,12 @@ __device__ unsigned long long g_wf2_trace[2 * 32 * 8];
 #define WF2_STAMP(k) do { } while (0)
 #endif
 constexpr int TR = 4, TC = 16, NT = TR * TC;            // Winograd tiles per workgroup tile: 4 rows x 16 columns = 8 x 32 output pixels
-constexpr int PR = 2 * TR + 2, PC = 2 * TC + 2;        // input patch per channel: 10 x 34
+constexpr int PR = 2 * TR + 2, PC = 2 * TC + 8;        // input patch per channel: 10 rows x 40 columns = the 34 needed (w0 - 1 .. w0 + 32) widened to
+                                                       // whole aligned float4s (w0 - 4 .. w0 + 35): the patch travels as 16-byte LDS-DMA lanes
+constexpr int PC4 = PC / 4, PX = 3;                    // float4s per row; column of w0 - 1 inside a row
 constexpr int CK = 8;                                  // channels per chunk
 constexpr int U_FLOATS = CK * 16 * 64, V_FLOATS = CK * 16 * NT, P_FLOATS = CK * PR * PC;      // 8192, 8192, 2720
-constexpr int P_STRIDE = (P_FLOATS + 63) / 64 * 64;      // a patch buffer holds whole 256-byte LDS-DMA pieces: 2752 (the last piece's tail is zeros)
+constexpr int P_STRIDE = (P_FLOATS + 255) / 256 * 256;   // a patch buffer holds whole 1 KB LDS-DMA pieces: 3328 floats (the last piece's tail is zeros)
 constexpr int LDS_FLOATS = 2 * U_FLOATS + 2 * V_FLOATS + 2 * P_STRIDE;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 
@@ -93,13 +96,13 @@ __device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff,
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-constexpr int P_PIECES = (P_FLOATS + 63) / 64;         // 256-byte LDS-DMA pieces of a patch: 43
-constexpr int P_SLOTS = (P_PIECES + 7) / 8;            // per wave: 6
-constexpr int LDS_SPARE = LDS_FLOATS * 4;              // 256 bytes behind everything: where a wave without a real piece in a slot aims
-static_assert(LDS_SPARE + 256 <= 160 * 1024, "LDS");
+constexpr int P_PIECES = (P_FLOATS + 255) / 256;       // 1 KB LDS-DMA pieces of a patch (64 lanes x 16 bytes): 13
+constexpr int P_SLOTS = (P_PIECES + 7) / 8;            // per wave: 2
+constexpr int LDS_SPARE = LDS_FLOATS * 4;              // 1 KB behind everything: where a wave without a real piece in a slot aims
+static_assert(LDS_SPARE + 1024 + 256 <= 160 * 1024, "LDS");
 
 __global__ __launch_bounds__(512, 2) void wf2conv_kernel(Wf2Args a) {
-  __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS + 64 + 64];      // + the DMA dump + the 64 biases
+  __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS + 256 + 64];      // + the DMA dump + the 64 biases
   float* const Us = lds;                               // [2][U_FLOATS]
   float* const Vs = lds + 2 * U_FLOATS;                // [2][V_FLOATS]
   float* const Ps = lds + 2 * U_FLOATS + 2 * V_FLOATS; // [2][P_STRIDE]
@@ -130,11 +133,11 @@ __global__ __launch_bounds__(512, 2) void wf2conv_kernel(Wf2Args a) {
     const int h0 = p_th * (2 * TR), w0 = p_tw * (2 * TC);
     p_img = __builtin_amdgcn_readfirstlane((unsigned)(p_n * a.Cin) * (unsigned)HW * 4u);
 #pragma unroll
-    for (int j = 0; j < P_SLOTS; ++j) {      // (the element's (k, r, c) is recomputed per tile -- divisions by constants -- rather than held in registers)
-      const int e = (wave + 8 * j) * 64 + lane;
-      const int k = e / (PR * PC), rem = e - k * (PR * PC), r = rem / PC, c = rem - r * PC;
-      const int hh = h0 - 1 + r, ww = w0 - 1 + c;
-      const bool ok = e < P_FLOATS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+    for (int j = 0; j < P_SLOTS; ++j) {      // (the float4's (k, r, c4) is recomputed per tile -- divisions by constants -- rather than held in registers)
+      const int f = (wave + 8 * j) * 64 + lane;      // float4 number f of [k][10][10]
+      const int k = f / (PR * PC4), rem = f - k * (PR * PC4), r = rem / PC4, c4 = rem - r * PC4;
+      const int hh = h0 - 1 + r, ww = w0 - 4 + 4 * c4;      // W is a multiple of 32 and w0 of 32: a float4 is inside the row or outside, never across
+      const bool ok = f < P_FLOATS / 4 && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
       vP[j] = ok ? (unsigned)(k * HW + hh * a.W + ww) * 4u : kOob;
     }
     p_tw += a.dG_w; if (p_tw >= a.NTW) { p_tw -= a.NTW; ++p_th; }
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void wf2conv_kernel(Wf2Args a) {
 #pragma unroll
       for (int j = 0; j < P_SLOTS; ++j) {
         const int piece = wave + 8 * j;
-        dma4(rX, vP[j], sb, piece < P_PIECES ? pb + (unsigned)piece * 256u : lds0 + (unsigned)LDS_SPARE);
+        dma16(rX, vP[j], sb, piece < P_PIECES ? pb + (unsigned)piece * 1024u : lds0 + (unsigned)LDS_SPARE);
       }
     }
     ++pu;
@@ -166,13 +169,12 @@ __global__ __launch_bounds__(512, 2) void wf2conv_kernel(Wf2Args a) {
   // V = B^T d B of (channel k = wave, tile = lane) of patch buffer `buf` into V stage `stage`;  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
   auto transform = [&](int buf, int stage) {
     const int trn = lane >> 4, tcn = lane & 15;
-    const float* p = Ps + buf * P_STRIDE + wave * (PR * PC) + (2 * trn) * PC + 2 * tcn;
+    const float* p = Ps + buf * P_STRIDE + wave * (PR * PC) + (2 * trn) * PC + PX + 2 * tcn;      // (odd column: four dword reads per row)
     float d[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float2 lo = *reinterpret_cast<const float2*>(p + i * PC), hi = *reinterpret_cast<const float2*>(p + i * PC + 2);
-      d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
-    }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j] = p[i * PC + j];
     float t[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -185,14 +187,11 @@ __global__ __launch_bounds__(512, 2) void wf2conv_kernel(Wf2Args a) {
   };
 
   f32x4 acc[16][2];
-#pragma unroll
-  for (int p = 0; p < 16; ++p)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) acc[p][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // the 64 MFMAs of a chunk in 8 groups (k-step ks, transform row i) of 8; the three operand reads of group g + 1 are issued BEFORE the
   // MFMAs of group g (two register sets)
-  auto mfmas = [&](int st, int c) {
+  auto mfmas = [&](int st, int c, auto first_c) {      // first_c: the tile's first chunk -- the products START the sums (C = 0), no clearing pass
+    constexpr bool FIRST = decltype(first_c)::value;
     const f32x4* U = reinterpret_cast<const f32x4*>(Us + st * U_FLOATS) + lq * 4 * 64 + ch * 32 + l16;
     const f32x4* V = reinterpret_cast<const f32x4*>(Vs + st * V_FLOATS) + lq * 4 * NT + tr * 16 + l16;
     f32x4 a0[2], a1[2], bb[2];
@@ -207,21 +206,23 @@ __global__ __launch_bounds__(512, 2) void wf2conv_kernel(Wf2Args a) {
       const int cur = g & 1, i = g & 3;
       if (g + 1 < 8) rd(g + 1, cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (WF2_ABL & 1) { acc[i * 4][0][0] += a0[cur][0] + a1[cur][1] + bb[cur][2]; continue; }
+      if (WF2_ABL & 1) { acc[i * 4][0][0] = (FIRST && g == 0 ? 0.f : acc[i * 4][0][0]) + a0[cur][0] + a1[cur][1] + bb[cur][2]; continue; }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        acc[i * 4 + q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[cur][q], bb[cur][q], acc[i * 4 + q][0], 0, 0, 0);
-        acc[i * 4 + q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[cur][q], bb[cur][q], acc[i * 4 + q][1], 0, 0, 0);
+        const bool fresh = FIRST && g < 4;      // (groups 0-3 = k-step 0 touch every accumulator once)
+        acc[i * 4 + q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[cur][q], bb[cur][q], fresh ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i * 4 + q][0], 0, 0, 0);
+        acc[i * 4 + q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[cur][q], bb[cur][q], fresh ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i * 4 + q][1], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   // output transform of a finished tile:  y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1];  lane holds (cout = 32 ch + 16 mb + 4 lq + r,
-  // tile column l16); the accumulators are cleared for the next tile.  The consumer's tile cursor moves like the producer's.
+  // tile column l16).  (The accumulators need no clearing: the next tile's first chunk starts its sums with C = 0.)  The consumer's tile
+  // cursor moves like the producer's.
   const int Hp = a.H / 2, Wp = a.W / 2;
   int c_tw = slot % a.NTW, c_th = (slot / a.NTW) % a.NTH, c_n = slot / (a.NTW * a.NTH);
-  float* const bias_s = lds + LDS_FLOATS + 64;      // the 64 biases in LDS (a global load per tile would expose its latency; registers are short)
+  float* const bias_s = lds + LDS_FLOATS + 256;      // the 64 biases in LDS (a global load per tile would expose its latency; registers are short)
   if (tid < 64) bias_s[tid] = a.bias ? a.bias[tid] : 0.f;
   auto epilogue = [&]() {
     const int oh = c_th * (2 * TR) + 2 * tr, ow = c_tw * (2 * TC) + 2 * l16;
@@ -238,15 +239,27 @@ __global__ __launch_bounds__(512, 2) void wf2conv_kernel(Wf2Args a) {
           const float m0 = acc[0 + j][mb][r], m1 = acc[4 + j][mb][r], m2 = acc[8 + j][mb][r], m3 = acc[12 + j][mb][r];
           s0[j] = m0 + m1 + m2;
           s1[j] = m1 - m2 - m3;
-          acc[0 + j][mb][r] = 0.f; acc[4 + j][mb][r] = 0.f; acc[8 + j][mb][r] = 0.f; acc[12 + j][mb][r] = 0.f;
         }
         const float bv = bias_s[ch * 32 + mb * 16 + lq * 4 + r];
+        const long cofs = (long)(mb * 16 + r);
+        if (!ydst) {
+          // only the pooled map is wanted: max first, bias and ReLU once -- the same bits as pooling the four finished outputs
+          // (x -> fl(x + b) and ReLU are monotone, so they commute with max exactly; a NaN wins only from the first position, as below)
+          const float q00 = s0[0] + s0[1] + s0[2], q01 = s0[1] - s0[2] - s0[3], q10 = s1[0] + s1[1] + s1[2], q11 = s1[1] - s1[2] - s1[3];
+          float m = q00;
+          if (q01 > m) m = q01;
+          if (q10 > m) m = q10;
+          if (q11 > m) m = q11;
+          m += bv;
+          if (a.relu) m = m < 0.f ? 0.f : m;
+          pdst[cofs * (Hp * Wp)] = m;
+          continue;
+        }
         float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
         float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
         if (a.relu) {
           y00 = y00 < 0.f ? 0.f : y00; y01 = y01 < 0.f ? 0.f : y01; y10 = y10 < 0.f ? 0.f : y10; y11 = y11 < 0.f ? 0.f : y11;
         }
-        const long cofs = (long)(mb * 16 + r);
         if (ydst) {
           float* dst = ydst + cofs * HW;
           *reinterpret_cast<float2*>(dst) = make_float2(y00, y01);
@@ -286,6 +299,8 @@ __global__ __launch_bounds__(512, 2) void wf2conv_kernel(Wf2Args a) {
     const int st = u & 1, c = u % a.KI;
     const bool more1 = u + 1 < total;
     WF2_STAMP(0);
+    // (next to a partner that streams fp32 MFMAs a wave's other instructions take ~27 cycles each instead of ~12; raising the wave
+    // priority around them changed nothing -- it is not arbitration --, tools/sessions/r05_s17.sh)
     if (!mfma_first) {
       if (!(WF2_ABL & 8)) {
         dma_u(c + 1 < a.KI ? c + 1 : 0, st ^ 1);       // U of unit u + 1
@@ -294,7 +309,8 @@ __global__ __launch_bounds__(512, 2) void wf2conv_kernel(Wf2Args a) {
       if (more1 && !(WF2_ABL & 4)) transform(st ^ 1, st ^ 1);
     }
     WF2_STAMP(1);
-    mfmas(st, c);
+    if (c == 0) mfmas(st, c, std::true_type{});
+    else mfmas(st, c, std::false_type{});
     WF2_STAMP(2);
     if (c == a.KI - 1) epilogue();
     WF2_STAMP(3);
@@ -336,8 +352,8 @@ int wf2_pack(const Wf2Plan& p, const float* w, float* packed, hipStream_t st) {
 
 int wf2_launch(const Wf2Plan& p, const float* x, const float* packed, const float* bias, float* y, float* y_pool, int relu, hipStream_t st) {
   MSCNN_REQUIRE(x && packed && (y || y_pool), "conv(winograd2x2 fused): null pointer");
-  MSCNN_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0 && (!y || reinterpret_cast<uintptr_t>(y) % 8 == 0),
-                "conv(winograd2x2 fused): packed weights must be 16-byte, y 8-byte aligned");
+  MSCNN_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && (!y || reinterpret_cast<uintptr_t>(y) % 8 == 0),
+                "conv(winograd2x2 fused): x and the packed weights must be 16-byte, y 8-byte aligned");
   Wf2Args a;
   a.x = x; a.up = packed; a.bias = bias; a.y = y; a.yp = y_pool;
   a.N = p.N; a.Cin = p.Cin; a.H = p.H; a.W = p.W; a.NTH = p.NTH; a.NTW = p.NTW; a.KI = p.KI; a.relu = relu; a.tiles = p.tiles;

@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5, session 18: the net with the final one-launch Winograd kernel: bench, net tests, op tests, timeline
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r5s18; mkdir -p $O; export PYTHONUNBUFFERED=1
+timeout 300 python bench.py --steps 40 --warmup 10 --layers > $O/bench.json 2> $O/bench_layers.txt
+( timeout 900 python -m pytest tests/test_gpu_net.py -m gpu -q -k "unfused or chains or default_flow or full_size_parity_vs_reference or vgg_like or partial_forward or batch_n" 2>&1 | tail -15 ) > $O/tests.txt 2>&1
+( timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "wf2conv or wconv or pool or conv_igemm" 2>&1 | tail -3 ) >> $O/tests.txt 2>&1
+timeout 120 python tools/wf2_trace.py > $O/trace.txt 2>&1
