@@ -101,7 +101,7 @@ typedef struct {
    * slower than the head kernel: opt-in), bit 5 = never that form, bit 6 = AUTO keeps F(3x3,3x3) where it would take F(4x4,3x3),
    * bit 7 = the Winograd plane GEMMs on the round-2 igemm kernel instead of wgemm.hip's, bit 8 = the scalar (host-checked)
    * F(4x4,3x3) transform kernels instead of the vectorised ones and the generic F(3x3,3x3) output transform on ROI maps instead of the LDS-staged one, bit 9 = never / bit 10 = wherever legal: proposal heads with the
-   * kernel's columns folded into M (KH x 1 convolution with KW * Cout channels + shift-and-add), bit 11 = a Cin = 3 layer (conv1_1) on the MFMA igemm kernel instead of its VALU kernel, bit 12 = F(4x4,3x3) input transform with one tile per lane instead of two, bit 15 = a 3x3 / pad 1 layer with 64 output channels on whole 4 x 128 tiles (conv1_2) stays on the igemm kernel instead of the ring kernel of wconv.hip (bit-identical for whole tiles; A/B, second witness), bit 14 = inverts the wave priority of the direct MFMA kernel's tile epilogue (raised by default on the 64 x 256 3x3 tile = conv1_2 only), bit 13 = (witness build only, `make -C mscnn_amd/csrc witness`; ignored by the product library) proposal heads on the packed-FMA kernel of tools/micro/headvalu.hip instead of the M = 4 MFMA kernel (headconv.hip); tune_variant with WINO_F3_X3: 1 = 128-row, 2 = 256-row GEMM tiles;
+   * kernel's columns folded into M (KH x 1 convolution with KW * Cout channels + shift-and-add), bit 11 = a Cin = 3 layer (conv1_1) on the MFMA igemm kernel instead of its VALU kernel, bit 12 = F(4x4,3x3) input transform with one tile per lane instead of two, bit 15 = a 3x3 / pad 1 layer with 64 output channels on whole 4 x 128 tiles (conv1_2) stays on the igemm kernel instead of the ring kernel of wconv.hip (bit-identical for whole tiles; A/B, second witness), bit 16 = (round 5) a 3x3 / pad 1 layer with 64 output channels on a full-resolution map (conv1_2: whole 8 x 32 blocks, >= 512 of them) stays on the direct ring kernel of wconv.hip instead of the one-launch Winograd F(2x2,3x3) kernel of wf2conv.hip that AUTO takes there (A/B, the direct witness; tune_variant 403 also plans smaller maps on it: tests), bit 14 = inverts the wave priority of the direct MFMA kernel's tile epilogue (raised by default on the 64 x 256 3x3 tile = conv1_2 only), bit 13 = (witness build only, `make -C mscnn_amd/csrc witness`; ignored by the product library) proposal heads on the packed-FMA kernel of tools/micro/headvalu.hip instead of the M = 4 MFMA kernel (headconv.hip); tune_variant with WINO_F3_X3: 1 = 128-row, 2 = 256-row GEMM tiles;
    * tune_variant 300 + v with a Winograd algo: wgemm tile variant v (1: 256 x 128, 2: 128 x 256, 3: 128 x 128, 4: 256 x 96, 5: 256 x 160; + 256 forces the
    * stream-K split, + 512 whole tiles). */
   int tune_variant, tune_grid, tune_flags;
@@ -118,7 +118,9 @@ MSCNN_API size_t mscnn_conv2d_workspace_bytes(const mscnn_conv_plan* plan);
  *   "igemm_<BM>x<BN>_k3x3_..." | "igemm_<BM>x<BN>_k1x1_..."                 direct implicit GEMM on v_mfma_f32_32x32x2_f32
  *   "igemm16_..." | "igemm16x3_..."                                          the same on fp16 / split-fp16 operands
  *   "conv3x3_c3_valu_f32"                                                    Cin = 3 (conv1_1)
- *   "wconv_64x512_k3x3" (conv1_2 on full-resolution maps) | "head4x4_k<Kh>x<Kw>_m<..>" | "head_kwfold_shiftadd_f32" | "head_gemm_shiftadd_f32" | "head_gemm_shiftadd_x3f16"   proposal heads
+ *   "winograd2x2_fused_k3x3_c64" (conv1_2 on full-resolution maps: ONE launch -- input transform, 16 plane products on v_mfma_f32_16x16x4_f32,
+ *                               output transform, ReLU and the 2x2 pooling inside a workgroup; executed FLOPs = 16 / 36 of the direct count)
+ *   "wconv_64x512_k3x3" (the same shape class as a direct convolution: DIRECT, or tune_flags bit 16) | "head4x4_k<Kh>x<Kw>_m<..>" | "head_kwfold_shiftadd_f32" | "head_gemm_shiftadd_f32" | "head_gemm_shiftadd_x3f16"   proposal heads
  *   "direct_f32"                                                             any stride / group / kernel size (generic kernel)
  * A name that starts with "winograd" is what the numerical checks of the C++ layer key on. */
 MSCNN_API const char* mscnn_conv2d_plan_kernel(const mscnn_conv_plan* plan);

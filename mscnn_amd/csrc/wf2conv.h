@@ -11,6 +11,7 @@ namespace mscnn {
 struct Wf2Plan {
   int N, Cin, H, W;                 // Cout = 64
   int NTH, NTW, KI, tiles;          // workgroup tiles of 8 rows x 32 columns (4 x 16 Winograd tiles), K chunks of 8 channels
+  int cus;                          // CUs of the device current at plan time: the persistent grid is min(tiles, cus) workgroups
   size_t packed_bytes;              // U = G g G^T in the layout Up[cin][xi][cout][nu]: 16 * 64 * Cin floats
 };
 

@@ -339,6 +339,12 @@ bool wf2_plan(int N, int Cin, int H, int W, int Cout, Wf2Plan* o) {
   o->NTH = H / (2 * TR); o->NTW = W / (2 * TC); o->KI = Cin / CK;
   o->tiles = N * o->NTH * o->NTW;
   o->packed_bytes = (size_t)16 * 64 * Cin * sizeof(float);
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    cus = 256;      // (planning on a box without a device)
+  }
+  o->cus = cus;
   return true;
 }
 
@@ -357,12 +363,9 @@ int wf2_launch(const Wf2Plan& p, const float* x, const float* packed, const floa
   Wf2Args a;
   a.x = x; a.up = packed; a.bias = bias; a.y = y; a.yp = y_pool;
   a.N = p.N; a.Cin = p.Cin; a.H = p.H; a.W = p.W; a.NTH = p.NTH; a.NTW = p.NTW; a.KI = p.KI; a.relu = relu; a.tiles = p.tiles;
-  // persistent grid: one workgroup per CU (149 KB of LDS each), slot s takes the tiles s, s + G, ...
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-    (void)hipGetLastError();
-    cus = 256;
-  }
+  // persistent grid: one workgroup per CU (155 KB of LDS each), slot s takes the tiles s, s + G, ... (no workgroup waits for another:
+  // the grid size is a performance choice, not a co-residency requirement)
+  const int cus = p.cus;
   const int G = p.tiles < cus ? p.tiles : cus;
   a.dG_w = G % p.NTW; a.dG_h = (G / p.NTW) % p.NTH; a.dG_n = G / (p.NTW * p.NTH);
   a.x_bytes = (unsigned)((size_t)p.N * p.Cin * p.H * p.W * sizeof(float));

@@ -25,7 +25,7 @@ def gemm_rows(path):
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
             n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-            if "wgemm_kernel" not in n:
+            if "wgemm_kernel" not in n and "wf2conv_kernel" not in n:      # the plane GEMM, or conv1_2's one-launch Winograd kernel
                 continue
             name = n
             c[r["Counter_Name"]].append(float(r["Counter_Value"]))
