@@ -414,6 +414,7 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="(accepted for old command lines: the f16x3 loop is opt-in now, see --alt)")
     ap.add_argument("--no-robust", action="store_true", help="skip the robustness leg (vgg_like weights: calibration fall-backs, all-direct floor)")
     ap.add_argument("--layers", action="store_true", help="print the per-layer tables (caffe time format) to stderr")
+    ap.add_argument("--dump-steps", action="store_true", help="print the wall time of every timed step to stderr (outlier hunting)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
                     help="multi-GPU exchange: libmscnn_dist's direct ncclAllGather (default), or torch.distributed's all_gather of the "
                          "same device bytes -- the route taken by itself when the direct communicator cannot be set up")
@@ -554,6 +555,12 @@ def main():
         if i == 0:      # the first frame after the weights were loaded: the layers' own Winograd-vs-direct checks ran inside it (untimed)
             numerics = numerics_since(mark)
     stats = {"R": [], "D": []}
+    # (the interpreter's cyclic garbage collector is kept out of the timed loops: a full collection over the modules torch imports
+    # takes ~40 ms and showed up as ONE 40 - 55 ms step around the 144th final-stage call of a batched stream -- tools/sessions/r05_s23.sh;
+    # it is the harness's, not the library's)
+    import gc
+    gc.collect()
+    gc.disable()
     sync()
     step_s = []
     pipe["on"] = can_pipeline
@@ -566,6 +573,9 @@ def main():
     pipe["on"] = False
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if args.dump_steps and rank == 0:
+        print("step_ms: " + " ".join(f"{1e3 * v:.2f}" for v in step_s), file=sys.stderr)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
