@@ -25,6 +25,24 @@
 
 namespace {
 
+// The transform kernels' one-touch streams as nontemporal accesses (bit-identical results).  WINO_NT bits (development A/B, make
+// wino_nt_<bits>): 1 = M loads of the plain F(4x4,3x3) output transform, 2 = M loads of the chained output -> input kernel whatever M's
+// size (the product decides by size at launch), 4 = its V stores.  Measured (tools/sessions/r05_s28.sh / r05_s29.sh,
+// profiles/r05_ab_nontemporal.txt): bit 1 helps everywhere (conv2_2 63 -> 56 us), bit 4 hurts everywhere.
+#ifndef WINO_NT
+#define WINO_NT 1
+#endif
+template <int BIT>
+__device__ __forceinline__ float ld_stream(const float* p) {
+  if constexpr ((WINO_NT & BIT) != 0) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int BIT>
+__device__ __forceinline__ void st_stream(float* p, float v) {
+  if constexpr ((WINO_NT & BIT) != 0) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
                                                           int BM, int CK, int MT, int KI) {
   const long img_stride = (long)MT * KI * CK * BM;
@@ -691,7 +709,7 @@ __global__ __launch_bounds__(256) void wino44_output_vec_kernel(const float* __r
     for (int j = 0; j < 6; ++j) {
       float col[6], o[4];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) col[i] = src[(i * 6 + j) * plane_stride];
+      for (int i = 0; i < 6; ++i) col[i] = ld_stream<1>(src + (i * 6 + j) * plane_stride);
       wino_f4::at6(col, o);
 #pragma unroll
       for (int i = 0; i < 4; ++i) r[i][j] = o[i];
@@ -757,7 +775,7 @@ __global__ __launch_bounds__(256) void wino44_output_vec_kernel(const float* __r
 // S strips x RW tile rows per step = the waves of a workgroup: the strips of one tile row belong to ONE workgroup, so that a row of V
 // (and of M) is touched as one contiguous run by one CU -- with the strips spread over workgroups (which land on different XCDs) the
 // 240-byte runs shared their cache lines across L2s and the kernel fell to 3.5 TB/s on the 240-column maps.
-template <int S, int RW, int RING>
+template <int S, int RW, int RING, int NTM>
 __global__ __launch_bounds__(64 * S * RW) void wino44_outin_kernel(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ y,
                                                            float* __restrict__ V, int N, int C, int H, int W, int tiles_h, int tiles_w,
                                                            int T_pad_m, int T_pad_v, int relu, int strip_w, int sgroups,
@@ -786,8 +804,16 @@ __global__ __launch_bounds__(64 * S * RW) void wino44_outin_kernel(const float* 
   auto load_m = [&](int q) {
     if (q <= r1 && q >= 0 && q < tiles_h && colq) {
       const float* src = M + (long)c * T_pad_m + ((long)n * tiles_h + q) * tiles_w + jq;
+      // (M larger than the Infinity Cache -- conv2_1's 318 MB -- is read nontemporally: 134 -> 119 us; planes that fit -- conv3 / conv4:
+      // 160 / 82 MB, still cached from the GEMM that wrote them -- are not: 61 -> 64, 33 -> 36 us.  profiles/r05_ab_nontemporal.txt)
+      // (a compile-time choice: with a run-time flag the optimiser merged the two loads into a plain one)
+      if constexpr (NTM != 0 || (WINO_NT & 2) != 0) {
 #pragma unroll
-      for (int e = 0; e < 36; ++e) m[e] = src[e * stride_m];
+        for (int e = 0; e < 36; ++e) m[e] = __builtin_nontemporal_load(src + e * stride_m);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 36; ++e) m[e] = src[e * stride_m];
+      }
     }
   };
   load_m(r0 - 1 + w);
@@ -864,7 +890,7 @@ __global__ __launch_bounds__(64 * S * RW) void wino44_outin_kernel(const float* 
         float o[6];
         wino_f4::bt6(r[i], o);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * stride_v] = o[j];
+        for (int j = 0; j < 6; ++j) st_stream<4>(dst + (i * 6 + j) * stride_v, o[j]);
       }
     }
     __syncthreads();
@@ -968,12 +994,15 @@ int wino44_output_into_input(const float* M, const float* bias, float* y, float*
   }
   const int chunks = cdiv(tiles_h, chunk_rows);
   const dim3 grid(sgroups * chunks * N, C);
-#define MSCNN_OUTIN(S_, RW_, RING_) wino44_outin_kernel<S_, RW_, RING_><<<grid, 64 * S_ * RW_, 0, st>>>(M, bias, y, V, N, C, H, W, tiles_h, tiles_w, T_pad_m, T_pad_v, relu, strip_w, sgroups, chunks, chunk_rows, amax)
+  const int nt_m = 36.0 * C * (double)T_pad_m * 4.0 > 200.0e6 ? 1 : 0;      // M does not fit the 256 MB Infinity Cache: stream it past the caches
+#define MSCNN_OUTIN_(S_, RW_, RING_, NT_) wino44_outin_kernel<S_, RW_, RING_, NT_><<<grid, 64 * S_ * RW_, 0, st>>>(M, bias, y, V, N, C, H, W, tiles_h, tiles_w, T_pad_m, T_pad_v, relu, strip_w, sgroups, chunks, chunk_rows, amax)
+#define MSCNN_OUTIN(S_, RW_, RING_) do { if (nt_m) MSCNN_OUTIN_(S_, RW_, RING_, 1); else MSCNN_OUTIN_(S_, RW_, RING_, 0); } while (0)
   if (S == 1) MSCNN_OUTIN(1, 4, 8);
   else if (S == 2) MSCNN_OUTIN(2, 2, 4);
   else if (S == 3) MSCNN_OUTIN(3, 2, 4);
   else MSCNN_OUTIN(4, 2, 4);
 #undef MSCNN_OUTIN
+#undef MSCNN_OUTIN_
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }
