@@ -699,17 +699,13 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
   if constexpr (C::PUBLISH) { if (a.amax_out) mscnn::publish_amax(am, a.amax_out, blockIdx.x); }
 }
 
-// Sums the partial slabs of every tile that was split across workgroups, in k order (deterministic), + bias + ReLU.
-// FIX_SPLIT workgroups per tile, each owning 4096 consecutive slab elements (16 per thread, float4 loads); the list of
-// contributing slabs is resolved once per workgroup (the 64-bit range arithmetic is kept out of the element loop).
-template <class C>
-__global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
-  __shared__ const float* s_slab[256];   // a tile has at most KI contributors; the plan refuses KI > 256 (plan_shape)
-  __shared__ int s_n;
-  const int tr = blockIdx.x / C::FIX_SPLIT, part = blockIdx.x % C::FIX_SPLIT;   // tr: index among the stream-K tiles
-  const int t = a.full_q * a.G + tr;
+// The contributors of stream-K tile `tr` (k order), resolved by the whole workgroup: thread 0 finds the first and the last
+// contributing workgroup, thread i the range of workgroup gf + i -- two 64-bit divisions each, which one thread looping over the list
+// had turned into microseconds of serial latency (r5).  s_slab[i] == nullptr: workgroup gf + i has an empty range (G > iterations).
+// Returns the length of the list; 0: one workgroup computed the whole tile.  s_hdr: two ints of LDS.
+__device__ __forceinline__ int slab_list(const IgemmArgs& a, int tr, int slab_elems, const float** s_slab, int* s_hdr) {
+  const long its = (long)tr * a.KI, ite = its + a.KI;
   if (threadIdx.x == 0) {
-    const long its = (long)tr * a.KI, ite = its + a.KI;
     int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
     long b, e;
     wg_range(a.total_iters, a.G, gf, b, e);
@@ -718,19 +714,32 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
     wg_range(a.total_iters, a.G, gl, b, e);
     while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
     while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
-    int n = 0;
-    if (gf != gl) {           // gf == gl: the tile was computed whole by one workgroup and is already in y
-      for (int g = gf; g <= gl && n < 256; ++g) {
-        wg_range(a.total_iters, a.G, g, b, e);
-        if (e <= b) continue;   // empty range: this workgroup contributed nothing
-        s_slab[n++] = a.ws + ((long)g * kSlabsPerWg + (b > its ? 0 : 1)) * (C::BM * C::BN);
-      }
-    }
-    s_n = n;
+    s_hdr[0] = gf;
+    s_hdr[1] = gf == gl ? 0 : min(gl - gf + 1, 256);
   }
   __syncthreads();
-  const int n = s_n;
-  if (n == 0) return;
+  const int n = s_hdr[1];
+  if ((int)threadIdx.x < n) {
+    const int g = s_hdr[0] + threadIdx.x;
+    long b, e;
+    wg_range(a.total_iters, a.G, g, b, e);
+    s_slab[threadIdx.x] = e <= b ? nullptr : a.ws + ((long)g * kSlabsPerWg + (b > its ? 0 : 1)) * slab_elems;
+  }
+  __syncthreads();
+  return n;
+}
+
+// Sums the partial slabs of every tile that was split across workgroups, in k order (deterministic), + bias + ReLU.
+// FIX_SPLIT workgroups per tile, each owning 4096 consecutive slab elements (16 per thread, float4 loads); the list of
+// contributing slabs is resolved once per workgroup (the 64-bit range arithmetic is kept out of the element loop).
+template <class C>
+__global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
+  __shared__ const float* s_slab[256];   // a tile has at most KI contributors; the plan refuses KI > 256 (plan_shape)
+  __shared__ int s_n[2];
+  const int tr = blockIdx.x / C::FIX_SPLIT, part = blockIdx.x % C::FIX_SPLIT;   // tr: index among the stream-K tiles
+  const int t = a.full_q * a.G + tr;
+  const int n = slab_list(a, tr, C::BM * C::BN, s_slab, s_n);
+  if (n == 0) return;       // the tile was computed whole by one workgroup and is already in y
   const int mt = a.nt_major ? t % a.MT : t / a.NT;
   const int nt = a.nt_major ? t / a.MT : t % a.NT;
   TileGeo<C> geo;
@@ -742,9 +751,16 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
   for (int j = 0; j < 4; ++j) {
     const int i = part * 4096 + (j * 256 + threadIdx.x) * 4;     // 4 consecutive pixels of one output channel row
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < n; ++s) {
-      const float4 u = *reinterpret_cast<const float4*>(s_slab[s] + i);
-      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    for (int s = 0; s < n; s += 4) {                       // four loads in flight, the additions in k order
+      float4 u[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const float* sl = s + d < n ? s_slab[s + d] : nullptr;
+        u[d] = sl ? *reinterpret_cast<const float4*>(sl + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        if (s + d < n && s_slab[s + d]) { v.x += u[d].x; v.y += u[d].y; v.z += u[d].z; v.w += u[d].w; }
     }
     const int m = i / C::BN, p = i % C::BN;
     const int co = mt * C::BM + m;
@@ -768,31 +784,10 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
 template <class C>
 __global__ __launch_bounds__(256) void igemm_fixup_pool_kernel(IgemmArgs a) {
   __shared__ const float* s_slab[256];
-  __shared__ int s_n;
+  __shared__ int s_n[2];
   const int tr = blockIdx.x / C::FIX_SPLIT, part = blockIdx.x % C::FIX_SPLIT;
   const int t = a.full_q * a.G + tr;
-  if (threadIdx.x == 0) {
-    const long its = (long)tr * a.KI, ite = its + a.KI;
-    int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
-    long b, e;
-    wg_range(a.total_iters, a.G, gf, b, e);
-    while (e <= its) { ++gf; wg_range(a.total_iters, a.G, gf, b, e); }
-    while (b > its) { --gf; wg_range(a.total_iters, a.G, gf, b, e); }
-    wg_range(a.total_iters, a.G, gl, b, e);
-    while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
-    while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
-    int n = 0;
-    if (gf != gl) {
-      for (int g = gf; g <= gl && n < 256; ++g) {
-        wg_range(a.total_iters, a.G, g, b, e);
-        if (e <= b) continue;
-        s_slab[n++] = a.ws + ((long)g * kSlabsPerWg + (b > its ? 0 : 1)) * (C::BM * C::BN);
-      }
-    }
-    s_n = n;
-  }
-  __syncthreads();
-  const int n = s_n;
+  const int n = slab_list(a, tr, C::BM * C::BN, s_slab, s_n);
   if (n == 0) return;      // computed whole by one workgroup: y and the pooled output are already written
   if constexpr (C::CAN_POOL) {
     const int mt = a.nt_major ? t % a.MT : t / a.NT;
@@ -812,6 +807,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_pool_kernel(IgemmArgs a) {
       const int i0 = m * C::BN + (2 * prow) * C::TW + 2 * pcol;
       float2 u0 = make_float2(0.f, 0.f), u1 = make_float2(0.f, 0.f);
       for (int s = 0; s < n; ++s) {
+        if (!s_slab[s]) continue;
         const float2 w0 = *reinterpret_cast<const float2*>(s_slab[s] + i0);
         const float2 w1 = *reinterpret_cast<const float2*>(s_slab[s] + i0 + C::TW);
         u0.x += w0.x; u0.y += w0.y; u1.x += w1.x; u1.y += w1.y;

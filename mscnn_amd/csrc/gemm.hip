@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {      // (min
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmArgs a) {
   __shared__ const float* s_slab[64];
-  __shared__ int s_n;
+  __shared__ int s_gf, s_n;
   const int t = blockIdx.x >> 2, part = blockIdx.x & 3;    // 4 workgroups per 128x128 tile
+  const long its = (long)t * a.KI, ite = its + a.KI;
   if (threadIdx.x == 0) {
-    const long its = (long)t * a.KI, ite = its + a.KI;
     int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
     long b, e;
     wg_range(a.total_iters, a.G, gf, b, e);
@@ -148,17 +148,19 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(GemmArgs a) {
     wg_range(a.total_iters, a.G, gl, b, e);
     while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
     while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
-    int n = 0;
-    if (gf != gl)
-      for (int g = gf; g <= gl && n < 64; ++g) {
-        wg_range(a.total_iters, a.G, g, b, e);
-        s_slab[n++] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * (BM * BN);
-      }
-    s_n = n;
+    s_gf = gf;
+    s_n = gf == gl ? 0 : min(gl - gf + 1, 64);
   }
   __syncthreads();
   const int n = s_n;
   if (n == 0) return;
+  if ((int)threadIdx.x < n) {      // the list is built by n threads at once: a range is two 64-bit divisions (r5)
+    const int g = s_gf + threadIdx.x;
+    long b, e;
+    wg_range(a.total_iters, a.G, g, b, e);
+    s_slab[threadIdx.x] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * (BM * BN);
+  }
+  __syncthreads();
   const int nt = t / a.MT, mt = t % a.MT;
   const int m0 = mt * BM, n0 = nt * BN;
 #pragma unroll

@@ -244,15 +244,23 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs a) {
   }
 }
 
-// Adds the partial slabs of every tile that was split across workgroups, in k order, + bias (+ ReLU).
-// One workgroup per (tile, output channel): 512 pixels, a float2 per thread, slab loads four deep.
+// Adds the partial slabs of every tile that was split across workgroups + bias (+ ReLU).  One workgroup per (tile, output channel,
+// quarter of the tile = 4 rows x 32 columns); its 256 threads are 8 slab groups x 32 float4 lanes: group s adds the s-th eighth of the
+// tile's contributor list in k order, eight loads in flight, and the eight partial sums are added in group order through LDS -- a
+// fixed order, so the result is reproducible bit for bit, and a list of 256 contributors is four rounds of loads instead of sixty-four.
+// The contributor list is built by the whole workgroup (thread i <-> workgroup gf + i: its range is two 64-bit divisions, which ONE
+// thread looping over 32 ... 256 contributors had turned into 5 ... 60 us of serial latency in the round-4 kernel).
 template <class C>
 __global__ __launch_bounds__(256) void head_fixup_kernel(HeadArgs a) {
   __shared__ const float* s_slab[256];
-  __shared__ int s_n;
-  const int t = blockIdx.x / a.Cout, co = blockIdx.x % a.Cout;
+  __shared__ __attribute__((aligned(16))) float s_part[8][128];
+  __shared__ int s_gf, s_n;
+  const int quarter = blockIdx.x & 3, tc = blockIdx.x >> 2;
+  const int t = tc / a.Cout, co = tc % a.Cout;
+  const int tw = t % a.NTW, th = (t / a.NTW) % a.NTH, img = t / (a.NTW * a.NTH);
+  if (th * C::TH + quarter * 4 >= a.Ho) return;              // the whole quarter lies below the map
+  const long its = (long)t * a.KI, ite = its + a.KI;
   if (threadIdx.x == 0) {
-    const long its = (long)t * a.KI, ite = its + a.KI;
     int gf = (int)(its * a.G / a.total_iters), gl = (int)((ite - 1) * a.G / a.total_iters);
     long b, e;
     wg_range(a.total_iters, a.G, gf, b, e);
@@ -261,44 +269,46 @@ __global__ __launch_bounds__(256) void head_fixup_kernel(HeadArgs a) {
     wg_range(a.total_iters, a.G, gl, b, e);
     while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
     while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
-    int n = 0;
-    if (gf != gl) {           // gf == gl: computed whole by one workgroup, already in y
-      for (int g = gf; g <= gl && n < 256; ++g) {
-        wg_range(a.total_iters, a.G, g, b, e);
-        if (e <= b) continue;
-        s_slab[n++] = a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * C::SLAB + co * C::BN;
-      }
-    }
-    s_n = n;
+    s_gf = gf;
+    s_n = gf == gl ? 0 : min(gl - gf + 1, 256);           // gf == gl: computed whole by one workgroup, already in y
   }
   __syncthreads();
   const int n = s_n;
   if (n == 0) return;
-  const int tw = t % a.NTW, th = (t / a.NTW) % a.NTH, img = t / (a.NTW * a.NTH);
-  const int co_stride = a.Ho * a.Wo;
-  const int p = threadIdx.x * 2;
-  float2 v = make_float2(0.f, 0.f);
-  int s = 0;
-  for (; s + 4 <= n; s += 4) {
-    const float2 u0 = *reinterpret_cast<const float2*>(s_slab[s] + p), u1 = *reinterpret_cast<const float2*>(s_slab[s + 1] + p);
-    const float2 u2 = *reinterpret_cast<const float2*>(s_slab[s + 2] + p), u3 = *reinterpret_cast<const float2*>(s_slab[s + 3] + p);
-    v.x += u0.x; v.y += u0.y;
-    v.x += u1.x; v.y += u1.y;
-    v.x += u2.x; v.y += u2.y;
-    v.x += u3.x; v.y += u3.y;
+  if ((int)threadIdx.x < n) {
+    const int g = s_gf + threadIdx.x;
+    long b, e;
+    wg_range(a.total_iters, a.G, g, b, e);
+    s_slab[threadIdx.x] = e <= b ? nullptr : a.ws + ((long)g * 2 + (b > its ? 0 : 1)) * C::SLAB + co * C::BN;   // (an empty range: G > iterations)
   }
-  for (; s < n; ++s) {
-    const float2 u = *reinterpret_cast<const float2*>(s_slab[s] + p);
-    v.x += u.x; v.y += u.y;
+  __syncthreads();
+  const int sg = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const int p = quarter * 128 + l * 4;
+  const int s0 = sg * n / 8, s1 = (sg + 1) * n / 8;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int D = 8;
+  for (int s = s0; s < s1; s += D) {
+    float4 u[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float* sl = s + j < s1 ? s_slab[s + j] : nullptr;
+      u[j] = sl ? *reinterpret_cast<const float4*>(sl + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (s + j < s1 && s_slab[s + j]) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
   }
-  const float bv = a.bias ? a.bias[co] : 0.f;
-  const int oh = th * C::TH + p / C::TW, ow = tw * C::TW + p % C::TW;
-  if (oh >= a.Ho) return;
-  float* yrow = a.y + ((long)img * a.Cout + co) * co_stride + oh * a.Wo;
-  float r0 = v.x + bv, r1 = v.y + bv;
-  if (a.relu) { r0 = r0 < 0.f ? 0.f : r0; r1 = r1 < 0.f ? 0.f : r1; }
-  if (ow < a.Wo) yrow[ow] = r0;
-  if (ow + 1 < a.Wo) yrow[ow + 1] = r1;
+  *reinterpret_cast<float4*>(&s_part[sg][l * 4]) = v;
+  __syncthreads();
+  if (threadIdx.x >= 128) return;
+  const int px = threadIdx.x;
+  float r = s_part[0][px];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) r += s_part[j][px];
+  r += a.bias ? a.bias[co] : 0.f;
+  if (a.relu) r = r < 0.f ? 0.f : r;
+  const int oh = th * C::TH + quarter * 4 + px / C::TW, ow = tw * C::TW + px % C::TW;
+  if (oh < a.Ho && ow < a.Wo) a.y[((long)img * a.Cout + co) * a.Ho * a.Wo + oh * a.Wo + ow] = r;
 }
 
 typedef void (*HeadFn)(HeadArgs);
@@ -315,8 +325,13 @@ const HeadEntry kHeads[] = {
     HENTRY(5, 3, 2, 8), HENTRY(7, 5, 2, 4),      // ped/cyc (7) and caltech (6): "3x5" = kernel_w 3 x kernel_h 5
     HENTRY(5, 5, 2, 8), HENTRY(7, 7, 2, 4),
     HENTRY(5, 3, 3, 8), HENTRY(7, 5, 3, 4),
+    // the same eight with half the channels per chunk (entry + kHalf): twice the (tile, chunk) units on maps of a few tiles
+    HENTRY(5, 5, 3, 4), HENTRY(7, 7, 3, 2),
+    HENTRY(5, 3, 2, 4), HENTRY(7, 5, 2, 2),
+    HENTRY(5, 5, 2, 4), HENTRY(7, 7, 2, 2),
+    HENTRY(5, 3, 3, 4), HENTRY(7, 5, 3, 2),
 };
-constexpr int kHeadsN = sizeof(kHeads) / sizeof(kHeads[0]);
+constexpr int kHalf = 8;
 
 }  // namespace
 
@@ -335,18 +350,27 @@ bool head_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp) {
   if (off || d.stride_h != 1 || d.stride_w != 1 || d.group != 1 || d.N == 0 || d.Cout > 12 || d.Cin > 1024) return false;
   if ((double)d.Cin * d.H * d.W * 4.0 >= 2.0e9 || (double)d.Cout * Ho * Wo * 4.0 >= 2.0e9) return false;
   const int nq = d.Cout <= 8 ? 2 : 3;
-  for (int i = 0; i < kHeadsN; ++i)
+  for (int i = 0; i < kHalf; ++i)
     if (kHeads[i].KH == d.Kh && kHeads[i].KW == d.Kw && kHeads[i].NQ == nq) hp->entry = i;
   if (hp->entry < 0) return false;
-  const HeadEntry& k = kHeads[hp->entry];
   hp->NTH = cdiv(Ho, 16);
   hp->NTW = cdiv(Wo, 32);
-  hp->KI = cdiv(d.Cin, k.CK);       // <= 256 contributors per tile (fix-up slab list)
   const long tiles = (long)d.N * hp->NTH * hp->NTW;
+  // Maps of a few tiles (the 36 x 120 / 18 x 60 / 9 x 30 levels of the 7s nets: 12 / 4 / 1 tiles) are latency chains, not
+  // throughput: half chunks double the units the split can hand out (a unit is 3.7 us of MFMAs instead of 7.3), one unit per
+  // workgroup while that still is one workgroup per CU.  Measured per level (r5, tools/sessions/r05_s40.sh): -2 ... -7 us.
+  // tune_variant 500 / 501: full / half chunks whatever the map.
+  const int variant = tune_env("MSCNN_TUNE_VARIANT", d.tune_variant);
+  const bool half = (variant == 501 || (variant != 500 && tiles <= 16)) && cdiv(d.Cin, kHeads[hp->entry + kHalf].CK) <= 256;
+  if (half) hp->entry += kHalf;
+  const HeadEntry& k = kHeads[hp->entry];
+  hp->KI = cdiv(d.Cin, k.CK);       // <= 256 contributors per tile (fix-up slab list)
   hp->total_iters = tiles * hp->KI;
   const int genv = tune_env("MSCNN_TUNE_GRID", d.tune_grid);   // tuning knob
-  long G = genv > 0 ? genv : 512;
-  if (hp->total_iters / 2 < G) G = hp->total_iters / 2;      // at least ~2 chunks per workgroup
+  long G;
+  if (genv > 0) G = genv < hp->total_iters ? genv : hp->total_iters;
+  else if (half) G = hp->total_iters <= 256 ? hp->total_iters : (hp->total_iters / 2 < 256 ? 256 : hp->total_iters / 2 > 512 ? 512 : hp->total_iters / 2);
+  else G = hp->total_iters / 2 < 512 ? hp->total_iters / 2 : 512;      // at least ~2 chunks per workgroup
   if (G < 1) G = 1;
   hp->G = (int)G;
   hp->tiles = (int)tiles;
@@ -391,7 +415,7 @@ int head_forward(const mscnn_conv_desc& d, const HeadPlan& hp, int Ho, int Wo, c
   a.NTH = hp.NTH; a.NTW = hp.NTW; a.KI = hp.KI; a.G = hp.G; a.relu = d.relu; a.total_iters = hp.total_iters;
   k.main_fn<<<hp.G, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
-  k.fix_fn<<<hp.tiles * d.Cout, 256, 0, st>>>(a);
+  k.fix_fn<<<hp.tiles * d.Cout * 4, 256, 0, st>>>(a);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

@@ -836,10 +836,17 @@ void BoxOutputLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, cons
   CHECK_GT(wbytes, 0u) << mscnn_last_error();
   void* ws = workspace_.Reserve(wbytes);
   cap_ = mscnn_boxoutput_max_rows(&d);
-  float* rois = static_cast<float*>(rois_.Reserve((size_t)cap_ * 5 * sizeof(float)));
-  float* props = static_cast<float*>(props_.Reserve((size_t)cap_ * 6 * sizeof(float)));
+  // the kernels write the tops themselves: the blobs are sized for the layer's row bound first (Blob::Reshape keeps the larger
+  // allocation) and cut to R rows below -- the two D2D copies behind the host round trip are gone (r5)
+  top[0]->Reshape(cap_, 5, 1, 1);
+  float* rois = top[0]->mutable_gpu_data();
+  float* props = nullptr;
+  if (output_proposal_with_score_) {
+    top[1]->Reshape(cap_, 6, 1, 1);
+    props = top[1]->mutable_gpu_data();
+  }
   int* count = static_cast<int*>(count_.Reserve(2 * sizeof(int)));
-  MSCNN_CHECK(mscnn_boxoutput_fwd_f32(&d, heads, rois, output_proposal_with_score_ ? props : nullptr, nullptr, cap_, count, ws, wbytes, S()));
+  MSCNN_CHECK(mscnn_boxoutput_fwd_f32(&d, heads, rois, props, nullptr, cap_, count, ws, wbytes, S()));
   // The only host round trip of the layer: R (4 bytes) is needed to Reshape the tops (layer.hpp:451-456 propagates it
   // to ROIPooling and the detection sub-net).  The reference moves all 7 head blobs D2H and the ROIs H2D here.
   int host_count[2];
@@ -849,11 +856,7 @@ void BoxOutputLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, cons
   CHECK_GE(R, 1); CHECK_LE(R, cap_);
   last_rows_ = R;
   top[0]->Reshape(R, 5, 1, 1);
-  HIP_CHECK(hipMemcpyAsync(top[0]->mutable_gpu_data(), rois, sizeof(float) * 5 * R, hipMemcpyDeviceToDevice, (hipStream_t)S()));
-  if (output_proposal_with_score_) {
-    top[1]->Reshape(R, 6, 1, 1);
-    HIP_CHECK(hipMemcpyAsync(top[1]->mutable_gpu_data(), props, sizeof(float) * 6 * R, hipMemcpyDeviceToDevice, (hipStream_t)S()));
-  }
+  if (output_proposal_with_score_) top[1]->Reshape(R, 6, 1, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ DecodeBBox

@@ -151,18 +151,21 @@ def test_conv_c3_bit_identical_to_the_igemm_kernel(hip, orc, case):
 @pytest.mark.parametrize("case", [(1, 512, 72, 240, 9, (5, 5), (2, 2)), (1, 512, 36, 120, 9, (7, 7), (3, 3)), (1, 512, 18, 60, 9, (5, 5), (2, 2)),
                                   (1, 512, 9, 30, 9, (7, 7), (3, 3)), (2, 96, 40, 70, 6, (5, 3), (2, 1)), (3, 64, 20, 33, 12, (5, 5), (2, 2))])
 @pytest.mark.parametrize("flags,name", [(0, "head4x4")])
-def test_conv_head_stream_k_is_deterministic(hip, orc, case, flags, name):
+@pytest.mark.parametrize("tune", [(0, 0), (500, 0), (501, 0), (500, 1 << 20), (501, 1 << 20)], ids=["auto", "full-chunks", "half-chunks", "full+one-per-wg", "half+one-per-wg"])
+def test_conv_head_stream_k_is_deterministic(hip, orc, case, flags, name, tune):
     """(The packed-FMA variant of the same split, tools/micro/headvalu.hip, left the product library in round 5: `make witness`.)
     The M = 4 head kernel splits its few tiles stream-K style and a fix-up launch adds the partial sums in k order: against the
     oracle (reference tolerance 1e-4) at the full-size head shapes of the 7s nets, bit-identical over 20 back-to-back launches,
     and exactly doubled after re-packing doubled weights.  (Round 3 tried the combine inside the launch -- last arrival reduces --
-    and measured it slower; this test is what it had to pass.)"""
+    and measured it slower; this test is what it had to pass.)  `tune`: the split itself -- full / half-size channel chunks
+    whatever the map (tune_variant 500 / 501; AUTO takes half chunks on maps of <= 16 tiles) and as many workgroups as there are
+    (tile, chunk) units (tune_grid, clamped to them): up to 256 contributors per tile through the fix-up's list."""
     N, Cin, H, W, Cout, k, pad = case
     rng = np.random.default_rng(99)
     x = np.maximum(rng.standard_normal((N, Cin, H, W)), 0).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, *k)) * np.sqrt(2.0 / (Cin * k[0] * k[1]))).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
-    p = hip.ConvPlan(N, Cin, H, W, Cout, k[0], k[1], pad, tune_flags=flags)
+    p = hip.ConvPlan(N, Cin, H, W, Cout, k[0], k[1], pad, tune_flags=flags, tune_variant=tune[0], tune_grid=tune[1])
     assert p.kernel.startswith(name)
     p.pack(dev(w))
     xd, bd = dev(x), dev(b)
