@@ -419,7 +419,20 @@ struct EmitArgs {
   float* props;
   int* aids;
   int cap, image, max_post;
+  int* count_out;      // the call's last image on the one-workgroup path: the scan kernel also does boxoutput_finish_kernel's work (r5)
 };
+
+// rows == 0: the reference's dummy row (box_output_layer.cpp:195-199, :214-218); count_out = {rows of the tops, real rows}
+__device__ __forceinline__ void boxoutput_finish(int rows, float* rois, float* props, int* aids, int* count_out) {
+  if (rows <= 0) {
+    rois[0] = 0; rois[1] = 1; rois[2] = 1; rois[3] = 10; rois[4] = 10;
+    if (props) for (int k = 0; k < 6; ++k) props[k] = 0.f;
+    if (aids) aids[0] = -1;
+    count_out[0] = 1; count_out[1] = 0;
+  } else {
+    count_out[0] = rows; count_out[1] = rows;
+  }
+}
 
 __global__ __launch_bounds__(256) void nms_scan_emit_kernel(const u64* __restrict__ mask, int wpr, int W, EmitArgs e,
                                                             int* __restrict__ cnt) {
@@ -430,7 +443,10 @@ __global__ __launch_bounds__(256) void nms_scan_emit_kernel(const u64* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   BO_STAMP(8);
   const int n = cnt[CNT_K];
-  if (n <= 0) return;
+  if (n <= 0) {
+    if (e.count_out && tid == 0) boxoutput_finish(cnt[CNT_ROWS], e.rois, e.props, e.aids, e.count_out);
+    return;
+  }
   const u64 mykeep = greedy_scan(mask, n, wpr, W, dyn_lds);
   BO_STAMP(9);
   if (wave == 0) {
@@ -468,7 +484,10 @@ __global__ __launch_bounds__(256) void nms_scan_emit_kernel(const u64* __restric
   }
   __syncthreads();
   BO_STAMP(10);
-  if (tid == 0) { cnt[CNT_ROWS] = row0 + kept_total; cnt[CNT_CAND] = 0; }
+  if (tid == 0) {
+    cnt[CNT_ROWS] = row0 + kept_total; cnt[CNT_CAND] = 0;
+    if (e.count_out) boxoutput_finish(row0 + kept_total, e.rois, e.props, e.aids, e.count_out);
+  }
 }
 
 // ---- large path (nms_large.h) ----------------------------------------------------------------------------------------------
@@ -526,15 +545,7 @@ __global__ __launch_bounds__(256) void big_keep_bytes_kernel(const int* __restri
 }
 
 __global__ void boxoutput_finish_kernel(int* __restrict__ cnt, float* rois, float* props, int* aids, int* count_out) {
-  const int rows = cnt[CNT_ROWS];
-  if (rows <= 0) {   // box_output_layer.cpp:195-199, :214-218
-    rois[0] = 0; rois[1] = 1; rois[2] = 1; rois[3] = 10; rois[4] = 10;
-    if (props) for (int k = 0; k < 6; ++k) props[k] = 0.f;
-    if (aids) aids[0] = -1;
-    count_out[0] = 1; count_out[1] = 0;
-  } else {
-    count_out[0] = rows; count_out[1] = rows;
-  }
+  boxoutput_finish(cnt[CNT_ROWS], rois, props, aids, count_out);
 }
 
 // stand-alone NMS (parity tests): keep_out bytes
@@ -683,7 +694,7 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
       MSCNN_HIP_TRY((big_nms_tiles<RoiTr>(sbox, cnt + CNT_K, 0, kcap, RoiTr::Params{thr, mode}, mask,
                                           reinterpret_cast<u64*>(ws + L.rinit), reinterpret_cast<int*>(ws + L.kidx),
                                           reinterpret_cast<float4*>(ws + L.kbox), cnt + CNT_BIG, launch_mask, st)));
-      EmitArgs eb{sbox, sscore, said, rois_out, props_out, anchor_ids_out, cap, img, d->max_post_nms_num};
+      EmitArgs eb{sbox, sscore, said, rois_out, props_out, anchor_ids_out, cap, img, d->max_post_nms_num, nullptr};
       big_emit_kernel<<<1, 256, 0, st>>>(eb, reinterpret_cast<const int*>(ws + L.kidx), cnt);
       MSCNN_POST_LAUNCH();
       continue;
@@ -692,12 +703,15 @@ extern "C" int mscnn_boxoutput_fwd_f32(const mscnn_boxoutput_desc* d, const floa
     MSCNN_POST_LAUNCH();
     nms_mask_kernel<<<dim3(kblocks, kblocks), 256, 0, st>>>(sbox, cnt + CNT_K, 0, d->iou_thr, d->nms_mode, mask, L.wpr);
     MSCNN_POST_LAUNCH();
-    EmitArgs e{sbox, sscore, said, rois_out, props_out, anchor_ids_out, cap, img, d->max_post_nms_num};
+    EmitArgs e{sbox, sscore, said, rois_out, props_out, anchor_ids_out, cap, img, d->max_post_nms_num,
+               img == d->num - 1 ? count_out_dev : nullptr};
     nms_scan_emit_kernel<<<1, 256, (size_t)2 * 64 * kblocks * sizeof(u64), st>>>(mask, L.wpr, kblocks, e, cnt);
     MSCNN_POST_LAUNCH();
   }
-  boxoutput_finish_kernel<<<1, 1, 0, st>>>(cnt, rois_out, props_out, anchor_ids_out, count_out_dev);
-  MSCNN_POST_LAUNCH();
+  if (L.big || d->num <= 0) {          // (the one-workgroup path finished in its last scan kernel)
+    boxoutput_finish_kernel<<<1, 1, 0, st>>>(cnt, rois_out, props_out, anchor_ids_out, count_out_dev);
+    MSCNN_POST_LAUNCH();
+  }
   return MSCNN_OK;
 }
 

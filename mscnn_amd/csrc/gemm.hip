@@ -307,18 +307,21 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(GemmArgs a) {
 // Small-N path (cls_pred N = 5, bbox_pred N = 20, K = 4096): one workgroup per row m.  The row of x is held in registers
 // (K / 256 values per thread), every output n is a register dot product + wave reduction, the 4 wave partials of all N
 // outputs are combined after ONE barrier.  W (N x K) is re-read by every workgroup out of L2.
-constexpr int kRowMaxN = 64, kRowMaxKPerThread = 16, kRowsPerBlock = 4;
+constexpr int kRowMaxN = 64, kRowMaxKPerThread = 16;
 // NB = outputs handled per pass, a compile-time bound: the NB dot products and their wave reductions are unrolled, so the 6-step
 // shuffle chains of different outputs interleave instead of running one after the other (bbox_pred, N = 20: 42 -> see
 // profiles/r03_layers_*.txt); the order of the additions inside one output is unchanged (bit-identical results).
-template <int NB>
+// kRowsPerBlock rows share every load of W (4; the 8-row instantiation is the A/B witness of round 5: with W's line requests halved
+// it is SLOWER -- bbox_pred 14.5 against 9.9 us back to back, 35 against 24 us inside the net, profiles/r05_ab_ip_rows.txt -- the
+// kernel is bound by its dependent chains per workgroup, not by W; mscnn_debug_inner_product_rows selects it).
+template <int NB, int kRowsPerBlock>
 __global__ __launch_bounds__(256) void ip_rowwise_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int M, int N,
                                                          int K, int relu) {
   __shared__ float red[kRowsPerBlock][4][kRowMaxN];
   const int m0 = blockIdx.x * kRowsPerBlock;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float xv[kRowsPerBlock][kRowMaxKPerThread];          // kRowsPerBlock rows share every load of W
+  float xv[kRowsPerBlock][kRowMaxKPerThread];
 #pragma unroll
   for (int r = 0; r < kRowsPerBlock; ++r)
 #pragma unroll
@@ -447,6 +450,10 @@ extern "C" int mscnn_inner_product_fwd_f16(const float* x, const void* w16, cons
   return inner_product_gemm(x, w16, true, bias, y, M, N, K, relu, as_stream(stream));
 }
 
+static int g_ip_rows = 0;
+// dev / test knob: rows per workgroup of the small-N kernel (8; anything else = the default 4).  The per-row arithmetic does not depend on it.
+extern "C" void mscnn_debug_inner_product_rows(int rows) { g_ip_rows = rows == 4 || rows == 8 ? rows : 0; }
+
 extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
                                            int relu, void* stream) {
   MSCNN_REQUIRE(M >= 0 && N > 0 && K > 0, "inner_product: bad shape M=%d N=%d K=%d", M, N, K);
@@ -456,8 +463,14 @@ extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const
   const bool aligned = (K % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(w) % 16 == 0);
   if (N < 64 || !aligned) {
     if (N <= kRowMaxN && K <= 256 * kRowMaxKPerThread) {
-      if (N <= 5) ip_rowwise_kernel<5><<<cdiv(M, kRowsPerBlock), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
-      else ip_rowwise_kernel<4><<<cdiv(M, kRowsPerBlock), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+      const bool r8 = g_ip_rows == 8;
+      if (N <= 5) {
+        if (r8) ip_rowwise_kernel<5, 8><<<cdiv(M, 8), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+        else ip_rowwise_kernel<5, 4><<<cdiv(M, 4), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+      } else {
+        if (r8) ip_rowwise_kernel<4, 8><<<cdiv(M, 8), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+        else ip_rowwise_kernel<4, 4><<<cdiv(M, 4), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
+      }
     } else {
       ip_generic_kernel<<<dim3(M, N < 64 ? N : 64), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
     }

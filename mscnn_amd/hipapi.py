@@ -86,6 +86,8 @@ def lib():
         L.mscnn_wgemm_force_whole_tiles.restype = None
         L.mscnn_wgemm_force_whole_tiles.argtypes = [C.c_int]
         L.mscnn_wgemm_whole_tiles_forced.argtypes = []
+        L.mscnn_debug_inner_product_rows.restype = None
+        L.mscnn_debug_inner_product_rows.argtypes = [C.c_int]
         L.mscnn_debug_wgemm_handoff_fault.restype = None
         L.mscnn_debug_wgemm_handoff_fault.argtypes = [C.c_int, C.c_uint]
         L.mscnn_inner_product_pack_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -611,3 +613,8 @@ def wgemm_whole_tiles_forced():
 def debug_wgemm_handoff_fault(drop_publish=False, spin_limit=0):
     """Fault injection for the tests: contributors never publish their partial sums; finishers give up after spin_limit polls."""
     lib().mscnn_debug_wgemm_handoff_fault(int(bool(drop_publish)), int(spin_limit))
+
+
+def debug_inner_product_rows(rows=0):
+    """Rows of x per workgroup of the small-N InnerProduct kernel: 8, anything else = the default 4 -- tests and A/B runs."""
+    lib().mscnn_debug_inner_product_rows(int(rows))

@@ -1012,7 +1012,8 @@ def test_inner_product_x3(hip, orc, M, N, K):
 
 # ------------------------------------------------------------------ inner product
 @pytest.mark.parametrize("M,N,K", [(1, 5, 64), (7, 20, 4096), (3, 128, 256), (130, 192, 1000), (257, 4096, 800), (1, 4096, 12800),
-                                   (3, 10, 9000), (5, 70, 33), (700, 20, 4096), (150, 512, 260), (700, 320, 1000)])
+                                   (3, 10, 9000), (5, 70, 33), (700, 20, 4096), (150, 512, 260), (700, 320, 1000), (676, 2, 4096), (676, 8, 4096),
+                                   (513, 5, 1000)])
 def test_inner_product(hip, orc, M, N, K):
     rng = np.random.default_rng(6)
     x = rng.standard_normal((M, K)).astype(np.float32)
@@ -1020,6 +1021,28 @@ def test_inner_product(hip, orc, M, N, K):
     b = rng.standard_normal(N).astype(np.float32)
     close(hip.inner_product(dev(x), dev(w), dev(b)).cpu().numpy(), orc.inner_product(x, w, b))
     close(hip.inner_product(dev(x), dev(w), None, relu=True).cpu().numpy(), orc.relu(orc.inner_product(x, w, None)))
+
+
+@pytest.mark.parametrize("M,N,K", [(676, 8, 4096), (676, 2, 4096), (515, 20, 1000), (9, 5, 4096)])
+def test_inner_product_small_n_rows_per_workgroup(hip, M, N, K):
+    """cls_pred / bbox_pred (N = classes / 4 x classes outputs over fc6's 4096): the kernel keeps 4 rows of x in registers per workgroup;
+    the 8-row instantiation (mscnn_debug_inner_product_rows, the witness of a round-5 A/B that it lost) computes the same bits: a row's
+    arithmetic does not depend on how many rows share the workgroup, ragged last workgroup included."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.relu(torch.randn((M, K), device="cuda", generator=g))
+    w = torch.randn((N, K), device="cuda", generator=g) * (2.0 / K) ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    try:
+        hip.debug_inner_product_rows(4)
+        y4 = hip.inner_product(x, w, b).clone()
+        hip.debug_inner_product_rows(8)
+        y8 = hip.inner_product(x, w, b).clone()
+    finally:
+        hip.debug_inner_product_rows(0)
+    ya = hip.inner_product(x, w, b)
+    assert torch.equal(y4, y8) and torch.equal(ya, y4)
+    ref = (x.double() @ w.double().T + b.double()).float()
+    assert float((ya - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("M,N,K", [(696, 4096, 12800), (193, 256, 64), (250, 384, 1024), (1000, 2048, 3200), (257, 4096, 800), (700, 256, 32)])
