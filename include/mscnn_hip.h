@@ -180,8 +180,8 @@ MSCNN_API int mscnn_pool2d_fwd_f32(const float* x, float* y, int N, int C, int H
  * y[M,N] = x[M,K] * w[N,K]^T + bias[N]  (transpose_ = false), optional fused ReLU. */
 MSCNN_API int mscnn_inner_product_fwd_f32(const float* x, const float* w, const float* bias, float* y,
                                 int M, int N, int K, int relu, void* stream);
-/* dev / test knob of the small-N kernel behind it (cls_pred / bbox_pred): rows of x per workgroup, 8 instead of the default 4 (anything
- * else: 4).  Measured slower (profiles/r05_ab_ip_rows.txt); kept as the witness of that A/B.  The per-row arithmetic is the same. */
+/* dev / test knob of the small-N kernel behind it (cls_pred / bbox_pred): rows of x per workgroup, 2, 4 or 8 (0 = the default: 4 for
+ * N <= 5, else 2 -- fewer rows measured faster, profiles/r05_ab_ip_rows.txt).  The per-row arithmetic is the same in every form. */
 MSCNN_API void mscnn_debug_inner_product_rows(int rows);
 
 /* The same InnerProduct (fp32, exact MFMA fmaf chains) on the plane-GEMM kernel of the Winograd layers (wgemm.hip: LDS-DMA operand ring,

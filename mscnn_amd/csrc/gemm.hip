@@ -311,9 +311,9 @@ constexpr int kRowMaxN = 64, kRowMaxKPerThread = 16;
 // NB = outputs handled per pass, a compile-time bound: the NB dot products and their wave reductions are unrolled, so the 6-step
 // shuffle chains of different outputs interleave instead of running one after the other (bbox_pred, N = 20: 42 -> see
 // profiles/r03_layers_*.txt); the order of the additions inside one output is unchanged (bit-identical results).
-// kRowsPerBlock rows share every load of W (4; the 8-row instantiation is the A/B witness of round 5: with W's line requests halved
-// it is SLOWER -- bbox_pred 14.5 against 9.9 us back to back, 35 against 24 us inside the net, profiles/r05_ab_ip_rows.txt -- the
-// kernel is bound by its dependent chains per workgroup, not by W; mscnn_debug_inner_product_rows selects it).
+// kRowsPerBlock rows share every load of W.  More rows per workgroup = fewer line requests for W, and measured SLOWER (r5,
+// profiles/r05_ab_ip_rows.txt: bbox_pred inside the net 19.3 / 24.0 / 35.2 us at 2 / 4 / 8 rows): the kernel is bound by the dependent
+// chain of one workgroup, not by W.  mscnn_debug_inner_product_rows picks the instantiation (tests: all of them bit-identical).
 template <int NB, int kRowsPerBlock>
 __global__ __launch_bounds__(256) void ip_rowwise_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int M, int N,
@@ -451,8 +451,8 @@ extern "C" int mscnn_inner_product_fwd_f16(const float* x, const void* w16, cons
 }
 
 static int g_ip_rows = 0;
-// dev / test knob: rows per workgroup of the small-N kernel (8; anything else = the default 4).  The per-row arithmetic does not depend on it.
-extern "C" void mscnn_debug_inner_product_rows(int rows) { g_ip_rows = rows == 4 || rows == 8 ? rows : 0; }
+// dev / test knob: rows per workgroup of the small-N kernel (2, 4 or 8; 0 = the default: 4 for N <= 5, else 2).  The per-row arithmetic does not depend on it.
+extern "C" void mscnn_debug_inner_product_rows(int rows) { g_ip_rows = rows == 2 || rows == 4 || rows == 8 ? rows : 0; }
 
 extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
                                            int relu, void* stream) {
@@ -463,14 +463,14 @@ extern "C" int mscnn_inner_product_fwd_f32(const float* x, const float* w, const
   const bool aligned = (K % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(w) % 16 == 0);
   if (N < 64 || !aligned) {
     if (N <= kRowMaxN && K <= 256 * kRowMaxKPerThread) {
-      const bool r8 = g_ip_rows == 8;
-      if (N <= 5) {
-        if (r8) ip_rowwise_kernel<5, 8><<<cdiv(M, 8), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
-        else ip_rowwise_kernel<5, 4><<<cdiv(M, 4), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
-      } else {
-        if (r8) ip_rowwise_kernel<4, 8><<<cdiv(M, 8), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
-        else ip_rowwise_kernel<4, 4><<<cdiv(M, 4), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
-      }
+      // N <= 5 (cls_pred): 4 rows, one pass of 5 outputs.  N > 5 (bbox_pred): 2 rows and 8 outputs per pass -- the kernel is a
+      // latency chain per workgroup (x loads -> per pass: W loads -> FMAs -> 6 shuffle steps), so shorter chains on more workgroups
+      // win: bbox_pred inside the net 24.0 (4 rows) -> 19.3 us (2 rows), 35.2 at 8 rows (profiles/r05_ab_ip_rows.txt).
+      const int rows = g_ip_rows ? g_ip_rows : (N <= 5 ? 4 : 2);
+#define MSCNN_IP_ROWWISE(NB_, R_) ip_rowwise_kernel<NB_, R_><<<cdiv(M, R_), 256, 0, st>>>(x, w, bias, y, M, N, K, relu)
+      if (N <= 5) { if (rows == 8) MSCNN_IP_ROWWISE(5, 8); else if (rows == 2) MSCNN_IP_ROWWISE(5, 2); else MSCNN_IP_ROWWISE(5, 4); }
+      else { if (rows == 8) MSCNN_IP_ROWWISE(4, 8); else if (rows == 2) MSCNN_IP_ROWWISE(8, 2); else MSCNN_IP_ROWWISE(4, 4); }
+#undef MSCNN_IP_ROWWISE
     } else {
       ip_generic_kernel<<<dim3(M, N < 64 ? N : 64), 256, 0, st>>>(x, w, bias, y, M, N, K, relu);
     }

@@ -616,5 +616,5 @@ def debug_wgemm_handoff_fault(drop_publish=False, spin_limit=0):
 
 
 def debug_inner_product_rows(rows=0):
-    """Rows of x per workgroup of the small-N InnerProduct kernel: 8, anything else = the default 4 -- tests and A/B runs."""
+    """Rows of x per workgroup of the small-N InnerProduct kernel: 2, 4 or 8; 0 = the default (4 for N <= 5, else 2) -- tests and A/B runs."""
     lib().mscnn_debug_inner_product_rows(int(rows))

@@ -1025,14 +1025,16 @@ def test_inner_product(hip, orc, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(676, 8, 4096), (676, 2, 4096), (515, 20, 1000), (9, 5, 4096)])
 def test_inner_product_small_n_rows_per_workgroup(hip, M, N, K):
-    """cls_pred / bbox_pred (N = classes / 4 x classes outputs over fc6's 4096): the kernel keeps 4 rows of x in registers per workgroup;
-    the 8-row instantiation (mscnn_debug_inner_product_rows, the witness of a round-5 A/B that it lost) computes the same bits: a row's
-    arithmetic does not depend on how many rows share the workgroup, ragged last workgroup included."""
+    """cls_pred / bbox_pred (N = classes / 4 x classes outputs over fc6's 4096): the kernel keeps 2 / 4 / 8 rows of x in registers per
+    workgroup and does 4, 5 or 8 outputs per pass (mscnn_debug_inner_product_rows; the default is what measured fastest in round 5).
+    A row's arithmetic does not depend on either: every form computes the same bits, ragged last workgroup included."""
     g = torch.Generator(device="cuda").manual_seed(M + N)
     x = torch.relu(torch.randn((M, K), device="cuda", generator=g))
     w = torch.randn((N, K), device="cuda", generator=g) * (2.0 / K) ** 0.5
     b = torch.randn(N, device="cuda", generator=g)
     try:
+        hip.debug_inner_product_rows(2)
+        y2 = hip.inner_product(x, w, b).clone()
         hip.debug_inner_product_rows(4)
         y4 = hip.inner_product(x, w, b).clone()
         hip.debug_inner_product_rows(8)
@@ -1040,6 +1042,7 @@ def test_inner_product_small_n_rows_per_workgroup(hip, M, N, K):
     finally:
         hip.debug_inner_product_rows(0)
     ya = hip.inner_product(x, w, b)
+    assert torch.equal(y2, y4)
     assert torch.equal(y4, y8) and torch.equal(ya, y4)
     ref = (x.double() @ w.double().T + b.double()).float()
     assert float((ya - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))

@@ -10,9 +10,9 @@ for M, N, K in [(676, 8, 4096), (676, 2, 4096), (300, 8, 4096), (1352, 8, 4096),
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.relu(torch.randn((M, K), device="cuda", generator=g)); w = torch.randn((N, K), device="cuda", generator=g) * 0.02
     b = torch.randn(N, device="cuda", generator=g)
-    res = {4: 0.0, 8: 0.0}
+    res = {2: 0.0, 4: 0.0, 8: 0.0}
     for rnd in range(4):
-        for rows in (4, 8):
+        for rows in (2, 4, 8):
             hip.debug_inner_product_rows(rows)
             for _ in range(10):
                 hip.inner_product(x, w, b)
@@ -23,4 +23,4 @@ for M, N, K in [(676, 8, 4096), (676, 2, 4096), (300, 8, 4096), (1352, 8, 4096),
             e1.record(); torch.cuda.synchronize()
             res[rows] += e0.elapsed_time(e1) / 200 / 4 * 1e3
     hip.debug_inner_product_rows(0)
-    print(f"M={M} N={N} K={K}:  4 rows/wg {res[4]:6.1f} us   8 rows/wg {res[8]:6.1f} us", flush=True)
+    print(f"M={M} N={N} K={K}:  2 rows/wg {res[2]:6.1f} us   4 rows/wg {res[4]:6.1f} us   8 rows/wg {res[8]:6.1f} us", flush=True)
