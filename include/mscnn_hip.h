@@ -104,7 +104,7 @@ typedef struct {
    * kernel's columns folded into M (KH x 1 convolution with KW * Cout channels + shift-and-add), bit 11 = a Cin = 3 layer (conv1_1) on the MFMA igemm kernel instead of its VALU kernel, bit 12 = F(4x4,3x3) input transform with one tile per lane instead of two, bit 15 = a 3x3 / pad 1 layer with 64 output channels on whole 4 x 128 tiles (conv1_2) stays on the igemm kernel instead of the ring kernel of wconv.hip (bit-identical for whole tiles; A/B, second witness), bit 16 = (round 5) a 3x3 / pad 1 layer with 64 output channels on a full-resolution map (conv1_2: whole 8 x 32 blocks, >= 512 of them) stays on the direct ring kernel of wconv.hip instead of the one-launch Winograd F(2x2,3x3) kernel of wf2conv.hip that AUTO takes there (A/B, the direct witness; tune_variant 403 also plans smaller maps on it: tests), bit 14 = inverts the wave priority of the direct MFMA kernel's tile epilogue (raised by default on the 64 x 256 3x3 tile = conv1_2 only), bit 13 = (witness build only, `make -C mscnn_amd/csrc witness`; ignored by the product library) proposal heads on the packed-FMA kernel of tools/micro/headvalu.hip instead of the M = 4 MFMA kernel (headconv.hip); tune_variant with WINO_F3_X3: 1 = 128-row, 2 = 256-row GEMM tiles;
    * tune_variant 300 + v with a Winograd algo: wgemm tile variant v (1: 256 x 128, 2: 128 x 256, 3: 128 x 128, 4: 256 x 96, 5: 256 x 160; + 256 forces the
    * stream-K split, + 512 whole tiles).  Proposal heads (headconv.hip, round 5): tune_variant 500 / 501 = full / half channel chunks
-   * whatever the map (AUTO: half chunks on maps of <= 16 tiles of 16 x 32 pixels); tune_grid > 0 = that many workgroups, clamped to the
+   * whatever the map (AUTO: half chunks on maps of <= 16 tiles of 16 x 32 pixels and for the 5-row kernels everywhere); tune_grid > 0 = that many workgroups, clamped to the
    * number of (tile, chunk) units. */
   int tune_variant, tune_grid, tune_flags;
 } mscnn_conv_desc;

@@ -356,12 +356,15 @@ bool head_plan(const mscnn_conv_desc& d, int Ho, int Wo, HeadPlan* hp) {
   hp->NTH = cdiv(Ho, 16);
   hp->NTW = cdiv(Wo, 32);
   const long tiles = (long)d.N * hp->NTH * hp->NTW;
-  // Maps of a few tiles (the 36 x 120 / 18 x 60 / 9 x 30 levels of the 7s nets: 12 / 4 / 1 tiles) are latency chains, not
-  // throughput: half chunks double the units the split can hand out (a unit is 3.7 us of MFMAs instead of 7.3), one unit per
-  // workgroup while that still is one workgroup per CU.  Measured per level (r5, tools/sessions/r05_s40.sh): -2 ... -7 us.
+  // Half chunks double the (tile, chunk) units the split can hand out (a unit is 3.7 us of MFMAs instead of 7.3):
+  //  * maps of a few tiles (the 36 x 120 / 18 x 60 / 9 x 30 levels of the 7s nets: 12 / 4 / 1 tiles) are latency chains, not
+  //    throughput: one unit per workgroup while that still is one workgroup per CU.  Measured per level (r5,
+  //    tools/sessions/r05_s40.sh / r05_s41.sh): -3 ... -4 us on the 5x5 heads, +- 0 on the 7x7 ones;
+  //  * the 8-channel-chunk kernels (5x5, 5x3) also on large maps: LFCN_1_5x5 (40 tiles) 84.6 - 86.1 -> 80.7 - 81.9 us (r05_s46.sh).
   // tune_variant 500 / 501: full / half chunks whatever the map.
   const int variant = tune_env("MSCNN_TUNE_VARIANT", d.tune_variant);
-  const bool half = (variant == 501 || (variant != 500 && tiles <= 16)) && cdiv(d.Cin, kHeads[hp->entry + kHalf].CK) <= 256;
+  const bool half = (variant == 501 || (variant != 500 && (tiles <= 16 || kHeads[hp->entry].CK == 8))) &&
+                    cdiv(d.Cin, kHeads[hp->entry + kHalf].CK) <= 256;
   if (half) hp->entry += kHalf;
   const HeadEntry& k = kHeads[hp->entry];
   hp->KI = cdiv(d.Cin, k.CK);       // <= 256 contributors per tile (fix-up slab list)
