@@ -18,7 +18,10 @@
 //     the patch [CK][16+KH-1][32+KW-1] and the chunk's packed weights wp[chunk][quad][reg][lane] are staged through
 //     registers into LDS (prefetched one chunk ahead); each wave then copies the weights LDS -> VGPRs once per chunk;
 //   * tiles are few (72x240 -> 40 tiles), so the (tile, chunk) space is cut stream-K style into G equal ranges;
-//     partial sums go to fp32 slabs and a fix-up kernel adds them in k order (deterministic) + bias.
+//     partial sums go to fp32 slabs and a fix-up kernel adds them in a fixed order (deterministic) + bias.  (r5) The fix-up is
+//     wide -- a workgroup per (tile quarter, channel), 8 slab groups adding in parallel, the contributor list built by the whole
+//     workgroup: 4 us instead of 11 - 18 --, so the split is fine: the 5-row kernels run chunks of 4 channels (the 7-row ones of 2
+//     on maps of <= 16 tiles), see head_plan.
 // Useful-work fraction: Cout / (4 * NQ) = 75 % for the 9-channel KITTI heads (vs 28 % with M = 32).
 // Measured (conv4_3 heads 5x5 / 7x7, 1 x 512 x 72 x 240): 81 / 140 us against 136 / 231 us for the 32-row igemm tile.
 // PMC (rocprofv3, 5x5 head): 12.29 M MFMAs, SQ_VALU_MFMA_BUSY_CYCLES = 8 cycles each, 57 % of the kernel's cycles at
