@@ -228,3 +228,39 @@ def test_f4_plan_plumbing_without_a_device():
     variant = lambda cin, h, w, cout: ((L.mscnn_conv2d_plan_weight_layout(hip.ConvPlan(1, cin, h, w, cout, 3, 3, (1, 1), device="cpu")._p) >> 8) & 0xffff) - 200      # noqa: E731
     assert variant(512, 36, 120, 512) == 2 and variant(512, 72, 240, 512) == 2 and variant(512, 18, 60, 512) == 1      # conv6_1: too few 256-row tiles for the chip -> 128 x 128
     assert variant(128, 288, 960, 128) == 1 and variant(512, 48, 160, 512) == 2
+
+
+def test_proposal_head_split_rule_through_the_plan():
+    """The split of the proposal-head kernels (headconv.hip: head_plan) as the C ABI shows it without a GPU: the packed-weight size is
+    KI x quads x registers x 64 lanes (so it names the channel chunk), the workspace is G workgroups x 2 slabs.  Round 5: the 5-row
+    kernels run chunks of 4 channels on every map, the 7-row ones chunks of 2 on maps of <= 16 tiles (16 x 32 pixels) and of 4 above;
+    one unit per workgroup up to 256 units, then half as many workgroups as units, at most 512; tune_variant 500 / 501 force full /
+    half chunks, tune_grid the workgroups (clamped to the units).  A batch change that moves a 7-row head across the 16-tile line
+    changes the weight layout id (the binding re-packs)."""
+    pytest.importorskip("torch")
+    from mscnn_amd import hipapi as hip
+    L = hip.lib()
+
+    def plan(N, H, W, k, cout=9, **kw):
+        p = hip.ConvPlan(N, 512, H, W, cout, k, k, (k // 2, k // 2), device="cpu", **kw)
+        return p.kernel, L.mscnn_conv2d_packed_weight_bytes(p._p), L.mscnn_conv2d_workspace_bytes(p._p), L.mscnn_conv2d_plan_weight_layout(p._p)
+
+    def packed(ck, taps, quads):
+        return (512 // ck) * quads * ((ck * taps + 15) // 16) * 64 * 4
+
+    def ws(G, quads):
+        return G * 2 * (quads * 4 * 512) * 4
+
+    for H, W, G in [(9, 30, 128), (18, 60, 256), (36, 120, 512), (72, 240, 512)]:        # 1 / 4 / 12 / 40 tiles, 128 units each
+        name, pb, wb, _ = plan(1, H, W, 5)
+        assert name == "head4x4_k5x5_m3x4" and pb == packed(4, 25, 3) and wb == ws(G, 3), (H, W)
+    for N, H, W, ck in [(1, 18, 60, 2), (1, 36, 120, 2), (2, 36, 120, 4)]:                 # 4 / 12 / 24 tiles
+        name, pb, wb, _ = plan(N, H, W, 7)
+        assert name == "head4x4_k7x7_m3x4" and pb == packed(ck, 49, 3) and wb == ws(512, 3), (N, H, W)
+    assert plan(1, 36, 120, 7)[3] != plan(2, 36, 120, 7)[3]
+    assert plan(1, 72, 240, 7)[0] == "head_kwfold_shiftadd_f32"                            # KW x Cout = 63: the kw-folded GEMM form
+    assert plan(1, 72, 240, 7, cout=7)[:3] == ("head4x4_k7x7_m2x4", packed(4, 49, 2), ws(512, 2))
+    assert plan(1, 72, 240, 7, cout=7, tune_variant=501)[1] == packed(2, 49, 2)
+    assert plan(1, 9, 30, 5, tune_variant=500)[1:3] == (packed(8, 25, 3), ws(32, 3))       # the round-4 split: >= 2 chunks per workgroup
+    assert plan(1, 9, 30, 5, tune_variant=500, tune_grid=1 << 20)[2] == ws(64, 3)
+    assert plan(1, 9, 30, 5, tune_grid=7)[2] == ws(7, 3)
