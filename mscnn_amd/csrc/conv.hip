@@ -700,9 +700,12 @@ __global__ __launch_bounds__(256, C::MIN_WG_PER_CU) void igemm_kernel(IgemmArgs 
 }
 
 // The contributors of stream-K tile `tr` (k order), resolved by the whole workgroup: thread 0 finds the first and the last
-// contributing workgroup, thread i the range of workgroup gf + i -- two 64-bit divisions each, which one thread looping over the list
-// had turned into microseconds of serial latency (r5).  s_slab[i] == nullptr: workgroup gf + i has an empty range (G > iterations).
-// Returns the length of the list; 0: one workgroup computed the whole tile.  s_hdr: two ints of LDS.
+// contributing workgroup, then the span gf .. gl is walked 256 workgroups at a time, thread i looking at workgroup gf + r + i -- two
+// 64-bit divisions each, which one thread looping over the list had turned into microseconds of serial latency (r5).  Workgroups with an
+// EMPTY range (fewer stream-K iterations than workgroups: a one- or two-tile remainder on a 512 / 768 grid spreads its KI contributors
+// over the whole grid) are compacted away, so the list holds exactly the non-empty contributors, of which there are at most KI <= 256
+// (plan_shape) however long the span is (r6: the r5 form cut the SPAN at 256 and lost contributors).
+// Returns the length of the list; 0: one workgroup computed the whole tile.  s_hdr: eight ints of LDS.
 __device__ __forceinline__ int slab_list(const IgemmArgs& a, int tr, int slab_elems, const float** s_slab, int* s_hdr) {
   const long its = (long)tr * a.KI, ite = its + a.KI;
   if (threadIdx.x == 0) {
@@ -715,18 +718,31 @@ __device__ __forceinline__ int slab_list(const IgemmArgs& a, int tr, int slab_el
     while (e <= ite - 1) { ++gl; wg_range(a.total_iters, a.G, gl, b, e); }
     while (b > ite - 1) { --gl; wg_range(a.total_iters, a.G, gl, b, e); }
     s_hdr[0] = gf;
-    s_hdr[1] = gf == gl ? 0 : min(gl - gf + 1, 256);
+    s_hdr[1] = gf == gl ? 0 : gl - gf + 1;
   }
   __syncthreads();
-  const int n = s_hdr[1];
-  if ((int)threadIdx.x < n) {
-    const int g = s_hdr[0] + threadIdx.x;
-    long b, e;
-    wg_range(a.total_iters, a.G, g, b, e);
-    s_slab[threadIdx.x] = e <= b ? nullptr : a.ws + ((long)g * kSlabsPerWg + (b > its ? 0 : 1)) * slab_elems;
+  const int gf = s_hdr[0], span = s_hdr[1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int n = 0;
+  for (int r = 0; r < span; r += 256) {
+    const float* ptr = nullptr;
+    if (r + (int)threadIdx.x < span) {
+      const int g = gf + r + threadIdx.x;
+      long b, e;
+      wg_range(a.total_iters, a.G, g, b, e);
+      if (e > b) ptr = a.ws + ((long)g * kSlabsPerWg + (b > its ? 0 : 1)) * slab_elems;
+    }
+    const unsigned long long m = __ballot(ptr != nullptr);
+    if (lane == 0) s_hdr[2 + wave] = __popcll(m);
+    __syncthreads();
+    int off = n;
+    for (int w = 0; w < wave; ++w) off += s_hdr[2 + w];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    if (ptr && off < 256) s_slab[off] = ptr;
+    n += s_hdr[2] + s_hdr[3] + s_hdr[4] + s_hdr[5];
+    __syncthreads();
   }
-  __syncthreads();
-  return n;
+  return min(n, 256);
 }
 
 // Sums the partial slabs of every tile that was split across workgroups, in k order (deterministic), + bias + ReLU.
@@ -735,7 +751,7 @@ __device__ __forceinline__ int slab_list(const IgemmArgs& a, int tr, int slab_el
 template <class C>
 __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
   __shared__ const float* s_slab[256];   // a tile has at most KI contributors; the plan refuses KI > 256 (plan_shape)
-  __shared__ int s_n[2];
+  __shared__ int s_n[8];
   const int tr = blockIdx.x / C::FIX_SPLIT, part = blockIdx.x % C::FIX_SPLIT;   // tr: index among the stream-K tiles
   const int t = a.full_q * a.G + tr;
   const int n = slab_list(a, tr, C::BM * C::BN, s_slab, s_n);
@@ -784,7 +800,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(IgemmArgs a) {
 template <class C>
 __global__ __launch_bounds__(256) void igemm_fixup_pool_kernel(IgemmArgs a) {
   __shared__ const float* s_slab[256];
-  __shared__ int s_n[2];
+  __shared__ int s_n[8];
   const int tr = blockIdx.x / C::FIX_SPLIT, part = blockIdx.x % C::FIX_SPLIT;
   const int t = a.full_q * a.G + tr;
   const int n = slab_list(a, tr, C::BM * C::BN, s_slab, s_n);

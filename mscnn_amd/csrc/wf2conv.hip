@@ -9,7 +9,7 @@
 // EVERYTHING a workgroup needs fits on a CU: the transformed filters of an 8-channel chunk are 32 KB, and the 16 plane products of a
 // 64-channel x 64-tile block are 256 KB of fp32 accumulators = half the CU's vector registers.  So one workgroup does the whole
 // algorithm for an 8 x 32 block of output pixels:
-//     per 8-channel chunk:  x patch (10 x 34 per channel) -> LDS;  V = B^T d B per (channel, tile) on the vector ALU -> LDS;
+//     per 8-channel chunk:  x patch (10 x 34 per channel, fetched as 10 x 40: 16-byte LDS-DMA lanes) -> LDS;  V = B^T d B per (channel, tile) on the vector ALU -> LDS;
 //                           M[p] += U[p] (64 x 8) x V[p] (8 x 64) for the 16 planes p on v_mfma_f32_16x16x4_f32
 //     after the last chunk: y = A^T M A + bias, ReLU, the 2x2 tile IS one pooling window: max -> the pooled map
 // and HBM sees x once (x 1.33 for the halo), the filters from L2, and y / the pooled map once.  Executed MFMA work: 2 x 16 x 64 x 64
@@ -19,7 +19,9 @@
 //   * tile = 4 x 16 Winograd tiles (n = row * 16 + column), 64 output channels; wave (ch, tr) owns channels 32 ch .. + 31 (two 16-row
 //     MFMA blocks) x the 16 tiles of tile row tr, for all 16 planes: 16 x 2 accumulators of 4 registers = 128 VGPRs per lane;
 //   * LDS: two stages of {U chunk [k 8][xi 4][cout 64][nu 4], V chunk [k 8][xi 4][tile 64][nu 4]} (32 KB each) + two patch buffers
-//     (8 x 10 x 34 floats): 149 KB.  The four nu of one (k, xi, row) are ONE ds_read_b128: 3 reads feed 8 MFMAs;
+//     (8 channels x 10 rows x 40 columns -- the 34 needed widened to aligned float4s -- in whole 1 KB LDS-DMA pieces: 13 KB each) + the
+//     DMA dump and the biases: ~156 KB of the CU's 160 (the static_asserts below).  The four nu of one (k, xi, row) are ONE
+//     ds_read_b128: 3 reads feed 8 MFMAs;
 //   * per chunk c, between two barriers: global loads of U chunk c + 1 and patch c + 2 are issued, patch c + 1 is transformed into
 //     the other V stage, the 64 MFMAs per wave of chunk c run, the loaded registers are written to LDS.  One barrier per chunk.
 // Numerics: F(2x2,3x3) with the standard points {0, 1, -1, inf} (B^T, G, A^T below): the mildest of the Winograd forms used here
@@ -53,8 +55,8 @@ constexpr int PR = 2 * TR + 2, PC = 2 * TC + 8;        // input patch per channe
                                                        // whole aligned float4s (w0 - 4 .. w0 + 35): the patch travels as 16-byte LDS-DMA lanes
 constexpr int PC4 = PC / 4, PX = 3;                    // float4s per row; column of w0 - 1 inside a row
 constexpr int CK = 8;                                  // channels per chunk
-constexpr int U_FLOATS = CK * 16 * 64, V_FLOATS = CK * 16 * NT, P_FLOATS = CK * PR * PC;      // 8192, 8192, 2720
-constexpr int P_STRIDE = (P_FLOATS + 255) / 256 * 256;   // a patch buffer holds whole 1 KB LDS-DMA pieces: 3328 floats (the last piece's tail is zeros)
+constexpr int U_FLOATS = CK * 16 * 64, V_FLOATS = CK * 16 * NT, P_FLOATS = CK * PR * PC;      // 8192, 8192, 3200
+constexpr int P_STRIDE = (P_FLOATS + 255) / 256 * 256;   // a patch buffer holds whole 1 KB LDS-DMA pieces: 13 x 256 = 3328 floats (the last piece's tail is never read)
 constexpr int LDS_FLOATS = 2 * U_FLOATS + 2 * V_FLOATS + 2 * P_STRIDE;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 
@@ -120,8 +122,9 @@ __global__ __launch_bounds__(512, 2) void wf2conv_kernel(Wf2Args a) {
   if (total == 0) return;
   const __amdgpu_buffer_rsrc_t rU = make_rsrc(a.up, (unsigned)(a.KI * U_FLOATS * 4)), rX = make_rsrc(a.x, a.x_bytes);
 
-  // ---- producer: LDS-DMA of the transformed filters (4 pieces of 1 KB per wave and unit) and of the input patch (6 slots of 256 B)
-  // this lane's patch elements in its wave's slots: element e = (wave + 8 j) * 64 + lane of [k][10][34], packed k << 16 | r << 8 | c
+  // ---- producer: LDS-DMA of the transformed filters (4 pieces of 1 KB per wave and unit) and of the input patch (13 pieces of 1 KB =
+  // 64 lanes x 16 bytes each, two slots per wave: wave w moves pieces w and w + 8, the slot of a piece >= 13 is aimed at the dump)
+  // this lane's float4 in slot j: number f = (wave + 8 j) * 64 + lane of the patch [k 8][r 10][c4 10]; vP[j] = its byte offset in x
   unsigned vP[P_SLOTS];
 #pragma unroll
   for (int j = 0; j < P_SLOTS; ++j) vP[j] = kOob;

@@ -174,6 +174,7 @@ class Net {
   unsigned long long handoff_seen_ = 0;
   int handoff_errors_ = 0;
   int last_start_ = 0, last_end_ = -1;
+  int suspect_start_ = -1;      // smallest `start` of the ranges run since the last synchronisation point that saw no hand-off event (-1: none)
   long forward_count_ = 0;
   DISABLE_COPY_AND_ASSIGN(Net);
 };

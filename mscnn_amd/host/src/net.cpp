@@ -54,56 +54,57 @@ void UpgradeNetInput(const NetParameter& in, vector<LayerParameter>* layers) {
   for (int i = 0; i < in.layer_size(); ++i) layers->push_back(in.layer(i).Clone());
 }
 
-static string SplitLayerName(const string& layer_name, const string& blob_name, const int blob_idx) {
-  std::ostringstream s;
-  s << blob_name << "_" << layer_name << "_" << blob_idx << "_split";
-  return s.str();
+// Fan-out.  A top that more than one bottom reads gets a Split layer right behind its producer and every reader a copy of its own;
+// the names ("<blob>_<producer>_<top index>_split[_<k>]") are the ones insert_splits.cpp:110-124 composes, because users address blobs
+// by them.  One table of blob VERSIONS (an in-place layer re-issues its bottom's name: the readers after it read the new version);
+// pass 1 counts the readers of each version, pass 2 emits the layers, handing out the copies in reading order.
+namespace {
+struct BlobVersion {
+  int layer, top;      // who wrote it
+  int readers;         // bottoms that read this version
+  int handed_out;      // copies already given to a reader (pass 2)
+};
+string SplitStem(const LayerParameter& producer, int top) {
+  return producer.top(top) + "_" + producer.name() + "_" + std::to_string(top) + "_split";
 }
-static string SplitBlobName(const string& layer_name, const string& blob_name, const int blob_idx, const int split_idx) {
-  std::ostringstream s;
-  s << blob_name << "_" << layer_name << "_" << blob_idx << "_split_" << split_idx;
-  return s.str();
-}
+}  // namespace
 
 void InsertSplits(const vector<LayerParameter>& in, vector<LayerParameter>* out) {
-  out->clear();
-  map<string, pair<int, int> > blob_name_to_last_top_idx;
-  map<pair<int, int>, pair<int, int> > bottom_idx_to_source_top_idx;
-  map<pair<int, int>, int> top_idx_to_bottom_count;
-  map<pair<int, int>, int> top_idx_to_bottom_split_idx;
+  vector<BlobVersion> versions;
+  map<string, int> newest;                           // blob name -> index of its newest version
+  vector<vector<int> > reads(in.size());             // reads[i][j]: the version bottom j of layer i reads
+  vector<int> first_top(in.size() + 1, 0);           // versions [first_top[i], first_top[i + 1]) are layer i's tops
   for (size_t i = 0; i < in.size(); ++i) {
-    const LayerParameter& lp = in[i];
-    for (int j = 0; j < lp.bottom_size(); ++j) {
-      const string& blob_name = lp.bottom(j);
-      CHECK(blob_name_to_last_top_idx.count(blob_name)) << "Unknown bottom blob '" << blob_name << "' (layer '" << lp.name() << "', bottom index " << j << ")";
-      const pair<int, int> top_idx = blob_name_to_last_top_idx[blob_name];
-      bottom_idx_to_source_top_idx[make_pair((int)i, j)] = top_idx;
-      ++top_idx_to_bottom_count[top_idx];
+    for (int j = 0; j < in[i].bottom_size(); ++j) {
+      const map<string, int>::const_iterator it = newest.find(in[i].bottom(j));
+      CHECK(it != newest.end()) << "Unknown bottom blob '" << in[i].bottom(j) << "' (layer '" << in[i].name() << "', bottom index " << j << ")";
+      reads[i].push_back(it->second);
+      ++versions[it->second].readers;
     }
-    for (int j = 0; j < lp.top_size(); ++j) blob_name_to_last_top_idx[lp.top(j)] = make_pair((int)i, j);
+    first_top[i] = (int)versions.size();
+    for (int j = 0; j < in[i].top_size(); ++j) {
+      newest[in[i].top(j)] = (int)versions.size();
+      versions.push_back(BlobVersion{(int)i, j, 0, 0});
+    }
   }
+  first_top[in.size()] = (int)versions.size();
+  out->clear();
   for (size_t i = 0; i < in.size(); ++i) {
     LayerParameter lp = in[i].Clone();
     for (int j = 0; j < lp.bottom_size(); ++j) {
-      const pair<int, int> top_idx = bottom_idx_to_source_top_idx[make_pair((int)i, j)];
-      if (top_idx_to_bottom_count[top_idx] > 1) {
-        const string layer_name = in[top_idx.first].name();
-        const string blob_name = lp.bottom(j);
-        lp.set_bottom(j, SplitBlobName(layer_name, blob_name, top_idx.second, top_idx_to_bottom_split_idx[top_idx]++));
-      }
+      BlobVersion& v = versions[reads[i][j]];
+      if (v.readers > 1) lp.set_bottom(j, SplitStem(in[v.layer], v.top) + "_" + std::to_string(v.handed_out++));
     }
     out->push_back(lp);
-    for (int j = 0; j < lp.top_size(); ++j) {
-      const pair<int, int> top_idx = make_pair((int)i, j);
-      const int split_count = top_idx_to_bottom_count[top_idx];
-      if (split_count > 1) {
-        LayerParameter sp;
-        sp.add_bottom(lp.top(j));
-        sp.set_name(SplitLayerName(lp.name(), lp.top(j), j));
-        sp.set_type("Split");
-        for (int k = 0; k < split_count; ++k) sp.add_top(SplitBlobName(lp.name(), lp.top(j), j, k));
-        out->push_back(sp);
-      }
+    for (int vi = first_top[i]; vi < first_top[i + 1]; ++vi) {
+      const BlobVersion& v = versions[vi];
+      if (v.readers < 2) continue;
+      LayerParameter sp;
+      sp.set_type("Split");
+      sp.set_name(SplitStem(in[i], v.top));
+      sp.add_bottom(in[i].top(v.top));
+      for (int k = 0; k < v.readers; ++k) sp.add_top(sp.name() + "_" + std::to_string(k));
+      out->push_back(sp);
     }
   }
 }
@@ -548,10 +549,16 @@ bool Net<Dtype>::HandoffEventPending() {
   return true;
 }
 
+// Called where the caller has just synchronised the stream.  No event: everything this net launched so far is known good (the ranges run
+// since are forgotten).  An event: EVERY range run since the last known-good point is suspect -- a caller that forwards 0 .. k and then
+// k + 1 .. end and only then synchronises may have the poisoned tile in the first range -- so the re-run goes from the smallest start
+// seen since that point to the end of the last range.
 template <typename Dtype>
 bool Net<Dtype>::HandoffRecover() {
-  if (!HandoffEventPending()) return false;
-  if (last_end_ >= last_start_) ForwardFromTo(last_start_, last_end_);
+  if (!HandoffEventPending()) { suspect_start_ = -1; return false; }
+  const int from = suspect_start_ >= 0 ? suspect_start_ : last_start_, to = last_end_;
+  suspect_start_ = -1;
+  if (to >= from) ForwardFromTo(from, to);
   return true;
 }
 
@@ -559,9 +566,15 @@ template <typename Dtype>
 Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   CHECK_GE(start, 0);
   CHECK_LT(end, (int)layers_.size());
+  if (suspect_start_ < 0) {
+    // nothing of this net is in flight unchecked: hand-off events raised so far belong to other nets on this device (the status word is
+    // per device), not to the frame that begins here
+    handoff_seen_ = mscnn_wgemm_handoff_event();
+    suspect_start_ = start;
+  } else if (start < suspect_start_) suspect_start_ = start;
   last_start_ = start; last_end_ = end;
   ++forward_count_;
-  bool handoff_restarted = false;
+  bool handoff_restart = false;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing_) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
   for (size_t i = 0; i < layers_.size(); ++i)      // (a paired ROIPooling skips only inside the call in which its partner ran)
@@ -658,9 +671,12 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
     // there left NaN tiles whose scores BoxOutput drops without a trace (NaN >= fg_thr is false, box_output_layer.cpp:128): look at
     // the status word now (a plain load of pinned memory) and run the range again on whole tiles (once: nothing is split afterwards;
     // all chains / deferred poolings in front of this layer have completed, so their per-call state is clean).
-    if (!handoff_restarted && std::strcmp(layers_[i]->type(), "BoxOutput") == 0 && HandoffEventPending()) {
-      handoff_restarted = true;
-      i = start - 1;
+    if (std::strcmp(layers_[i]->type(), "BoxOutput") == 0) {
+      if (HandoffEventPending()) {
+        handoff_restart = true;    // leave the loop: the call's own tear-down below, then the whole call again (its set-up included:
+        break;                     // the max |x| slots a NaN tile has already raised are zeroed again, chain / skip marks re-made)
+      }
+      suspect_start_ = i + 1;      // the stream was synchronised and nothing was reported: only what follows is still unchecked
     }
   }
   if (timing_) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
@@ -690,6 +706,13 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   for (size_t i = 0; i < layers_.size(); ++i) {
     if (ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get())) c->set_amax_trusted(false);
     else if (InnerProductLayer<Dtype>* ip = dynamic_cast<InnerProductLayer<Dtype>*>(layers_[i].get())) ip->set_amax_trusted(false);
+  }
+  if (handoff_restart) {
+    // (whole-tile scheduling is forced by now: the second pass cannot raise the event again, so this recursion is one level deep.  The
+    // restart covers every range since the last known-good point, like HandoffRecover)
+    const int from = suspect_start_ >= 0 && suspect_start_ < start ? suspect_start_ : start;
+    --forward_count_;
+    return ForwardFromTo(from, end);
   }
   if (watch_period_ > 0 && start == 0 && end == (int)layers_.size() - 1 && ++watch_frame_ % watch_period_ == 0) NumericsWatchStep();
   return 0;

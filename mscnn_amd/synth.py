@@ -8,6 +8,11 @@ selecting the regime: "dense" (every anchor passes fg_thr: 2000-box sort + NMS w
 import numpy as np
 
 
+# class-0 bias of every proposal head: how many anchors pass fg_thr ("dense" = all of them, "sparse" ~5 %; "mid" in between,
+# more than the top-K)
+HEAD_BIAS = {"dense": -6.0, "mid": 8.2, "sparse": 11.5}
+
+
 def frame(height, width, seed=1701, org_hw=(375, 1242)):
     """uint8-valued RGB frame of org_hw, low-pass filtered noise + a few rectangles, bilinear-resized to (height, width),
     BGR, minus the Caffe mean (104, 117, 123), NCHW float32 (run_mscnn_detection.m:64-69; the resize itself is outside
@@ -81,7 +86,7 @@ def weights(layer_names, layer_types, param_shapes, regime="dense", cls_num=None
             # fg = max(4 classes) - class 0 then has sigma ~2 (target) with the class rows scaled to sigma 1.64.
             w[:ncls] *= 1.14
             w[ncls:] *= 0.13
-            b[0] = {"dense": -6.0, "mid": 8.2, "sparse": 11.5}[regime]
+            b[0] = HEAD_BIAS[regime]
             if style == "vgg_like":      # the features feeding the heads are ~20x hotter in this regime: keep scores / deltas in range
                 w *= {"LFCN_1": 0.05, "LFCN_2": 0.025, "LFCN_3": 0.015, "LFCN_4": 0.015}.get(name[:6], 0.02)
         elif name in ("cls_pred", "bbox_pred"):
@@ -98,3 +103,12 @@ def load_into(net, regime="dense", style="he"):
         for p, arr in enumerate(blobs):
             net.set_param(name, p, arr)
     return ws
+
+
+def set_regime(net, regime):
+    """Switches a net that already holds load_into()'s weights to another regime: only the class-0 bias of the LFCN_* heads differs."""
+    for name, typ in zip(net.layer_names, net.layer_types):
+        if typ == "Convolution" and name.startswith("LFCN_"):
+            b = net.get_param(name, 1)
+            b[0] = HEAD_BIAS[regime]
+            net.set_param(name, 1, b)

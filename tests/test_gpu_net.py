@@ -54,6 +54,7 @@ FULL_SIZE = [
     ("kitti_car/mscnn-7s-576", {}, "mid", 2, (375, 1242)),              # > 2000 anchors pass fg_thr: full top-K sort + NMS (the
                                                                         # "dense" weights select the same 2000, scores shifted)
     ("kitti_car/mscnn-7s-576", {}, "sparse", 2, (375, 1242)),           # fewer candidates than the top-K
+    ("kitti_car/mscnn-7s-576", {}, "dense", 2, (375, 1242)),            # SURVEY 8(d) "dense": all 45,630 anchors pass fg_thr
     ("kitti_car/mscnn-8s-768-trainval", {}, "mid", 2, (375, 1242)),     # 1x3x768x2560, 8 heads, 81,600 anchors
     ("kitti_ped_cyc/mscnn-7s-576-2x", {}, "mid", 2, (375, 1242)),       # deconv 2x, 7x5 ROI pooling, fc6 2048
     ("caltech/mscnn-7s-480", {}, "mid", 2, (480, 640)),
@@ -151,6 +152,17 @@ def _check_net(model, size, regime, cls_id, org_hw, backend, precision, style, c
         j = m.argmax(1)
         matched = (m[np.arange(len(a)), j] >= 0.99) & (np.abs(dets[:, 4] - de[j, 4]) <= 1e-4)
         assert matched.mean() >= 0.98, f"only {matched.mean():.3f} of {len(a)} detections matched"
+        # north star: "fp32 scores / boxes within 1e-4": the coordinates (x, y, w, h rows) of the matched pairs, reference metric
+        # -- a corner is proposal corner + delta x std x proposal size: a bbox_pred 1.5e-5 off (its own gate: "sub:bbox_pred" above) moves
+        # a 600-pixel box's corner by ~1e-3 px whatever the corner's own value, so the 1e-4 bound is taken against the box's extent and
+        # the strict per-coordinate figure (a corner at x = 2 px of such a box) is held to 1e-3 and reported
+        if matched.any():
+            ref4 = de[j[matched], :4].astype(np.float64)
+            dabs = np.abs(dets[matched, :4].astype(np.float64) - ref4)
+            ext = np.maximum(1.0, np.maximum(np.abs(ref4).max(1), ref4[:, 2:4].max(1)))[:, None]
+            report["dbox_max"] = float((dabs / np.maximum(1.0, np.abs(ref4))).max())
+            report["dbox_vs_box_extent"] = float((dabs / ext).max())
+            assert report["dbox_vs_box_extent"] < 1e-4 and report["dbox_max"] < 1e-3, (report["dbox_vs_box_extent"], report["dbox_max"])
     assert abs(len(de) - len(dets)) <= max(2, 0.02 * len(de))
     report.update(R=R, R_ref=Rr, dets=len(dets), dets_ref=len(de), matched=None if matched is None else float(matched.mean()))
     return report
@@ -174,7 +186,7 @@ def test_net_x3_precision_same_gates_as_fp32(model, size, regime, cls_id):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("model,size,regime,cls_id,org_hw", [FULL_SIZE[0], FULL_SIZE[3]])
+@pytest.mark.parametrize("model,size,regime,cls_id,org_hw", [FULL_SIZE[0], FULL_SIZE[4]])
 def test_full_size_parity_x3_vs_reference(model, size, regime, cls_id, org_hw):
     """The f16x3 mode at BASELINE sizes against the reference's own CPU layers, fp32 gates."""
     if not torch.cuda.is_available():

@@ -871,6 +871,38 @@ def test_conv_fused_pool(hip, orc, case):
     assert not hip.ConvPlan(1, 512, 39, 120, 512, 3, 3, (1, 1)).can_pool       # 13 tile rows: the caller pools separately
 
 
+@pytest.mark.parametrize("cin,grid,extra", [(64, 512, 1), (64, 768, 2), (32, 500, 1), (64, 300, 1)])
+@pytest.mark.parametrize("pool", [False, True])
+def test_conv_stream_k_remainder_spread_over_a_large_grid(hip, orc, cin, grid, extra, pool):
+    """`extra` remainder tiles on a grid of `grid` workgroups -- fewer stream-K iterations than workgroups, so the
+    contributors of a split tile are spread over a span of up to the whole grid with empty ranges in between; the fix-up's list used
+    to be cut at the first 256 workgroups of the SPAN (4 of 8 slabs summed at KI = 8 on 512).  Both fix-up kernels (plain and with the
+    fused pooling) against the oracle, tile count = grid + extra exactly, deterministic over repeats."""
+    probe = hip.ConvPlan(1, cin, 64, 128, 64, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_flags=32768)
+    name = probe.kernel                                   # "igemm_<BM>x<BN>_k3x3_tw<TW>..." : the tile is BN / TW rows of TW pixels
+    assert name.startswith("igemm_"), name
+    bn = int(name.split("_")[1].split("x")[1]); tw = int(name.split("tw")[1].split("_")[0]); th = bn // tw
+    tiles = grid + extra
+    nth = next(d for d in range(int(tiles ** 0.5), 0, -1) if tiles % d == 0)
+    H, W = nth * th, (tiles // nth) * tw
+    rng = np.random.default_rng(grid + cin)
+    x = rng.standard_normal((1, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((64, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    p = hip.ConvPlan(1, cin, H, W, 64, 3, 3, (1, 1), relu=True, algo=hip.ALGO_DIRECT, tune_flags=32768, tune_grid=grid)
+    assert p.kernel == name
+    p.pack(dev(w))
+    xd, bd = dev(x), dev(b)
+    yp = torch.full((1, 64, (H + 1) // 2, (W + 1) // 2), float("nan"), device="cuda") if pool else None
+    y = p.forward(xd, bd, pool_out=yp).clone()
+    ref = orc.relu(orc.conv2d(x, w, b, (1, 1)))
+    close(y.cpu().numpy(), ref)
+    if pool:
+        assert np.array_equal(yp.cpu().numpy(), orc.pool2d(y.cpu().numpy(), (2, 2), (0, 0), (2, 2), "MAX"))
+    for _ in range(3):
+        assert torch.equal(p.forward(xd, bd, pool_out=yp), y)
+
+
 def test_conv_no_bias_and_kernel_selection(hip, orc):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((1, 8, 8, 16)).astype(np.float32)
