@@ -392,6 +392,19 @@ def _free_port():
         return so.getsockname()[1]
 
 
+def _set_affinity_all_threads(mask):
+    """sched_setaffinity on every thread the process has (worker pools created while the rank was pinned keep their mask otherwise)."""
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    for t in tids:
+        try:
+            os.sched_setaffinity(t, mask)
+        except OSError:
+            pass
+
+
 def _refuse(msg):
     print("bench.py: " + msg, file=sys.stderr, flush=True)
     sys.exit(2)
@@ -422,6 +435,15 @@ def _launch_check(args, rank, world, local_rank):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if args.transport:
         assert mdist.dist_lib().mscnn_dist_use_transport(args.transport.encode()) == 0, mdist.dist_lib().mscnn_dist_last_error().decode()
+    # host placement exactly as a GPU rank gets it, on a synthetic topology (no GPU here to ask for its PCI address): the product's
+    # planner decides the slice, this process applies it
+    placement = None
+    if args.fake_cpulists:
+        lists = args.fake_cpulists.split(";")
+        assert len(lists) == world, (len(lists), world)
+        cpus = mdist.plan_cpus(lists, rank)
+        os.sched_setaffinity(0, mdist.parse_cpulist(cpus))
+        placement = {"rank": rank, "cpus": cpus, "applied": sorted(os.sched_getaffinity(0))}
 
     def exchange(b):
         box = [b]
@@ -452,6 +474,8 @@ def _launch_check(args, rank, world, local_rank):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert seen == {world}, seen
+    placements = [None] * world
+    dist.all_gather_object(placements, placement)
     gather_world, seen_ranks = gather.comm_world, sorted(gather.ranks_seen)
     gather.close()
     dist.destroy_process_group()
@@ -460,7 +484,7 @@ def _launch_check(args, rank, world, local_rank):
                           "steps": args.steps, "config": {"gather": f"libmscnn_dist: ncclAllGather of the device pack (pipelined, two in flight), "
                                                                       f"{gather_world} ranks in the communicator (ncclCommCount)",
                                                           "comm_count": gather_world, "ranks_seen": seen_ranks,
-                                                          "transport": args.transport or "librccl"}}), flush=True)
+                                                          "transport": args.transport or "librccl", "per_rank": placements}}), flush=True)
     sys.exit(0)
 
 
@@ -495,6 +519,11 @@ def main():
                     help="multi-GPU exchange inside the timed loops: pipelined = mscnn_dist_all_gather_begin/_end (the collective and "
                          "the D2H copy of image i on the communicator's own stream under image i + 1's trunk; all K images' packs are on "
                          "the host before the closing barrier), sync = one blocking exchange per image")
+    ap.add_argument("--no-pin", action="store_true",
+                    help="do not confine the rank to the CPUs of its GPU's NUMA node (mscnn_dist_pin_host_thread; default: pinned, ranks "
+                         "sharing a node get disjoint core slices)")
+    ap.add_argument("--fake-cpulists", default="",
+                    help="launch-check only: ';'-separated GPU-local CPU lists, one per rank (a synthetic topology for mscnn_dist_plan_cpus)")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher self-check without a GPU (CPU tests): rendezvous + the product's exchange on --transport, no measurement")
     ap.add_argument("--transport", default="", help="collective library for mscnn_dist_use_transport (an RCCL build elsewhere, or the test stub)")
@@ -517,6 +546,17 @@ def main():
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
         _refuse(f"rank {rank} needs GPU {local_rank}; {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible (bench.py needs MI355X GPUs)")
+    # host placement first (threads created from here on inherit it): the CPUs of this rank's GPU's NUMA node, cut into disjoint slices
+    # for the ranks that share the node.  The CPU-reference leg (N = 1) gets the original mask back.
+    mask0 = os.sched_getaffinity(0)
+    placement = None
+    if not args.no_pin:
+        from mscnn_amd import dist as mdist_pin
+        try:
+            placement = mdist_pin.pin_host_thread(local_rank, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+            os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, placement["n_cpus"]))))
+        except Exception as e:      # never a reason to lose the run: report it in the line
+            placement = {"error": str(e)}
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or launched:
@@ -562,7 +602,7 @@ def main():
         dist.all_gather_object(allf, flags[0])
         assert all(f == allf[0] for f in allf), "ranks disagree on the gather route"
     stats = {"R": [], "D": []}
-    pipe = {"on": False, "inflight": 0}
+    pipe = {"on": False, "inflight": 0, "gather_s": []}
     can_pipeline = hasattr(gather, "begin") and args.gather_mode == "pipelined"
     comm_count = getattr(gather, "comm_world", None)      # ncclCommCount of the product's communicator (None: the torch route / N = 1)
     if gather is not None:
@@ -589,13 +629,21 @@ def main():
         if gather is None:
             return take([net.detect(**kw)])                   # final stage on device; detections land on the host
         if pipe["on"]:                                        # final stage into the device pack; exchange i runs under image i + 1
-            gather.begin(net.detect_device(cap, **kw))
+            ptr = net.detect_device(cap, **kw)
+            tg = time.perf_counter()
+            gather.begin(ptr)
             pipe["inflight"] += 1
+            out = None
             if pipe["inflight"] == 2:
                 pipe["inflight"] -= 1
-                return take(gather.end())
-            return None
-        return take(gather(net.detect_device(cap, **kw)))     # one blocking all_gather, packs on the host
+                out = take(gather.end())
+            pipe["gather_s"].append(time.perf_counter() - tg)      # host time inside the exchange calls (begin + the wait in end)
+            return out
+        ptr = net.detect_device(cap, **kw)
+        tg = time.perf_counter()
+        out = take(gather(ptr))                               # one blocking all_gather, packs on the host
+        pipe["gather_s"].append(time.perf_counter() - tg)
+        return out
 
     def drain():                                              # the last image's packs (inside the timed region, before the barrier)
         while pipe["inflight"]:
@@ -613,7 +661,7 @@ def main():
         checks, switched, errs = net.auto_calibrate_state()
         return {"winograd_layers": checks - mark[0], "max_err_vs_direct_kernel": float(f"{max(errs.values(), default=0.0):.3g}"),
                 "tol": CALIBRATION_TOL, "fallback_layers": switched[mark[1]:],
-                "how": "automatic (Net default): first forward after a weight change, tol 5e-5; numerics watch every 100 frames"}
+                "how": "automatic (Net default): first forward after a weight change, tol 5e-5; numerics watch every 25 frames (one band of one layer, deferred verdict)"}
 
     def numerics_mark():
         checks, switched, _ = net.auto_calibrate_state()
@@ -637,6 +685,7 @@ def main():
     sync()
     step_s = []
     pipe["on"] = can_pipeline
+    pipe["gather_s"] = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         ts = time.perf_counter()
@@ -646,6 +695,7 @@ def main():
     pipe["on"] = False
     sync()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     gc.enable()
     if args.dump_steps and rank == 0:
         print("step_ms: " + " ".join(f"{1e3 * v:.2f}" for v in step_s), file=sys.stderr)
@@ -655,6 +705,16 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
+    # every rank's own view of the timed loop (N > 1): where a scaling loss comes from -- a slow rank (placement, clocks), or the exchange
+    per_rank = None
+    if dist is not None:
+        ss_r, gs_r = np.sort(np.array(step_s)) * 1e3, np.sort(np.array(pipe["gather_s"] or [0.0])) * 1e6
+        mine = {"rank": rank, "step_ms_p50": round(float(np.median(ss_r)), 4), "step_ms_p90": round(float(ss_r[int(round(0.9 * (len(ss_r) - 1)))]), 4),
+                "step_ms_max": round(float(ss_r[-1]), 4), "gather_host_us_p50": round(float(np.median(gs_r)), 1),
+                "gather_host_us_p90": round(float(gs_r[int(round(0.9 * (len(gs_r) - 1)))]), 1), "loop_s": round(elapsed_local, 5),
+                "placement": placement}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     main_stats, stats = stats, {"R": [], "D": []}      # the headline loop's ROI / detection counts (later loops append to their own)
 
     # ---- second timed loop, same contract, in the split-fp16 mode (fp32-grade: held to the fp32 parity gates below).  The
@@ -887,6 +947,7 @@ def main():
                   "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                   "step_ms": {"median": round(float(np.median(ss)), 4), "p10": round(float(ss[int(0.10 * (len(ss) - 1))]), 4),
                               "p90": round(float(ss[int(round(0.90 * (len(ss) - 1)))]), 4), "min": round(float(ss[0]), 4),
+                              "p99": round(float(ss[int(round(0.99 * (len(ss) - 1)))]), 4),
                               "max": round(float(ss[-1]), 4), "note": "rank 0, wall time per step incl. the host sync at its end"},
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                   "config": {"workload": f"{args.model} {'fp16 MFMA operands / fp32 accumulate' if args.dtype == 'f16' else 'fp32 (Winograd GEMMs as 3 x fp16 MFMA on split operands)' if args.dtype == 'f16x3' else 'fp32'}, batch={B} per GPU, {B}x3x{H}x{W} frame{'s' if B > 1 else ''} resident in HBM -> detections on host "
@@ -896,6 +957,7 @@ def main():
                              # harness settings that changed what the timed loop contains over the rounds: the interpreter's cyclic GC is
                              # off inside the timed loops since round 5; the f16x3 second loop is opt-in (--alt) since round 5
                              "gc_disabled": True, "alt_loop": bool(alt),
+                             "host_placement": placement, "per_rank": per_rank,
                              # what the collective library reported (ncclCommCount) and the senders' ranks found in the packs of the timed loop
                              "comm_count": comm_count, "ranks_seen": sorted(getattr(gather, "ranks_seen", [])) if gather is not None else None,
                              "handoff": {**dict(zip(("events_answered", "whole_tiles_forced"), net.handoff_state())),
@@ -915,6 +977,7 @@ def main():
             result["cpu_baseline"] = None      # (the reference's CPU path is timed beside the batch-1 line)
         if not args.no_cpu_baseline and world == 1 and B == 1:      # rank 0 at N = 1 only (host work; other ranks would idle)
             table = []
+            _set_affinity_all_threads(mask0)    # the reference's CPU path gets every core the process was given, not this rank's slice
             cb = cpu_baseline(args.model, args.regime, max(1, int(round(Rm))), net=net, kw=kw, layer_table=table, dtype=args.dtype,
                               alt_dtype=alt["dtype"] if alt else None, other_regimes=[(r, net_cap if r == "max_rois" else None) for r in (regimes or {}) if r != args.regime])
             net_cap = None
@@ -936,7 +999,17 @@ def main():
                     print(f"{nm:>28s}\tforward: {t * 1e3:.3f} ms.", file=sys.stderr)
         wchecks, wsw = net.numerics_watch_state()
         if numerics is not None:
-            numerics["watch"] = {"period": 100, "checks_so_far": wchecks, "switched": wsw}
+            # the watch is ON in the timed loop (Net default: every 25th whole forward one band of one Winograd layer is recomputed with
+            # the direct kernel behind the frame, no host synchronisation; that frame also runs the layer outside its chain).  Timed step i is
+            # whole forward number warmup + i + 1 of this net: the watch frames of the headline loop are known, their cost is reported
+            wp = 25
+            wf = [i for i in range(args.steps) if (max(args.warmup, 1) + i + 1) % wp == 0]
+            other = [i for i in range(args.steps) if i not in wf]
+            sms = np.array(step_s) * 1e3
+            numerics["watch"] = {"period": wp, "checks_so_far": wchecks, "switched": wsw, "watch_frames_in_timed_loop": len(wf),
+                                 "watch_frame_ms_median": round(float(np.median(sms[wf])), 4) if wf else None,
+                                 "other_frame_ms_median": round(float(np.median(sms[other])), 4) if other else None,
+                                 "how": "deferred band check (mscnn_net_set_numerics_watch): verdict collected by a later forward, no frame waits"}
         result["parity_ok"] = parity_ok      # null when the reference leg did not run (N > 1 or --no-cpu-baseline)
         # rows of SURVEY 8 whose oracle has no pin on the reference itself: a17 = the MATLAB final stage (run_mscnn_detection.m:75-120,
         # utils/bbNms.m:112-126) -- no MATLAB / Octave in the image; two independently written restatements agree, nothing more.

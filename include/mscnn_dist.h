@@ -73,6 +73,28 @@ MSCNN_DIST_API int mscnn_dist_all_gather_end(mscnn_dist* d, const void** gathere
 /* Barrier over the communicator (a 4-byte ncclAllReduce + stream wait): brackets the timed region of the benchmark. */
 MSCNN_DIST_API int mscnn_dist_barrier(mscnn_dist* d, void* stream);
 
+/* ---- host placement of the ranks (no reference counterpart: the reference's only multi-GPU code is the training-time P2PSync,
+ * src/caffe/parallel.cpp; this belongs to the one-thread-per-GPU inference design above) ------------------------------------------
+ * A rank's driver thread issues ~45 launches and one stream synchronisation per 4.5 ms frame: it must sit on the CPUs of its GPU's
+ * NUMA node, and ranks that share a node must not share cores (their BLAS / OpenMP / RCCL helper threads inherit the mask).
+ *
+ * mscnn_dist_plan_cpus: pure planning.  local_cpulists[r] = the CPUs local to rank r's GPU in the kernel's list syntax
+ *   ("0-15,128-143"; "" = unknown), allowed_cpulist = the CPUs this process may use (NULL / "" = the calling thread's current
+ *   affinity mask).  Ranks with the same effective list (local AND allowed) share it in equal slices, cut inside every run of
+ *   consecutive CPU numbers (so a core and its SMT sibling stay together); *out receives rank's slice in the same syntax.
+ * mscnn_dist_pin_host_thread: reads <sysfs_root>/bus/pci/devices/<hipDeviceGetPCIBusId>/local_cpulist of the ranks' devices
+ *   (rank r <-> device r when all `world` devices are visible to the process and device == rank; else only this process's device is
+ *   known and its node is cut into `world` slices), plans as above inside the thread's current mask, and applies the result with
+ *   sched_setaffinity to the calling thread (and, with MSCNN_DIST_PIN_PROCESS, to the threads the process already has); threads the
+ *   calling thread creates later inherit it.  Call it
+ *   first thing in a rank, before the net / communicator are created.  sysfs_root NULL = "/sys".  report (optional) receives one
+ *   JSON object: rank, device, pci, numa_node, cpus, n_cpus, ranks_sharing_node, all_devices_visible, threads_pinned, threads. */
+MSCNN_DIST_API int mscnn_dist_plan_cpus(const char* const* local_cpulists, int world, int rank, const char* allowed_cpulist,
+                                        char* out, size_t out_bytes);
+#define MSCNN_DIST_PIN_PROCESS 1u      /* one process per GPU: also move the threads the process already has (thread-per-GPU drivers: 0) */
+MSCNN_DIST_API int mscnn_dist_pin_host_thread(int device, int rank, int world, unsigned flags, const char* sysfs_root, char* report,
+                                              size_t report_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,6 +252,11 @@ MSCNN_API int mscnn_deconv2d_fwd_f32(const float* x, const float* w, const float
 /* out_dev[0] = max_i |a[i] - ref[i]| / max(floor, |ref[i]|) (+inf if any NaN): the parity metric of the test-suite on the
  * device; used by the host runtime's per-layer numerical calibration (Winograd against the direct sum). */
 MSCNN_API int mscnn_max_rel_diff_f32(const float* a, const float* ref, size_t count, float floor, float* out_dev, void* stream);
+/* The same metric over `planes` runs of `run` consecutive floats -- plane p of a at a + p * a_stride, of ref at ref + p * ref_stride (a
+ * band of rows of an NCHW blob against a band computed elsewhere) -- with floor = max(1, sqrt(sumsq_dev[0] / sumsq_count)) read ON THE
+ * DEVICE: the host runtime's numerics watch chains mscnn_sum_squares_f32 -> this call without a host round trip in between. */
+MSCNN_API int mscnn_max_rel_diff_strided_f32(const float* a, size_t a_stride, const float* ref, size_t ref_stride, size_t planes, size_t run,
+                                             const double* sumsq_dev, double sumsq_count, float* out_dev, void* stream);
 /* out_dev[0] = sum_i x[i]^2 in double: the scale (rms) of a blob, the floor of the calibration metric on hot activations. */
 MSCNN_API int mscnn_sum_squares_f32(const float* x, size_t count, double* out_dev, void* stream);
 

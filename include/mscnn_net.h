@@ -107,11 +107,13 @@ MSCNN_NET_API int mscnn_net_chain_pairs(const mscnn_net* net, int* producers, in
 MSCNN_NET_API int mscnn_net_auto_calibrate_state(const mscnn_net* net, int* checks, int* switched_layers, int cap);
 MSCNN_NET_API int mscnn_net_calibrate_numerics(mscnn_net* net, double tol, int* num_switched);
 MSCNN_NET_API double mscnn_net_layer_calibration_err(const mscnn_net* net, int layer);
-/* The same check on live frames: every period-th whole forward re-computes ONE Winograd layer (round robin over the layers) with the
- * direct kernel on the frame just processed; a layer off by more than tol runs the direct kernel from the next frame on.  ON by
- * default with period 100, tol 5e-5 (one extra layer + one host sync per 100 frames: < 0.3 % of a 7s-576 stream); period 0
- * switches the watch off.  _state: *checks = layer checks done so far; returns how many layers were switched and
- * writes up to cap of their indices. */
+/* The same comparison on live frames (the numerics watch): every period-th whole forward looks at ONE Winograd layer (round robin) --
+ * the layer runs outside its convolution chain in that frame, and one band of it (a few rows / images: ~30 us of direct-kernel work; round robin too) is
+ * recomputed with the direct kernel BEHIND the frame on the same stream, with no host synchronisation; the verdict is collected by a
+ * later forward, and a layer off by more than tol runs the direct kernel from the frame after.  No frame waits for a check: a watch
+ * frame is 2 - 4 % longer (7s-576), the others not at all.  ON by default with period 25, tol 5e-5 (~0.1 % of a stream); period 0
+ * switches the watch off.  _state: waits for a verdict that is still out, then *checks = band checks done so far; returns how many
+ * layers were switched and writes up to cap of their indices. */
 MSCNN_NET_API int mscnn_net_set_numerics_watch(mscnn_net* net, int period, double tol);
 MSCNN_NET_API int mscnn_net_numerics_watch_state(const mscnn_net* net, int* checks, int* switched_layers, int cap);
 MSCNN_NET_API int mscnn_net_num_blobs(const mscnn_net* net);

@@ -267,6 +267,23 @@ __global__ __launch_bounds__(kThreads) void max_rel_diff_kernel(const float* __r
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// the same over `planes` runs of `run` consecutive floats (a band of rows of an NCHW blob against a band computed elsewhere), the floor
+// max(1, rms) taken from a sum of squares that is still on the device (no host round trip between the two reductions)
+__global__ __launch_bounds__(kThreads) void max_rel_diff_strided_kernel(const float* __restrict__ a, long a_stride, const float* __restrict__ ref,
+                                                                        long ref_stride, long planes, long run, const double* __restrict__ sumsq,
+                                                                        double sumsq_count, unsigned* __restrict__ out) {
+  const float floor_ = fmaxf(1.f, (float)sqrt(sumsq[0] / sumsq_count));
+  float m = 0.f;
+  const long n = planes * run;
+  for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    const long p = i / run, j = i - p * run;
+    const float r = ref[p * ref_stride + j], d = fabsf(a[p * a_stride + j] - r) / fmaxf(floor_, fabsf(r));
+    m = (d != d) ? __builtin_inff() : fmaxf(m, d);
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 // sum of squares in double (the scale of a blob for the calibration metric): per-wave partial sums, one f64 atomicAdd per wave
 __global__ __launch_bounds__(kThreads) void sum_squares_kernel(const float* __restrict__ x, long n, double* __restrict__ out) {
   double s = 0.0;
@@ -294,6 +311,17 @@ extern "C" int mscnn_max_rel_diff_f32(const float* a, const float* ref, size_t c
   if (count == 0) return MSCNN_OK;
   max_rel_diff_kernel<<<grid_for((long)count), kThreads, 0, as_stream(stream)>>>(a, ref, (long)count, floor_,
                                                                                  reinterpret_cast<unsigned*>(out_dev));
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+extern "C" int mscnn_max_rel_diff_strided_f32(const float* a, size_t a_stride, const float* ref, size_t ref_stride, size_t planes, size_t run,
+                                              const double* sumsq_dev, double sumsq_count, float* out_dev, void* stream) {
+  MSCNN_REQUIRE(out_dev && sumsq_dev && sumsq_count > 0 && (planes * run == 0 || (a && ref)), "max_rel_diff_strided: bad argument");
+  MSCNN_HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float), as_stream(stream)));
+  if (planes * run == 0) return MSCNN_OK;
+  max_rel_diff_strided_kernel<<<grid_for((long)(planes * run)), kThreads, 0, as_stream(stream)>>>(
+      a, (long)a_stride, ref, (long)ref_stride, (long)planes, (long)run, sumsq_dev, sumsq_count, reinterpret_cast<unsigned*>(out_dev));
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

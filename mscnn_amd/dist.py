@@ -45,6 +45,8 @@ def dist_lib():
         L.mscnn_dist_all_gather_end.argtypes = [C.c_void_p, C.c_void_p]
         L.mscnn_dist_world.argtypes = [C.c_void_p]
         L.mscnn_dist_rank.argtypes = [C.c_void_p]
+        L.mscnn_dist_plan_cpus.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.mscnn_dist_pin_host_thread.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_char_p, C.c_char_p, C.c_size_t]
         _dlib = L
     return _dlib
 
@@ -52,6 +54,34 @@ def dist_lib():
 def _dcheck(rc):
     if rc != 0:
         raise DistError(dist_lib().mscnn_dist_last_error().decode())
+
+
+def plan_cpus(local_cpulists, rank, allowed=None):
+    """mscnn_dist_plan_cpus: the CPU slice (kernel list syntax, e.g. "0-3,128-131") of rank `rank` given every rank's GPU-local CPU
+    list; ranks on the same NUMA node get disjoint slices inside `allowed` (default: this thread's affinity mask)."""
+    world = len(local_cpulists)
+    arr = (C.c_char_p * world)(*[s.encode() for s in local_cpulists])
+    out = C.create_string_buffer(8192)
+    _dcheck(dist_lib().mscnn_dist_plan_cpus(arr, world, rank, allowed.encode() if allowed else None, out, len(out)))
+    return out.value.decode()
+
+
+def parse_cpulist(text):
+    cpus = set()
+    for part in text.replace("\n", "").split(","):
+        if part.strip():
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def pin_host_thread(device, rank, world, sysfs_root=None):
+    """mscnn_dist_pin_host_thread: confine this process (all its threads, and every thread created later) to the rank's slice of the
+    CPUs of its GPU's NUMA node.  Returns the library's report as a dict.  Call before the net / communicator exist."""
+    import json
+    rep = C.create_string_buffer(2048)
+    _dcheck(dist_lib().mscnn_dist_pin_host_thread(device, rank, world, 1, sysfs_root.encode() if sysfs_root else None, rep, len(rep)))      # 1 = MSCNN_DIST_PIN_PROCESS
+    return json.loads(rep.value.decode())
 
 
 def shard(num_images, rank, world):

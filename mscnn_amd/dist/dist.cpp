@@ -87,6 +87,8 @@ struct mscnn_dist {
   int head = 0, tail = 0, inflight = 0;
 };
 
+extern "C" void mscnn_dist_set_error_text(const char* text) { set_error("%s", text); }      // (library-internal: placement.cpp)
+
 extern "C" {
 
 const char* mscnn_dist_last_error(void) { return g_err; }

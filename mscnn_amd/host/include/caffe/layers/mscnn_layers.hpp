@@ -134,6 +134,15 @@ class ConvolutionLayer : public Layer<Dtype> {
   // max |y - y_direct| / max(1, |y_direct|) of the current algorithm against the direct kernel on the given bottom
   // (device scratch only; the layer's tops are not touched).  0 when the layer already runs a direct kernel.
   double ErrorAgainstDirect(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
+  // The numerics watch's form of the same comparison (round 6): ONE BAND of the layer -- a few rows of the map with a one-row halo
+  // (3x3 / pad 1 trunk layers), or a few of the images / ROIs (small maps, roi_c1): ~30 us of direct-kernel work, at most an eighth of the layer -- is recomputed with
+  // the direct kernel and compared with the same rows of the top blob this Forward wrote, everything ENQUEUED behind the frame on the
+  // layer's stream: no host synchronisation, no second full-size convolution.  The verdict is read later (PollBandCheck), so a frame's
+  // latency never contains a check; it applies from the frame after it is known.
+  //   BeginBandCheck: false when there is nothing to check (a direct kernel, an empty or unwritten top, a check still in flight).
+  //   PollBandCheck: 0 nothing in flight, 1 still running (wait = false), 2 done: *err = max |dy| / max(1, |y|, rms(y)) over the band.
+  bool BeginBandCheck(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top, int band_seq);
+  int PollBandCheck(double* err, bool wait);
   // the last ErrorAgainstDirect compared two results of an all-zero bottom (a zero warm-up frame): it says nothing about the layer's
   // numerics on data -- the first-forward check stays armed for the next bottom
   bool last_check_vacuous() const { return last_check_vacuous_; }
@@ -173,6 +182,12 @@ class ConvolutionLayer : public Layer<Dtype> {
   double selfcheck_tol_ = kDefaultSelfcheckTol, selfcheck_err_ = 0.0;
   bool selfcheck_pending_ = true, selfcheck_ran_ = false, selfcheck_fell_back_ = false, last_check_vacuous_ = false;
   bool wino_checked_ = false;             // a Winograd result of the current weights / algorithm has been compared with the direct kernel
+  struct BandTicket {                     // a band check in flight: the direct plan it runs on, its completion event, the pinned verdict
+    mscnn_conv_plan* plan = nullptr;
+    void* done = nullptr;                 // hipEvent_t
+    float* host = nullptr;                // pinned: [0] the metric
+    bool inflight = false;
+  } band_;
   bool profiling_;
   const ConvolutionLayer* amax_src_ = nullptr;
   const unsigned* amax_in_ = nullptr;

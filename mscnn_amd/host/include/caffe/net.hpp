@@ -106,14 +106,19 @@ class Net {
   void SetAutoCalibrate(double tol);
   int auto_calibrate_checks() const { return auto_checks_; }
   const vector<int>& auto_calibrate_switched() const { return auto_switched_; }
-  // The same check while a stream of frames runs: every `period`-th whole Forward re-computes ONE Winograd layer (round robin) with
-  // the direct kernel on the frame just processed and switches it to the direct kernel for good when it is off by more than tol --
-  // the calibration of the first frame is re-examined on live data at the cost of one extra layer per `period` frames.  ON by default
-  // (every kDefaultWatchPeriod-th frame, tolerance 5e-5: < 0.3 % of a 7s-576 stream); period 0 turns it off.
-  static constexpr int kDefaultWatchPeriod = 100;
+  // The same comparison while a stream of frames runs (the numerics watch): every `period`-th whole Forward looks at ONE Winograd
+  // layer (round robin) -- the layer runs outside its convolution chain in that frame so that its blobs exist, and one band of it (a few
+  // rows / images: ~30 us of direct-kernel work; round robin too) is recomputed with the direct kernel BEHIND the frame on the same stream, without a
+  // host synchronisation.  The verdict is collected by a later Forward (or by the state accessors below); a layer that strayed by more
+  // than tol runs the direct kernel for good from the frame after.  A watch frame costs the un-chaining of one layer plus that band
+  // (2 - 4 % of a 7s-576 frame); no frame ever waits for a check.  ON by default (every
+  // kDefaultWatchPeriod-th frame, tolerance 5e-5: ~0.1 % of a stream); period 0 turns it off.
+  static constexpr int kDefaultWatchPeriod = 25;
   void SetNumericsWatch(int period, double tol);
-  int numerics_watch_checks() const { return watch_checks_; }
-  const vector<int>& numerics_watch_switched() const { return watch_switched_; }
+  // (both wait for a verdict that is still out, so that what they return is final for the frames forwarded so far)
+  int numerics_watch_checks() { WatchCollect(true); return watch_checks_; }
+  const vector<int>& numerics_watch_switched() { WatchCollect(true); return watch_switched_; }
+  void WatchCollect(bool wait);
   // Health of the plane-GEMM kernel's stream-K hand-off (include/mscnn_hip.h: mscnn_wgemm_handoff_event).  A launch whose finisher
   // gave up on a contributor leaves a NaN tile behind and its tag in a pinned status word; the Net looks at that word wherever the
   // stream has just been synchronised anyway -- behind BoxOutput's row-count read inside ForwardFromTo (covers the trunk and the
@@ -163,8 +168,9 @@ class Net {
   bool chain_fusion_ = true;
   int SplitSource(int blob) const;      // through Split layers (their tops share the bottom's data) to the blob that holds the data
   vector<double> calib_err_;
-  void NumericsWatchStep();
+  int NextWatchLayer() const;
   int watch_period_ = kDefaultWatchPeriod, watch_frame_ = 0, watch_next_ = 0, watch_checks_ = 0;
+  int watch_pending_ = -1, watch_band_ = 0;      // layer whose band check is in flight (-1: none); band index (advances once per trip round the layers)
   double watch_tol_ = 5e-5;
   int auto_checks_ = 0;
   double auto_tol_ = 5e-5;      // (= ConvolutionLayer::kDefaultSelfcheckTol; 0 once SetAutoCalibrate(0) opted out)

@@ -108,6 +108,10 @@ void SplitLayer<Dtype>::Forward_cpu(const vector<Blob<Dtype>*>& bottom, const ve
 // ------------------------------------------------------------------------------------------------ Convolution
 template <typename Dtype>
 ConvolutionLayer<Dtype>::~ConvolutionLayer() {
+  if (band_.inflight && band_.done) (void)hipEventSynchronize((hipEvent_t)band_.done);      // its kernels read this layer's weights
+  if (band_.plan) mscnn_conv2d_plan_destroy(band_.plan);
+  if (band_.done) (void)hipEventDestroy((hipEvent_t)band_.done);
+  if (band_.host) (void)hipHostFree(band_.host);
   if (plan_) mscnn_conv2d_plan_destroy(plan_);
 }
 
@@ -256,6 +260,118 @@ double ConvolutionLayer<Dtype>::ErrorAgainstDirect(const vector<Blob<Dtype>*>& b
   HIP_CHECK(hipStreamSynchronize((hipStream_t)S()));
   mscnn_conv2d_plan_destroy(dp);
   return e;
+}
+
+namespace {
+// the band checks' own scratch (separate from CheckScratch: a band check may still be running on the device when a first-forward
+// check of another layer reserves -- and possibly re-allocates -- its buffers)
+struct BandScratch { DeviceBuffer x, packed, ws, y, scal; };
+thread_local BandScratch* g_band_scratch[64] = {nullptr};
+}  // namespace
+
+template <typename Dtype>
+bool ConvolutionLayer<Dtype>::BeginBandCheck(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top, int band_seq) {
+  if (band_.inflight || bottom[0]->count() == 0 || top[0]->count() == 0 || top_stale_ || !plan_) return false;
+  if (std::strncmp(mscnn_conv2d_plan_kernel(plan_), "winograd", 8) != 0) return false;
+  const int N = bottom[0]->num(), H = bottom[0]->height(), W = bottom[0]->width();
+  const int Ho = top[0]->height(), Wo = top[0]->width();
+  const bool roi_pending = roi_src_ && roi_src_->pending() && bottom[0] == roi_src_->window();
+  // the band: rows [r0, r0 + rows) of every image with a one-row halo (3x3 / pad 1 / stride 1 on a map of >= 32 rows), else
+  // images [n0, n0 + bn) whole
+  const bool by_rows = kernel_h_ == 3 && kernel_w_ == 3 && pad_h_ == 1 && pad_w_ == 1 && stride_h_ == 1 && stride_w_ == 1 && H >= 32 && !roi_pending;
+  // its size: what the direct kernel recomputes in ~30 us (kBandFlops of the layer's direct-convolution FLOPs; the halo rows count),
+  // never more than an eighth of the layer -- conv2_2: 6 of 288 rows, conv4_x: 2 of 72, roi_c1: 10 ROIs
+  const double kBandFlops = 2.5e9, flops = std::max(1.0, mscnn_conv2d_plan_flops(plan_));
+  int bn = N, n0 = 0, r0 = 0, rows = Ho, in0 = 0, bh = H;
+  if (by_rows) {
+    const int hb = std::max(2, std::min((H + 7) / 8, (int)(H * kBandFlops / flops) - 2)), nb = (H + hb - 1) / hb;
+    r0 = (band_seq % nb) * hb;
+    rows = std::min(hb, H - r0);
+    in0 = std::max(r0 - 1, 0);
+    bh = std::min(r0 + rows + 1, H) - in0;
+  } else {
+    const int per = std::max(1, std::min((N + 7) / 8, (int)(N * kBandFlops / flops))), nb = (N + per - 1) / per;
+    n0 = (band_seq % nb) * per;
+    bn = std::min(per, N - n0);
+  }
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  CHECK(dev >= 0 && dev < 64);
+  if (!g_band_scratch[dev]) g_band_scratch[dev] = new BandScratch();
+  BandScratch& sc = *g_band_scratch[dev];
+  hipStream_t st = (hipStream_t)S();
+  // the band of the bottom, contiguous
+  const size_t plane_in = (size_t)H * W, band_in = (size_t)bh * W;
+  const float* xb = nullptr;
+  if (by_rows) {
+    float* xd = static_cast<float*>(sc.x.Reserve(sizeof(float) * (size_t)N * channels_ * band_in));
+    HIP_CHECK(hipMemcpy2DAsync(xd, sizeof(float) * band_in, bottom[0]->gpu_data() + (size_t)in0 * W, sizeof(float) * plane_in,
+                               sizeof(float) * band_in, (size_t)N * channels_, hipMemcpyDeviceToDevice, st));
+    xb = xd;
+  } else if (roi_pending) {      // the R x 2C x ph x pw blob was never written (pooled inside roi_c1's input stage): pool the band's ROIs
+    ROIPoolingLayer<Dtype>* a = roi_src_;
+    ROIPoolingLayer<Dtype>* b = roi_src_->partner();
+    const vector<Blob<Dtype>*>& pb = a->pending_bottoms();
+    if (!b || pb.size() != 2 || pb[1]->num() != N || a->channels() + b->channels() != channels_) return false;
+    float* xd = static_cast<float*>(sc.x.Reserve(sizeof(float) * (size_t)bn * channels_ * plane_in));
+    ROIPoolingLayer<Dtype>* both[2] = {a, b};
+    for (ROIPoolingLayer<Dtype>* r : both)
+      MSCNN_CHECK(mscnn_roipool_fwd_f32(pb[0]->gpu_data(), pb[1]->gpu_data() + (size_t)n0 * 5, xd, bn, pb[0]->num(), r->channels(), pb[0]->height(),
+                                        pb[0]->width(), r->pooled_height(), r->pooled_width(), r->spatial_scale(), r->pad_ratio(), channels_,
+                                        r->window_c_offset(), st));
+    xb = xd;
+  } else {
+    xb = bottom[0]->gpu_data() + (size_t)n0 * channels_ * plane_in;
+  }
+  // a direct plan of the band's shape with its own packed weights and workspace
+  mscnn_conv_desc d;
+  d.N = bn; d.Cin = channels_; d.H = bh; d.W = W; d.Cout = num_output_;
+  d.Kh = kernel_h_; d.Kw = kernel_w_; d.pad_h = pad_h_; d.pad_w = pad_w_; d.stride_h = stride_h_; d.stride_w = stride_w_;
+  d.group = group_; d.relu = relu_ ? 1 : 0; d.algo = MSCNN_CONV_ALGO_DIRECT; d.tune_variant = d.tune_grid = d.tune_flags = 0;
+  if (band_.plan) { mscnn_conv2d_plan_destroy(band_.plan); band_.plan = nullptr; }
+  MSCNN_CHECK(mscnn_conv2d_plan_create(&d, &band_.plan));
+  const size_t pbytes = mscnn_conv2d_packed_weight_bytes(band_.plan), wbytes = mscnn_conv2d_workspace_bytes(band_.plan);
+  float* pk = pbytes ? static_cast<float*>(sc.packed.Reserve(pbytes)) : nullptr;
+  const float* w = this->blobs_[0]->gpu_data();
+  MSCNN_CHECK(mscnn_conv2d_pack_weights(band_.plan, w, pk, S()));
+  const int bho = by_rows ? bh : Ho;                                   // rows of the direct band's output
+  const size_t ycount = (size_t)bn * num_output_ * bho * Wo;
+  float* yd = static_cast<float*>(sc.y.Reserve(sizeof(float) * ycount));
+  unsigned char* scal = static_cast<unsigned char*>(sc.scal.Reserve(32));
+  double* ss = reinterpret_cast<double*>(scal);
+  float* ed = reinterpret_cast<float*>(scal + 16);
+  MSCNN_CHECK(mscnn_conv2d_fwd_f32(band_.plan, xb, w, pk, bias_term_ ? this->blobs_[1]->gpu_data() : nullptr, yd, wbytes ? sc.ws.Reserve(wbytes) : nullptr,
+                                   wbytes, S()));
+  MSCNN_CHECK(mscnn_sum_squares_f32(yd, ycount, ss, S()));
+  // rows [r0 - in0, + rows) of the direct band are the ones whose halo is real (rows beside them saw the band's artificial zero padding)
+  const float* tb = top[0]->gpu_data() + (by_rows ? (size_t)r0 * Wo : (size_t)n0 * num_output_ * Ho * Wo);
+  if (by_rows)
+    MSCNN_CHECK(mscnn_max_rel_diff_strided_f32(tb, (size_t)Ho * Wo, yd + (size_t)(r0 - in0) * Wo, (size_t)bho * Wo, (size_t)N * num_output_,
+                                               (size_t)rows * Wo, ss, (double)ycount, ed, S()));
+  else
+    MSCNN_CHECK(mscnn_max_rel_diff_strided_f32(tb, ycount, yd, ycount, 1, ycount, ss, (double)ycount, ed, S()));
+  if (!band_.host) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&band_.host), 64, hipHostMallocDefault));
+  if (!band_.done) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); band_.done = e; }
+  HIP_CHECK(hipMemcpyAsync(band_.host, ed, sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipEventRecord((hipEvent_t)band_.done, st));
+  band_.inflight = true;
+  return true;
+}
+
+template <typename Dtype>
+int ConvolutionLayer<Dtype>::PollBandCheck(double* err, bool wait) {
+  if (!band_.inflight) return 0;
+  if (wait) HIP_CHECK(hipEventSynchronize((hipEvent_t)band_.done));
+  else {
+    const hipError_t q = hipEventQuery((hipEvent_t)band_.done);
+    if (q == hipErrorNotReady) return 1;
+    HIP_CHECK(q);
+  }
+  band_.inflight = false;
+  *err = (double)band_.host[0];
+  mscnn_conv2d_plan_destroy(band_.plan);
+  band_.plan = nullptr;
+  return 2;
 }
 
 template <typename Dtype>

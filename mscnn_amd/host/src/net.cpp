@@ -510,30 +510,46 @@ void Net<Dtype>::SetAutoCalibrate(double tol) {
 
 template <typename Dtype>
 void Net<Dtype>::SetNumericsWatch(int period, double tol) {
+  WatchCollect(true);      // (a verdict still out is judged by the tolerance it was started under)
   watch_period_ = period; watch_tol_ = tol; watch_frame_ = 0;
   if (period == 0 && auto_tol_ == 0.0) ConvolutionLayer<Dtype>::ReleaseCheckScratch();
 }
 
+// The numerics watch (round 6 form: no check inside a frame's latency).  On a watch frame ONE Winograd layer -- round robin -- runs
+// outside its convolution chain, so that its bottom and top blobs exist, and one band of it (round robin as well) is recomputed with
+// the direct kernel BEHIND the frame on the same stream (ConvolutionLayer::BeginBandCheck: a copy of the band, a direct convolution an
+// eighth of the layer's size, two reductions, 4 bytes to pinned memory, an event).  Nobody waits for it: the verdict is collected at
+// the end of a later whole forward (or when somebody asks for the watch's state) and, when the layer strayed, it runs the direct
+// kernel from the frame after that.
 template <typename Dtype>
-void Net<Dtype>::NumericsWatchStep() {
+int Net<Dtype>::NextWatchLayer() const {
   const int L = (int)layers_.size();
   for (int k = 0; k < L; ++k) {
     const int i = (watch_next_ + k) % L;
     ConvolutionLayer<Dtype>* c = dynamic_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
     if (!c || fused_away_[i] || c->algo() == 1 || c->algo() == 4 || std::strncmp(c->kernel_name(), "winograd", 8) != 0) continue;
-    watch_next_ = (i + 1) % L;
-    ++watch_checks_;
-    for (int bb : bottom_id_vecs_[i]) MaterializeBlob(bb);      // (blobs inside a convolution chain are written on demand)
-    for (int tb : top_id_vecs_[i]) MaterializeBlob(tb);
-    calib_err_[i] = c->ErrorAgainstDirect(bottom_vecs_[i], top_vecs_[i]);
-    if (!(calib_err_[i] <= watch_tol_)) {
-      LOG(WARNING) << "layer " << layer_names_[i] << ": Winograd result off the direct sum by " << calib_err_[i] << " > " << watch_tol_
-                   << " on a live frame: using the direct kernel from the next frame on";
-      c->set_algo(1);
-      c->set_calibrated_direct(true);
-      watch_switched_.push_back(i);
-    }
-    return;
+    return i;
+  }
+  return -1;
+}
+
+template <typename Dtype>
+void Net<Dtype>::WatchCollect(bool wait) {
+  if (watch_pending_ < 0) return;
+  const int i = watch_pending_;
+  ConvolutionLayer<Dtype>* c = static_cast<ConvolutionLayer<Dtype>*>(layers_[i].get());
+  double e = 0.0;
+  const int r = c->PollBandCheck(&e, wait);
+  if (r == 1) return;
+  watch_pending_ = -1;
+  if (r != 2) return;
+  calib_err_[i] = e;
+  if (!(e <= watch_tol_) && c->algo() != 1) {      // (NaN counts as a failure)
+    LOG(WARNING) << "layer " << layer_names_[i] << ": Winograd result off the direct sum by " << e << " > " << watch_tol_
+                 << " on a live frame: using the direct kernel from the next frame on";
+    c->set_algo(1);
+    c->set_calibrated_direct(true);
+    watch_switched_.push_back(i);
   }
 }
 
@@ -575,6 +591,14 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   last_start_ = start; last_end_ = end;
   ++forward_count_;
   bool handoff_restart = false;
+  // a watch frame: the verdict still out (if any) is taken first -- its kernels ran in front of everything this call will enqueue --,
+  // then the layer to look at in this frame is chosen; it runs outside its chains below
+  const bool whole = start == 0 && end == (int)layers_.size() - 1;
+  int watch_layer = -1;
+  if (watch_period_ > 0 && whole && (watch_frame_ + 1) % watch_period_ == 0) {
+    WatchCollect(true);
+    watch_layer = NextWatchLayer();
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing_) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
   for (size_t i = 0; i < layers_.size(); ++i)      // (a paired ROIPooling skips only inside the call in which its partner ran)
@@ -626,12 +650,13 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   for (size_t k = 0; k < chain_pairs_.size(); ++k) {
     const ChainPair& cp = chain_pairs_[k];
     ConvolutionLayer<Dtype>* c = static_cast<ConvolutionLayer<Dtype>*>(layers_[cp.producer].get());
+    const bool watched = watch_layer >= 0 && (cp.producer == watch_layer || cp.consumer == watch_layer);      // its blobs must exist
     if (cp.consumer < 0) {      // (a top read by the fused pooling only)
-      c->set_pool_only_live(fusion_ && chain_fusion_ && start <= cp.producer && cp.producer <= end);
+      c->set_pool_only_live(fusion_ && chain_fusion_ && !watched && start <= cp.producer && cp.producer <= end);
       if (!(start <= cp.producer && cp.producer <= end)) MaterializeBlob(cp.blob);
       continue;
     }
-    const bool both = start <= cp.producer && cp.consumer <= end;
+    const bool both = start <= cp.producer && cp.consumer <= end && !watched;
     c->set_chain_live(fusion_ && chain_fusion_ && both);
     static_cast<ConvolutionLayer<Dtype>*>(layers_[cp.consumer].get())->set_chain_live(false);
     // a blob the last Forward left unwritten whose producer does not run in this call: write it now, from the bottom its layer was
@@ -641,7 +666,8 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   for (size_t k = 0; k < chain_pairs_.size(); ++k) {      // (a consumer that is itself a producer: its own live mark, set above, stands)
     const ChainPair& cp = chain_pairs_[k];
     if (cp.consumer < 0) continue;
-    const bool both = start <= cp.producer && cp.consumer <= end;
+    const bool watched = watch_layer >= 0 && (cp.producer == watch_layer || cp.consumer == watch_layer);
+    const bool both = start <= cp.producer && cp.consumer <= end && !watched;
     static_cast<ConvolutionLayer<Dtype>*>(layers_[cp.producer].get())->set_chain_live(fusion_ && chain_fusion_ && both);
   }
   for (int i = start; i <= end; ++i) {
@@ -680,6 +706,15 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
     }
   }
   if (timing_) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+  if (watch_layer >= 0 && !handoff_restart) {
+    ConvolutionLayer<Dtype>* c = static_cast<ConvolutionLayer<Dtype>*>(layers_[watch_layer].get());
+    watch_next_ = (watch_layer + 1) % (int)layers_.size();
+    if (watch_next_ <= watch_layer) ++watch_band_;          // one band per trip round the layers
+    if (c->BeginBandCheck(bottom_vecs_[watch_layer], top_vecs_[watch_layer], watch_band_)) {
+      watch_pending_ = watch_layer;
+      ++watch_checks_;
+    }
+  }
   // a paired ROIPooling's skip mark must not outlive the call in which its partner ran (a range that ends between the two, then a
   // direct Layer::Forward on the second: it has to pool, not skip)
   for (size_t i = 0; i < layers_.size(); ++i)
@@ -714,7 +749,10 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
     --forward_count_;
     return ForwardFromTo(from, end);
   }
-  if (watch_period_ > 0 && start == 0 && end == (int)layers_.size() - 1 && ++watch_frame_ % watch_period_ == 0) NumericsWatchStep();
+  if (watch_period_ > 0 && whole) {
+    ++watch_frame_;
+    if (watch_layer < 0) WatchCollect(false);      // (never blocks: a verdict that is not in yet is taken by a later frame)
+  }
   return 0;
 }
 

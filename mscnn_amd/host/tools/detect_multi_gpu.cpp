@@ -29,6 +29,7 @@ namespace {
 struct Options {
   std::string prototxt, caffemodel, precision = "f32";
   int gpus = 0, images = 16, cls_id = 2, cap = 2000;
+  bool verbose = false;
 };
 
 #define NET_CHECK(expr) do { if ((expr) != 0) { fprintf(stderr, "[rank %d] %s: %s\n", rank, #expr, mscnn_net_last_error()); std::exit(2); } } while (0)
@@ -88,6 +89,11 @@ void make_frame(int k, int H, int W, std::vector<float>* out) {
 }
 
 void worker(int rank, int world, const Options& opt, const unsigned char* id, std::vector<double>* seconds, std::vector<int>* total_dets) {
+  // this thread (and the helper threads it will create) onto its GPU's NUMA node, in a slice of its own among the ranks sharing the node
+  char placement[512] = "";
+  if (mscnn_dist_pin_host_thread(rank, rank, world, 0, nullptr, placement, sizeof(placement)) != 0)
+    fprintf(stderr, "[rank %d] not pinned: %s\n", rank, mscnn_dist_last_error());
+  else if (opt.verbose) fprintf(stderr, "[rank %d] %s\n", rank, placement);
   mscnn_net* net = nullptr;
   NET_CHECK(mscnn_net_create_from_file(opt.prototxt.c_str(), rank, &net));            // also binds this thread to device `rank`
   if (!opt.caffemodel.empty()) NET_CHECK(mscnn_net_load_caffemodel(net, opt.caffemodel.c_str()));
@@ -177,6 +183,7 @@ int main(int argc, char** argv) {
     else if (a == "--precision") opt.precision = next();
     else if (a == "--cls-id") opt.cls_id = std::atoi(next());
     else if (a == "--cap") opt.cap = std::atoi(next());
+    else if (a == "--verbose") opt.verbose = true;
     else if (opt.prototxt.empty()) opt.prototxt = a;
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
   }

@@ -296,3 +296,59 @@ def test_bench_gpus_2_launches_itself_with_two_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["launch_check"] is True and out["value"] is None
     assert "2 ranks in the communicator (ncclCommCount)" in out["config"]["gather"] and "pipelined" in out["config"]["gather"]
     assert out["config"]["comm_count"] == 2 and out["config"]["ranks_seen"] == [0, 1]
+
+
+def test_bench_gpus_8_launch_check_with_host_placement(tmp_path):
+    """The 8-rank launch nobody can rehearse on hardware here: `python bench.py --gpus 8 --launch-check` starts EIGHT
+    ranks under torch.distributed.run, every rank takes its CPU slice from the product's planner (mscnn_dist_plan_cpus) on a synthetic
+    two-socket topology laid over this container's CPUs -- ranks 0-3 local to the first half, 4-7 to the second -- applies it, and the
+    pipelined exchange of libmscnn_dist.so runs at world 8 on the transport stub.  The line: n_gpus 8, eight senders seen in every
+    exchange, eight disjoint CPU slices, each inside its socket's half."""
+    import json
+    stubs = _build_stubs(tmp_path)
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 8:
+        pytest.skip("fewer than 8 CPUs: eight disjoint slices do not exist")
+    half = len(cpus) // 2
+
+    def fmt(v):
+        return ",".join(str(c) for c in v)
+    lists = [fmt(cpus[:half])] * 4 + [fmt(cpus[half:])] * 4
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LD_PRELOAD"] = stubs["fake_hip"]
+    env["OMP_NUM_THREADS"] = "1"
+    r = _bench(["--gpus", "8", "--steps", "6", "--warmup", "1", "--launch-check", "--transport", stubs["fake_rccl"],
+                "--fake-cpulists", ";".join(lists)], env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["comm_count"] == 8 and out["config"]["ranks_seen"] == list(range(8))
+    per = out["config"]["per_rank"]
+    assert [p["rank"] for p in per] == list(range(8))
+    seen = set()
+    for p in per:
+        mine = set(p["applied"])
+        assert mine and not (mine & seen), (p, seen)                     # disjoint
+        assert mine <= set(cpus[:half] if p["rank"] < 4 else cpus[half:]), p   # inside its own "socket"
+        seen |= mine
+
+
+def test_plan_cpus_two_socket_node():
+    """mscnn_dist_plan_cpus on the topology the 8-GPU node is expected to have (4 GPUs per socket, SMT siblings listed as a second run):
+    every rank gets cores AND their siblings of its own socket, slices are disjoint and cover the node; an `allowed` mask narrower than
+    the node (container) is respected; unknown locality falls back to the allowed set; more ranks than CPUs share."""
+    from mscnn_amd import dist as md
+    node = ["0-63,128-191"] * 4 + ["64-127,192-255"] * 4
+    got = [md.parse_cpulist(md.plan_cpus(node, r, allowed="0-255")) for r in range(8)]
+    assert got[0] == set(range(0, 16)) | set(range(128, 144)) and got[5] == set(range(80, 96)) | set(range(208, 224))
+    assert all(len(g) == 32 for g in got) and set().union(*got) == set(range(256))
+    assert sum(len(g) for g in got) == 256                                  # disjoint
+    inside = [md.parse_cpulist(md.plan_cpus(node, r, allowed="0-31")) for r in range(8)]
+    assert all(g <= set(range(32)) and g for g in inside)
+    # (the second socket's ranks find none of their CPUs in the mask and fall back to it: all eight then share 0-31, four CPUs each)
+    assert inside[0] == {0, 1, 2, 3} and inside[7] == {28, 29, 30, 31} and sum(len(g) for g in inside) == 32
+    assert md.parse_cpulist(md.plan_cpus(["", ""], 1, allowed="0-7")) == {4, 5, 6, 7}
+    assert md.parse_cpulist(md.plan_cpus(["0-1"] * 4, 3, allowed="0-1")) == {1} or md.parse_cpulist(md.plan_cpus(["0-1"] * 4, 3, allowed="0-1")) == {0, 1}
+    with pytest.raises(md.DistError):
+        md.plan_cpus(["0-3", "x"], 0, allowed="0-7")
