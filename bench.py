@@ -342,7 +342,7 @@ def _measured_traffic():
     kernel_sources_sha16 matches the wgemm.hip / winograd.hip of this tree."""
     sha = _kernel_sources_sha16()
     seen = []
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_wgemm.json")
         try:
             t = json.load(open(path))
@@ -362,20 +362,29 @@ def _measured_traffic():
 
 
 def _measured_mfma_busy():
-    """MFMA-pipe utilisation of the plane-GEMM kernel from the PMC counters (tools/pmc_mfma.py -> profiles/r05_mfma_busy.json), under the
+    """MFMA-pipe utilisation of the plane-GEMM kernel from the PMC counters (tools/pmc_mfma.py -> profiles/rNN_mfma_busy.json), under the
     same rule as `traffic`: reported only while wgemm.hip / winograd.hip are byte-identical to the sources it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r05_mfma_busy.json")
-    try:
-        t = json.load(open(path))
-        if t.get("kernel_sources_sha16") != _kernel_sources_sha16():
-            return {"mfma_busy": None, "mfma_busy_source": f"profiles/r05_mfma_busy.json was measured on other kernel sources ({t.get('kernel_sources_sha16')}): not reported"}
-        return {"mfma_busy": t["mfma_busy_time_weighted"],
-                "mfma_busy_per_layer": {k: {"busy": v.get("mfma_busy"), "clock_ghz": v.get("clock_ghz"), "avg_us": v.get("avg_us")} for k, v in t["layers"].items()},
-                "mfma_busy_source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the kernel stand-alone per layer, time-weighted "
-                                    "(rocprofv3 --pmc, tools/pmc_mfma.py -> profiles/r05_mfma_busy.json; profiled clock in clock_ghz: busy x clock / 2.4 "
-                                    "is the fraction of the 157.3 TFLOP/s peak the pipe was issued at, tile padding included)"}
-    except (OSError, ValueError, KeyError):
-        return {"mfma_busy": None, "mfma_busy_source": "no PMC measurement in profiles/ (tools/pmc_mfma.py)"}
+    sha, other = _kernel_sources_sha16(), []
+    for rnd in ("r06", "r05"):
+        rel = f"profiles/{rnd}_mfma_busy.json"
+        try:
+            t = json.load(open(os.path.join(ROOT, rel)))
+        except (OSError, ValueError):
+            continue
+        try:
+            if t.get("kernel_sources_sha16") != sha:
+                other.append(f"{rel} ({t.get('kernel_sources_sha16')})")
+                continue
+            return {"mfma_busy": t["mfma_busy_time_weighted"],
+                    "mfma_busy_per_layer": {k: {"busy": v.get("mfma_busy"), "clock_ghz": v.get("clock_ghz"), "avg_us": v.get("avg_us")} for k, v in t["layers"].items()},
+                    "mfma_busy_source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the kernel stand-alone per layer, time-weighted "
+                                        f"(rocprofv3 --pmc, tools/pmc_mfma.py -> {rel}; profiled clock in clock_ghz: busy x clock / 2.4 "
+                                        "is the fraction of the 157.3 TFLOP/s peak the pipe was issued at, tile padding included)"}
+        except KeyError:
+            continue
+    if other:
+        return {"mfma_busy": None, "mfma_busy_source": "measured on other kernel sources: " + ", ".join(other) + ": not reported"}
+    return {"mfma_busy": None, "mfma_busy_source": "no PMC measurement in profiles/ (tools/pmc_mfma.py)"}
 
 
 class _CudaPtr:
@@ -1000,7 +1009,7 @@ def main():
         wchecks, wsw = net.numerics_watch_state()
         if numerics is not None:
             # the watch is ON in the timed loop (Net default: every 25th whole forward one band of one Winograd layer is recomputed with
-            # the direct kernel behind the frame, no host synchronisation; that frame also runs the layer outside its chain).  Timed step i is
+            # the direct kernel behind the frame, no host synchronisation; that frame also writes the layer's bottom / top blobs although it stays chained).  Timed step i is
             # whole forward number warmup + i + 1 of this net: the watch frames of the headline loop are known, their cost is reported
             wp = 25
             wf = [i for i in range(args.steps) if (max(args.warmup, 1) + i + 1) % wp == 0]

@@ -108,7 +108,7 @@ MSCNN_NET_API int mscnn_net_auto_calibrate_state(const mscnn_net* net, int* chec
 MSCNN_NET_API int mscnn_net_calibrate_numerics(mscnn_net* net, double tol, int* num_switched);
 MSCNN_NET_API double mscnn_net_layer_calibration_err(const mscnn_net* net, int layer);
 /* The same comparison on live frames (the numerics watch): every period-th whole forward looks at ONE Winograd layer (round robin) --
- * the layer runs outside its convolution chain in that frame, and one band of it (a few rows / images: ~30 us of direct-kernel work; round robin too) is
+ * its bottom and top blobs are written in that frame (it stays in its convolution chain), and one band of it (a few rows / images: ~30 us of direct-kernel work; round robin too) is
  * recomputed with the direct kernel BEHIND the frame on the same stream, with no host synchronisation; the verdict is collected by a
  * later forward, and a layer off by more than tol runs the direct kernel from the frame after.  No frame waits for a check: a watch
  * frame is 2 - 4 % longer (7s-576), the others not at all.  ON by default with period 25, tol 5e-5 (~0.1 % of a stream); period 0

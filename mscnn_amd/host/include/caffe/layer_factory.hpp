@@ -1,5 +1,10 @@
-// LayerRegistry: string -> creator map keyed by the prototxt `type:` (mirror of
-// include/caffe/layer_factory.hpp:58-137).  REGISTER_LAYER_CLASS(Type) registers TypeLayer<float>.
+// The layer factory of the drop-in surface: prototxt `type:` string -> constructor.  What user code touches keeps the reference's
+// names (include/caffe/layer_factory.hpp:58-137): LayerRegistry<Dtype>::{Creator, CreatorRegistry, Registry, AddCreator, CreateLayer,
+// LayerTypeList}, LayerRegisterer<Dtype>, REGISTER_LAYER_CLASS(Type), REGISTER_LAYER_CREATOR(type, creator) -- a reference-style user
+// layer (tests/boundary/*.cpp) registers itself with the same one line.  The implementation is this build's own: one table per Dtype
+// in a function-local static (constructed on first use, so registration from static initialisers of any translation unit is safe),
+// looked up with find(); only `float` is ever registered (the reference also instantiates `double`, common.hpp:41-44 -- no deploy net
+// uses it).
 #ifndef MSCNN_CAFFE_LAYER_FACTORY_HPP_
 #define MSCNN_CAFFE_LAYER_FACTORY_HPP_
 
@@ -19,41 +24,39 @@ class LayerRegistry {
   typedef std::map<string, Creator> CreatorRegistry;
 
   static CreatorRegistry& Registry() {
-    static CreatorRegistry* g_registry_ = new CreatorRegistry();
-    return *g_registry_;
+    static CreatorRegistry table;
+    return table;
   }
+  // one creator per type string; a second registration of the same string is a programming error, reported by name
   static void AddCreator(const string& type, Creator creator) {
-    CreatorRegistry& registry = Registry();
-    CHECK_EQ(registry.count(type), 0u) << "Layer type " << type << " already registered.";
-    registry[type] = creator;
+    const bool fresh = Registry().insert(std::make_pair(type, creator)).second;
+    CHECK(fresh) << "Layer type " << type << " already registered.";
   }
   static shared_ptr<Layer<Dtype> > CreateLayer(const LayerParameter& param) {
-    const string& type = param.type();
-    CreatorRegistry& registry = Registry();
-    CHECK_EQ(registry.count(type), 1u) << "Unknown layer type: " << type << " (known types: " << LayerTypeListString() << ")";
-    return registry[type](param);
+    const typename CreatorRegistry::const_iterator hit = Registry().find(param.type());
+    if (hit == Registry().end()) {
+      string known;
+      for (const string& t : LayerTypeList()) known += (known.empty() ? "" : ", ") + t;
+      LOG(FATAL) << "Unknown layer type: " << param.type() << " (known types: " << known << ")";
+    }
+    return hit->second(param);
   }
   static vector<string> LayerTypeList() {
-    vector<string> layer_types;
-    for (typename CreatorRegistry::iterator iter = Registry().begin(); iter != Registry().end(); ++iter) layer_types.push_back(iter->first);
-    return layer_types;
+    vector<string> types;
+    types.reserve(Registry().size());
+    for (const auto& entry : Registry()) types.push_back(entry.first);      // (std::map: already in alphabetical order)
+    return types;
   }
 
  private:
-  LayerRegistry() {}
-  static string LayerTypeListString() {
-    string s;
-    for (const string& t : LayerTypeList()) s += (s.empty() ? "" : ", ") + t;
-    return s;
-  }
+  LayerRegistry();      // a namespace of statics: never instantiated
 };
 
+// an object whose construction registers: what the macros below place at namespace scope
 template <typename Dtype>
 class LayerRegisterer {
  public:
-  LayerRegisterer(const string& type, shared_ptr<Layer<Dtype> > (*creator)(const LayerParameter&)) {
-    LayerRegistry<Dtype>::AddCreator(type, creator);
-  }
+  LayerRegisterer(const string& type, typename LayerRegistry<Dtype>::Creator creator) { LayerRegistry<Dtype>::AddCreator(type, creator); }
 };
 
 #define REGISTER_LAYER_CREATOR(type, creator) static LayerRegisterer<float> g_creator_f_##type(#type, creator<float>)

@@ -91,6 +91,9 @@ class ConvolutionLayer : public Layer<Dtype> {
   // The top's only reader is the fused-away 2x2 pooling (conv2_2, conv3_3): while live, an F(4x4,3x3) Forward writes the pooled blob
   // only (mscnn_conv2d_plan_can_pool_only); the top is top_stale() and re-created on demand like a chain's
   void set_pool_only_live(bool on) { pool_only_live_ = on; }
+  // (round 6) this Forward writes the top blob even as a chain producer (the output stage then writes the next layer's planes AND y) or
+  // where the pooling is its only reader: the numerics watch needs the blobs of the layer it looks at, without leaving the chain
+  void set_keep_top(bool on) { keep_top_ = on; }
   bool top_stale() const { return top_stale_; }
   // Forward with the chain (and a prepared input) ignored: writes the top blob from the bottom blob
   void ForwardUnchained(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
@@ -173,7 +176,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   ROIPoolingLayer<Dtype>* roi_src_ = nullptr;
   bool last_fused_roipool_ = false;       // the last Forward pooled inside its input stage (kernel_name() says so)
   ConvolutionLayer* chain_next_ = nullptr;
-  bool chain_live_ = false, pool_only_live_ = false, top_stale_ = false, last_chained_ = false;
+  bool chain_live_ = false, pool_only_live_ = false, top_stale_ = false, last_chained_ = false, keep_top_ = false;
   bool prepared_ = false;                 // the previous layer of the chain wrote this layer's planes at ws_off_ (this Forward only)
   size_t ws_off_ = 0, next_off_ = 0;      // this layer's / the next layer's region of the shared workspace while a chain runs
   bool fuse_next_now_ = false;            // decided by the head of the chain for this Forward

@@ -107,10 +107,10 @@ class Net {
   int auto_calibrate_checks() const { return auto_checks_; }
   const vector<int>& auto_calibrate_switched() const { return auto_switched_; }
   // The same comparison while a stream of frames runs (the numerics watch): every `period`-th whole Forward looks at ONE Winograd
-  // layer (round robin) -- the layer runs outside its convolution chain in that frame so that its blobs exist, and one band of it (a few
+  // layer (round robin) -- its bottom and top are written as blobs in that frame although it stays in its convolution chain, and one band of it (a few
   // rows / images: ~30 us of direct-kernel work; round robin too) is recomputed with the direct kernel BEHIND the frame on the same stream, without a
   // host synchronisation.  The verdict is collected by a later Forward (or by the state accessors below); a layer that strayed by more
-  // than tol runs the direct kernel for good from the frame after.  A watch frame costs the un-chaining of one layer plus that band
+  // than tol runs the direct kernel for good from the frame after.  A watch frame costs up to two extra blob writes plus that band
   // (2 - 4 % of a 7s-576 frame); no frame ever waits for a check.  ON by default (every
   // kDefaultWatchPeriod-th frame, tolerance 5e-5: ~0.1 % of a stream); period 0 turns it off.
   static constexpr int kDefaultWatchPeriod = 25;

@@ -500,7 +500,7 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     if (mscnn_conv2d_plan_can_pool(plan_)) pooled = pooled_top_->mutable_gpu_data();
   }
   last_chained_ = false;
-  const bool pool_only = pool_only_live_ && pooled && !selfcheck_pending_ && mscnn_conv2d_plan_can_pool_only(plan_);
+  const bool pool_only = pool_only_live_ && !keep_top_ && pooled && !selfcheck_pending_ && mscnn_conv2d_plan_can_pool_only(plan_);
   if (was_prepared || fuse_next_now_) {
     // a member of a running chain: planes prepared by the previous member (x = NULL) and / or written for the next one (its top blob
     // is then NOT written: top_stale_)
@@ -508,9 +508,9 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     const size_t nb = nx ? mscnn_conv2d_workspace_bytes(nx->plan_) : 0;
     void* nws = nx ? static_cast<unsigned char*>(shared_ws[dev]->Reserve(next_off_ + nb)) + next_off_ : nullptr;
     MSCNN_CHECK(mscnn_conv2d_fwd_chain_f32(plan_, nx ? nx->plan_ : nullptr, was_prepared ? nullptr : bottom[0]->gpu_data(), packed, bias,
-                                           nx || pool_only ? nullptr : top[0]->mutable_gpu_data(), nx ? nullptr : pooled, ws, wbytes, nws,
+                                           (nx && !keep_top_) || pool_only ? nullptr : top[0]->mutable_gpu_data(), nx ? nullptr : pooled, ws, wbytes, nws,
                                            nb, S()));
-    if (nx) { nx->prepared_ = true; top_stale_ = true; last_chained_ = true; }
+    if (nx) { nx->prepared_ = true; top_stale_ = !keep_top_; last_chained_ = true; }
     else top_stale_ = pool_only;
     fuse_next_now_ = false;
   } else {

@@ -515,8 +515,9 @@ void Net<Dtype>::SetNumericsWatch(int period, double tol) {
   if (period == 0 && auto_tol_ == 0.0) ConvolutionLayer<Dtype>::ReleaseCheckScratch();
 }
 
-// The numerics watch (round 6 form: no check inside a frame's latency).  On a watch frame ONE Winograd layer -- round robin -- runs
-// outside its convolution chain, so that its bottom and top blobs exist, and one band of it (round robin as well) is recomputed with
+// The numerics watch (round 6 form: no check inside a frame's latency).  On a watch frame ONE Winograd layer -- round robin -- has its
+// bottom and top written as blobs although it stays in its convolution chain (the producers write y beside the next layer's planes
+// / the pooled map: ConvolutionLayer::set_keep_top), and one band of it (round robin as well) is recomputed with
 // the direct kernel BEHIND the frame on the same stream (ConvolutionLayer::BeginBandCheck: a copy of the band, a direct convolution an
 // eighth of the layer's size, two reductions, 4 bytes to pinned memory, an event).  Nobody waits for it: the verdict is collected at
 // the end of a later whole forward (or when somebody asks for the watch's state) and, when the layer strayed, it runs the direct
@@ -592,7 +593,7 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   ++forward_count_;
   bool handoff_restart = false;
   // a watch frame: the verdict still out (if any) is taken first -- its kernels ran in front of everything this call will enqueue --,
-  // then the layer to look at in this frame is chosen; it runs outside its chains below
+  // then the layer to look at in this frame is chosen; the producers of its bottom and top keep their top blobs below
   const bool whole = start == 0 && end == (int)layers_.size() - 1;
   int watch_layer = -1;
   if (watch_period_ > 0 && whole && (watch_frame_ + 1) % watch_period_ == 0) {
@@ -650,13 +651,14 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   for (size_t k = 0; k < chain_pairs_.size(); ++k) {
     const ChainPair& cp = chain_pairs_[k];
     ConvolutionLayer<Dtype>* c = static_cast<ConvolutionLayer<Dtype>*>(layers_[cp.producer].get());
-    const bool watched = watch_layer >= 0 && (cp.producer == watch_layer || cp.consumer == watch_layer);      // its blobs must exist
+    // (the layer under watch needs its bottom and its top as blobs: the producer of either writes y beside the planes / the pooled map)
+    c->set_keep_top(watch_layer >= 0 && (cp.producer == watch_layer || cp.consumer == watch_layer));
     if (cp.consumer < 0) {      // (a top read by the fused pooling only)
-      c->set_pool_only_live(fusion_ && chain_fusion_ && !watched && start <= cp.producer && cp.producer <= end);
+      c->set_pool_only_live(fusion_ && chain_fusion_ && start <= cp.producer && cp.producer <= end);
       if (!(start <= cp.producer && cp.producer <= end)) MaterializeBlob(cp.blob);
       continue;
     }
-    const bool both = start <= cp.producer && cp.consumer <= end && !watched;
+    const bool both = start <= cp.producer && cp.consumer <= end;
     c->set_chain_live(fusion_ && chain_fusion_ && both);
     static_cast<ConvolutionLayer<Dtype>*>(layers_[cp.consumer].get())->set_chain_live(false);
     // a blob the last Forward left unwritten whose producer does not run in this call: write it now, from the bottom its layer was
@@ -666,8 +668,7 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   for (size_t k = 0; k < chain_pairs_.size(); ++k) {      // (a consumer that is itself a producer: its own live mark, set above, stands)
     const ChainPair& cp = chain_pairs_[k];
     if (cp.consumer < 0) continue;
-    const bool watched = watch_layer >= 0 && (cp.producer == watch_layer || cp.consumer == watch_layer);
-    const bool both = start <= cp.producer && cp.consumer <= end && !watched;
+    const bool both = start <= cp.producer && cp.consumer <= end;
     static_cast<ConvolutionLayer<Dtype>*>(layers_[cp.producer].get())->set_chain_live(fusion_ && chain_fusion_ && both);
   }
   for (int i = start; i <= end; ++i) {
@@ -722,6 +723,7 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
   for (size_t k = 0; k < chain_pairs_.size(); ++k) {
     static_cast<ConvolutionLayer<Dtype>*>(layers_[chain_pairs_[k].producer].get())->set_chain_live(false);
     static_cast<ConvolutionLayer<Dtype>*>(layers_[chain_pairs_[k].producer].get())->set_pool_only_live(false);
+    static_cast<ConvolutionLayer<Dtype>*>(layers_[chain_pairs_[k].producer].get())->set_keep_top(false);
     if (chain_pairs_[k].consumer >= 0) static_cast<ConvolutionLayer<Dtype>*>(layers_[chain_pairs_[k].consumer].get())->set_chain_live(false);
   }
   // books of the layers' own first-forward checks (safe-by-default numerics: ConvolutionLayer::set_selfcheck)

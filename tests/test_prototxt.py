@@ -84,6 +84,82 @@ def test_7s576_graph_splits_and_shapes():
     assert sum(t == "Convolution" for t in n.layer_types) == 23 and sum(t == "Pooling" for t in n.layer_types) == 6
 
 
+def _expected_splits(layers):
+    """The reference's naming rule (util/insert_splits.cpp:14-124), restated independently of the host runtime's implementation: for
+    every top VERSION (an in-place layer re-issues its bottom's name) count the bottoms that read it; a version with more than one
+    reader gets a Split layer "<blob>_<layer>_<top index>_split" behind its producer and reader k reads "..._split_<k>", in net order."""
+    newest, readers, reads = {}, {}, []
+    for li, (name, typ, bottoms, tops) in enumerate(layers):
+        mine = []
+        for b in bottoms:
+            mine.append(newest[b])
+            readers[newest[b]] = readers.get(newest[b], 0) + 1
+        reads.append(mine)
+        for ti, t in enumerate(tops):
+            newest[t] = (li, ti)
+    out, handed = [], {}
+    for li, (name, typ, bottoms, tops) in enumerate(layers):
+        nb = []
+        for b, v in zip(bottoms, reads[li]):
+            if readers[v] > 1:
+                k = handed.get(v, 0); handed[v] = k + 1
+                pl, pt = v
+                nb.append(f"{layers[pl][3][pt]}_{layers[pl][0]}_{pt}_split_{k}")
+            else:
+                nb.append(b)
+        out.append((name, typ, nb, list(tops)))
+        for ti, t in enumerate(tops):
+            n = readers.get((li, ti), 0)
+            if n > 1:
+                stem = f"{t}_{name}_{ti}_split"
+                out.append((stem, "Split", [t], [f"{stem}_{k}" for k in range(n)]))
+    return out
+
+
+def test_split_insertion_on_in_place_layers_multiple_tops_and_fan_out():
+    """Net construction's Split insertion (host/src/net.cpp InsertSplits, rewritten in round 6) on the cases the deploy files mix: a top
+    read three times, an in-place ReLU between a producer and two readers (the readers must split the ReLU's version of the blob, not
+    the convolution's), a layer with two tops each read twice, and a blob read once (no Split).  Names, order and wiring against the
+    rule restated above."""
+    txt = '''
+    name: "s" input: "data" input_dim: 1 input_dim: 3 input_dim: 16 input_dim: 16
+    layer { name: "a" type: "Convolution" bottom: "data" top: "a" convolution_param { num_output: 4 kernel_size: 3 pad: 1 } }
+    layer { name: "a_relu" type: "ReLU" bottom: "a" top: "a" }
+    layer { name: "b" type: "Convolution" bottom: "a" top: "b" convolution_param { num_output: 4 kernel_size: 3 pad: 1 } }
+    layer { name: "c" type: "Convolution" bottom: "a" top: "c" convolution_param { num_output: 4 kernel_size: 3 pad: 1 } }
+    layer { name: "d" type: "Convolution" bottom: "a" top: "d" convolution_param { num_output: 4 kernel_size: 3 pad: 1 } }
+    layer { name: "sum" type: "Eltwise" bottom: "b" bottom: "c" bottom: "d" top: "sum" eltwise_param { operation: SUM } }
+    layer { name: "cat" type: "Concat" bottom: "sum" bottom: "sum" top: "cat" }
+    layer { name: "e" type: "Convolution" bottom: "cat" top: "e" convolution_param { num_output: 2 kernel_size: 1 } }
+    '''
+    n = Net(prototxt_text=txt, fusion=False)
+    got = [(n.layer_names[i], n.layer_types[i], n.layer_bottoms(i), n.layer_tops(i)) for i in range(len(n.layer_names))]
+    src = [("input", "Input", [], ["data"]), ("a", "Convolution", ["data"], ["a"]), ("a_relu", "ReLU", ["a"], ["a"]),
+           ("b", "Convolution", ["a"], ["b"]), ("c", "Convolution", ["a"], ["c"]), ("d", "Convolution", ["a"], ["d"]),
+           ("sum", "Eltwise", ["b", "c", "d"], ["sum"]), ("cat", "Concat", ["sum", "sum"], ["cat"]), ("e", "Convolution", ["cat"], ["e"])]
+    want = _expected_splits(src)
+    assert got == want, (got, want)
+    names = [g[0] for g in got]
+    assert "a_a_relu_0_split" in names and "a_a_0_split" not in names          # the in-place ReLU's version is the one that fans out
+    assert got[names.index("a_a_relu_0_split")][3] == ["a_a_relu_0_split_0", "a_a_relu_0_split_1", "a_a_relu_0_split_2"]
+    assert got[names.index("cat")][2] == ["sum_sum_0_split_0", "sum_sum_0_split_1"]                       # one layer reading a blob twice
+    # a layer with two tops, each read twice: the 7s-576 deploy's BoxOutput ("proposals" feeds both ROI poolings; the score top is an output)
+    d = Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576"), fusion=False)
+    dn = list(d.layer_names)
+    assert dn[dn.index("proposals") + 1] == "proposals_proposals_0_split"
+    full = [(d.layer_names[i], d.layer_types[i], d.layer_bottoms(i), d.layer_tops(i)) for i in range(len(dn))]
+    unsplit = [l for l in full if l[1] != "Split"]
+    # undo the split renaming to get the source graph back, then demand the rule reproduces the whole net
+    stems = {l[0]: l[2][0] for l in full if l[1] == "Split"}
+    def unrename(b):
+        for stem, blob in stems.items():
+            if b.startswith(stem + "_"):
+                return blob
+        return b
+    source = [(nm, ty, [unrename(b) for b in bo], to) for (nm, ty, bo, to) in unsplit]
+    assert _expected_splits(source) == full
+
+
 def test_convolution_chains_are_wired_at_construction(monkeypatch):
     """Round 4: the Net registers (a) every convolution whose top has exactly one running reader, a 3x3 convolution right behind it
     (the blob between them may stay unwritten while both run chained), (b) every convolution whose top is read by its fused 2x2
