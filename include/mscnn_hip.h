@@ -257,6 +257,8 @@ MSCNN_API int mscnn_max_rel_diff_f32(const float* a, const float* ref, size_t co
  * DEVICE: the host runtime's numerics watch chains mscnn_sum_squares_f32 -> this call without a host round trip in between. */
 MSCNN_API int mscnn_max_rel_diff_strided_f32(const float* a, size_t a_stride, const float* ref, size_t ref_stride, size_t planes, size_t run,
                                              const double* sumsq_dev, double sumsq_count, float* out_dev, void* stream);
+/* dst_dev[0 .. n) = values_host[0 .. n), n <= 4, in ONE launch (values travel as kernel arguments): the header words of a detection pack. */
+MSCNN_API int mscnn_store_words_i32(int* dst_dev, const int* values_host, int n, void* stream);
 /* out_dev[0] = sum_i x[i]^2 in double: the scale (rms) of a blob, the floor of the calibration metric on hot activations. */
 MSCNN_API int mscnn_sum_squares_f32(const float* x, size_t count, double* out_dev, void* stream);
 

@@ -176,6 +176,16 @@ typedef struct {
 } mscnn_detect_params;
 MSCNN_NET_API int mscnn_net_detect(mscnn_net* net, const mscnn_detect_params* p, double* dets_host, int* ids_host,
                                    int cap, int* num_dets, int* num_rois);
+/* The same stage for a STREAM of frames (batch-1 nets), pipelined: _begin runs the final stage of the forward just done into the
+ * device pack, enqueues ONE copy of it into one of two pinned host slots behind an event on the net's stream, and returns at once --
+ * the caller goes on with the next frame (set_blob / forward); _end waits for the OLDEST frame in flight and unpacks it: frame i's
+ * detections reach the host under frame i + 1's trunk instead of idling the device for a host round trip per frame.  At most two
+ * frames in flight; cap as in mscnn_net_detect_device (BoxOutput's max_nms_num bounds R).  Results are bit-identical to
+ * mscnn_net_detect.  A stream-K hand-off time-out while frames are in flight can not be answered by a re-run here (the input blob
+ * already holds a later frame): _end then FAILS, naming it, after forcing whole-tile scheduling -- submit the frames begun since the
+ * last _end again. */
+MSCNN_NET_API int mscnn_net_detect_begin(mscnn_net* net, const mscnn_detect_params* p, int cap);
+MSCNN_NET_API int mscnn_net_detect_end(mscnn_net* net, double* dets_host, int* ids_host, int cap, int* num_dets, int* num_rois);
 /* The same stage for image `image` of a batched forward (the MATLAB stage is per image: its NMS never mixes images; mscnn_net_detect
  * itself refuses a net whose input holds more than one image).  ids_host = rows of the net's ROI blobs (bbox_pred, cls_pred,
  * proposals_score), *num_rois = the image's own ROI count. */

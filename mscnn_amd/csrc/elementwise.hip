@@ -284,6 +284,12 @@ __global__ __launch_bounds__(kThreads) void max_rel_diff_strided_kernel(const fl
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// up to four 32-bit words in ONE launch (a pack header {R, cap, 0}: three 4-byte memsets were three blit launches)
+__global__ void store_words_kernel(int* __restrict__ dst, int4 v, int n) {
+  const int t = threadIdx.x;
+  if (t < n) dst[t] = t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w;
+}
+
 // sum of squares in double (the scale of a blob for the calibration metric): per-wave partial sums, one f64 atomicAdd per wave
 __global__ __launch_bounds__(kThreads) void sum_squares_kernel(const float* __restrict__ x, long n, double* __restrict__ out) {
   double s = 0.0;
@@ -311,6 +317,14 @@ extern "C" int mscnn_max_rel_diff_f32(const float* a, const float* ref, size_t c
   if (count == 0) return MSCNN_OK;
   max_rel_diff_kernel<<<grid_for((long)count), kThreads, 0, as_stream(stream)>>>(a, ref, (long)count, floor_,
                                                                                  reinterpret_cast<unsigned*>(out_dev));
+  MSCNN_POST_LAUNCH();
+  return MSCNN_OK;
+}
+
+extern "C" int mscnn_store_words_i32(int* dst_dev, const int* values_host, int n, void* stream) {
+  MSCNN_REQUIRE(dst_dev && values_host && n >= 1 && n <= 4, "store_words: 1 .. 4 words");
+  int4 v = make_int4(values_host[0], n > 1 ? values_host[1] : 0, n > 2 ? values_host[2] : 0, n > 3 ? values_host[3] : 0);
+  store_words_kernel<<<1, 64, 0, as_stream(stream)>>>(dst_dev, v, n);
   MSCNN_POST_LAUNCH();
   return MSCNN_OK;
 }

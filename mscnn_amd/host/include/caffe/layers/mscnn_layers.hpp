@@ -4,6 +4,7 @@
 #ifndef MSCNN_CAFFE_LAYERS_HPP_
 #define MSCNN_CAFFE_LAYERS_HPP_
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -81,6 +82,12 @@ class ConvolutionLayer : public Layer<Dtype> {
   // channels [0, C) and [C, 2C) in the order of their Concat offsets).  While the pair is pending and the planned kernel can pool in
   // its input stage (mscnn_conv2d_plan_can_fuse_roipool) Forward reads the feature map itself; otherwise it asks for the blob.
   void FuseRoiPoolInput(ROIPoolingLayer<Dtype>* first) { roi_src_ = first; }
+  // (round 6) the fused ROI pooling's maps (a channel-last copy of the feature blob + its sliding maxima: they depend on the feature
+  // blob only) built EARLY by the Net -- under BoxOutput's host round trip (BoxOutputLayer::set_before_sync) -- when the last Forward
+  // pooled in the input stage and nothing argues against doing so again; the next Forward uses them if its feature blob is this one,
+  // InvalidateRoiMaps (every Net::ForwardFromTo starts with it) drops them.
+  void PrebuildRoiMaps(const Blob<Dtype>* feat);
+  void InvalidateRoiMaps() { roi_maps_feat_ = nullptr; }
   // Net-level fusion (round 4): `next` is the ONLY reader of this layer's top and a same-resolution 3x3 / pad 1 convolution.  While
   // the Net marks the pair live (both run in the same ForwardFromTo call) and both planned kernels are the fp32 F(4x4,3x3) form
   // (mscnn_conv2d_plan_can_chain), this layer's output stage writes next's input-transform planes and NOT its top blob
@@ -175,6 +182,9 @@ class ConvolutionLayer : public Layer<Dtype> {
   int algo_, tune_[3];
   ROIPoolingLayer<Dtype>* roi_src_ = nullptr;
   bool last_fused_roipool_ = false;       // the last Forward pooled inside its input stage (kernel_name() says so)
+  DeviceBuffer roi_maps_;                 // PrebuildRoiMaps: the maps, the feature data they were built from, its shape
+  const Dtype* roi_maps_feat_ = nullptr;
+  int roi_maps_shape_[4] = {0, 0, 0, 0};
   ConvolutionLayer* chain_next_ = nullptr;
   bool chain_live_ = false, pool_only_live_ = false, top_stale_ = false, last_chained_ = false, keep_top_ = false;
   bool prepared_ = false;                 // the previous layer of the chain wrote this layer's planes at ws_off_ (this Forward only)
@@ -432,6 +442,7 @@ template <typename Dtype>
 class BoxOutputLayer : public Layer<Dtype> {
  public:
   explicit BoxOutputLayer(const LayerParameter& param) : Layer<Dtype>(param), forwarded_(false) {}
+  virtual ~BoxOutputLayer();
   virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
   virtual inline const char* type() const { return "BoxOutput"; }
@@ -439,6 +450,10 @@ class BoxOutputLayer : public Layer<Dtype> {
   virtual inline int MinTopBlobs() const { return 1; }
   virtual inline int MaxTopBlobs() const { return 2; }
   int last_num_rois() const { return last_rows_; }
+  // (round 6) Work that does not depend on the row count, enqueued between BoxOutput's kernels and the host's wait for {R, real rows}:
+  // the device runs it while the host takes R, reshapes the tops and launches what follows -- the frame's one host round trip no
+  // longer idles the GPU.  The Net puts the sliding-maximum maps of the fused ROI pooling there (they depend on conv4_3 only).
+  void set_before_sync(std::function<void()> f) { before_sync_ = std::move(f); }
  protected:
   MSCNN_NO_CPU_PATH("BoxOutput")
   virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top);
@@ -448,6 +463,10 @@ class BoxOutputLayer : public Layer<Dtype> {
   DeviceBuffer workspace_, count_;
   int cap_, last_rows_;
   bool forwarded_;
+  std::function<void()> before_sync_;
+  void* count_ready_ = nullptr;      // hipEvent_t behind BoxOutput's kernels
+  int* host_count_ = nullptr;        // host-coherent pinned landing place of {R, real rows}, and the address the device writes it through
+  int* host_count_dev_ = nullptr;
 };
 
 // include/caffe/layers/decode_bbox_layer.hpp (TEST phase)

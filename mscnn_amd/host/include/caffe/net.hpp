@@ -128,6 +128,10 @@ class Net {
   //   HandoffRecover(): call right after synchronising Caffe::stream() on outputs of the last ForwardFromTo.  false = nothing was
   //   reported; true = the range has been run again (asynchronously, like any Forward): read the outputs again.
   bool HandoffRecover();
+  // For callers that pipeline frames and therefore can NOT have a range run again (mscnn_net_detect_end): true when a hand-off event
+  // was raised since the last look -- whole tiles are forced and the event is counted as in HandoffRecover, nothing is re-run.
+  // (the stream is synchronised only up to the frame being collected: what was enqueued behind it stays "unchecked in flight")
+  bool HandoffEventSeen() { return HandoffEventPending(); }
   int handoff_errors() const { return handoff_errors_; }
 
  protected:

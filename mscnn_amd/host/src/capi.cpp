@@ -20,12 +20,20 @@ struct mscnn_net {
   caffe::DeviceBuffer det_ws;
   caffe::DeviceBuffer img_in, img_ws;      // set_image: the uint8 frame and the resize scratch
   caffe::DeviceBuffer det_pack;            // detect: [count | dets | ids] in one allocation -> ONE D2H copy, one sync
-  void* det_host = nullptr;                // pinned staging for that copy
+  void* det_host = nullptr;                // host-coherent pinned memory: the blocking detect's pack (written by the kernels themselves)
+  void* det_host_dev = nullptr;            // ... as the device addresses it
   size_t det_host_bytes = 0;
   std::vector<int> row_end;                // detect_image: end row of every image in the ROI blobs, of forward number rows_forward
   long rows_forward = -1;
+  // detect_begin / detect_end: two pinned slots, each behind an event on the net's stream
+  struct Slot { caffe::DeviceBuffer pack; void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; int cap = 0, handoff_errors = 0; } slot[2];
+  int slot_head = 0, slot_tail = 0, slots_inflight = 0;
   ~mscnn_net() {
     if (det_host) (void)hipHostFree(det_host);
+    for (Slot& sl : slot) {
+      if (sl.done) { (void)hipEventSynchronize(sl.done); (void)hipEventDestroy(sl.done); }
+      if (sl.host) (void)hipHostFree(sl.host);
+    }
   }
 };
 
@@ -341,7 +349,21 @@ size_t mscnn_net_detect_pack_bytes(int cap) {
 
 // Final stage into the fixed-capacity device pack [count, R, cap, 0 | cap x 5 doubles | cap ints]; no host transfer.
 // [row0, row0 + rows) of the ROI blobs (rows < 0: all of them -- the batch-1 form)
-static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap, int* R_out, bool with_header, int row0 = 0, int nrows = -1) {
+// the net's host-side landing place for packs: host-coherent pinned memory, also addressable by the device (det_host_dev)
+static void ensure_det_host(mscnn_net* n, size_t total) {
+  if (n->det_host_bytes >= total) return;
+  if (n->det_host) HIP_CHECK(hipHostFree(n->det_host));
+  n->det_host = nullptr; n->det_host_bytes = 0; n->det_host_dev = nullptr;
+  HIP_CHECK(hipHostMalloc(&n->det_host, total, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_CHECK(hipHostGetDevicePointer(&n->det_host_dev, n->det_host, 0));
+  n->det_host_bytes = total;
+}
+
+// pack_at: a device-visible address to write the pack to instead of a device buffer (host-coherent pinned memory: the kernels only ever
+// WRITE the pack, so the blocking mscnn_net_detect lets them write straight into the host's copy)
+static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap, int* R_out, bool with_header, int row0 = 0, int nrows = -1,
+                             caffe::DeviceBuffer* pack_buf = nullptr, char* pack_at = nullptr) {
+  caffe::DeviceBuffer& det_pack = pack_buf ? *pack_buf : n->det_pack;
   CHECK(p != nullptr);
   CHECK(n->net->has_blob("bbox_pred") && n->net->has_blob("cls_pred") && n->net->has_blob("proposals_score"))
       << "net has no bbox_pred / cls_pred / proposals_score outputs";
@@ -365,13 +387,11 @@ static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap
   if (with_header && R > cap) {
     // Multi-GPU pack: a rank that fails here alone would leave the others blocked in the all_gather.  Mark the overflow in the header
     // {-1, R, cap, 0} and take part in the exchange: mscnn_net_unpack_detections then fails on EVERY rank, naming the numbers.
-    char* pk = static_cast<char*>(n->det_pack.Reserve(mscnn_net_detect_pack_bytes(cap)));
+    char* pk = static_cast<char*>(det_pack.Reserve(mscnn_net_detect_pack_bytes(cap)));
     hipStream_t s0 = (hipStream_t)Caffe::stream();
     int* h = reinterpret_cast<int*>(pk);
-    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h), -1, 1, s0));
-    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h + 1), R, 1, s0));
-    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h + 2), cap, 1, s0));
-    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h + 3), 0, 1, s0));
+    const int words[4] = {-1, R, cap, 0};
+    MSCNN_CHECK(mscnn_store_words_i32(h, words, 4, s0));
     if (R_out) *R_out = R;
     return;
   }
@@ -386,16 +406,15 @@ static void detect_into_pack(mscnn_net* n, const mscnn_detect_params* p, int cap
   const size_t wb = mscnn_detections_workspace_bytes(R);
   void* ws = n->det_ws.Reserve(wb);
   const size_t rows = (size_t)(cap > 0 ? cap : 1), total = mscnn_net_detect_pack_bytes(cap);
-  char* pack = static_cast<char*>(n->det_pack.Reserve(total));
+  char* pack = pack_at ? pack_at : static_cast<char*>(det_pack.Reserve(total));
   int* hdr = reinterpret_cast<int*>(pack);
   double* dets = reinterpret_cast<double*>(pack + 16);
   int* ids = reinterpret_cast<int*>(pack + 16 + sizeof(double) * 5 * rows);
   hipStream_t st = (hipStream_t)Caffe::stream();
   // header {count (written by the kernels), R, cap, 0}: only the multi-GPU pack needs R / cap on the device -- two 4-byte fills
   if (with_header) {
-    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hdr + 1), R, 1, st));
-    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hdr + 2), cap, 1, st));
-    HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hdr + 3), 0, 1, st));
+    const int words[3] = {R, cap, 0};
+    MSCNN_CHECK(mscnn_store_words_i32(hdr + 1, words, 3, st));      // (one launch; three 4-byte memsets were three)
   }
   MSCNN_CHECK(mscnn_detections_fwd(&d, bbox->gpu_data() + (size_t)row0 * per_row_box, cls->gpu_data() + (size_t)row0 * per_row_cls,
                                    props->gpu_data() + (size_t)row0 * 6, R, dets, ids, hdr, ws, wb, st));
@@ -435,6 +454,53 @@ int mscnn_net_detect_device(mscnn_net* n, const mscnn_detect_params* p, int cap,
   });
 }
 
+// ---- the final stage of a STREAM of frames: frame i's detections travel to the host under frame i + 1's trunk ----------------------
+int mscnn_net_detect_begin(mscnn_net* n, const mscnn_detect_params* p, int cap) {
+  return guarded([&] {
+    CHECK(n->slots_inflight < 2) << "detect_begin: two frames already in flight (call mscnn_net_detect_end)";
+    mscnn_net::Slot& sl = n->slot[n->slot_head];
+    detect_into_pack(n, p, cap, nullptr, true, 0, -1, &sl.pack);      // (a device pack per slot: its copy may still run when the next frame's stage starts)
+    const size_t total = mscnn_net_detect_pack_bytes(cap);
+    if (sl.bytes < total) {
+      if (sl.host) HIP_CHECK(hipHostFree(sl.host));
+      sl.host = nullptr; sl.bytes = 0;
+      HIP_CHECK(hipHostMalloc(&sl.host, total, hipHostMallocDefault));
+      sl.bytes = total;
+    }
+    if (!sl.done) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    hipStream_t st = (hipStream_t)Caffe::stream();
+    // (the copy stays in the compute stream: on a stream of its own, beside the next frame's first kernels, it measured the same --
+    // 224.85 against 224.83 images/s over 300 frames, tools/sessions/r06_s8.sh -- and needed a device pack per slot to be safe)
+    HIP_CHECK(hipMemcpyAsync(sl.host, sl.pack.get(), total, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipEventRecord(sl.done, st));
+    sl.cap = cap;
+    sl.handoff_errors = n->net->handoff_errors();      // (an event of THIS frame's trunk was answered inside its forward, before this point)
+    n->slot_head ^= 1;
+    ++n->slots_inflight;
+  });
+}
+
+int mscnn_net_detect_end(mscnn_net* n, double* dets_host, int* ids_host, int cap, int* num_dets, int* num_rois) {
+  return guarded([&] {
+    CHECK(n->slots_inflight > 0) << "detect_end: nothing in flight";
+    mscnn_net::Slot& sl = n->slot[n->slot_tail];
+    CHECK_EQ(sl.cap, cap) << "detect_end: the oldest frame in flight was begun with another capacity";
+    HIP_CHECK(hipEventSynchronize(sl.done));
+    n->slot_tail ^= 1;
+    --n->slots_inflight;
+    // A stream-K hand-off that timed out since the last look may have poisoned a tile of THIS frame or of the one enqueued behind it,
+    // and neither can be run again from here (the input blob already holds a later frame): whole-tile scheduling is forced for the
+    // process as everywhere else, and the caller is told to submit its last two frames again.
+    // (the event may also have been noticed already -- and counted -- by the NEXT frame's forward, behind its BoxOutput read: that forward
+    // restarted itself, but this frame's pack had left the device by then)
+    const bool seen_now = n->net->HandoffEventSeen();
+    CHECK(!seen_now && n->net->handoff_errors() == sl.handoff_errors) << "a stream-K hand-off timed out while frames were in flight (mscnn_net_handoff_state): whole-tile "
+                                          "scheduling from now on; the frames begun since the last mscnn_net_detect_end must be submitted again";
+    const int rc = mscnn_net_unpack_detections(sl.host, cap, dets_host, ids_host, num_dets, num_rois);
+    CHECK_EQ(rc, 0) << g_err;
+  });
+}
+
 int mscnn_net_unpack_detections(const void* pack_host, int cap, double* dets_host, int* ids_host, int* num_dets, int* num_rois) {
   return guarded([&] {
     CHECK(pack_host && num_dets);
@@ -456,35 +522,30 @@ int mscnn_net_detect(mscnn_net* n, const mscnn_detect_params* p, double* dets_ho
                      int* num_rois) {
   return guarded([&] {
     CHECK(p && dets_host && num_dets);
-    // single-GPU form: the pack is sized by this image's ROI count, so the one D2H copy moves 16 + 44 R bytes
-    int R = 0;
-    int rows = n->net->has_blob("proposals_score") ? n->net->blob_by_name("proposals_score")->num() : 0;
-    detect_into_pack(n, p, rows, &R, false);
-    size_t total = mscnn_net_detect_pack_bytes(rows);
-    if (n->det_host_bytes < total) {
-      if (n->det_host) HIP_CHECK(hipHostFree(n->det_host));
-      n->det_host = nullptr; n->det_host_bytes = 0;
-      HIP_CHECK(hipHostMalloc(&n->det_host, total, hipHostMallocDefault));
-      n->det_host_bytes = total;
-    }
+    // single-GPU form: the pack is sized by this image's ROI count (16 + 44 R bytes) and -- round 6 -- lives in host-coherent pinned
+    // memory that the final stage's kernels write directly (they only ever store into the pack): no D2H copy behind them, the host
+    // waits for the stream and reads.  (An in-stream copy cost ~11 us of copy-engine start-up + its own time per frame:
+    // profiles/r06_kernel_gaps.txt.)  Above 4032 ROIs -- the tiled path, whose kernels are not audited for that -- the pack stays on
+    // the device and is copied as before.
+    int R = 0, rows = 0;
     hipStream_t st = (hipStream_t)Caffe::stream();
-    HIP_CHECK(hipMemcpyAsync(n->det_host, n->det_pack.get(), total, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (n->net->HandoffRecover()) {
-      // a stream-K hand-off of roi_c1 / fc6 timed out in the forward these detections come from (mscnn_net_handoff_state): the Net has
-      // run the frame again on whole tiles -- redo this stage on the new outputs
-      rows = n->net->blob_by_name("proposals_score")->num();
-      detect_into_pack(n, p, rows, &R, false);
-      total = mscnn_net_detect_pack_bytes(rows);
-      if (n->det_host_bytes < total) {
-        HIP_CHECK(hipHostFree(n->det_host));
-        n->det_host = nullptr; n->det_host_bytes = 0;
-        HIP_CHECK(hipHostMalloc(&n->det_host, total, hipHostMallocDefault));
-        n->det_host_bytes = total;
+    auto run = [&]() {
+      rows = n->net->has_blob("proposals_score") ? n->net->blob_by_name("proposals_score")->num() : 0;
+      const size_t total = mscnn_net_detect_pack_bytes(rows);
+      ensure_det_host(n, total);
+      if (rows >= 1 && rows <= 4032) {
+        *static_cast<volatile int*>(n->det_host) = -1;
+        detect_into_pack(n, p, rows, &R, false, 0, -1, nullptr, static_cast<char*>(n->det_host_dev));
+      } else {
+        detect_into_pack(n, p, rows, &R, false);
+        HIP_CHECK(hipMemcpyAsync(n->det_host, n->det_pack.get(), total, hipMemcpyDeviceToHost, st));
       }
-      HIP_CHECK(hipMemcpyAsync(n->det_host, n->det_pack.get(), total, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
-    }
+    };
+    run();
+    // a stream-K hand-off of roi_c1 / fc6 timed out in the forward these detections come from (mscnn_net_handoff_state): the Net has
+    // run the frame again on whole tiles -- redo this stage on the new outputs
+    if (n->net->HandoffRecover()) run();
     const char* hp = static_cast<const char*>(n->det_host);
     const int Dd = *reinterpret_cast<const int*>(hp);
     CHECK_LE(Dd, cap) << "detections buffer too small";
@@ -511,12 +572,7 @@ int mscnn_net_detect_image(mscnn_net* n, const mscnn_detect_params* p, int image
     for (int attempt = 0; attempt < 2; ++attempt) {
       detect_into_pack(n, p, rows, &R, false, row0, rows);
       total = mscnn_net_detect_pack_bytes(rows);
-      if (n->det_host_bytes < total) {
-        if (n->det_host) HIP_CHECK(hipHostFree(n->det_host));
-        n->det_host = nullptr; n->det_host_bytes = 0;
-        HIP_CHECK(hipHostMalloc(&n->det_host, total, hipHostMallocDefault));
-        n->det_host_bytes = total;
-      }
+      ensure_det_host(n, total);
       HIP_CHECK(hipMemcpyAsync(n->det_host, n->det_pack.get(), total, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
       if (attempt == 1 || !n->net->HandoffRecover()) break;
@@ -580,12 +636,7 @@ int mscnn_net_detect_cascade(mscnn_net* n, const mscnn_detect_params* p, float d
     MSCNN_CHECK(mscnn_detections_cascade_fwd(&d, det_thr, boxes->gpu_data(), prob->gpu_data(), props->gpu_data(), R,
                                              reinterpret_cast<double*>(pack + 16), reinterpret_cast<int*>(pack + 16 + sizeof(double) * 5 * rows),
                                              reinterpret_cast<int*>(pack), ws, wb, st));
-    if (n->det_host_bytes < total) {
-      if (n->det_host) HIP_CHECK(hipHostFree(n->det_host));
-      n->det_host = nullptr; n->det_host_bytes = 0;
-      HIP_CHECK(hipHostMalloc(&n->det_host, total, hipHostMallocDefault));
-      n->det_host_bytes = total;
-    }
+    ensure_det_host(n, total);
     HIP_CHECK(hipMemcpyAsync(n->det_host, pack, total, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     const char* hp = static_cast<const char*>(n->det_host);

@@ -481,9 +481,14 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     const vector<Blob<Dtype>*>& pb = a->pending_bottoms();
     if (!selfcheck_pending_ && !pooled_top_ && b && lo->window_c_offset() == 0 && hi->window_c_offset() == C && pb.size() == 2 &&
         mscnn_conv2d_plan_can_fuse_roipool(plan_, C, a->pooled_height(), a->pooled_width())) {
-      const size_t fbytes = mscnn_conv2d_roipool_workspace_bytes(plan_, pb[0]->num(), C, pb[0]->height(), pb[0]->width());
+      // maps the Net had built under BoxOutput's host round trip (PrebuildRoiMaps), if they are of this very feature blob
+      const float* maps = roi_maps_feat_ && roi_maps_feat_ == pb[0]->gpu_data() && roi_maps_shape_[0] == pb[0]->num() && roi_maps_shape_[1] == C &&
+                                  roi_maps_shape_[2] == pb[0]->height() && roi_maps_shape_[3] == pb[0]->width()
+                              ? static_cast<const float*>(roi_maps_.get()) : nullptr;
+      roi_maps_feat_ = nullptr;
+      const size_t fbytes = maps ? wbytes : mscnn_conv2d_roipool_workspace_bytes(plan_, pb[0]->num(), C, pb[0]->height(), pb[0]->width());
       void* fws = shared_ws[dev]->Reserve(fbytes);
-      MSCNN_CHECK(mscnn_conv2d_fwd_roipool_pair_f32(plan_, pb[0]->gpu_data(), nullptr, pb[0]->num(), C, pb[0]->height(), pb[0]->width(),
+      MSCNN_CHECK(mscnn_conv2d_fwd_roipool_pair_f32(plan_, pb[0]->gpu_data(), maps, pb[0]->num(), C, pb[0]->height(), pb[0]->width(),
                                                     pb[1]->gpu_data(), a->spatial_scale(), lo->pad_ratio(), hi->pad_ratio(), packed, bias,
                                                     top[0]->mutable_gpu_data(), fws, fbytes, S()));
       last_fused_roipool_ = true;
@@ -544,6 +549,20 @@ void ConvolutionLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, co
     }
     else selfcheck_pending_ = false;      // a direct kernel for THIS shape (see the re-arming at the top of Forward_gpu)
   }
+}
+
+template <typename Dtype>
+void ConvolutionLayer<Dtype>::PrebuildRoiMaps(const Blob<Dtype>* feat) {
+  roi_maps_feat_ = nullptr;
+  // only where the last Forward took the fused path and the coming one has no reason not to (a pending first-forward check makes it
+  // ask for the blob instead); a wrong guess costs the maps' 70 us, never a wrong result (Forward checks the pointer and the shape)
+  ROIPoolingLayer<Dtype>* a = roi_src_;
+  if (!a || !last_fused_roipool_ || selfcheck_pending_ || pooled_top_ || feat->count() == 0 || feat->channels() != a->channels()) return;
+  const int N = feat->num(), C = feat->channels(), H = feat->height(), W = feat->width();
+  float* maps = static_cast<float*>(roi_maps_.Reserve(mscnn_roipool_maps_bytes(N, C, H, W)));
+  MSCNN_CHECK(mscnn_roipool_maps_build_f32(feat->gpu_data(), maps, N, C, H, W, S()));
+  roi_maps_feat_ = feat->gpu_data();
+  roi_maps_shape_[0] = N; roi_maps_shape_[1] = C; roi_maps_shape_[2] = H; roi_maps_shape_[3] = W;
 }
 
 template <typename Dtype>
@@ -942,6 +961,12 @@ static void FillBoxOutputDesc(const LayerParameter& lp, const vector<Blob<Dtype>
 }
 
 template <typename Dtype>
+BoxOutputLayer<Dtype>::~BoxOutputLayer() {
+  if (count_ready_) (void)hipEventDestroy((hipEvent_t)count_ready_);
+  if (host_count_) (void)hipHostFree(host_count_);
+}
+
+template <typename Dtype>
 void BoxOutputLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
   const int n = (int)bottom.size();
   mscnn_boxoutput_desc d;
@@ -961,13 +986,25 @@ void BoxOutputLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, cons
     top[1]->Reshape(cap_, 6, 1, 1);
     props = top[1]->mutable_gpu_data();
   }
-  int* count = static_cast<int*>(count_.Reserve(2 * sizeof(int)));
-  MSCNN_CHECK(mscnn_boxoutput_fwd_f32(&d, heads, rois, props, nullptr, cap_, count, ws, wbytes, S()));
+  // {R, real rows} land in host-coherent pinned memory straight from the last kernel's two stores (it only ever writes them): no D2H
+  // copy sits in the stream between BoxOutput and what follows -- an 8-byte hipMemcpyAsync held the next kernel back for ~24 us of
+  // copy-engine latency (profiles/r06_kernel_gaps.txt).  The host waits for an event behind the kernels, then reads the two words.
+  if (!host_count_) {
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_count_), 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+    void* dp = nullptr;
+    HIP_CHECK(hipHostGetDevicePointer(&dp, host_count_, 0));
+    host_count_dev_ = static_cast<int*>(dp);
+  }
+  static_cast<volatile int*>(host_count_)[0] = -1;
+  MSCNN_CHECK(mscnn_boxoutput_fwd_f32(&d, heads, rois, props, nullptr, cap_, host_count_dev_, ws, wbytes, S()));
   // The only host round trip of the layer: R (4 bytes) is needed to Reshape the tops (layer.hpp:451-456 propagates it
   // to ROIPooling and the detection sub-net).  The reference moves all 7 head blobs D2H and the ROIs H2D here.
-  int host_count[2];
-  HIP_CHECK(hipMemcpyAsync(host_count, count, sizeof(host_count), hipMemcpyDeviceToHost, (hipStream_t)S()));
-  HIP_CHECK(hipStreamSynchronize((hipStream_t)S()));
+  if (!count_ready_) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); count_ready_ = e; }
+  HIP_CHECK(hipEventRecord((hipEvent_t)count_ready_, (hipStream_t)S()));
+  // what the hook enqueues runs on the device while the host takes R and goes on (the wait is for BoxOutput's kernels, not for the stream)
+  if (before_sync_) before_sync_();
+  HIP_CHECK(hipEventSynchronize((hipEvent_t)count_ready_));
+  const volatile int* host_count = host_count_;
   const int R = host_count[0];
   CHECK_GE(R, 1); CHECK_LE(R, cap_);
   last_rows_ = R;

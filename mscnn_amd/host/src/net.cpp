@@ -348,6 +348,24 @@ void Net<Dtype>::ApplyFusion() {
           DeferredPool dp;
           dp.first_layer = first; dp.conv_layer = reader; dp.blob = tb;
           deferred_pools_.push_back(dp);
+          // The pooling's maps depend on the feature blob only.  When that blob is complete before the BoxOutput layer that selects
+          // the ROIs runs (conv4_3 of the plain nets; not the "-2x" nets' Deconvolution, which follows BoxOutput), they are built
+          // UNDER BoxOutput's host round trip: enqueued behind the row count's D2H copy, they keep the device busy while the host
+          // takes R, reshapes and launches the sub-net (29 us of idle device per 7s-576 frame otherwise: profiles/r06_kernel_gaps.txt).
+          const int feat_blob = source(bottom_id_vecs_[first][0]), rois_blob = source(bottom_id_vecs_[first][1]);
+          int feat_layer = -1, rois_layer = -1;
+          for (size_t l = 0; l < layers_.size(); ++l)
+            for (int t : top_id_vecs_[l]) {
+              if (t == feat_blob) feat_layer = (int)l;      // (the LAST writer: in-place layers re-issue the blob)
+              if (t == rois_blob) rois_layer = (int)l;
+            }
+          if (feat_layer >= 0 && rois_layer > feat_layer && string(layers_[rois_layer]->type()) == "BoxOutput") {
+            const int conv_layer = reader, pool_layer = first;
+            static_cast<BoxOutputLayer<Dtype>*>(layers_[rois_layer].get())->set_before_sync([this, conv_layer, pool_layer]() {
+              if (!fusion_ || last_end_ < conv_layer) return;      // (the sub-net is not part of this call)
+              static_cast<ConvolutionLayer<Dtype>*>(layers_[conv_layer].get())->PrebuildRoiMaps(bottom_vecs_[pool_layer][0]);
+            });
+          }
         }
       }
     }
@@ -606,9 +624,12 @@ Dtype Net<Dtype>::ForwardFromTo(int start, int end) {
     if (string(layers_[i]->type()) == "ROIPooling") static_cast<ROIPoolingLayer<Dtype>*>(layers_[i].get())->set_skip(false);
   // a deferred ROI pooling still pending from an earlier call reads blobs this range is about to rewrite without re-running the
   // pooling itself: write its blob first, from the bottoms it was given (the reference's blob would hold exactly that)
-  for (size_t k = 0; k < deferred_pools_.size(); ++k)
+  for (size_t k = 0; k < deferred_pools_.size(); ++k) {
     if (start <= deferred_pools_[k].first_layer && end < deferred_pools_[k].first_layer)
       static_cast<ROIPoolingLayer<Dtype>*>(layers_[deferred_pools_[k].first_layer].get())->Materialize();
+    // maps built early for an earlier frame's feature blob are never carried into this call (BoxOutput's hook rebuilds them)
+    static_cast<ConvolutionLayer<Dtype>*>(layers_[deferred_pools_[k].conv_layer].get())->InvalidateRoiMaps();
+  }
   {
     // split-fp16 convolutions take the bound of their input from the producing convolution when it runs in this same call
     // from the top (slots zeroed here, once); a partial range makes them measure it themselves

@@ -67,6 +67,7 @@ def lib():
             "mscnn_net_detect_pack_bytes": [ci], "mscnn_net_detect_device": [vp, vp, ci, vp],
             "mscnn_net_unpack_detections": [vp, ci, vp, vp, vp, vp],
             "mscnn_net_handoff_state": [vp, vp],
+            "mscnn_net_detect_begin": [vp, vp, ci], "mscnn_net_detect_end": [vp, vp, vp, ci, vp, vp],
             "mscnn_net_reshape_input": [vp, cs, vp, ci], "mscnn_net_detect_image": [vp, vp, ci, vp, vp, ci, vp, vp],
         }
         for name, args in sig.items():
@@ -309,6 +310,23 @@ class Net:
         ptr = C.c_void_p()
         _check(lib().mscnn_net_detect_device(self._h, C.byref(p), cap, C.byref(ptr)))
         return ptr.value
+
+    def detect_begin(self, cap, cls_id, ratios, org_hw, bbox_mean=(0, 0, 0, 0), bbox_std=(0.1, 0.1, 0.2, 0.2), proposal_thr=-10.0,
+                     nms_overlap=0.5):
+        """mscnn_net_detect_begin: final stage of the forward just done + an asynchronous copy of its pack to pinned host memory; go
+        on with the next frame and collect with detect_end (at most two frames in flight)."""
+        p = self._params(cls_id, ratios, org_hw, bbox_mean, bbox_std, proposal_thr, nms_overlap)
+        _check(lib().mscnn_net_detect_begin(self._h, C.byref(p), cap))
+
+    def detect_end(self, cap):
+        """mscnn_net_detect_end: (dets [D, 5] float64, ids [D] int32, R) of the oldest frame in flight."""
+        rows = max(cap, 1)
+        if getattr(self, "_end_rows", 0) != rows:
+            self._end_dets = np.zeros((rows, 5), np.float64); self._end_ids = np.zeros(rows, np.int32); self._end_rows = rows
+        D = C.c_int(); R = C.c_int()
+        _check(lib().mscnn_net_detect_end(self._h, self._end_dets.ctypes.data_as(C.c_void_p), self._end_ids.ctypes.data_as(C.c_void_p), cap,
+                                          C.byref(D), C.byref(R)))
+        return self._end_dets[:D.value].copy(), self._end_ids[:D.value].copy(), R.value
 
     def detect_cascade(self, bbox_blob, prob_blob, proposal_blob, cls_id, ratios, org_hw, det_thr=0.0, nms_overlap=0.5, cap=4096):
         """Final stage of the cascade drivers (run_cascademscnn.m:84-127) for one cascade output; returns (dets, ids, R)."""

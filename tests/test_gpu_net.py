@@ -1092,3 +1092,40 @@ def test_convolution_chains_keep_every_blob_bit_identical():
         net.forward()
     dn, du = n.detect(**kw), u.detect(**kw)
     assert dn[0].tobytes() == du[0].tobytes() and np.array_equal(dn[1], du[1]) and len(dn[0]) > 0
+
+
+def test_detect_begin_end_pipelined_is_bit_identical_to_detect():
+    """mscnn_net_detect_begin / _end (round 6): the final stage of a STREAM of frames -- frame i's pack is copied to pinned memory
+    behind an event while the caller already forwards frame i + 1 -- hands out exactly what the blocking mscnn_net_detect returns for
+    the same frames (detections, ROI rows, R), in order, with two frames in flight; a third begin and an end with nothing in flight
+    are refused by name."""
+    n = mnet.Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=192, width=448, max_nms_num=300))
+    synth.load_into(n, "mid")
+    H, W = n.blob_shape("data")[2:]
+    kw = dict(cls_id=2, ratios=(H / 375.0, W / 1242.0), org_hw=(375, 1242))
+    frames = [synth.frame(H, W, seed=40 + i) for i in range(4)]
+    want = []
+    for f in frames:
+        n.set_blob("data", f)
+        n.forward()
+        want.append(n.detect(**kw))
+    assert len({w[2] for w in want}) > 1 and all(len(w[0]) > 0 for w in want)      # different ROI counts frame to frame
+    cap = 300
+    got = []
+    for i, f in enumerate(frames):
+        n.set_blob("data", f)
+        n.forward()
+        n.detect_begin(cap, **kw)
+        if i >= 1:
+            got.append(n.detect_end(cap))                       # frame i - 1, collected after frame i was enqueued
+    with pytest.raises(mnet.NetError, match="nothing in flight|in flight"):
+        n.detect_end(cap); n.detect_end(cap)                    # the second one has nothing left
+    assert len(got) == 3
+    n.set_blob("data", frames[3]); n.forward(); n.detect_begin(cap, **kw)
+    n.set_blob("data", frames[0]); n.forward(); n.detect_begin(cap, **kw)
+    with pytest.raises(mnet.NetError, match="two frames already in flight"):
+        n.detect_begin(cap, **kw)
+    got.append(n.detect_end(cap))
+    last = n.detect_end(cap)
+    for (d, ids, R), (dw, iw, Rw) in zip(got + [last], want + [want[0]]):
+        assert R == Rw and np.array_equal(ids, iw) and np.array_equal(d, dw)

@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 6, session 9: the blocking final stage writing its pack straight into host-coherent memory: final-stage / net tests, the line, gaps
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r6s9; mkdir -p $O; export PYTHONUNBUFFERED=1
+( timeout 1500 python -m pytest tests/test_gpu_net.py tests/test_gpu_ops.py tests/test_gpu_dist.py tests/test_golden.py -m gpu -q -x -k "detect or detections or final or cascade or boxoutput or batch_n or caffe_net_small or layerwise or dist or gather or launcher or witness or 4032" 2>&1 | tail -12 ) > $O/tests.txt 2>&1
+timeout 500 python bench.py --layers > $O/bench.json 2> $O/layers.txt
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-robust --no-regimes > /dev/null 2> $GRAFT_REPO_ROOT/$O/kt.err
+cd $GRAFT_REPO_ROOT; find $O/kt -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/kgaps.py {} 3 > $O/kernel_gaps.txt 2>&1; rm -rf $O/kt
