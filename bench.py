@@ -540,6 +540,13 @@ def main():
                          "pinned memory behind an event and collected under frame i + 1's trunk (two in flight; all K frames' detections are "
                          "on the host before the timed region ends): + 0.6 % throughput over 300 frames (tools/sessions/r06_s8.sh), but a "
                          "step's host time no longer belongs to one frame.  The line reports the other mode beside the headline (detect_modes)")
+    ap.add_argument("--tiles", default="auto", choices=["auto", "split", "whole"],
+                    help="scheduling of the plane GEMM's last partial round: split = stream-K hand-off between co-resident workgroups, whole = "
+                         "whole tiles only (mscnn_wgemm_force_whole_tiles: no workgroup ever waits for another; fc6 then runs the register-"
+                         "staged GEMM -- what the Net falls back to after a hand-off time-out).  Measured on one GPU: whole costs 2.1 % (223.7 "
+                         "-> 218.8 images/s, profiles/r06_ab_whole_tiles.txt).  auto = split at N = 1, whole at N > 1: RCCL's kernels share "
+                         "the CUs with the next frame's trunk there, a time-out would cost 0.5 s and a frame, and nobody could rehearse an "
+                         "8-GPU run -- 2 % for a run that can not stall (config.handoff.tiles says which)")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher self-check without a GPU (CPU tests): rendezvous + the product's exchange on --transport, no measurement")
     ap.add_argument("--transport", default="", help="collective library for mscnn_dist_use_transport (an RCCL build elsewhere, or the test stub)")
@@ -708,6 +715,9 @@ def main():
         return (checks, len(switched))
 
     from mscnn_amd import hipapi as _hipapi
+    tiles_mode = args.tiles if args.tiles != "auto" else ("whole" if world > 1 else "split")
+    if tiles_mode == "whole":
+        _hipapi.wgemm_force_whole_tiles(True)
     handoff_ev0 = _hipapi.wgemm_handoff_event()      # the device's hand-off status word before any frame
     numerics = None
     mark = (0, 0)
@@ -1001,7 +1011,7 @@ def main():
                              "host_placement": placement, "per_rank": per_rank,
                              # what the collective library reported (ncclCommCount) and the senders' ranks found in the packs of the timed loop
                              "comm_count": comm_count, "ranks_seen": sorted(getattr(gather, "ranks_seen", [])) if gather is not None else None,
-                             "handoff": {**dict(zip(("events_answered", "whole_tiles_forced"), net.handoff_state())),
+                             "handoff": {"tiles": tiles_mode, **dict(zip(("events_answered", "whole_tiles_forced"), net.handoff_state())),
                                          "status_word_changed": _hipapi.wgemm_handoff_event() != handoff_ev0}},
                   "numerics": numerics, "roofline": roofline}
         if args.model == DEFAULT_MODEL:

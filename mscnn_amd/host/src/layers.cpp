@@ -714,7 +714,10 @@ void InnerProductLayer<Dtype>::Forward_gpu(const vector<Blob<Dtype>*>& bottom, c
                                             top[0]->mutable_gpu_data(), M_, N_, K_, relu_ ? 1 : 0, S()));
     return;
   }
-  used_wg_ = algo_ == 0 && mscnn_inner_product_wg_supported(M_, N_, K_);
+  // (after a hand-off time-out the process runs whole tiles only: fc6's 96 tiles would then occupy 96 of the 256 CUs -- 0.6 -> 1.6 ms,
+  // 20 % of a 7s-576 frame, profiles/r06_ab_whole_tiles.txt -- so it goes back to the register-staged GEMM, whose k-split is summed
+  // by a fix-up launch and never waits for another workgroup: + 30 us instead of + 1000)
+  used_wg_ = algo_ == 0 && !mscnn_wgemm_whole_tiles_forced() && mscnn_inner_product_wg_supported(M_, N_, K_);
   if (used_wg_) {      // fc6-class: the plane-GEMM kernel (wgemm.hip) with the weights kept transposed
     float* wt = static_cast<float*>(wt_.Reserve(mscnn_inner_product_wg_packed_bytes(N_, K_)));
     if (wt_dirty_) {
