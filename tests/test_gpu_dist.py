@@ -116,3 +116,39 @@ def test_bench_plain_gpus_n_refuses_on_a_box_with_fewer_devices():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and f"--gpus {n} but only {n - 1} GPU(s) visible" in r.stderr, (r.returncode, r.stderr[-1000:])
     assert "n_gpus" not in r.stdout
+
+
+def test_pin_host_thread_on_the_real_topology():
+    """mscnn_dist_pin_host_thread on the box's own sysfs (round 6): GPU 0's PCI address and NUMA node are found, the CPUs it assigns are
+    a non-empty subset of the mask the process had and of the GPU's local_cpulist, every thread of the process is moved, and as rank
+    1 of 2 on the same device (a process that sees only its own GPU) it gets the OTHER half of the same node.  Run in a child process:
+    the affinity of the test runner is not touched."""
+    import json
+    import sys
+    code = r'''
+import json, os, sys
+sys.path.insert(0, %r)
+from mscnn_amd import dist as md
+before = sorted(os.sched_getaffinity(0))
+rep = md.pin_host_thread(0, 0, 1)
+after = sorted(os.sched_getaffinity(0))
+bdf = rep["pci"]
+local = open("/sys/bus/pci/devices/%%s/local_cpulist" %% bdf).read().strip()
+os.sched_setaffinity(0, before)
+half = [md.pin_host_thread(0, r, 2) for r in (0,)]      # rank 0 of 2 on the one visible device: one slice of two
+h0 = sorted(os.sched_getaffinity(0))
+print(json.dumps({"before": before, "after": after, "rep": rep, "local": sorted(md.parse_cpulist(local)), "half0": h0, "rep_half": half[0]}))
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rep = out["rep"]
+    assert rep["device"] == 0 and rep["pci"].count(":") == 2 and rep["n_cpus"] == len(out["after"]) >= 1
+    assert set(out["after"]) <= set(out["before"])
+    if out["local"] and set(out["local"]) & set(out["before"]):
+        assert set(out["after"]) <= set(out["local"])                      # on its GPU's NUMA node
+    assert rep["threads_pinned"] == rep["threads"] >= 1
+    assert sorted(mdist.parse_cpulist(rep["cpus"])) == out["after"]
+    # two ranks on the node: rank 0 gets half of what one rank got (when there is more than one CPU to share)
+    if len(out["after"]) >= 2:
+        assert set(out["half0"]) < set(out["after"]) and out["rep_half"]["ranks_sharing_node"] == 2
