@@ -350,7 +350,7 @@ void Net<Dtype>::ApplyFusion() {
           deferred_pools_.push_back(dp);
           // The pooling's maps depend on the feature blob only.  When that blob is complete before the BoxOutput layer that selects
           // the ROIs runs (conv4_3 of the plain nets; not the "-2x" nets' Deconvolution, which follows BoxOutput), they are built
-          // UNDER BoxOutput's host round trip: enqueued behind the row count's D2H copy, they keep the device busy while the host
+          // UNDER BoxOutput's host round trip: enqueued behind BoxOutput's kernels and in front of the host's wait, they keep the device busy while the host
           // takes R, reshapes and launches the sub-net (29 us of idle device per 7s-576 frame otherwise: profiles/r06_kernel_gaps.txt).
           const int feat_blob = source(bottom_id_vecs_[first][0]), rois_blob = source(bottom_id_vecs_[first][1]);
           int feat_layer = -1, rois_layer = -1;
@@ -536,8 +536,8 @@ void Net<Dtype>::SetNumericsWatch(int period, double tol) {
 // The numerics watch (round 6 form: no check inside a frame's latency).  On a watch frame ONE Winograd layer -- round robin -- has its
 // bottom and top written as blobs although it stays in its convolution chain (the producers write y beside the next layer's planes
 // / the pooled map: ConvolutionLayer::set_keep_top), and one band of it (round robin as well) is recomputed with
-// the direct kernel BEHIND the frame on the same stream (ConvolutionLayer::BeginBandCheck: a copy of the band, a direct convolution an
-// eighth of the layer's size, two reductions, 4 bytes to pinned memory, an event).  Nobody waits for it: the verdict is collected at
+// the direct kernel BEHIND the frame on the same stream (ConvolutionLayer::BeginBandCheck: a copy of the band, a direct convolution of
+// that band -- ~30 us of work --, two reductions, 4 bytes to pinned memory, an event).  Nobody waits for it: the verdict is collected at
 // the end of a later whole forward (or when somebody asks for the watch's state) and, when the layer strayed, it runs the direct
 // kernel from the frame after that.
 template <typename Dtype>
