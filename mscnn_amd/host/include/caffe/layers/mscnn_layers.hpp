@@ -198,7 +198,7 @@ class ConvolutionLayer : public Layer<Dtype> {
   struct BandTicket {                     // a band check in flight: the direct plan it runs on, its completion event, the pinned verdict
     mscnn_conv_plan* plan = nullptr;
     void* done = nullptr;                 // hipEvent_t
-    float* host = nullptr;                // pinned: [0] the metric
+    float* host = nullptr;                // this layer's word of the (thread, device)'s pinned verdict array: the metric
     bool inflight = false;
   } band_;
   bool profiling_;

@@ -111,7 +111,6 @@ ConvolutionLayer<Dtype>::~ConvolutionLayer() {
   if (band_.inflight && band_.done) (void)hipEventSynchronize((hipEvent_t)band_.done);      // its kernels read this layer's weights
   if (band_.plan) mscnn_conv2d_plan_destroy(band_.plan);
   if (band_.done) (void)hipEventDestroy((hipEvent_t)band_.done);
-  if (band_.host) (void)hipHostFree(band_.host);
   if (plan_) mscnn_conv2d_plan_destroy(plan_);
 }
 
@@ -265,7 +264,12 @@ double ConvolutionLayer<Dtype>::ErrorAgainstDirect(const vector<Blob<Dtype>*>& b
 namespace {
 // the band checks' own scratch (separate from CheckScratch: a band check may still be running on the device when a first-forward
 // check of another layer reserves -- and possibly re-allocates -- its buffers)
-struct BandScratch { DeviceBuffer x, packed, ws, y, scal; };
+struct BandScratch {
+  DeviceBuffer x, packed, ws, y, scal;
+  float* host = nullptr;      // pinned: one verdict word per layer that ever ran a band check on this (thread, device)
+  int host_used = 0;
+  static constexpr int kHostWords = 1024;
+};
 thread_local BandScratch* g_band_scratch[64] = {nullptr};
 }  // namespace
 
@@ -297,7 +301,17 @@ bool ConvolutionLayer<Dtype>::BeginBandCheck(const vector<Blob<Dtype>*>& bottom,
   int dev = 0;
   HIP_CHECK(hipGetDevice(&dev));
   CHECK(dev >= 0 && dev < 64);
-  if (!g_band_scratch[dev]) g_band_scratch[dev] = new BandScratch();
+  if (!g_band_scratch[dev]) {
+    // everything a band check of ANY layer of these nets needs, once (a watch frame must not pay an allocation -- and the device
+    // synchronisation of the hipFree behind a growing buffer -- the first time each layer's turn comes: that was + 0.6 ms on four frames
+    // of the first trip round the layers, tools/sessions/r06_s13.sh): a 512 -> 512 / 1024 -> 512 direct plan's packed weights, the
+    // direct kernel's stream-K slabs, the band and its output
+    g_band_scratch[dev] = new BandScratch();
+    BandScratch& s0 = *g_band_scratch[dev];
+    s0.packed.Reserve((size_t)24 << 20); s0.ws.Reserve((size_t)96 << 20); s0.x.Reserve((size_t)8 << 20); s0.y.Reserve((size_t)8 << 20);
+    s0.scal.Reserve(32);
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s0.host), sizeof(float) * BandScratch::kHostWords, hipHostMallocDefault));
+  }
   BandScratch& sc = *g_band_scratch[dev];
   hipStream_t st = (hipStream_t)S();
   // the band of the bottom, contiguous
@@ -350,7 +364,10 @@ bool ConvolutionLayer<Dtype>::BeginBandCheck(const vector<Blob<Dtype>*>& bottom,
                                                (size_t)rows * Wo, ss, (double)ycount, ed, S()));
   else
     MSCNN_CHECK(mscnn_max_rel_diff_strided_f32(tb, ycount, yd, ycount, 1, ycount, ss, (double)ycount, ed, S()));
-  if (!band_.host) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&band_.host), 64, hipHostMallocDefault));
+  if (!band_.host) {      // this layer's word of the (thread, device)'s pinned verdict array
+    CHECK_LT(sc.host_used, BandScratch::kHostWords);
+    band_.host = sc.host + sc.host_used++;
+  }
   if (!band_.done) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); band_.done = e; }
   HIP_CHECK(hipMemcpyAsync(band_.host, ed, sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipEventRecord((hipEvent_t)band_.done, st));
