@@ -111,7 +111,7 @@ MSCNN_NET_API double mscnn_net_layer_calibration_err(const mscnn_net* net, int l
  * its bottom and top blobs are written in that frame (it stays in its convolution chain), and one band of it (a few rows / images: ~30 us of direct-kernel work; round robin too) is
  * recomputed with the direct kernel BEHIND the frame on the same stream, with no host synchronisation; the verdict is collected by a
  * later forward, and a layer off by more than tol runs the direct kernel from the frame after.  No frame waits for a check: a watch
- * frame is 2 - 4 % longer (7s-576), the others not at all.  ON by default with period 25, tol 5e-5 (~0.1 % of a stream); period 0
+ * frame is 2 - 8 % longer (7s-576), the others not at all.  ON by default with period 25, tol 5e-5 (~0.1 % of a stream); period 0
  * switches the watch off.  _state: waits for a verdict that is still out, then *checks = band checks done so far; returns how many
  * layers were switched and writes up to cap of their indices. */
 MSCNN_NET_API int mscnn_net_set_numerics_watch(mscnn_net* net, int period, double tol);

@@ -111,7 +111,7 @@ class Net {
   // rows / images: ~30 us of direct-kernel work; round robin too) is recomputed with the direct kernel BEHIND the frame on the same stream, without a
   // host synchronisation.  The verdict is collected by a later Forward (or by the state accessors below); a layer that strayed by more
   // than tol runs the direct kernel for good from the frame after.  A watch frame costs up to two extra blob writes plus that band
-  // (2 - 4 % of a 7s-576 frame); no frame ever waits for a check.  ON by default (every
+  // (2 - 8 % of a 7s-576 frame); no frame ever waits for a check.  ON by default (every
   // kDefaultWatchPeriod-th frame, tolerance 5e-5: ~0.1 % of a stream); period 0 turns it off.
   static constexpr int kDefaultWatchPeriod = 25;
   void SetNumericsWatch(int period, double tol);
