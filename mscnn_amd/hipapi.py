@@ -81,6 +81,11 @@ def lib():
         L.mscnn_inner_product_wg_workspace_bytes.argtypes = [C.c_int] * 3
         L.mscnn_inner_product_wg_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mscnn_inner_product_wg_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.mscnn_max_rel_diff_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p]
+        L.mscnn_sum_squares_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.mscnn_max_rel_diff_strided_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_double,
+                                                     C.c_void_p, C.c_void_p]
+        L.mscnn_store_words_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.mscnn_wgemm_handoff_event.restype = C.c_ulonglong
         L.mscnn_wgemm_handoff_event.argtypes = []
         L.mscnn_wgemm_force_whole_tiles.restype = None
@@ -315,6 +320,35 @@ def relu(x, slope=0.0, inplace=False):
     y = x if inplace else torch.empty_like(x)
     _check(lib().mscnn_relu_fwd_f32(_dev(x), _dev(y), x.numel(), slope, _stream()))
     return y
+
+
+def sum_squares(x):
+    """mscnn_sum_squares_f32: a float64 device scalar holding sum x^2."""
+    out = torch.zeros(1, dtype=torch.float64, device=x.device)
+    _check(lib().mscnn_sum_squares_f32(_dev(x), x.numel(), _dev(out), _stream()))
+    return out
+
+
+def max_rel_diff(a, ref, floor=1.0):
+    """mscnn_max_rel_diff_f32: max |a - ref| / max(floor, |ref|) (+inf when a NaN is involved), a float32 device scalar."""
+    out = torch.zeros(1, dtype=torch.float32, device=a.device)
+    _check(lib().mscnn_max_rel_diff_f32(_dev(a), _dev(ref), a.numel(), floor, _dev(out), _stream()))
+    return out
+
+
+def max_rel_diff_strided(a, a_stride, ref, ref_stride, planes, run, sumsq, sumsq_count):
+    """mscnn_max_rel_diff_strided_f32: the same over `planes` runs of `run` floats (plane p at a + p * a_stride / ref + p * ref_stride),
+    floor = max(1, sqrt(sumsq[0] / sumsq_count)) read on the device from `sumsq` (a float64 device scalar)."""
+    out = torch.zeros(1, dtype=torch.float32, device=a.device)
+    _check(lib().mscnn_max_rel_diff_strided_f32(_dev(a), a_stride, _dev(ref), ref_stride, planes, run, _dev(sumsq), float(sumsq_count), _dev(out),
+                                                _stream()))
+    return out
+
+
+def store_words(dst, values):
+    """mscnn_store_words_i32: dst[0 .. len(values)) = values (1 .. 4 int32 words) in one launch."""
+    arr = (C.c_int * len(values))(*[int(v) for v in values])
+    _check(lib().mscnn_store_words_i32(_dev(dst), arr, len(values), _stream()))
 
 
 def pool_out_dim(i, k, p, s):

@@ -63,6 +63,40 @@ def test_pool(hip, orc, shape, k, p, s, m):
         close(y, ref, 1e-6)
 
 
+def test_parity_metric_kernels_on_device(hip):
+    """The device forms of the suite's own metric (the host runtime's Winograd-vs-direct checks run on them): mscnn_sum_squares_f32,
+    mscnn_max_rel_diff_f32, and the strided form the numerics watch uses on a band of rows of an NCHW blob -- floor max(1, rms) taken on
+    the device from the preceding reduction -- against numpy in float64; a NaN anywhere in the compared range gives +inf, a NaN outside
+    it does not; mscnn_store_words_i32 writes 1 .. 4 words and nothing else."""
+    rng = np.random.default_rng(11)
+    C_, H, W = 5, 19, 33
+    ref = (rng.standard_normal((C_, H, W)) * 7).astype(np.float32)
+    a = (ref + rng.standard_normal(ref.shape).astype(np.float32) * 1e-3).astype(np.float32)
+    ss = hip.sum_squares(dev(ref))
+    assert abs(float(ss.cpu()[0]) - float((ref.astype(np.float64) ** 2).sum())) <= 1e-9 * float((ref.astype(np.float64) ** 2).sum())
+    want = (np.abs(a.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))).max()
+    assert abs(float(hip.max_rel_diff(dev(a), dev(ref)).cpu()[0]) - want) <= 1e-6 * want
+    # rows [r0, r0 + rows) of every plane of `a` against a band that holds rows [r0 - 1, r0 + rows + 1): what BeginBandCheck compares
+    r0, rows = 6, 4
+    band = np.ascontiguousarray(ref[:, r0 - 1:r0 + rows + 1])
+    rms = np.sqrt((band.astype(np.float64) ** 2).mean())
+    got = hip.max_rel_diff_strided(dev(a).view(-1)[r0 * W:], H * W, dev(band).view(-1)[W:], (rows + 2) * W,
+                                   C_, rows * W, hip.sum_squares(dev(band)), band.size)
+    w2 = (np.abs(a[:, r0:r0 + rows].astype(np.float64) - ref[:, r0:r0 + rows]) / np.maximum(max(1.0, rms), np.abs(ref[:, r0:r0 + rows]))).max()
+    assert abs(float(got.cpu()[0]) - w2) <= 1e-5 * w2, (float(got.cpu()[0]), w2)
+    bad = a.copy(); bad[2, r0 + 1, 5] = np.nan
+    assert np.isinf(float(hip.max_rel_diff_strided(dev(bad).view(-1)[r0 * W:], H * W, dev(band).view(-1)[W:], (rows + 2) * W, C_, rows * W,
+                                                   hip.sum_squares(dev(band)), band.size).cpu()[0]))
+    bad = a.copy(); bad[2, r0 - 1, 5] = np.nan; bad[1, r0 + rows, 0] = np.nan          # outside the compared rows: not seen
+    assert np.isfinite(float(hip.max_rel_diff_strided(dev(bad).view(-1)[r0 * W:], H * W, dev(band).view(-1)[W:], (rows + 2) * W, C_, rows * W,
+                                                      hip.sum_squares(dev(band)), band.size).cpu()[0]))
+    buf = torch.full((8,), -7, dtype=torch.int32, device="cuda")
+    hip.store_words(buf[2:], [11, -3, 2 ** 31 - 1])
+    assert buf.cpu().tolist() == [-7, -7, 11, -3, 2 ** 31 - 1, -7, -7, -7]
+    with pytest.raises(Exception):
+        hip.store_words(buf, [1, 2, 3, 4, 5])
+
+
 def test_pool_kat_on_device(hip):
     plane = np.array([[1, 2, 5, 2, 3], [9, 4, 1, 4, 8], [1, 2, 5, 2, 3]], np.float32)
     y = hip.pool2d(dev(np.tile(plane, (2, 2, 1, 1))), (2, 2), (0, 0), (1, 1)).cpu().numpy()
