@@ -1129,3 +1129,47 @@ def test_detect_begin_end_pipelined_is_bit_identical_to_detect():
     last = n.detect_end(cap)
     for (d, ids, R), (dw, iw, Rw) in zip(got + [last], want + [want[0]]):
         assert R == Rw and np.array_equal(ids, iw) and np.array_equal(d, dw)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("model,size,org_hw", [("kitti_car/mscnn-7s-576", dict(height=288, width=960, max_nms_num=600), (375, 1242)),
+                                               ("caltech/mscnn-7s-480", dict(height=240, width=320, max_nms_num=150), (480, 640))])
+def test_stream_of_frames_fused_host_machinery_is_bit_identical_to_the_eager_net(model, size, org_hw):
+    """A soak of the host-side machinery of round 6 over a stream of DIFFERENT frames (the ROI count changes every frame): the default Net
+    -- ROI maps built under BoxOutput's round trip from the previous frame's decision, the row count and the detection pack written into
+    host-coherent memory by the kernels, convolution chains, the numerics watch every 3rd frame (producers keeping their tops, a band
+    check in flight behind every third frame) and the pipelined final stage on every other frame -- must hand out, frame by frame,
+    exactly the detections, ROI rows and blobs of an eager net (fusion off, watch off) fed the same frames.  Stale state of any of
+    these (maps of an earlier frame, a count read too early, a pack slot reused, a top left unwritten) would show as a difference."""
+    txt = zoo.prototxt(model, **size)
+    a = mnet.Net(prototxt_text=txt)
+    b = mnet.Net(prototxt_text=txt, fusion=False)
+    synth.load_into(a, "mid"); synth.load_into(b, "mid")
+    b.set_numerics_watch(0)
+    a.set_numerics_watch(3, 5e-5)
+    H, W = a.blob_shape("data")[2:]
+    kw = dict(cls_id=2, ratios=(H / float(org_hw[0]), W / float(org_hw[1])), org_hw=org_hw)
+    cap = size["max_nms_num"]
+    frames = [synth.frame(H, W, seed=300 + i, org_hw=org_hw) for i in range(24)]
+    frames[7] = np.zeros_like(frames[0])                                 # a frame with nothing in it (the dummy-row path) in the middle
+    want = []
+    for f in frames:
+        b.set_blob("data", f)
+        b.forward()
+        want.append((b.detect(**kw), b.get_blob("proposals"), b.get_blob("fc6")))
+    assert len({w[0][2] for w in want}) >= 5                              # the ROI count really varies
+    pending = None
+    for i, f in enumerate(frames):
+        a.set_blob("data", f)
+        a.forward()
+        if i % 2 == 0:
+            got = a.detect(**kw)
+        else:                                                            # pipelined: collect right away (one in flight)
+            a.detect_begin(cap, **kw)
+            got = a.detect_end(cap)
+        (dw, iw, Rw), pw, fw = want[i]
+        assert got[2] == Rw and np.array_equal(got[1], iw) and np.array_equal(got[0], dw), (i, got[2], Rw)
+        if i % 5 == 0:                                                   # blobs, some of them re-created on demand in the fused net
+            assert np.array_equal(a.get_blob("proposals"), pw) and np.array_equal(a.get_blob("fc6"), fw), i
+    checks, switched = a.numerics_watch_state()
+    assert checks >= 6 and switched == []
