@@ -55,6 +55,7 @@ FULL_SIZE = [
                                                                         # "dense" weights select the same 2000, scores shifted)
     ("kitti_car/mscnn-7s-576", {}, "sparse", 2, (375, 1242)),           # fewer candidates than the top-K
     ("kitti_car/mscnn-7s-576", {}, "dense", 2, (375, 1242)),            # SURVEY 8(d) "dense": all 45,630 anchors pass fg_thr
+    ("kitti_car/mscnn-7s-576", {"iou_thr": 1.01}, "mid", 2, (375, 1242)),   # no proposal suppressed: R = the top-K cap 2000, the sub-net's upper bound (bench.py regimes.max_rois)
     ("kitti_car/mscnn-8s-768-trainval", {}, "mid", 2, (375, 1242)),     # 1x3x768x2560, 8 heads, 81,600 anchors
     ("kitti_ped_cyc/mscnn-7s-576-2x", {}, "mid", 2, (375, 1242)),       # deconv 2x, 7x5 ROI pooling, fc6 2048
     ("caltech/mscnn-7s-480", {}, "mid", 2, (480, 640)),
@@ -186,7 +187,7 @@ def test_net_x3_precision_same_gates_as_fp32(model, size, regime, cls_id):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("model,size,regime,cls_id,org_hw", [FULL_SIZE[0], FULL_SIZE[4]])
+@pytest.mark.parametrize("model,size,regime,cls_id,org_hw", [FULL_SIZE[0], FULL_SIZE[5]])
 def test_full_size_parity_x3_vs_reference(model, size, regime, cls_id, org_hw):
     """The f16x3 mode at BASELINE sizes against the reference's own CPU layers, fp32 gates."""
     if not torch.cuda.is_available():
@@ -1173,3 +1174,39 @@ def test_stream_of_frames_fused_host_machinery_is_bit_identical_to_the_eager_net
             assert np.array_equal(a.get_blob("proposals"), pw) and np.array_equal(a.get_blob("fc6"), fw), i
     checks, switched = a.numerics_watch_state()
     assert checks >= 6 and switched == []
+
+
+def test_net_final_stage_above_4032_rois_keeps_the_device_pack_path():
+    """mscnn_net_detect writes its pack straight into host-coherent memory up to 4032 ROIs (round 6); above that -- the tiled sort / NMS
+    path of the final stage -- the pack stays on the device and is copied.  A reduced 7s-576 net with max_nms_num 5000 and iou_thr 1.01
+    in the dense regime hands more than 4032 ROIs to the sub-net: BoxOutput (its own tiled path) bit-exact against the oracle on the
+    device's head blobs, the final stage index-exact against the oracle on the device's outputs, and a second call (the host buffer
+    re-used after a larger frame) equal to the first."""
+    from oracle import pynet, pyoracle as orc
+    n = mnet.Net(prototxt_text=zoo.prototxt("kitti_car/mscnn-7s-576", height=192, width=640, max_nms_num=5000, iou_thr=1.01, min_size=1))
+    ws = synth.load_into(n, "dense")
+    H, W = n.blob_shape("data")[2:]
+    x = synth.frame(H, W, seed=77)
+    n.set_blob("data", x)
+    n.forward()
+    R = n.blob_shape("proposals")[0]
+    assert R > 4032, R
+    layers = layer_list(n)
+    bo = [l for l in layers if l[1] == "BoxOutput"][0]
+    r2 = pynet.forward([bo], ws, {b: n.get_blob(b) for b in bo[2]})
+    assert np.array_equal(n.get_blob("proposals"), r2["proposals"]) and np.array_equal(n.get_blob("proposals_score"), r2["proposals_score"])
+    kw = dict(cls_id=2, ratios=(H / 375.0, W / 1242.0), org_hw=(375, 1242))
+    dets, ids, Rd = n.detect(cap=8192, **kw)
+    dref, iref = orc.detections(n.get_blob("bbox_pred"), n.get_blob("cls_pred"), n.get_blob("proposals_score").reshape(R, 6), **kw)
+    assert Rd == R and np.array_equal(ids, iref) and rel_err(dets, dref) < 1e-4
+    # a frame with few ROIs next (the sparse heads: the host-coherent path), then the large one again
+    synth.set_regime(n, "sparse")
+    n.set_blob("data", x); n.forward()
+    d0, i0, R0 = n.detect(cap=8192, **kw)
+    assert 1 <= R0 <= 4032, R0
+    dr0, ir0 = orc.detections(n.get_blob("bbox_pred"), n.get_blob("cls_pred"), n.get_blob("proposals_score").reshape(R0, 6), **kw)
+    assert np.array_equal(i0, ir0) and rel_err(d0, dr0) < 1e-4
+    synth.set_regime(n, "dense")
+    n.set_blob("data", x); n.forward()
+    d2, i2, R2 = n.detect(cap=8192, **kw)
+    assert R2 == R and np.array_equal(i2, ids) and np.array_equal(d2, dets)
