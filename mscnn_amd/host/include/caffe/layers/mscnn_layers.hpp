@@ -460,7 +460,7 @@ class BoxOutputLayer : public Layer<Dtype> {
   float fg_thr_, iou_thr_;
   string nms_type_;
   bool output_proposal_with_score_;
-  DeviceBuffer workspace_, count_;
+  DeviceBuffer workspace_;
   int cap_, last_rows_;
   bool forwarded_;
   std::function<void()> before_sync_;
